@@ -1,0 +1,226 @@
+/*
+ * yv4.h -- C-ABI of libyv4_hip.so: the MI355X (gfx950) YOLOv4 hot path.
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain
+ * device pointers + sizes + a hipStream_t passed as void*, allocates nothing,
+ * never synchronises the host, and returns 0 on success or a negative YV4_E_*
+ * code (yv4_last_error() holds the message of the last failure on the calling
+ * thread).  No torch types cross this boundary.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   yv4_mish_fwd / yv4_mish_bwd   mmdet/ops/mish_cuda/src/mish.cc:14-39
+ *                                 (pybind mish_forward / mish_backward),
+ *                                 math mmdet/ops/mish_cuda/src/mish.h:16-29,
+ *                                 kernels src/kernel/mish_cuda.cu:25-71
+ *   yv4_conv_bn_act_fwd           mmcv ConvModule as used by
+ *                                 mmdet/models/backbones/darknetcsp.py:15-35
+ *                                 (Conv2d -> BN(eval) -> act), residual add of
+ *                                 darknetcsp.py:60-64, CSP-level cat->BN->act of
+ *                                 darknetcsp.py:106-109,149-153,220-229 and the
+ *                                 biased head conv yolocsp_head.py:180-185
+ *   yv4_spp_pool_fwd              darknetcsp.py:176-181,203-206,222-226
+ *                                 (MaxPool2d k=5,9,13 s=1 + cat)
+ *   yv4_resample_nearest_fwd      necks/yolo_neck_csp.py:213-219,229
+ *                                 (F.interpolate nearest + torch.cat)
+ *   yv4_decode_filter             dense_heads/yolocsp_head.py:255-294,357-372,
+ *                                 core/bbox/coder/yolov4_bbox_coder.py:39-67,
+ *                                 core/anchor/anchor_generator.py:207-270,
+ *                                 core/post_processing/bbox_nms.py:36-67
+ *   yv4_nms_images / yv4_nms_prepare
+ *                                 mmcv.ops.nms.batched_nms called at
+ *                                 core/post_processing/bbox_nms.py:84-88
+ *   yv4_nchw_to_nhwc / yv4_nhwc_to_nchw
+ *                                 layout adaptors at the module boundary (the
+ *                                 reference is NCHW, yolocsp_head.py:264 permutes)
+ */
+#ifndef YV4_H_
+#define YV4_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YV4_ABI_VERSION 1
+
+/* error codes */
+#define YV4_OK 0
+#define YV4_E_INVALID (-1)   /* bad argument (null pointer, bad shape, bad enum) */
+#define YV4_E_UNSUPPORTED (-2) /* valid request this build has no kernel for */
+#define YV4_E_LAUNCH (-3)    /* hipLaunch / hip runtime error */
+#define YV4_E_CAPACITY (-4)  /* caller-provided workspace too small */
+
+/* element types of the standalone activation op */
+#define YV4_F32 0
+#define YV4_F16 1
+#define YV4_BF16 2
+#define YV4_F64 3
+
+/* activations of the fused conv epilogue (Mish everywhere in v4/v5,
+ * LeakyReLU(slope) in the v3 path, Swish when a config overrides act_cfg) */
+#define YV4_ACT_NONE 0
+#define YV4_ACT_MISH 1
+#define YV4_ACT_LEAKY 2
+#define YV4_ACT_SWISH 3
+
+int yv4_abi_version(void);
+const char* yv4_last_error(void);
+/* Name of the gfx target the kernels were compiled for ("gfx950"). */
+const char* yv4_arch(void);
+
+/* ---- Mish (standalone op; on the fast path Mish is a conv epilogue) -------
+ * out[i] = x*tanh(x < 20 ? log1p(exp(x)) : x);   n elements, contiguous.
+ * bwd: gin = gout * (x*(1-tsp^2)*(1-exp(-sp)) + tsp), from the saved INPUT. */
+int yv4_mish_fwd(const void* in, void* out, size_t n, int dtype, void* stream);
+int yv4_mish_bwd(const void* gout, const void* in, void* gin, size_t n,
+                 int dtype, void* stream);
+
+/* ---- layout adaptors -------------------------------------------------------
+ * src NCHW (N,C,H,W) contiguous fp32 -> dst NHWC with `dst_cstride` channels per
+ * pixel, written at channel offset dst_coff; channels [C, C+zero_pad) are zeroed
+ * (the stem pads Cin 3 -> 4). */
+int yv4_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W,
+                     int dst_cstride, int dst_coff, int zero_pad, void* stream);
+int yv4_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W,
+                     int src_cstride, int src_coff, void* stream);
+
+/* ---- fused conv ------------------------------------------------------------
+ * Implicit-GEMM convolution on fp32 MFMA, NHWC activations:
+ *   acc[m][co] = sum_{kh,kw,ci} x[n, ho*stride-pad+kh, wo*stride-pad+kw, ci]
+ *                               * w[co][(kh*KW+kw)*Cin + ci]
+ *   v = acc*scale1[co] + shift1[co];  v = act1(v);
+ *   if (residual) v += residual[m][co];
+ *   if (scale2)   v = act2(v*scale2[co] + shift2[co]);
+ *   y[m*y_cstride + y_coff + co] = v
+ * scale1/shift1 carry the folded eval-mode BN (or 1 / bias for a bare or biased
+ * conv); scale2/shift2 carry the CSP-level BN applied to the concat half this
+ * conv produces.  x / residual / y are channel-strided views so that producers
+ * write straight into concat buffers (torch.cat disappears). Cin % 4 == 0,
+ * x_cstride % 4 == 0, x_coff % 4 == 0 are required (16-byte loads). */
+typedef struct yv4_conv_desc {
+  int32_t N, H, W, Cin;      /* input  */
+  int32_t Ho, Wo, Cout;      /* output */
+  int32_t KH, KW, stride, pad;
+  int32_t x_cstride, x_coff; /* floats per input pixel / channel offset  */
+  int32_t y_cstride, y_coff;
+  int32_t r_cstride, r_coff; /* residual view (ignored when residual==NULL) */
+  int32_t act1, act2;        /* YV4_ACT_* */
+  float slope1, slope2;      /* LeakyReLU negative slopes */
+  int32_t tile;              /* 0 = auto; else a YV4_TILE_* id (benchmarking) */
+} yv4_conv_desc;
+
+#define YV4_TILE_AUTO 0
+#define YV4_TILE_128x128 1
+#define YV4_TILE_128x64 2
+#define YV4_TILE_64x64 3
+#define YV4_TILE_64x128 4
+
+int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const float* w,
+                        const float* scale1, const float* shift1,
+                        const float* scale2, const float* shift2,
+                        const float* residual, float* y, void* stream);
+/* Algorithmic work of one launch, for the roofline: 2*M*Cout*K flops. */
+double yv4_conv_flops(const yv4_conv_desc* d);
+/* Tile id the auto heuristic picks for d (so callers can report it). */
+int yv4_conv_pick_tile(const yv4_conv_desc* d);
+
+/* ---- SPP -------------------------------------------------------------------
+ * buf is an NHWC view with `cstride` channels per pixel.  Reads channels
+ * [coff, coff+C) and writes MaxPool2d(k, stride 1, pad k/2) for k = 5, 9, 13 to
+ * [coff+C, coff+2C), [coff+2C, coff+3C), [coff+3C, coff+4C) -- i.e. the
+ * torch.cat([x, mp5, mp9, mp13], 1) buffer is completed in place. C % 4 == 0. */
+int yv4_spp_pool_fwd(float* buf, int N, int H, int W, int C, int cstride,
+                     int coff, void* stream);
+
+/* ---- nearest resample into a concat buffer ---------------------------------
+ * dst[n, y, x, dst_coff + c] = src[n, sy(y), sx(x), src_coff + c] with
+ * sy = min(floor(y * Hs / Hd), Hs-1) (torch 'nearest').  Hs==Hd is a plain
+ * channel-slice copy. C % 4 == 0. */
+int yv4_resample_nearest_fwd(const float* src, float* dst, int N, int Hs, int Ws,
+                             int Hd, int Wd, int C, int src_cstride,
+                             int src_coff, int dst_cstride, int dst_coff,
+                             void* stream);
+
+/* ---- decode + threshold ----------------------------------------------------
+ * One call handles every level of a batch.  Level l's pred map is NHWC
+ * (N, H_l, W_l, A*(5+num_classes)) fp32.  For anchor-box index
+ * j = level_base_l + (y*W_l + x)*A + a of image n:
+ *   s = sigmoid(p);  cx = (2 s0 - 1)*stride + x*stride + stride/2 ... (the
+ *   reference's literal op order, see csrc/postproc.hip)
+ *   boxes[n][j] = decoded box / scale_factor[n]   (if scale_factor != NULL)
+ *   conf[n][j]  = s4
+ *   for each class c with s_{5+c}*s4 > score_thr: append the candidate key
+ *       (~bits(score) << 32 | (j*num_classes + c)) to keys[n*key_cap + ...],
+ *       and fold the box into max_coord[n] (the per-image boxes.max()).
+ * counts[n] / max_coord[n] must be zero / -inf-initialised by
+ * yv4_decode_reset().  If more than key_cap candidates pass for an image the
+ * count keeps counting (so the caller can see the overflow) but keys beyond the
+ * capacity are dropped. */
+typedef struct yv4_level_desc {
+  const float* pred;  /* device pointer, NHWC */
+  int32_t H, W;
+  int32_t stride;     /* featmap stride in pixels (8/16/32) */
+  /* base anchors (x1,y1,x2,y2) of one grid cell, A <= 8 rows, exactly as
+   * YOLOAnchorGenerator.gen_single_level_base_anchors builds them
+   * (core/anchor/anchor_generator.py:639-665): centre stride/2, float32 */
+  float base_anchors[8][4];
+} yv4_level_desc;
+
+int yv4_decode_reset(int32_t* counts, float* max_coord, int N, void* stream);
+int yv4_decode_filter(const yv4_level_desc* levels, int num_levels, int N, int A,
+                      int num_classes, float score_thr,
+                      const float* scale_factor /* (N,4) device or NULL */,
+                      float* boxes /* (N, total_anchors, 4) */,
+                      float* conf /* (N, total_anchors) or NULL */,
+                      float* cls /* (N, total_anchors, num_classes) sigmoid, or NULL */,
+                      uint64_t* keys, int64_t key_cap, int32_t* counts,
+                      float* max_coord, void* stream);
+
+/* ---- batched NMS -----------------------------------------------------------
+ * Per image n (one workgroup each): sort its counts[n] candidate keys by
+ * (score desc, flat index asc), then greedy NMS in that order on the
+ * class-offset boxes  box + label*(max_coord[n] + 1)  (mmcv batched_nms
+ * semantics), suppressing j when inter/(area_i + area_j - inter) > iou_thr
+ * (fp32, IEEE division).  Stops after max_out survivors (multiclass_nms
+ * `max_num`).  A candidate's box is boxes[n][flat / fused_classes] and its
+ * label flat % fused_classes; with fused_classes == 0 the box is
+ * boxes[n][flat] and the label labels[n*label_stride + flat] (the standalone
+ * batched_nms op).
+ * Outputs per image: out_dets (max_out,5) = x1,y1,x2,y2,score (un-offset
+ * boxes), out_labels (max_out) int32, out_index (max_out) int64 = flat index of
+ * each survivor, out_count.  Images with counts[n] >= split_thr (mmcv
+ * `split_thr`, 10000) or > key_cap take mmcv's per-class path: they are only
+ * flagged here (out_count[n] = -1) and must go through yv4_nms_split. */
+int yv4_nms_images(uint64_t* keys /* sorted in place */, int64_t key_cap, const int32_t* counts,
+                   const float* max_coord, const float* boxes,
+                   int64_t boxes_per_image, const int32_t* labels,
+                   int64_t label_stride, int fused_classes, int N,
+                   float iou_thr, int max_out, int split_thr, float* out_dets,
+                   int32_t* out_labels, int64_t* out_index, int32_t* out_count,
+                   void* stream);
+
+/* mmcv's n >= split_thr path for ONE image: per-class NMS, survivors re-sorted
+ * by (score desc, flat index asc), first max_out returned.  `keys` holds that
+ * image's n candidate keys (any order); work must hold yv4_nms_split_work(n)
+ * bytes.  n is a host value: the caller reads counts[] back first (the
+ * reference syncs at the same place, bbox_nms.py:66). */
+size_t yv4_nms_split_work(int64_t n);
+int yv4_nms_split(const uint64_t* keys, int64_t n, float max_coord,
+                  const float* boxes, const int32_t* labels, int fused_classes,
+                  float iou_thr, int max_out, void* work, float* out_dets,
+                  int32_t* out_labels, int64_t* out_index, int32_t* out_count,
+                  void* stream);
+
+/* Build candidate keys for the standalone batched_nms op from plain
+ * boxes/scores (n candidates of one image): keys[i] = ~bits(score_i)<<32 | i,
+ * counts[0] = n, max_coord[0] = max over all box coordinates. */
+int yv4_nms_prepare(const float* boxes, const float* scores, int64_t n,
+                    uint64_t* keys, int32_t* counts, float* max_coord,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YV4_H_ */

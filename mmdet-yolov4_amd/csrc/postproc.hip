@@ -1,0 +1,489 @@
+// Post-processing of the YOLOv4 head on gfx950: sigmoid + anchor decode + score
+// threshold (one pass over the NHWC pred maps) and per-image batched NMS.
+//
+// Built with -ffp-contract=off: the reference computes these in separate fp32 ops
+// (mul then add, never fma) and the NMS decision `inter/(a+b-inter) > thr` must be
+// reproduced bit for bit.
+//
+// Reference code restated here:
+//   decode   mmdet/models/dense_heads/yolocsp_head.py:263-285 (sigmoid, 2s-1, (2s)^2),
+//            mmdet/core/bbox/coder/yolov4_bbox_coder.py:51-67,
+//            mmdet/core/anchor/anchor_generator.py:255-270 (grid = base + shift),
+//            yolocsp_head.py:357-366 (cls *= conf, boxes /= scale_factor),
+//            mmdet/core/post_processing/bbox_nms.py:54,66 (scores > score_thr)
+//   nms      mmcv.ops.nms.batched_nms / nms (mmcv-full 1.3.x, not vendored in the
+//            reference; call site bbox_nms.py:84): class offset box + label*(max+1),
+//            order by score descending, greedy suppression when
+//            inter / (area_i + area_j - inter) > iou_threshold, offset = 0.
+//            Tie-break (unspecified by mmcv): lower flat candidate index first.
+#include "yv4_common.h"
+
+namespace yv4 {
+
+// ---- order-preserving float <-> uint32 (descending score = ascending key) ---------
+__device__ __forceinline__ uint32_t score_to_key(float s) {
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending order of floats
+  return ~u;                                       // descending
+}
+__device__ __forceinline__ float key_to_score(uint32_t k) {
+  uint32_t u = ~k;
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  // valid for any mix of signs when *addr starts at -inf
+  if (v >= 0.f)
+    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else
+    atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ void decode_reset_kernel(int32_t* counts, float* max_coord, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    counts[i] = 0;
+    max_coord[i] = -__builtin_huge_valf();
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// decode + filter.  A workgroup owns 64 consecutive anchor boxes of one (image, level):
+// their 64*(5+C) logits are contiguous in the NHWC pred map, are read once, coalesced,
+// and go through sigmoid into LDS.  Then thread t works on box t/4 and classes
+// t%4, t%4+4, ...
+// ---------------------------------------------------------------------------------
+constexpr int kDecBoxes = 64;
+constexpr int kMaxLevels = 8;
+
+struct DecodeArgs {
+  const float* pred[kMaxLevels];
+  int H[kMaxLevels], W[kMaxLevels], stride[kMaxLevels];
+  int level_base[kMaxLevels];   // first anchor-box index of the level inside an image
+  int block_base[kMaxLevels + 1];  // first workgroup (per image) of the level
+  float base[kMaxLevels][8][4];
+  int num_levels, N, A, C, total_anchors;
+  float score_thr;
+  const float* scale_factor;
+  float* boxes;
+  float* conf;
+  float* cls;
+  uint64_t* keys;
+  int64_t key_cap;
+  int32_t* counts;
+  float* max_coord;
+};
+
+__global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [64][attr] sigmoid values
+  const int n = blockIdx.y;
+  int lvl = 0;
+  while (lvl + 1 < p.num_levels && (int)blockIdx.x >= p.block_base[lvl + 1]) ++lvl;
+  const int attr = 5 + p.C;
+  const int boxes_lvl = p.H[lvl] * p.W[lvl] * p.A;
+  const int b0 = ((int)blockIdx.x - p.block_base[lvl]) * kDecBoxes;  // first box of this workgroup in the level
+  const int nb = min(kDecBoxes, boxes_lvl - b0);
+  const float* src = p.pred[lvl] + ((size_t)n * boxes_lvl + b0) * attr;
+  const int nval = nb * attr;
+  for (int i = threadIdx.x; i < nval; i += 256) sm[i] = sigmoid_f32(src[i]);
+  __syncthreads();
+
+  const int b = threadIdx.x >> 2;
+  const int part = threadIdx.x & 3;
+  if (b >= nb) return;
+  const float* s = sm + b * attr;
+  const int jl = b0 + b;  // box index within the level: (y*W + x)*A + a
+  const int a = jl % p.A;
+  const int cell = jl / p.A;
+  const int gx = cell % p.W[lvl];
+  const int gy = cell / p.W[lvl];
+  const float stride = (float)p.stride[lvl];
+  // anchor = base + shift  (anchor_generator.py:255-266)
+  const float sx = (float)(gx * p.stride[lvl]);
+  const float sy = (float)(gy * p.stride[lvl]);
+  const float ax1 = p.base[lvl][a][0] + sx, ay1 = p.base[lvl][a][1] + sy;
+  const float ax2 = p.base[lvl][a][2] + sx, ay2 = p.base[lvl][a][3] + sy;
+  // yolocsp_head.py:273-275
+  const float px = s[0] * 2.f - 1.f;
+  const float py = s[1] * 2.f - 1.f;
+  const float tw = s[2] * 2.f, th = s[3] * 2.f;
+  const float pw = tw * tw, ph = th * th;
+  // yolov4_bbox_coder.py:51-66
+  const float xc = (ax1 + ax2) * 0.5f, yc = (ay1 + ay2) * 0.5f;
+  const float aw = ax2 - ax1, ah = ay2 - ay1;
+  const float xcp = px * stride + xc, ycp = py * stride + yc;
+  const float wp = pw * aw, hp = ph * ah;
+  float x1 = xcp - wp / 2.f, y1 = ycp - hp / 2.f, x2 = xcp + wp / 2.f, y2 = ycp + hp / 2.f;
+  if (p.scale_factor) {  // yolocsp_head.py:365-366
+    const float* sf = p.scale_factor + n * 4;
+    x1 /= sf[0]; y1 /= sf[1]; x2 /= sf[2]; y2 /= sf[3];
+  }
+  const float cf = s[4];
+  const int j = p.level_base[lvl] + jl;
+  const size_t gj = (size_t)n * p.total_anchors + j;
+  if (part == 0) {
+    reinterpret_cast<float4*>(p.boxes)[gj] = make_float4(x1, y1, x2, y2);
+    if (p.conf) p.conf[gj] = cf;
+  }
+  bool any = false;
+  for (int c = part; c < p.C; c += 4) {
+    const float sc = s[5 + c];
+    if (p.cls) p.cls[gj * p.C + c] = sc;
+    const float score = sc * cf;  // yolocsp_head.py:358
+    if (score > p.score_thr) {    // bbox_nms.py:54
+      any = true;
+      const int slot = atomicAdd(&p.counts[n], 1);
+      if (slot < p.key_cap) {
+        const uint32_t flat = (uint32_t)j * (uint32_t)p.C + (uint32_t)c;
+        p.keys[(size_t)n * p.key_cap + slot] = ((uint64_t)score_to_key(score) << 32) | flat;
+      }
+    }
+  }
+  if (any) {  // boxes.max() over the surviving candidates (mmcv batched_nms)
+    atomic_max_float(&p.max_coord[n], fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// NMS, one 1024-thread workgroup per image.
+//   1. sort the image's keys in LDS (bitonic, padded to a power of two <= 16384) and
+//      write them back in place;
+//   2. walk the sorted list in chunks of 256: (a) test the chunk against everything
+//      kept so far, (b) build the 256x256 suppression bitmask of the chunk, (c) one
+//      thread resolves the chunk greedily and appends survivors to the outputs.
+// The greedy result equals the sequential loop of mmcv's nms (see oracle/nms_ref.c).
+// ---------------------------------------------------------------------------------
+constexpr int kNmsThreads = 1024;
+constexpr int kChunk = 256;
+constexpr int kSortCap = 16384;   // >= split_thr (10000) rounded up to a power of two
+constexpr int kKeptLds = 1024;    // kept boxes cached in LDS; the rest are re-read from the outputs
+
+struct NmsArgs {
+  uint64_t* keys;
+  int64_t key_cap;
+  const int32_t* counts;
+  const float* max_coord;
+  const float* boxes;
+  int64_t boxes_per_image;
+  const int32_t* labels;
+  int64_t label_stride;
+  int fused_classes;
+  float iou_thr;
+  int max_out;
+  int split_thr;
+  float* out_dets;
+  int32_t* out_labels;
+  int64_t* out_index;
+  int32_t* out_count;
+};
+
+__device__ __forceinline__ bool iou_gt(const float4 bi, const float ai, const float4 bj, const float aj, const float thr) {
+  const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+  const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+  const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+  const float inter = w * h;
+  const float ovr = inter / (ai + aj - inter);
+  return ovr > thr;
+}
+
+__global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n = p.counts[img];
+  if (n <= 0) {
+    if (tid == 0) p.out_count[img] = 0;
+    return;
+  }
+  if (n >= p.split_thr || n > p.key_cap || n > kSortCap) {
+    if (tid == 0) p.out_count[img] = -1;  // caller must use yv4_nms_split
+    return;
+  }
+  uint64_t* gkeys = p.keys + (size_t)img * p.key_cap;
+
+  // ---- 1. sort ------------------------------------------------------------------
+  {
+    uint64_t* sk = reinterpret_cast<uint64_t*>(lds_raw);
+    int P = 1;
+    while (P < n) P <<= 1;
+    if (P < 2) P = 2;
+    for (int i = tid; i < P; i += kNmsThreads) sk[i] = i < n ? gkeys[i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (P >> 1); t += kNmsThreads) {
+          const int i = ((t / j) * (j << 1)) + (t % j);
+          const int ixj = i + j;
+          const bool up = (i & k) == 0;
+          const uint64_t a = sk[i], b = sk[ixj];
+          if ((a > b) == up) {
+            sk[i] = b;
+            sk[ixj] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < n; i += kNmsThreads) gkeys[i] = sk[i];
+    __syncthreads();
+  }
+
+  // ---- 2. greedy NMS over sorted chunks -------------------------------------------
+  // LDS carve (aliases the sort buffer)
+  float4* cbox = reinterpret_cast<float4*>(lds_raw);                       // [256] class-offset boxes
+  float* carea = reinterpret_cast<float*>(cbox + kChunk);                  // [256]
+  uint64_t* cmask = reinterpret_cast<uint64_t*>(carea + kChunk);           // [256][4]
+  uint64_t* calive = cmask + kChunk * 4;                                   // [4]
+  float4* cobox = reinterpret_cast<float4*>(calive + 4);                   // [256] original boxes
+  uint64_t* ckey = reinterpret_cast<uint64_t*>(cobox + kChunk);            // [256]
+  int32_t* clabel = reinterpret_cast<int32_t*>(ckey + kChunk);             // [256]
+  float4* kbox = reinterpret_cast<float4*>(clabel + kChunk);               // [kKeptLds]
+  float* karea = reinterpret_cast<float*>(kbox + kKeptLds);                // [kKeptLds]
+  int32_t* kcount = reinterpret_cast<int32_t*>(karea + kKeptLds);          // [1]
+
+  const float off_unit = p.max_coord[img] + 1.f;  // max_coordinate + 1 (mmcv batched_nms)
+  const float* ibox = p.boxes + (size_t)img * p.boxes_per_image * 4;
+  const int32_t* ilab = p.labels ? p.labels + (size_t)img * p.label_stride : nullptr;
+  float* odet = p.out_dets + (size_t)img * p.max_out * 5;
+  int32_t* olab = p.out_labels + (size_t)img * p.max_out;
+  int64_t* oidx = p.out_index + (size_t)img * p.max_out;
+  if (tid == 0) *kcount = 0;
+  __syncthreads();
+
+  for (int c0 = 0; c0 < n; c0 += kChunk) {
+    const int cn = min(kChunk, n - c0);
+    const int kept = *kcount;
+    if (kept >= p.max_out) break;
+    // load the chunk
+    if (tid < kChunk) {
+      float4 ob = make_float4(0.f, 0.f, 0.f, 0.f), bb = ob;
+      float ar = 0.f;
+      uint64_t key = 0;
+      int lab = 0;
+      if (tid < cn) {
+        key = gkeys[c0 + tid];
+        const uint32_t flat = (uint32_t)key;
+        uint32_t bi;
+        if (p.fused_classes > 0) {
+          bi = flat / (uint32_t)p.fused_classes;
+          lab = (int)(flat - bi * (uint32_t)p.fused_classes);
+        } else {
+          bi = flat;
+          lab = ilab ? ilab[flat] : 0;
+        }
+        ob = reinterpret_cast<const float4*>(ibox)[bi];
+        const float off = (float)lab * off_unit;  // idxs.to(boxes) * (max + 1)
+        bb = make_float4(ob.x + off, ob.y + off, ob.z + off, ob.w + off);
+        ar = (bb.z - bb.x) * (bb.w - bb.y);
+      }
+      cbox[tid] = bb;
+      carea[tid] = ar;
+      cobox[tid] = ob;
+      ckey[tid] = key;
+      clabel[tid] = lab;
+    }
+    __syncthreads();
+    // (a) chunk vs kept: thread -> (candidate i = tid & 255, quarter q = tid >> 8)
+    {
+      const int i = tid & (kChunk - 1);
+      const int q = tid >> 8;
+      bool dead = false;
+      if (i < cn) {
+        const float4 bj = cbox[i];
+        const float aj = carea[i];
+        for (int k = q; k < kept && !dead; k += 4) {
+          float4 bk;
+          float ak;
+          if (k < kKeptLds) {
+            bk = kbox[k];
+            ak = karea[k];
+          } else {
+            const float off = (float)olab[k] * off_unit;
+            bk = make_float4(odet[k * 5 + 0] + off, odet[k * 5 + 1] + off, odet[k * 5 + 2] + off, odet[k * 5 + 3] + off);
+            ak = (bk.z - bk.x) * (bk.w - bk.y);
+          }
+          dead = iou_gt(bk, ak, bj, aj, p.iou_thr);
+        }
+      } else {
+        dead = true;
+      }
+      // combine the four quarters: every wave holds 64 candidates of one quarter
+      const unsigned long long live = __ballot(!dead);
+      if (q == 0 && (tid & 63) == 0) calive[tid >> 6] = live;
+      __syncthreads();
+      if (q != 0 && (tid & 63) == 0) atomicAnd(reinterpret_cast<unsigned long long*>(&calive[(tid & 255) >> 6]), live);
+    }
+    // (b) chunk x chunk bitmask: thread -> (row i = tid >> 2, word w = tid & 3)
+    {
+      const int i = tid >> 2;
+      const int w = tid & 3;
+      uint64_t bits = 0;
+      if (i < cn) {
+        const float4 bi = cbox[i];
+        const float ai = carea[i];
+        const int j0 = w * 64;
+        for (int jj = 0; jj < 64; ++jj) {
+          const int j = j0 + jj;
+          if (j > i && j < cn && iou_gt(bi, ai, cbox[j], carea[j], p.iou_thr)) bits |= 1ull << jj;
+        }
+      }
+      cmask[i * 4 + w] = bits;
+    }
+    __syncthreads();
+    // (c) sequential resolve by one thread
+    if (tid == 0) {
+      uint64_t removed[4] = {0, 0, 0, 0};
+      int k = kept;
+      for (int w = 0; w < 4 && k < p.max_out; ++w) {
+        uint64_t cur = calive[w] & ~removed[w];
+        while (cur && k < p.max_out) {
+          const int b = __builtin_ctzll(cur);
+          const int i = w * 64 + b;
+          // keep candidate i
+          const float4 ob = cobox[i];
+          const uint64_t key = ckey[i];
+          odet[k * 5 + 0] = ob.x;
+          odet[k * 5 + 1] = ob.y;
+          odet[k * 5 + 2] = ob.z;
+          odet[k * 5 + 3] = ob.w;
+          odet[k * 5 + 4] = key_to_score((uint32_t)(key >> 32));
+          olab[k] = clabel[i];
+          oidx[k] = (int64_t)(uint32_t)key;
+          if (k < kKeptLds) {
+            kbox[k] = cbox[i];
+            karea[k] = carea[i];
+          }
+          ++k;
+          removed[0] |= cmask[i * 4 + 0];
+          removed[1] |= cmask[i * 4 + 1];
+          removed[2] |= cmask[i * 4 + 2];
+          removed[3] |= cmask[i * 4 + 3];
+          const uint64_t above = b == 63 ? 0ull : (~0ull << (b + 1));
+          cur = calive[w] & ~removed[w] & above;
+        }
+      }
+      *kcount = k;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (tid == 0) p.out_count[img] = *kcount;
+}
+
+constexpr size_t kNmsLdsSort = (size_t)kSortCap * sizeof(uint64_t);
+constexpr size_t kNmsLdsChunk = (size_t)kChunk * (16 + 4 + 32 + 16 + 8 + 4) + 32 + (size_t)kKeptLds * 20 + 16;
+constexpr size_t kNmsLds = kNmsLdsSort > kNmsLdsChunk ? kNmsLdsSort : kNmsLdsChunk;
+
+// keys / max for the standalone batched_nms op
+__global__ __launch_bounds__(256) void nms_prepare_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                          int64_t n, uint64_t* keys, float* max_coord) {
+  float m = -__builtin_huge_valf();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    keys[i] = ((uint64_t)score_to_key(scores[i]) << 32) | (uint32_t)i;
+    const float4 b = reinterpret_cast<const float4*>(boxes)[i];
+    m = fmaxf(m, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > -__builtin_huge_valf()) atomic_max_float(max_coord, m);
+}
+
+__global__ void nms_prepare_count_kernel(int32_t* counts, float* max_coord, int32_t n) {
+  counts[0] = n;
+  max_coord[0] = -__builtin_huge_valf();
+}
+
+}  // namespace yv4
+
+using namespace yv4;
+
+extern "C" int yv4_decode_reset(int32_t* counts, float* max_coord, int N, void* stream) {
+  YV4_REQUIRE(counts && max_coord && N > 0, "decode_reset: bad argument");
+  hipLaunchKernelGGL(decode_reset_kernel, dim3((N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     counts, max_coord, N);
+  YV4_CHECK_LAUNCH("decode_reset");
+  return YV4_OK;
+}
+
+extern "C" int yv4_decode_filter(const yv4_level_desc* levels, int num_levels, int N, int A, int num_classes,
+                                 float score_thr, const float* scale_factor, float* boxes, float* conf, float* cls,
+                                 uint64_t* keys, int64_t key_cap, int32_t* counts, float* max_coord, void* stream) {
+  YV4_REQUIRE(levels && boxes && keys && counts && max_coord, "decode_filter: null pointer");
+  YV4_REQUIRE(num_levels > 0 && num_levels <= kMaxLevels, "decode_filter: 1..%d levels supported", kMaxLevels);
+  YV4_REQUIRE(N > 0 && N <= 65535 && A > 0 && A <= 8 && num_classes > 0, "decode_filter: bad N/A/num_classes");
+  YV4_REQUIRE(key_cap > 0, "decode_filter: key_cap must be positive");
+  YV4_REQUIRE(((uintptr_t)boxes & 15) == 0, "decode_filter: boxes must be 16-byte aligned");
+  DecodeArgs a;
+  long long total = 0;
+  int blocks = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    YV4_REQUIRE(levels[l].pred && levels[l].H > 0 && levels[l].W > 0 && levels[l].stride > 0,
+                "decode_filter: level %d is malformed", l);
+    a.pred[l] = levels[l].pred;
+    a.H[l] = levels[l].H;
+    a.W[l] = levels[l].W;
+    a.stride[l] = levels[l].stride;
+    a.level_base[l] = (int)total;
+    a.block_base[l] = blocks;
+    for (int k = 0; k < 8; ++k)
+      for (int c = 0; c < 4; ++c) a.base[l][k][c] = levels[l].base_anchors[k][c];
+    const long long nb = (long long)levels[l].H * levels[l].W * A;
+    total += nb;
+    blocks += (int)((nb + kDecBoxes - 1) / kDecBoxes);
+  }
+  a.block_base[num_levels] = blocks;
+  YV4_REQUIRE(total * num_classes < (1LL << 32), "decode_filter: anchors*classes = %lld overflows the 32-bit flat index",
+              total * num_classes);
+  a.num_levels = num_levels; a.N = N; a.A = A; a.C = num_classes; a.total_anchors = (int)total;
+  a.score_thr = score_thr; a.scale_factor = scale_factor; a.boxes = boxes; a.conf = conf; a.cls = cls;
+  a.keys = keys; a.key_cap = key_cap; a.counts = counts; a.max_coord = max_coord;
+  const size_t lds = (size_t)kDecBoxes * (5 + num_classes) * sizeof(float);
+  YV4_REQUIRE(lds <= 64 * 1024, "decode_filter: num_classes %d too large for the LDS tile", num_classes);
+  hipLaunchKernelGGL(decode_filter_kernel, dim3(blocks, N), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+  YV4_CHECK_LAUNCH("decode_filter");
+  return YV4_OK;
+}
+
+extern "C" int yv4_nms_images(uint64_t* keys, int64_t key_cap, const int32_t* counts, const float* max_coord,
+                              const float* boxes, int64_t boxes_per_image, const int32_t* labels, int64_t label_stride,
+                              int fused_classes, int N, float iou_thr, int max_out, int split_thr, float* out_dets,
+                              int32_t* out_labels, int64_t* out_index, int32_t* out_count, void* stream) {
+  YV4_REQUIRE(keys && counts && max_coord && boxes && out_dets && out_labels && out_index && out_count,
+              "nms_images: null pointer");
+  YV4_REQUIRE(N > 0 && max_out > 0 && key_cap > 0 && boxes_per_image > 0, "nms_images: bad sizes");
+  YV4_REQUIRE(fused_classes >= 0, "nms_images: fused_classes must be >= 0");
+  YV4_REQUIRE(((uintptr_t)boxes & 15) == 0, "nms_images: boxes must be 16-byte aligned");
+  if (split_thr <= 0 || split_thr > kSortCap) split_thr = kSortCap + 1;
+  NmsArgs a;
+  a.keys = keys; a.key_cap = key_cap; a.counts = counts; a.max_coord = max_coord; a.boxes = boxes;
+  a.boxes_per_image = boxes_per_image; a.labels = labels; a.label_stride = label_stride;
+  a.fused_classes = fused_classes; a.iou_thr = iou_thr; a.max_out = max_out; a.split_thr = split_thr;
+  a.out_dets = out_dets; a.out_labels = out_labels; a.out_index = out_index; a.out_count = out_count;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nms_images_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)kNmsLds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(nms_images_kernel, dim3(N), dim3(kNmsThreads), kNmsLds, reinterpret_cast<hipStream_t>(stream), a);
+  YV4_CHECK_LAUNCH("nms_images");
+  return YV4_OK;
+}
+
+extern "C" int yv4_nms_prepare(const float* boxes, const float* scores, int64_t n, uint64_t* keys, int32_t* counts,
+                               float* max_coord, void* stream) {
+  YV4_REQUIRE(keys && counts && max_coord, "nms_prepare: null pointer");
+  YV4_REQUIRE(n >= 0 && n < (1LL << 31), "nms_prepare: n out of range");
+  YV4_REQUIRE(n == 0 || (boxes && scores), "nms_prepare: null boxes/scores");
+  YV4_REQUIRE(((uintptr_t)boxes & 15) == 0, "nms_prepare: boxes must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(nms_prepare_count_kernel, dim3(1), dim3(1), 0, s, counts, max_coord, (int32_t)n);
+  if (n > 0) {
+    unsigned g = (unsigned)((n + 255) / 256);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(nms_prepare_kernel, dim3(g), dim3(256), 0, s, boxes, scores, n, keys, max_coord);
+  }
+  YV4_CHECK_LAUNCH("nms_prepare");
+  return YV4_OK;
+}

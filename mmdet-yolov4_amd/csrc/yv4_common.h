@@ -1,0 +1,56 @@
+// Shared helpers of the gfx950 YOLOv4 kernels (device math + host error plumbing).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "yv4.h"
+
+namespace yv4 {
+
+// ---- host side ---------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define YV4_REQUIRE(cond, ...)              \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::yv4::set_error(__VA_ARGS__);        \
+      return YV4_E_INVALID;                 \
+    }                                       \
+  } while (0)
+
+#define YV4_CHECK_LAUNCH(what)                                               \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      ::yv4::set_error("%s: %s", what, hipGetErrorString(e__));              \
+      return YV4_E_LAUNCH;                                                   \
+    }                                                                        \
+  } while (0)
+
+// ---- device math -------------------------------------------------------------
+// Mish, mmdet/ops/mish_cuda/src/mish.h:16-18:  x * tanh(x < 20 ? log1p(exp(x)) : x).
+// tanh(log1p(e)) == (e*e + 2e) / (e*e + 2e + 2) exactly, which needs one exp and
+// one divide and keeps full relative precision for very negative x.
+__device__ __forceinline__ float mish_f32(float x) {
+  if (x >= 20.f) return x;  // tanh(x) rounds to 1 in fp32 for x >= 9.02
+  const float e = expf(x);
+  const float n = e * (e + 2.f);
+  return x * (n / (n + 2.f));
+}
+
+__device__ __forceinline__ float sigmoid_f32(float x) {
+  return 1.f / (1.f + expf(-x));
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case YV4_ACT_MISH: return mish_f32(v);
+    case YV4_ACT_LEAKY: return v >= 0.f ? v : v * slope;
+    case YV4_ACT_SWISH: return v * sigmoid_f32(v);
+    default: return v;
+  }
+}
+
+}  // namespace yv4
