@@ -1,0 +1,23 @@
+"""MI355X-native YOLOv4 hot path behind the mmdet-yolov4 registry surface.
+
+Importing the package registers ``DarknetCSP``, ``YOLOV4Neck``/``YOLOV5Neck``,
+``YOLOCSPHead``, ``SingleStageDetector``, ``YOLOV4AnchorGenerator``,
+``YOLOV4BBoxCoder`` and the ``Mish`` activation under the reference's names.  Numbers
+come from ``lib/libyv4_hip.so`` (C-ABI: ``include/yv4.h``); there is no CPU fallback.
+"""
+from . import _lib
+from .registry import (ACTIVATION_LAYERS, ANCHOR_GENERATORS, BACKBONES, BBOX_CODERS, DETECTORS, HEADS, LOSSES,
+                       MODELS, NECKS, Config, ConfigDict, Registry, build_anchor_generator, build_backbone,
+                       build_bbox_coder, build_detector, build_from_cfg, build_head, build_neck)
+from .bricks import Mish, build_activation_layer, build_norm_layer
+from .ops import MishFunction, batched_nms, mish_backward, mish_forward, multiclass_nms, nms
+from .anchor_generator import YOLOAnchorGenerator, YOLOV4AnchorGenerator
+from .bbox_coder import YOLOV4BBoxCoder
+from .darknetcsp import (Bottleneck, BottleneckCSP, BottleneckCSP2, Conv, CSPStage, DarknetCSP, Focus, SPPV4,
+                         SPPV4Stage, SPPV5, SPPV5Stage, BottleneckStage)
+from .yolo_neck_csp import YOLOV4Neck, YOLOV5Neck
+from .yolocsp_head import YOLOCSPHead
+from .single_stage import SingleStageDetector, bbox2result
+from .plan import Plan
+
+__all__ = [n for n in dir() if not n.startswith('_')]

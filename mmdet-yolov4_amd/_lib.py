@@ -1,0 +1,119 @@
+"""ctypes binding of ``libyv4_hip.so`` (the C-ABI declared in ``include/yv4.h``).
+
+The library is the product: there is no CPU fallback.  ``lib()`` raises
+``RuntimeError`` when the shared object has not been built, and every wrapper
+raises on a non-zero status with the library's own error message.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libyv4_hip.so')
+CSRC_DIR = os.path.join(_HERE, 'csrc')
+
+# ---- constants mirrored from include/yv4.h -------------------------------------
+ABI_VERSION = 1
+F32, F16, BF16, F64 = 0, 1, 2, 3
+ACT_NONE, ACT_MISH, ACT_LEAKY, ACT_SWISH = 0, 1, 2, 3
+TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
+TILE_NAMES = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '64x128'}
+
+
+class ConvDesc(C.Structure):
+    """``yv4_conv_desc``."""
+    _fields_ = [(n, C.c_int32) for n in (
+        'N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride', 'pad',
+        'x_cstride', 'x_coff', 'y_cstride', 'y_coff', 'r_cstride', 'r_coff',
+        'act1', 'act2')] + [('slope1', C.c_float), ('slope2', C.c_float),
+                            ('tile', C.c_int32)]
+
+
+class LevelDesc(C.Structure):
+    """``yv4_level_desc``."""
+    _fields_ = [('pred', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32),
+                ('stride', C.c_int32), ('base_anchors', (C.c_float * 4) * 8)]
+
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+#: every exported symbol: name -> (restype, argtypes).  tests/test_abi.py checks
+#: this table against include/yv4.h and against the built library.
+SIGNATURES = {
+    'yv4_abi_version': (C.c_int, []),
+    'yv4_last_error': (C.c_char_p, []),
+    'yv4_arch': (C.c_char_p, []),
+    'yv4_mish_fwd': (C.c_int, [_vp, _vp, _sz, _i, _vp]),
+    'yv4_mish_bwd': (C.c_int, [_vp, _vp, _vp, _sz, _i, _vp]),
+    'yv4_nchw_to_nhwc': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'yv4_nhwc_to_nchw': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'yv4_conv_bn_act_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _vp, _vp]),
+    'yv4_conv_flops': (C.c_double, [C.POINTER(ConvDesc)]),
+    'yv4_conv_pick_tile': (C.c_int, [C.POINTER(ConvDesc)]),
+    'yv4_spp_pool_fwd': (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'yv4_resample_nearest_fwd': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i,
+                                           _i, _i, _i, _i, _vp]),
+    'yv4_decode_reset': (C.c_int, [_vp, _vp, _i, _vp]),
+    'yv4_decode_filter': (C.c_int, [C.POINTER(LevelDesc), _i, _i, _i, _i, _f,
+                                    _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
+                                    _vp]),
+    'yv4_nms_images': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i,
+                                 _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'yv4_nms_split_work': (_sz, [_i64]),
+    'yv4_nms_split': (C.c_int, [_vp, _i64, _f, _vp, _vp, _i, _f, _i, _vp, _vp,
+                                _vp, _vp, _vp, _vp]),
+    'yv4_nms_prepare': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 into ``lib/libyv4_hip.so`` (in-tree)."""
+    cmd = ['make', '-C', CSRC_DIR, '-j4']
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError('building libyv4_hip.so failed (see output above)')
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and return the bound library.  No fallback: raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: the HIP extension has not been built. '
+                'Run `python -c "import __graft_entry__ as g; g.build()"` (or '
+                f'`make -C {CSRC_DIR}`). There is no CPU fallback for this path.')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        got = handle.yv4_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f'libyv4_hip.so ABI {got} != binding ABI {ABI_VERSION}; rebuild')
+        _lib = handle
+    return _lib
+
+
+class Yv4Error(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().yv4_last_error().decode('utf-8', 'replace')
+        raise Yv4Error(f'{what} failed with status {status}: {msg}')

@@ -299,8 +299,11 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
             bk = kbox[k];
             ak = karea[k];
           } else {
-            const float off = (float)olab[k] * off_unit;
-            bk = make_float4(odet[k * 5 + 0] + off, odet[k * 5 + 1] + off, odet[k * 5 + 2] + off, odet[k * 5 + 3] + off);
+            // written earlier by thread 0 of this workgroup: read around the L1
+            const volatile float* vd = odet;
+            const volatile int32_t* vl = olab;
+            const float off = (float)vl[k] * off_unit;
+            bk = make_float4(vd[k * 5 + 0] + off, vd[k * 5 + 1] + off, vd[k * 5 + 2] + off, vd[k * 5 + 3] + off);
             ak = (bk.z - bk.x) * (bk.w - bk.y);
           }
           dead = iou_gt(bk, ak, bj, aj, p.iou_thr);
@@ -486,4 +489,19 @@ extern "C" int yv4_nms_prepare(const float* boxes, const float* scores, int64_t 
   }
   YV4_CHECK_LAUNCH("nms_prepare");
   return YV4_OK;
+}
+
+extern "C" size_t yv4_nms_split_work(int64_t n) {
+  (void)n;
+  return 0;
+}
+
+extern "C" int yv4_nms_split(const uint64_t* keys, int64_t n, float max_coord, const float* boxes,
+                             const int32_t* labels, int fused_classes, float iou_thr, int max_out, void* work,
+                             float* out_dets, int32_t* out_labels, int64_t* out_index, int32_t* out_count,
+                             void* stream) {
+  (void)keys; (void)n; (void)max_coord; (void)boxes; (void)labels; (void)fused_classes; (void)iou_thr;
+  (void)max_out; (void)work; (void)out_dets; (void)out_labels; (void)out_index; (void)out_count; (void)stream;
+  set_error("nms_split: the n >= split_thr per-class path is not built yet");
+  return YV4_E_UNSUPPORTED;
 }

@@ -1,0 +1,364 @@
+"""Launch plan of the fused inference path.
+
+A ``Plan`` is the flattened, fused form of a module tree: NHWC fp32 buffers in HBM,
+channel-sliced views of them (a ``torch.cat`` becomes two producers writing into one
+buffer at different channel offsets), and an ordered list of C-ABI launches
+(``include/yv4.h``).  Modules contribute through their ``emit(plan, x, ...)`` methods;
+``Plan.run()`` replays the list on the current HIP stream with no host sync and no
+allocation, so it can be captured into a hipGraph (``Plan.capture()``).
+
+What is fused away relative to the reference's eager graph:
+BN and Mish (108 + 108 elementwise passes) -> conv epilogue; residual add -> conv
+epilogue; every channel ``cat`` -> channel-offset stores; CSP-level cat->BN->Mish
+(darknetcsp.py:106-109,149-153,220-229) -> a second affine+act stage in the producing
+convs' epilogues; permute+reshape of the pred maps (yolocsp_head.py:264) -> NHWC is
+already that layout.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, LevelDesc, check
+
+
+class Buf:
+    """One NHWC fp32 allocation: (N, H, W, C) with C floats per pixel."""
+
+    def __init__(self, N, H, W, C_, name=''):
+        self.N, self.H, self.W, self.C = int(N), int(H), int(W), int(C_)
+        self.name = name
+        self.tensor = None
+
+    @property
+    def numel(self):
+        return self.N * self.H * self.W * self.C
+
+    def ptr(self):
+        return self.tensor.data_ptr()
+
+
+class View:
+    """Channels [coff, coff+C) of a Buf."""
+
+    def __init__(self, buf, coff, C_):
+        assert 0 <= coff and coff + C_ <= buf.C, (coff, C_, buf.C)
+        self.buf, self.coff, self.C = buf, int(coff), int(C_)
+
+    N = property(lambda s: s.buf.N)
+    H = property(lambda s: s.buf.H)
+    W = property(lambda s: s.buf.W)
+    cstride = property(lambda s: s.buf.C)
+
+    def slice(self, off, C_):
+        return View(self.buf, self.coff + off, C_)
+
+    @property
+    def shape_nchw(self):
+        return (self.N, self.C, self.H, self.W)
+
+    def __repr__(self):
+        return f'View({self.buf.name}[{self.N},{self.H},{self.W},{self.coff}:{self.coff + self.C}/{self.cstride}])'
+
+
+class Op:
+    """One launch.  ``kind`` in {'conv','spp','resample','to_nhwc','to_nchw','decode',
+    'nms','reset'}; ``flops``/``bytes`` are the ALGORITHMIC work."""
+
+    def __init__(self, kind, name, fn, flops=0.0, nbytes=0.0, info=None):
+        self.kind, self.name, self.fn = kind, name, fn
+        self.flops, self.bytes, self.info = float(flops), float(nbytes), info or {}
+
+
+def act_id(act_module):
+    """Map an activation nn.Module to (YV4_ACT_*, slope)."""
+    if act_module is None:
+        return _lib.ACT_NONE, 0.0
+    n = type(act_module).__name__
+    if n == 'Mish':
+        return _lib.ACT_MISH, 0.0
+    if n == 'LeakyReLU':
+        return _lib.ACT_LEAKY, float(act_module.negative_slope)
+    if n in ('Swish', 'SiLU'):
+        return _lib.ACT_SWISH, 0.0
+    if n == 'Identity':
+        return _lib.ACT_NONE, 0.0
+    raise NotImplementedError(f'activation {n} has no fused epilogue (built: Mish, LeakyReLU, Swish/SiLU, none)')
+
+
+def bn_affine(bn):
+    """Eval-mode BatchNorm as y = x*s + t, computed like ATen's CPU transform
+    (alpha = weight * invstd, beta = bias - mean * alpha) in fp32."""
+    w = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(bn.running_mean)
+    b = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(bn.running_mean)
+    invstd = 1.0 / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    s = w * invstd
+    t = b - bn.running_mean.detach().float() * s
+    return s.contiguous(), t.contiguous()
+
+
+def pack_conv_weight(weight, cin_pad=None):
+    """(Cout, Cin, KH, KW) -> (Cout, KH*KW*Cin_pad) with K ordered (kh, kw, ci), the order
+    the kernel's NHWC gather walks; Cin is zero-padded to a multiple of 4."""
+    Cout, Cin, KH, KW = weight.shape
+    cp = cin_pad if cin_pad is not None else (Cin + 3) // 4 * 4
+    w = weight.detach().float().permute(0, 2, 3, 1)  # Cout, KH, KW, Cin
+    if cp != Cin:
+        w = torch.nn.functional.pad(w, (0, cp - Cin))
+    return w.reshape(Cout, KH * KW * cp).contiguous(), cp
+
+
+class Plan:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.bufs = []
+        self.ops = []
+        self.params = []      # device tensors kept alive (packed weights, scales, descs)
+        self.inputs = []      # (Buf view, C_real) filled from NCHW tensors by run()
+        self.finalized = False
+        self.graph = None
+        self._static_inputs = None
+
+    # ---- buffers -----------------------------------------------------------------
+    def new_buf(self, N, H, W, C_, name=''):
+        b = Buf(N, H, W, C_, name or f'b{len(self.bufs)}')
+        self.bufs.append(b)
+        return View(b, 0, C_)
+
+    def _dev(self, t):
+        t = t.to(self.device).contiguous()
+        self.params.append(t)
+        return t
+
+    def add_input_nchw(self, N, C_, H, W, name='input', pad4=True):
+        """Declare an NCHW fp32 input; returns its NHWC view (channels zero-padded to a
+        multiple of 4 unless pad4=False, which keeps the buffer dense)."""
+        cp = (C_ + 3) // 4 * 4 if pad4 else C_
+        v = self.new_buf(N, H, W, cp, name)
+        slot = {'view': v, 'C': C_, 'src': None}
+        self.inputs.append(slot)
+
+        def fn(stream, slot=slot, v=v, C_=C_, cp=cp):
+            src = slot['src']
+            check(_lib.lib().yv4_nchw_to_nhwc(src.data_ptr(), v.buf.ptr(), v.N, C_, v.H, v.W, cp, 0,
+                                              cp - C_, stream), 'yv4_nchw_to_nhwc')
+        self.ops.append(Op('to_nhwc', name, fn, nbytes=2.0 * 4 * N * C_ * H * W))
+        return v
+
+    # ---- ops ---------------------------------------------------------------------
+    def conv(self, x, weight, s1, t1, act1=(0, 0.0), stride=1, pad=None, residual=None, s2=None,
+             t2=None, act2=(0, 0.0), out=None, name='conv', tile=0):
+        """Fused conv launch.  weight: (Cout, Cin, KH, KW) torch tensor (any device)."""
+        Cout, Cin, KH, KW = weight.shape
+        wp, cp = pack_conv_weight(weight)
+        assert x.C == cp or (x.C == Cin and Cin % 4 == 0), f'{name}: input view has {x.C} channels, conv wants {Cin}'
+        if pad is None:
+            pad = KH // 2
+        Ho = (x.H + 2 * pad - KH) // stride + 1
+        Wo = (x.W + 2 * pad - KW) // stride + 1
+        if out is None:
+            out = self.new_buf(x.N, Ho, Wo, Cout, name)
+        assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, Cout), f'{name}: output view mismatch {out} vs {(x.N, Ho, Wo, Cout)}'
+        if residual is not None:
+            assert (residual.N, residual.H, residual.W, residual.C) == (x.N, Ho, Wo, Cout), f'{name}: residual mismatch'
+        d = ConvDesc()
+        d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, cp
+        d.Ho, d.Wo, d.Cout = Ho, Wo, Cout
+        d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+        d.x_cstride, d.x_coff = x.cstride, x.coff
+        d.y_cstride, d.y_coff = out.cstride, out.coff
+        d.r_cstride, d.r_coff = (residual.cstride, residual.coff) if residual is not None else (0, 0)
+        d.act1, d.slope1 = act1
+        d.act2, d.slope2 = act2 if s2 is not None else (0, 0.0)
+        d.tile = tile
+        wp = self._dev(wp)
+        s1 = self._dev(s1.float())
+        t1 = self._dev(t1.float())
+        s2d = self._dev(s2.float()) if s2 is not None else None
+        t2d = self._dev(t2.float()) if s2 is not None else None
+        self.params.append(d)
+        xb, ob, rb = x.buf, out.buf, (residual.buf if residual is not None else None)
+
+        def fn(stream, d=d, xb=xb, ob=ob, rb=rb, wp=wp, s1=s1, t1=t1, s2d=s2d, t2d=t2d):
+            check(_lib.lib().yv4_conv_bn_act_fwd(
+                C.byref(d), xb.ptr(), wp.data_ptr(), s1.data_ptr(), t1.data_ptr(),
+                s2d.data_ptr() if s2d is not None else None,
+                t2d.data_ptr() if t2d is not None else None,
+                rb.ptr() if rb is not None else None, ob.ptr(), stream), 'yv4_conv_bn_act_fwd')
+        M = x.N * Ho * Wo
+        flops = 2.0 * M * Cout * KH * KW * Cin          # algorithmic: real Cin, not the padded one
+        nbytes = 4.0 * (x.N * x.H * x.W * Cin + M * Cout + Cout * KH * KW * Cin)
+        if residual is not None:
+            nbytes += 4.0 * M * Cout
+        self.ops.append(Op('conv', name, fn, flops, nbytes,
+                           dict(Cin=Cin, Cout=Cout, k=KH, stride=stride, H=x.H, W=x.W, Ho=Ho, Wo=Wo,
+                                N=x.N, desc=d)))
+        return out
+
+    def spp(self, cat_view, C_, name='spp'):
+        """cat_view: view of 4*C_ channels whose first C_ are filled; fills the other 3*C_."""
+        assert cat_view.C == 4 * C_
+        b = cat_view.buf
+
+        def fn(stream, b=b, v=cat_view, C_=C_):
+            check(_lib.lib().yv4_spp_pool_fwd(b.ptr(), v.N, v.H, v.W, C_, v.cstride, v.coff, stream),
+                  'yv4_spp_pool_fwd')
+        self.ops.append(Op('spp', name, fn, nbytes=4.0 * 4 * cat_view.N * cat_view.H * cat_view.W * C_))
+        return cat_view
+
+    def resample(self, src, dst, name='resample'):
+        """Nearest resample src -> dst (same N and C; dst's H/W are the target size)."""
+        assert src.N == dst.N and src.C == dst.C
+
+        def fn(stream, s=src, d=dst):
+            check(_lib.lib().yv4_resample_nearest_fwd(s.buf.ptr(), d.buf.ptr(), s.N, s.H, s.W, d.H, d.W,
+                                                      s.C, s.cstride, s.coff, d.cstride, d.coff, stream),
+                  'yv4_resample_nearest_fwd')
+        self.ops.append(Op('resample', name, fn,
+                           nbytes=4.0 * src.C * src.N * (src.H * src.W + dst.H * dst.W)))
+        return dst
+
+    def add_output_nchw(self, view, name='out'):
+        """Materialise a view as a fresh NCHW tensor on every run; returns the slot index."""
+        slot = {'view': view, 'dst': None}
+
+        def fn(stream, slot=slot, v=view):
+            check(_lib.lib().yv4_nhwc_to_nchw(v.buf.ptr(), slot['dst'].data_ptr(), v.N, v.C, v.H, v.W,
+                                              v.cstride, v.coff, stream), 'yv4_nhwc_to_nchw')
+        self.ops.append(Op('to_nchw', name, fn, nbytes=2.0 * 4 * view.N * view.C * view.H * view.W))
+        self.outputs = getattr(self, 'outputs', [])
+        self.outputs.append(slot)
+        return len(self.outputs) - 1
+
+    def postprocess(self, pred_views, strides, base_anchors, num_classes, score_thr, iou_thr, max_per_img,
+                    split_thr=10000, rescale=True, want_cls=False):
+        """decode+filter and per-image NMS over the head's NHWC pred maps.
+        base_anchors: list (per level) of (A,4) float tensors.  Returns a dict of result
+        tensors (allocated at finalize)."""
+        N = pred_views[0].N
+        A = base_anchors[0].shape[0]
+        attr = 5 + num_classes
+        total = 0
+        for v in pred_views:
+            assert v.C == A * attr and v.coff == 0 and v.cstride == v.C, 'pred maps must be dense NHWC'
+            total += v.H * v.W * A
+        levels = (LevelDesc * len(pred_views))()
+        res = dict(N=N, total_anchors=total, num_classes=num_classes, max_per_img=max_per_img,
+                   key_cap=total * num_classes, want_cls=want_cls, rescale=rescale,
+                   iou_thr=iou_thr, split_thr=split_thr, score_thr=score_thr)
+        self.post = res
+        self.params.append(levels)
+
+        def alloc():
+            dev = self.device
+            res['boxes'] = torch.empty((N, total, 4), dtype=torch.float32, device=dev)
+            res['conf'] = torch.empty((N, total), dtype=torch.float32, device=dev)
+            res['cls'] = torch.empty((N, total, num_classes), dtype=torch.float32, device=dev) if want_cls else None
+            res['keys'] = torch.empty((N, res['key_cap']), dtype=torch.int64, device=dev)
+            res['counts'] = torch.zeros(N, dtype=torch.int32, device=dev)
+            res['max_coord'] = torch.zeros(N, dtype=torch.float32, device=dev)
+            res['scale_factor'] = torch.ones((N, 4), dtype=torch.float32, device=dev)
+            res['dets'] = torch.zeros((N, max_per_img, 5), dtype=torch.float32, device=dev)
+            res['labels'] = torch.zeros((N, max_per_img), dtype=torch.int32, device=dev)
+            res['index'] = torch.zeros((N, max_per_img), dtype=torch.int64, device=dev)
+            res['count'] = torch.zeros(N, dtype=torch.int32, device=dev)
+            for i, v in enumerate(pred_views):
+                levels[i].pred = v.buf.ptr()
+                levels[i].H, levels[i].W, levels[i].stride = v.H, v.W, int(strides[i])
+                ba = base_anchors[i].float().cpu()
+                for a in range(A):
+                    for c in range(4):
+                        levels[i].base_anchors[a][c] = float(ba[a, c])
+        res['_alloc'] = alloc
+
+        def reset(stream):
+            check(_lib.lib().yv4_decode_reset(res['counts'].data_ptr(), res['max_coord'].data_ptr(), N, stream),
+                  'yv4_decode_reset')
+
+        def decode(stream):
+            check(_lib.lib().yv4_decode_filter(
+                levels, len(pred_views), N, A, num_classes, float(score_thr),
+                res['scale_factor'].data_ptr() if rescale else None, res['boxes'].data_ptr(),
+                res['conf'].data_ptr(), res['cls'].data_ptr() if want_cls else None,
+                res['keys'].data_ptr(), res['key_cap'], res['counts'].data_ptr(),
+                res['max_coord'].data_ptr(), stream), 'yv4_decode_filter')
+
+        def nms(stream):
+            check(_lib.lib().yv4_nms_images(
+                res['keys'].data_ptr(), res['key_cap'], res['counts'].data_ptr(), res['max_coord'].data_ptr(),
+                res['boxes'].data_ptr(), total, None, 0, num_classes, N, float(iou_thr), max_per_img,
+                int(split_thr), res['dets'].data_ptr(), res['labels'].data_ptr(), res['index'].data_ptr(),
+                res['count'].data_ptr(), stream), 'yv4_nms_images')
+        self.ops.append(Op('reset', 'decode_reset', reset))
+        self.ops.append(Op('decode', 'decode_filter', decode, nbytes=4.0 * N * total * attr))
+        self.ops.append(Op('nms', 'nms_images', nms))
+        return res
+
+    # ---- lifecycle ---------------------------------------------------------------
+    def finalize(self):
+        for b in self.bufs:
+            b.tensor = torch.empty(b.numel, dtype=torch.float32, device=self.device)
+        if getattr(self, 'post', None) is not None:
+            self.post['_alloc']()
+        self.finalized = True
+        return self
+
+    def total_flops(self):
+        return sum(o.flops for o in self.ops)
+
+    def activation_bytes(self):
+        return sum(b.numel for b in self.bufs) * 4
+
+    def _launch_all(self, stream):
+        for op in self.ops:
+            op.fn(stream)
+
+    def run(self, *inputs):
+        """Replay the plan on the current stream.  inputs: NCHW fp32 CUDA tensors."""
+        if not self.finalized:
+            raise RuntimeError('Plan.finalize() has not been called')
+        if self.device.type != 'cuda':
+            raise RuntimeError('Plan.run needs a CUDA (ROCm) device: the HIP path has no CPU fallback')
+        assert len(inputs) == len(self.inputs), f'plan takes {len(self.inputs)} inputs'
+        for slot, t in zip(self.inputs, inputs):
+            v = slot['view']
+            if tuple(t.shape) != (v.N, slot['C'], v.H, v.W):
+                raise ValueError(f'input shape {tuple(t.shape)} != planned {(v.N, slot["C"], v.H, v.W)}')
+            if t.dtype != torch.float32 or not t.is_cuda:
+                raise ValueError('inputs must be fp32 CUDA tensors')
+            t = t.contiguous()
+            if self.graph is not None:
+                slot['src'].copy_(t)
+            else:
+                slot['src'] = t
+        for slot in getattr(self, 'outputs', []):
+            if self.graph is None or slot['dst'] is None:
+                v = slot['view']
+                slot['dst'] = torch.empty(v.shape_nchw, dtype=torch.float32, device=self.device)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._launch_all(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return [s['dst'] for s in getattr(self, 'outputs', [])]
+
+    def capture(self):
+        """Capture the launch list into a hipGraph (torch.cuda.CUDAGraph is the plumbing).
+        Inputs become static buffers that run() copies into."""
+        assert self.finalized and self.graph is None
+        for slot in self.inputs:
+            v = slot['view']
+            slot['src'] = torch.zeros((v.N, slot['C'], v.H, v.W), dtype=torch.float32, device=self.device)
+        for slot in getattr(self, 'outputs', []):
+            v = slot['view']
+            slot['dst'] = torch.empty(v.shape_nchw, dtype=torch.float32, device=self.device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up outside capture (function attributes, lazy init)
+            self._launch_all(C.c_void_p(side.cuda_stream))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._launch_all(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        self.graph = g
+        return self

@@ -1,0 +1,122 @@
+"""``SingleStageDetector`` under the reference's registry name.
+
+Mirror of ``mmdet/models/detectors/single_stage.py:35-112`` and the parts of
+``mmdet/models/detectors/base.py:111-169`` an inference caller touches
+(``forward(return_loss=False)`` -> ``forward_test`` -> ``simple_test``), with
+``bbox2result`` of ``mmdet/core/bbox/transforms.py:99-113``.
+
+``simple_test`` replays ONE plan for the whole pipeline -- NCHW->NHWC, 115 fused convs,
+SPP, 2 upsamples, decode+filter, NMS -- built once per (batch, height, width) by
+``compile``; the host touches the device twice per batch (scale factors in, detections
+out).
+"""
+import numpy as np
+import torch
+
+from .bricks import HipModule
+from .plan import Plan
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+from .yolocsp_head import collect_results, set_scale_factors
+
+
+def bbox2result(bboxes, labels, num_classes):
+    """core/bbox/transforms.py:99-113."""
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)]
+    if isinstance(bboxes, torch.Tensor):
+        bboxes = bboxes.detach().cpu().numpy()
+        labels = labels.detach().cpu().numpy()
+    return [bboxes[labels == i, :] for i in range(num_classes)]
+
+
+@DETECTORS.register_module()
+class SingleStageDetector(HipModule):
+
+    def __init__(self, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None,
+                 init_cfg=None):
+        super().__init__(init_cfg)
+        if pretrained is not None:
+            backbone = dict(backbone, pretrained=pretrained)
+        self.backbone = build_backbone(backbone)
+        if neck is not None:
+            self.neck = build_neck(neck)
+        bbox_head = dict(bbox_head, train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.fp16_enabled = False
+        self._engines = {}
+
+    @property
+    def with_neck(self):
+        return hasattr(self, 'neck') and self.neck is not None
+
+    # ---- plan ------------------------------------------------------------------------------
+    def emit_feat(self, plan, x):
+        feats = self.backbone.emit(plan, x)
+        if self.with_neck:
+            feats = self.neck.emit(plan, feats)
+        return feats
+
+    def emit(self, plan, x):
+        """forward_dummy graph: image -> NHWC pred maps."""
+        return self.bbox_head.emit(plan, self.emit_feat(plan, x))
+
+    def compile(self, batch, height, width, device='cuda', rescale=True, graph=False):
+        """Build (and cache) the end-to-end inference plan for one input geometry."""
+        key = (batch, height, width, str(device), bool(rescale), self._param_version())
+        eng = self._engines.get(key)
+        if eng is None:
+            self._engines.clear()
+            plan = Plan(device)
+            x = plan.add_input_nchw(batch, 3, height, width, name='img')
+            preds = self.emit(plan, x)
+            self.bbox_head.emit_postprocess(plan, preds, rescale=rescale)
+            plan.pred_views = preds
+            plan.finalize()
+            if graph:
+                plan.capture()
+            eng = plan
+            self._engines[key] = eng
+        return eng
+
+    # ---- reference API ------------------------------------------------------------------------
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        if self.with_neck:
+            x = self.neck(x)
+        return x
+
+    def forward_dummy(self, img):
+        return self.bbox_head(self.extract_feat(img))
+
+    def simple_test(self, img, img_metas, rescale=False):
+        self._check_eval()
+        N, _, H, W = img.shape
+        plan = self.compile(N, H, W, device=img.device, rescale=rescale)
+        set_scale_factors(plan.post, img_metas, rescale)
+        plan.run(img)
+        bbox_list = collect_results(plan.post, with_nms=True, head=self.bbox_head)
+        return [bbox2result(d, l, self.bbox_head.num_classes) for d, l in bbox_list]
+
+    def _check_eval(self):
+        if self.training:
+            raise NotImplementedError('inference entry points need .eval() (train-mode BN is not built yet)')
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError(f'{name} must be a list, but got {type(var)}')
+        if len(imgs) != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        if len(imgs) == 1:
+            return self.simple_test(imgs[0], img_metas[0], **kwargs)
+        raise NotImplementedError('aug_test (TTA) is not built')
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
+        raise NotImplementedError('SingleStageDetector.forward_train is not built yet: see DESIGN.md scope')

@@ -1,0 +1,221 @@
+"""``YOLOCSPHead`` under the reference's registry name.
+
+Mirror of ``mmdet/models/dense_heads/yolocsp_head.py:53-382`` for inference: three
+biased 1x1 pred convs (``convs_pred.{0,1,2}.{weight,bias}``), ``forward`` returning the
+1-tuple-of-tuple of NCHW pred maps (Q5), and ``get_bboxes`` returning, per image,
+``(dets (n,5) fp32, labels (n,) int64)``.
+
+On the HIP path ``get_bboxes`` is two launches over the batch -- ``yv4_decode_filter``
+(sigmoid, xy/wh transform, anchor decode, conf*cls, rescale, threshold, compaction;
+yolocsp_head.py:263-285,357-366 + bbox_nms.py:36-67) and ``yv4_nms_images``
+(``batched_nms``, bbox_nms.py:84-88) -- with no host sync in between; the reference's
+per-image python loop (:298-309), its (anchors x 81) score matrix and its 29 MB expanded
+box tensor never exist.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .bricks import HipModule, normal_init
+from .plan import Plan
+from .registry import HEADS, LOSSES, ConfigDict, build_anchor_generator, build_bbox_coder, build_loss
+
+
+@HEADS.register_module()
+class YOLOCSPHead(HipModule):
+
+    def __init__(self, num_classes, in_channels,
+                 anchor_generator=dict(type='YOLOV4AnchorGenerator',
+                                       base_sizes=[[(12, 16), (19, 36), (40, 28)],
+                                                   [(36, 75), (76, 55), (72, 146)],
+                                                   [(142, 110), (192, 243), (459, 401)]],
+                                       strides=[8, 16, 32]),
+                 bbox_coder=dict(type='YOLOV4BBoxCoder'), featmap_strides=[8, 16, 32], one_hot_smoother=0.,
+                 conv_cfg=None, norm_cfg=dict(type='BN', requires_grad=True, eps=0.001, momentum=0.03),
+                 act_cfg=dict(type='Mish'),
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=32.),
+                 loss_conf=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=64.),
+                 loss_bbox=dict(type='GIoULoss', loss_weight=3.2), class_agnostic=False, train_cfg=None,
+                 test_cfg=None, init_cfg=None):
+        super().__init__(init_cfg)
+        assert len(in_channels) == len(featmap_strides)
+        self.num_classes = num_classes
+        self.in_channels = in_channels
+        self.featmap_strides = featmap_strides
+        self.train_cfg = ConfigDict(train_cfg) if isinstance(train_cfg, dict) else train_cfg
+        self.test_cfg = ConfigDict(test_cfg) if isinstance(test_cfg, dict) else test_cfg
+        self.assigner = None
+        self.sampler = None
+        self.shape_match_thres = 4.
+        self.conf_iou_loss_ratio = 1.
+        self.conf_level_balance_weight = [4.0, 1.0, 0.4, 0.1, 0.1]
+        self.class_freq = None
+        self.num_obj_avg = 8
+        if self.train_cfg is not None:
+            for key, attr in (('conf_iou_loss_ratio', 'conf_iou_loss_ratio'),
+                              ('conf_level_balance_weight', 'conf_level_balance_weight'),
+                              ('class_frequency', 'class_freq'), ('num_obj_per_image', 'num_obj_avg'),
+                              ('shape_match_thres', 'shape_match_thres')):
+                if hasattr(self.train_cfg, key):
+                    setattr(self, attr, self.train_cfg[key])
+        self.one_hot_smoother = one_hot_smoother
+        self.conv_cfg, self.norm_cfg, self.act_cfg = conv_cfg, norm_cfg, act_cfg
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.anchor_generator = build_anchor_generator(anchor_generator)
+        self.class_agnostic = class_agnostic
+        if class_agnostic:
+            raise NotImplementedError('class_agnostic heads have no fused decode kernel yet')
+        # loss configs are kept for the training row of the scope table (not built yet)
+        self.loss_cls_cfg, self.loss_conf_cfg, self.loss_bbox_cfg = loss_cls, loss_conf, loss_bbox
+        self.loss_bbox_weight = dict(loss_bbox).get('loss_weight', 1.0)
+        self.num_anchors = self.anchor_generator.num_base_anchors
+        self._init_layers()
+        self.fp16_enabled = False
+        self._post_cache = {}
+
+    @property
+    def num_levels(self):
+        return len(self.featmap_strides)
+
+    @property
+    def num_attrib(self):
+        return 5 + self.num_classes if not self.class_agnostic else 5
+
+    def _init_layers(self):
+        self.convs_pred = nn.ModuleList()
+        for i in range(self.num_levels):
+            self.convs_pred.append(nn.Conv2d(self.in_channels[i], self.num_anchors[i] * self.num_attrib, 1))
+
+    def init_weights(self):
+        """yolocsp_head.py:187-201 with the values it intends (Q4: the reference's in-place
+        edit of a leaf view raises on modern torch; done here under no_grad)."""
+        for m in self.convs_pred:
+            normal_init(m, std=0.01)
+        with torch.no_grad():
+            for m, stride in zip(self.convs_pred, self.featmap_strides):
+                b = m.bias.view(-1, self.num_attrib)
+                b[:, 4] += math.log(self.num_obj_avg / (640 / stride) ** 2)
+                if not self.class_agnostic:
+                    if self.class_freq is None:
+                        b[:, 5:] += math.log(0.6 / (self.num_classes - 0.99))
+                    else:
+                        cf = torch.as_tensor(self.class_freq, dtype=b.dtype)
+                        b[:, 5:] += torch.log(cf / cf.sum())
+
+    # ---- plan contribution ----------------------------------------------------------------
+    def emit(self, plan, feats):
+        """1x1 pred convs -> dense NHWC pred maps (the layout yolocsp_head.py:264 permutes to)."""
+        assert len(feats) == self.num_levels
+        outs = []
+        for i, x in enumerate(feats):
+            conv = self.convs_pred[i]
+            s = torch.ones(conv.out_channels)
+            t = conv.bias.detach().float()
+            outs.append(plan.conv(x, conv.weight, s, t, (0, 0.0), stride=1, pad=0, name=f'pred_conv{i}'))
+        return tuple(outs)
+
+    def emit_postprocess(self, plan, pred_views, cfg=None, rescale=True, want_cls=False):
+        cfg = self.test_cfg if cfg is None else cfg
+        nms_cfg = dict(cfg['nms'])
+        if nms_cfg.get('type', 'nms') != 'nms':
+            raise NotImplementedError('only nms type "nms" is built')
+        nms_pre = cfg.get('nms_pre', -1)
+        total = sum(v.H * v.W * self.num_anchors[i] for i, v in enumerate(pred_views))
+        if 0 < nms_pre < total:
+            raise NotImplementedError('nms_pre top-k pre-selection is not built (the configs use nms_pre=-1)')
+        return plan.postprocess(
+            pred_views, self.featmap_strides, self.anchor_generator.base_anchors, self.num_classes,
+            score_thr=cfg['score_thr'], iou_thr=nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr')),
+            max_per_img=cfg['max_per_img'], split_thr=nms_cfg.get('split_thr', ops.SPLIT_THR_DEFAULT),
+            rescale=rescale, want_cls=want_cls)
+
+    # ---- reference API ----------------------------------------------------------------------
+    def forward(self, feats):
+        return self._run_plan((tuple(feats),), 'tuple'),
+
+    def get_bboxes(self, pred_maps, img_metas, cfg=None, rescale=False, with_nms=True):
+        """pred_maps: NCHW tensors as returned by ``forward``.  Returns
+        ``[(dets(n,5), labels(n,) int64)] * num_images``."""
+        assert len(pred_maps) == self.num_levels
+        for t in pred_maps:
+            ops._need_cuda(t, 'pred_map')
+        cfg = self.test_cfg if cfg is None else cfg
+        key = (tuple(tuple(p.shape) for p in pred_maps), bool(rescale), bool(with_nms), repr(dict(cfg)))
+        plan = self._post_cache.get(key)
+        if plan is None:
+            self._post_cache.clear()
+            plan = Plan(pred_maps[0].device)
+            views = []
+            for i, p in enumerate(pred_maps):
+                N, Cc, H, W = p.shape
+                views.append(plan.add_input_nchw(N, Cc, H, W, name=f'pred{i}', pad4=False))
+            self.emit_postprocess(plan, views, cfg, rescale=rescale, want_cls=not with_nms)
+            plan.finalize()
+            self._post_cache[key] = plan
+        set_scale_factors(plan.post, img_metas, rescale)
+        plan.run(*[p.float() for p in pred_maps])
+        return collect_results(plan.post, with_nms=with_nms, head=self)
+
+    def loss(self, *args, **kwargs):
+        raise NotImplementedError('YOLOCSPHead.loss (training) is not built yet: see DESIGN.md scope')
+
+    def forward_train(self, *args, **kwargs):
+        raise NotImplementedError('YOLOCSPHead.forward_train (training) is not built yet: see DESIGN.md scope')
+
+
+def set_scale_factors(post, img_metas, rescale):
+    if not rescale:
+        return
+    sf = torch.tensor([[float(v) for v in m['scale_factor']] for m in img_metas], dtype=torch.float32)
+    assert sf.shape == (post['N'], 4), f'scale_factor must be 4 numbers per image, got {tuple(sf.shape)}'
+    post['scale_factor'].copy_(sf, non_blocking=False)
+
+
+def collect_results(post, with_nms=True, head=None):
+    """One D2H round trip for the whole batch -> the reference's per-image list."""
+    N = post['N']
+    if not with_nms:
+        # aug_test branch, yolocsp_head.py:377-382 (class score multiplied by conf twice, Q8)
+        out = []
+        for n in range(N):
+            cls = post['cls'][n] * post['conf'][n][:, None]
+            cls = cls * post['conf'][n][:, None]
+            score, cid = cls.max(dim=-1)
+            out.append((torch.cat((post['boxes'][n], score[:, None]), dim=-1), cid))
+        return out
+    counts = post['count'].cpu()
+    if bool((counts < 0).any()):
+        _run_split_path(post, counts)
+        counts = post['count'].cpu()
+    out = []
+    for n in range(N):
+        k = int(counts[n])
+        if k == 0:
+            # multiclass_nms empty case (Q7): boxes (0,4), labels int64 (0,)
+            out.append((post['dets'].new_zeros((0, 4)), torch.zeros((0,), dtype=torch.int64,
+                                                                    device=post['dets'].device)))
+        else:
+            out.append((post['dets'][n, :k].clone(), post['labels'][n, :k].to(torch.int64)))
+    return out
+
+
+def _run_split_path(post, counts):
+    """Images whose candidate count reached mmcv's split_thr take the per-class path."""
+    from ._lib import lib, check
+    L = lib()
+    maxc = post['max_coord'].cpu()
+    stream = ops.stream_ptr()
+    for n in range(post['N']):
+        if int(counts[n]) >= 0:
+            continue
+        cnt = int(post['counts'][n].item())
+        if cnt > post['key_cap']:
+            raise RuntimeError('candidate key buffer overflow')
+        work = torch.empty(max(L.yv4_nms_split_work(cnt), 16), dtype=torch.uint8, device=post['dets'].device)
+        check(L.yv4_nms_split(post['keys'][n].data_ptr(), cnt, float(maxc[n]), post['boxes'][n].data_ptr(), None,
+                              post['num_classes'], float(post['iou_thr']), post['max_per_img'], work.data_ptr(),
+                              post['dets'][n].data_ptr(), post['labels'][n].data_ptr(),
+                              post['index'][n].data_ptr(), post['count'][n:n + 1].data_ptr(), stream),
+              'yv4_nms_split')

@@ -1,0 +1,215 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference).
+
+Run in the build container only:   python tests/golden/make_golden.py
+The fixtures are data (inputs + the reference's outputs); the reference's source never
+enters this repository.  See _ref_import.py for how the reference is imported without
+mmcv-full, and for the one part that is NOT the reference's arithmetic (batched_nms).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _ref_import  # noqa: E402
+from oracle import build_ref  # noqa: E402
+
+
+def randomize(module, gen):
+    """Non-trivial BN statistics / affine so that folding is exercised."""
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.empty_like(m.weight).uniform_(0.5, 1.5, generator=gen))
+                m.bias.copy_(torch.empty_like(m.bias).normal_(0, 0.2, generator=gen))
+                m.running_mean.copy_(torch.empty_like(m.running_mean).normal_(0, 0.2, generator=gen))
+                m.running_var.copy_(torch.empty_like(m.running_var).uniform_(0.5, 1.5, generator=gen))
+            elif isinstance(m, torch.nn.Conv2d):
+                fan_in = m.weight[0].numel()
+                m.weight.copy_(torch.empty_like(m.weight).normal_(0, (1.5 / fan_in) ** 0.5, generator=gen))
+
+
+def quantize_fp16(module):
+    """Round every float entry to an fp16-representable value so the fixture can store the
+    checkpoint losslessly in half the bytes (the reference then RUNS on these fp32 values)."""
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.is_floating_point():
+                t.copy_(t.half().float())
+
+
+def sd_np(prefix, module):
+    out = {}
+    for k, v in module.state_dict().items():
+        a = v.detach().cpu().numpy()
+        if a.dtype == np.float32:
+            assert np.array_equal(a.astype(np.float16).astype(np.float32), a), k
+            a = a.astype(np.float16)
+        out[f'sd/{prefix}.{k}'] = a
+    return out
+
+
+def make_mish(ref, out):
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(4096, generator=gen) * 6
+    special = torch.tensor([20.0, -20.0, 19.999, 20.001, 88.0, -88.0, 0.0, -0.0, 1e-40, -1e-40, 50.0, -50.0, 9.0, 17.0])
+    x[:special.numel()] = special
+    g = torch.randn(4096, generator=gen)
+    act = ref.mish.Mish()
+    xr = x.clone().requires_grad_(True)
+    y = act(xr)
+    y.backward(g)
+    x64 = x.double().clone().requires_grad_(True)
+    y64 = act(x64)
+    y64.backward(g.double())
+    np.savez_compressed(out, x=x.numpy(), g=g.numpy(), y=y.detach().numpy(), gin=xr.grad.numpy(),
+                        y64=y64.detach().numpy(), gin64=x64.grad.numpy())
+    print('mish', out)
+
+
+def run_detector(ref, name, scale, backbone_out, neck_type, neck_in, neck_out, csp_rep, img_hw, seed, out,
+                 obj_bias, cls_bias, head_std):
+    gen = torch.Generator().manual_seed(seed)
+    dk, nk, hd = ref.darknetcsp, ref.neck, ref.head
+    backbone = dk.DarknetCSP(scale=scale, out_indices=backbone_out)
+    Neck = nk.YOLOV4Neck if neck_type == 'v4' else nk.YOLOV5Neck
+    neck = Neck(in_channels=neck_in, out_channels=neck_out, csp_repetition=csp_rep)
+    test_cfg = ref.ConfigDict(min_bbox_size=0, nms_pre=-1, score_thr=0.001,
+                              nms=dict(type='nms', iou_threshold=0.65), max_per_img=300)
+    head = hd.YOLOCSPHead(num_classes=80, in_channels=neck_out, train_cfg=None, test_cfg=test_cfg)
+    for m in (backbone, neck, head):
+        randomize(m, gen)
+        torch.nn.Module.eval(m)          # DarknetCSP.train() returns None (Q3)
+    N = 2
+    img = (torch.randint(0, 256, (N, 3) + img_hw, generator=gen).float() - 114.0) / 255.0
+    for m in (backbone, neck):
+        quantize_fp16(m)
+    # head: logits = bias + std * noise; std is bisected so that about `head_std` (a target
+    # candidate count per image) scores pass the 0.001 threshold
+    from oracle import yolov4_oracle as O
+    base_w = [torch.empty_like(c.weight).normal_(0, 1, generator=gen) for c in head.convs_pred]
+    with torch.no_grad():
+        nfeat = neck(backbone(img))
+        lo, hi = 1e-4, 1.0
+        for _ in range(30):
+            std = (lo * hi) ** 0.5
+            for conv, bw in zip(head.convs_pred, base_w):
+                conv.weight.copy_(bw * std)
+                b = conv.bias.view(3, 85)
+                b.zero_()
+                b[:, 4] = obj_bias
+                b[:, 5:] = cls_bias
+            quantize_fp16(head)
+            _, cf, cl = O.decode_maps(head(nfeat)[0], 80)
+            cnt = float(((cl * cf[:, :, None]) > 0.001).sum()) / N
+            if cnt > head_std:
+                hi = std
+            else:
+                lo = std
+    scale_factors = np.array([[1.0, 1.0, 1.0, 1.0], [1.5, 1.25, 1.5, 1.25]], dtype=np.float32)
+    img_metas = [dict(scale_factor=scale_factors[i]) for i in range(N)]
+    data = {'img': img.numpy(), 'scale_factors': scale_factors}
+    with torch.no_grad():
+        stage_outs = []
+        x = img
+        for lname in backbone.layers:
+            x = getattr(backbone, lname)(x)
+            stage_outs.append(x)
+        feats = backbone(img)
+        nouts = neck(feats)
+        preds = head(nouts)[0]
+        dets = head.get_bboxes(preds, img_metas, rescale=True)
+        dets_norescale = head.get_bboxes(preds, img_metas, rescale=False)
+    for i, s in enumerate(stage_outs):
+        data[f'stage{i}'] = s.numpy()
+    for i, f in enumerate(feats):
+        data[f'feat{i}'] = f.numpy()
+    for i, f in enumerate(nouts):
+        data[f'neck{i}'] = f.numpy()
+    for i, f in enumerate(preds):
+        data[f'pred{i}'] = f.numpy()
+    for i, (d, l) in enumerate(dets):
+        data[f'dets{i}'] = d.numpy()
+        data[f'labels{i}'] = l.numpy()
+        print(f'  {name} img{i}: {d.shape[0]} dets')
+    for i, (d, l) in enumerate(dets_norescale):
+        data[f'dets_norescale{i}'] = d.numpy()
+        data[f'labels_norescale{i}'] = l.numpy()
+    # candidate counts (to know which NMS path the fixture exercises)
+    boxes, conf, cls = O.decode_maps(preds, 80)
+    data['dec_boxes'] = boxes.numpy()
+    data['dec_conf'] = conf.numpy()
+    data['dec_cls_first8'] = cls[:, :, :8].numpy()
+    cnt = [(int(((cls[n] * conf[n][:, None]) > 0.001).sum())) for n in range(N)]
+    data['num_candidates'] = np.array(cnt)
+    print(f'  {name} candidates per image: {cnt}')
+    data.update(sd_np('backbone', backbone))
+    data.update(sd_np('neck', neck))
+    data.update(sd_np('bbox_head', head))
+    data['meta_stages'] = np.array(scale[0] if not isinstance(scale, str) else [scale])
+    data['meta_reps'] = np.array([-1 if r is None else r for r in scale[1]]) if not isinstance(scale, str) else np.array([0])
+    data['meta_channels'] = np.array(scale[2]) if not isinstance(scale, str) else np.array([0])
+    data['meta_out_indices'] = np.array(backbone_out)
+    data['meta_neck_in'] = np.array(neck_in)
+    data['meta_neck_out'] = np.array(neck_out)
+    data['meta_csp_rep'] = np.array(csp_rep)
+    data['state_keys'] = np.array([k[3:] for k in data if k.startswith('sd/')])
+    np.savez_compressed(out, **data)
+    print(name, out, f'{os.path.getsize(out) / 1e6:.2f} MB')
+
+
+def make_nms(ref, out):
+    """multiclass_nms (reference glue, bbox_nms.py) over synthetic clustered candidates."""
+    rng = np.random.RandomState(7)
+    data = {}
+
+    def case(tag, K, C, thr, spread, ties):
+        centers = rng.rand(40, 2) * 300
+        which = rng.randint(0, 40, K)
+        cxy = centers[which] + rng.randn(K, 2) * spread
+        wh = np.abs(rng.randn(K, 2)) * 20 + 10
+        b = np.concatenate([cxy - wh / 2, cxy + wh / 2], 1).astype(np.float32)
+        s = (rng.rand(K, C) ** 6).astype(np.float32)
+        if ties:
+            s[::5] = np.float32(0.25)          # exact-tie scores
+            b[1::9] = b[0:-1:9][:b[1::9].shape[0]]  # duplicate boxes -> IoU exactly 1
+        sc = np.concatenate([s, np.zeros((K, 1), np.float32)], 1)
+        d, l, inds = ref.nms.multiclass_nms(torch.from_numpy(b), torch.from_numpy(sc), thr,
+                                            dict(type='nms', iou_threshold=0.65), 300, return_inds=True)
+        data[f'{tag}_boxes'], data[f'{tag}_scores'] = b, sc
+        data[f'{tag}_thr'] = np.float32(thr)
+        data[f'{tag}_dets'], data[f'{tag}_labels'], data[f'{tag}_inds'] = d.numpy(), l.numpy(), inds.numpy()
+        n = int((s > thr).sum())
+        print(f'  nms case {tag}: {n} candidates -> {d.shape[0]} dets')
+    case('small', 600, 5, 0.05, 6.0, True)          # ~3000 candidates > thr? (single-call path)
+    case('mid', 1500, 8, 0.3, 8.0, True)
+    case('split', 3000, 8, 0.001, 10.0, False)      # >= 10000 candidates -> per-class path
+    case('empty', 50, 3, 2.0, 5.0, False)           # nothing passes (Q7 shapes)
+    np.savez_compressed(out, **data)
+    print('nms', out)
+
+
+def main():
+    if not _ref_import.available():
+        print('reference not present: nothing to do')
+        return
+    ext = build_ref.load_ext()
+    ref = _ref_import.install_shim(ext)
+    torch.manual_seed(0)
+    make_mish(ref, os.path.join(HERE, 'mish.npz'))
+    v4 = [['conv', 'bottleneck', 'csp', 'csp', 'csp', 'sppv4'], [None, 1, 1, 2, 2, 1], [4, 8, 16, 32, 64, 64]]
+    run_detector(ref, 'tiny_v4', v4, [3, 4, 5], 'v4', [32, 64, 64], [32, 64, 128], 2, (64, 96), 3,
+                 os.path.join(HERE, 'tiny_v4.npz'), obj_bias=-4.0, cls_bias=-4.5, head_std=2500)
+    v5 = [['focus', 'csp', 'csp', 'csp', 'sppv5'], [None, 1, 2, 2, 1], [8, 16, 32, 64, 128]]
+    run_detector(ref, 'tiny_v5', v5, [2, 3, 4], 'v5', [32, 64, 128], [32, 64, 128], 1, (64, 64), 5,
+                 os.path.join(HERE, 'tiny_v5.npz'), obj_bias=-3.5, cls_bias=-4.0, head_std=12000)
+    make_nms(ref, os.path.join(HERE, 'nms.npz'))
+
+
+if __name__ == '__main__':
+    main()
