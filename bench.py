@@ -1,0 +1,262 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the YOLOv4-L 608x608 fp32 inference hot path
+(NCHW->NHWC, 115 fused MFMA convs, SPP, PAN resamples, decode+threshold, per-image NMS,
+detections copied to pinned host memory) on N MI355X GPUs, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Images are independent (per-image NMS, eval-mode BN), so ranks shard the batch with no
+data-path collective: weak scaling, value = all ranks' images / max-over-ranks time.
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     fp32 MFMA: algorithmic conv FLOPs / HIP-event time of the conv launches
+               measured inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline the CPU oracle (plain torch CPU restatement of the reference) timed on this
+               box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+MODELS = {
+    'yolov4l': dict(scale='v4l5p', neck_in=[256, 512, 512], neck_out=[256, 512, 1024], csp_rep=2),
+    'yolov4s': dict(scale='v4s5p', neck_in=[128, 256, 256], neck_out=[128, 256, 512], csp_rep=1),
+}
+
+
+def model_cfg(name):
+    m = MODELS[name]
+    return dict(
+        type='SingleStageDetector',
+        backbone=dict(type='DarknetCSP', scale=m['scale'], out_indices=[3, 4, 5]),
+        neck=dict(type='YOLOV4Neck', in_channels=m['neck_in'], out_channels=m['neck_out'],
+                  csp_repetition=m['csp_rep']),
+        bbox_head=dict(type='YOLOCSPHead', num_classes=80, in_channels=m['neck_out']),
+        train_cfg=dict(),
+        test_cfg=dict(min_bbox_size=0, nms_pre=-1, score_thr=0.001, nms=dict(type='nms', iou_threshold=0.65),
+                      max_per_img=300))
+
+
+def synthetic_images(batch, size, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (batch, 3, size, size), generator=g, dtype=torch.uint8)
+    return ((img.float() - 114.0) / 255.0).to(device)     # img_norm_cfg of configs/yolov4/*
+
+
+def init_head(det, plan, img, target_per_img, logit_std=2.0):
+    """Random head whose logits have std ~2 around a common bias, the bias bisected so that
+    about `target_per_img` (box, class) scores pass score_thr -- the realistic post-process
+    regime (an untrained head passes ~everything)."""
+    import mmdet_yolov4_amd as pkg
+    from mmdet_yolov4_amd.plan import pack_conv_weight
+    head_ops = [o for o in plan.ops if o.kind == 'conv' and o.name.startswith('pred_conv')]
+    g = torch.Generator().manual_seed(1234)
+    with torch.no_grad():
+        for conv, op in zip(det.bbox_head.convs_pred, head_ops):
+            # features are Mish outputs of unit-variance pre-activations: E[x^2] ~ 0.45
+            std = logit_std / (0.45 * conv.in_channels) ** 0.5
+            conv.weight.copy_(torch.empty(conv.weight.shape).normal_(0, std, generator=g).to(conv.weight.device))
+            op.info['launch']['w'].copy_(pack_conv_weight(conv.weight)[0])
+    lo, hi = -16.0, 0.0
+    count = 0.0
+    for _ in range(16):
+        b = 0.5 * (lo + hi)
+        with torch.no_grad():
+            for conv, op in zip(det.bbox_head.convs_pred, head_ops):
+                bias = conv.bias.view(3, 85)
+                bias.zero_()
+                bias[:, 4:] = b
+                op.info['launch']['t1'].copy_(conv.bias)
+        plan.run(img)
+        torch.cuda.synchronize()
+        count = float(plan.post['counts'].float().mean())
+        if count > target_per_img:
+            hi = b
+        else:
+            lo = b
+    return count
+
+
+def cpu_baseline(det, size, budget_s=25.0):
+    """The CPU oracle (oracle/: the reference's graph in torch CPU ops + C NMS) on this box."""
+    from oracle import yolov4_oracle as O
+    sd = {k: v.detach().cpu().clone() for k, v in det.state_dict().items()}
+    stages, reps = O.ARCH[det_scale(det)]
+    img = synthetic_images(1, size, 99, 'cpu')
+    sf = [[1.0, 1.0, 1.0, 1.0]]
+    torch.set_num_threads(os.cpu_count() or 1)
+    n, t_total = 0, 0.0
+    with torch.no_grad():
+        O.simple_test(img, sd, stages, reps, [3, 4, 5], sf, 80)      # warm-up (oneDNN primitive cache)
+        while t_total < budget_s and n < 8:
+            t0 = time.perf_counter()
+            O.simple_test(img, sd, stages, reps, [3, 4, 5], sf, 80)
+            t_total += time.perf_counter() - t0
+            n += 1
+    return dict(value=round(n / t_total, 4), unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} single-image 608x608 forwards+decode+NMS of the CPU oracle after 1 warm-up '
+                       f'({t_total:.1f} s), same weights as the GPU run')
+
+
+def det_scale(det):
+    return det._bench_scale
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--size', type=int, default=608)
+    ap.add_argument('--model', default='yolov4l', choices=sorted(MODELS))
+    ap.add_argument('--candidates', type=float, default=2000.0, help='target NMS candidates per image')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--layers', default='', help='write a per-conv timing table (JSON) to this path')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    import mmdet_yolov4_amd as pkg
+    from mmdet_yolov4_amd.calibrate import calibrate_bn
+    pkg._lib.lib()                                  # fail loudly if the HIP extension is missing
+
+    torch.manual_seed(0)                            # identical weights on every rank
+    det = pkg.build_detector(model_cfg(args.model))
+    det.init_weights()
+    det._bench_scale = MODELS[args.model]['scale']
+    det.eval().to(dev)
+    img = synthetic_images(args.batch, args.size, 1000 + rank, dev)
+
+    plan = det.compile(args.batch, args.size, args.size, device=dev, rescale=True)
+    calibrate_bn(plan, img)
+    ncand = init_head(det, plan, img, args.candidates)
+
+    conv_ops = [o for o in plan.ops if o.kind == 'conv']
+    stream = torch.cuda.current_stream()
+    sptr = __import__('ctypes').c_void_p(stream.cuda_stream)
+    post = plan.post
+    host_dets = torch.empty(post['dets'].shape, dtype=torch.float32, pin_memory=True)
+    host_labels = torch.empty(post['labels'].shape, dtype=torch.int32, pin_memory=True)
+    host_count = torch.empty(post['count'].shape, dtype=torch.int32, pin_memory=True)
+    plan.inputs[0]['src'] = img
+
+    def step(events=None):
+        for op in plan.ops:
+            if events is not None and op.kind == 'conv':
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                op.fn(sptr)
+                e1.record(stream)
+                events.append((op, e0, e1))
+            else:
+                op.fn(sptr)
+        host_dets.copy_(post['dets'], non_blocking=True)
+        host_labels.copy_(post['labels'], non_blocking=True)
+        host_count.copy_(post['count'], non_blocking=True)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert int(host_count.min()) >= 0, 'an image took the split NMS path; lower --candidates'
+
+    # ---- roofline of the dominant kernel (the fused MFMA conv), from the timed region ------
+    per_tile = {}
+    per_layer = {}
+    for op, e0, e1 in events:
+        ms = e0.elapsed_time(e1)
+        tile = pkg._lib.TILE_NAMES[pkg._lib.lib().yv4_conv_pick_tile(__import__('ctypes').byref(op.info['desc']))]
+        a = per_tile.setdefault(tile, [0.0, 0.0, 0])
+        a[0] += op.flops
+        a[1] += ms * 1e-3
+        a[2] += 1
+        b = per_layer.setdefault(id(op), [op, 0.0, 0, tile])
+        b[1] += ms * 1e-3
+        b[2] += 1
+    conv_flops = sum(v[0] for v in per_tile.values())
+    conv_time = sum(v[1] for v in per_tile.values())
+    dom = max(per_tile, key=lambda k: per_tile[k][1])
+    dflops, dtime, dn = per_tile[dom]
+    roofline = dict(bound='mfma', kernel=f'conv_mfma_f32_kernel<{dom}>',
+                    achieved=round(dflops / dtime / 1e12, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=round(dflops / dtime / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                    launches=dn, avg_launch_us=round(dtime / dn * 1e6, 2),
+                    gflop_per_launch=round(dflops / dn / 1e9, 3),
+                    all_convs_tflops=round(conv_flops / conv_time / 1e12, 2),
+                    all_convs_frac=round(conv_flops / conv_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    conv_share_of_step=round(conv_time / args.steps / (elapsed / args.steps), 4))
+    if args.layers and rank == 0:
+        rows = []
+        for op, tsum, n, tile in per_layer.values():
+            i = op.info
+            rows.append(dict(name=op.name, Cin=i['Cin'], Cout=i['Cout'], k=i['k'], stride=i['stride'], H=i['H'],
+                             W=i['W'], tile=tile, us=round(tsum / n * 1e6, 1),
+                             tflops=round(op.flops / (tsum / n) / 1e12, 1), gflop=round(op.flops / 1e9, 2)))
+        with open(args.layers, 'w') as f:
+            json.dump(rows, f, indent=1)
+
+    if rank == 0:
+        total_images = args.batch * world * args.steps
+        out = dict(
+            metric='images/sec (inference) YOLOv4 608x608', value=round(total_images / elapsed, 2),
+            unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
+            vs_baseline=None, dtype='f32', data='synthetic',
+            config=dict(workload=f'{args.model} (DarknetCSP v4l5p + YOLOV4Neck + YOLOCSPHead, 80 classes) '
+                                 f'{args.size}x{args.size} fp32 inference, batch {args.batch}/GPU: image -> '
+                                 'fused conv path -> decode -> per-class NMS -> detections on host '
+                                 '(BASELINE.json configs[1])',
+                        global_batch=args.batch * world, per_gpu_batch=args.batch, input=f'{args.size}x{args.size}',
+                        weights='random init (seed 0), BN statistics fitted on the batch, head bias set for '
+                                f'~{ncand:.0f} NMS candidates/image', parallelism=f'replicated weights, batch '
+                                f'sharded over {world} rank(s), no collective'),
+            roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(det, args.size)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -81,10 +81,11 @@ class Conv(HipModule):
 
     def emit(self, plan, x, out=None, residual=None, post=None, name=None):
         s, t, a = self.stage1()
-        s2, t2, a2 = post if post is not None else (None, None, (0, 0.0))
+        s2, t2, a2, bn2 = post if post is not None else (None, None, (0, 0.0), None)
         return plan.conv(x, self.conv.weight, s, t, a, stride=self.stride, pad=self.padding,
                          residual=residual, s2=s2, t2=t2, act2=a2, out=out,
-                         name=name or f'conv{self.kernel_size}x{self.kernel_size}')
+                         name=name or f'conv{self.kernel_size}x{self.kernel_size}',
+                         bn1=(self.norm, 0, self.out_channels) if self.with_norm else None, bn2=bn2)
 
     def forward(self, x):
         return self._run_plan((x,), 'flat')
@@ -93,15 +94,17 @@ class Conv(HipModule):
 def emit_bare_conv(plan, conv, x, stage, out=None, name='conv1x1_bare'):
     """A bias-free ``nn.Conv2d`` whose only epilogue is its half of a CSP-level BN + act."""
     assert conv.bias is None and conv.groups == 1
-    s, t, a = stage
-    return plan.conv(x, conv.weight, s, t, a, stride=conv.stride[0], pad=conv.padding[0], out=out, name=name)
+    s, t, a, bn = stage
+    return plan.conv(x, conv.weight, s, t, a, stride=conv.stride[0], pad=conv.padding[0], out=out, name=name,
+                     bn1=bn)
 
 
 def csp_halves(bn, act, hidden):
     """Split the CSP-level BN over the two concat halves (inference only)."""
     s, t = bn_affine(bn)
     a = act_id(act)
-    return (s[:hidden].contiguous(), t[:hidden].contiguous(), a), (s[hidden:].contiguous(), t[hidden:].contiguous(), a)
+    return ((s[:hidden].contiguous(), t[:hidden].contiguous(), a, (bn, 0, hidden)),
+            (s[hidden:].contiguous(), t[hidden:].contiguous(), a, (bn, hidden, 2 * hidden)))
 
 
 class Bottleneck(HipModule):

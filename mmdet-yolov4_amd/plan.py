@@ -147,8 +147,10 @@ class Plan:
 
     # ---- ops ---------------------------------------------------------------------
     def conv(self, x, weight, s1, t1, act1=(0, 0.0), stride=1, pad=None, residual=None, s2=None,
-             t2=None, act2=(0, 0.0), out=None, name='conv', tile=0):
-        """Fused conv launch.  weight: (Cout, Cin, KH, KW) torch tensor (any device)."""
+             t2=None, act2=(0, 0.0), out=None, name='conv', tile=0, bn1=None, bn2=None):
+        """Fused conv launch.  weight: (Cout, Cin, KH, KW) torch tensor (any device).
+        bn1 / bn2: optional (BatchNorm module, lo, hi) naming the BN channels that stage 1 /
+        stage 2 of the epilogue were folded from (used by calibrate.py only)."""
         Cout, Cin, KH, KW = weight.shape
         wp, cp = pack_conv_weight(weight)
         assert x.C == cp or (x.C == Cin and Cin % 4 == 0), f'{name}: input view has {x.C} channels, conv wants {Cin}'
@@ -171,20 +173,19 @@ class Plan:
         d.act1, d.slope1 = act1
         d.act2, d.slope2 = act2 if s2 is not None else (0, 0.0)
         d.tile = tile
-        wp = self._dev(wp)
-        s1 = self._dev(s1.float())
-        t1 = self._dev(t1.float())
-        s2d = self._dev(s2.float()) if s2 is not None else None
-        t2d = self._dev(t2.float()) if s2 is not None else None
+        # everything the launch reads sits in one mutable record (calibrate.py swaps entries)
+        L = dict(d=d, x=x.buf, y=out.buf, res=residual.buf if residual is not None else None,
+                 w=self._dev(wp), s1=self._dev(s1.float()), t1=self._dev(t1.float()),
+                 s2=self._dev(s2.float()) if s2 is not None else None,
+                 t2=self._dev(t2.float()) if s2 is not None else None)
         self.params.append(d)
-        xb, ob, rb = x.buf, out.buf, (residual.buf if residual is not None else None)
 
-        def fn(stream, d=d, xb=xb, ob=ob, rb=rb, wp=wp, s1=s1, t1=t1, s2d=s2d, t2d=t2d):
+        def fn(stream, L=L):
             check(_lib.lib().yv4_conv_bn_act_fwd(
-                C.byref(d), xb.ptr(), wp.data_ptr(), s1.data_ptr(), t1.data_ptr(),
-                s2d.data_ptr() if s2d is not None else None,
-                t2d.data_ptr() if t2d is not None else None,
-                rb.ptr() if rb is not None else None, ob.ptr(), stream), 'yv4_conv_bn_act_fwd')
+                C.byref(L['d']), L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(), L['t1'].data_ptr(),
+                L['s2'].data_ptr() if L['s2'] is not None else None,
+                L['t2'].data_ptr() if L['t2'] is not None else None,
+                L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), stream), 'yv4_conv_bn_act_fwd')
         M = x.N * Ho * Wo
         flops = 2.0 * M * Cout * KH * KW * Cin          # algorithmic: real Cin, not the padded one
         nbytes = 4.0 * (x.N * x.H * x.W * Cin + M * Cout + Cout * KH * KW * Cin)
@@ -192,7 +193,7 @@ class Plan:
             nbytes += 4.0 * M * Cout
         self.ops.append(Op('conv', name, fn, flops, nbytes,
                            dict(Cin=Cin, Cout=Cout, k=KH, stride=stride, H=x.H, W=x.W, Ho=Ho, Wo=Wo,
-                                N=x.N, desc=d)))
+                                N=x.N, desc=d, launch=L, out=out, bn1=bn1, bn2=bn2)))
         return out
 
     def spp(self, cat_view, C_, name='spp'):

@@ -393,7 +393,7 @@ def test_fused_postprocess_bit_exact_selection(golden, gpu_device, name):
         boxes = post['boxes'][n].cpu()
         score = (post['cls'][n] * post['conf'][n][:, None]).cpu()
         mb = torch.cat([score, score.new_zeros(score.shape[0], 1)], 1)
-        rd, rl, rinds = O.multiclass_nms(boxes, mb, 0.001, dict(type='nms', iou_threshold=0.65), 300, return_inds=True)
+        rd, rl, rinds = O.multiclass_nms(boxes, mb, 0.001, dict(type='nms', iou_threshold=0.65), 300, return_flat=True)
         k = int(cnt[n])
         assert k == rd.shape[0]
         np.testing.assert_array_equal(post['index'][n, :k].cpu().numpy(), rinds.numpy())

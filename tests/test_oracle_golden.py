@@ -103,6 +103,7 @@ def test_multiclass_nms_fixture(golden, tag):
     d, l, inds = O.multiclass_nms(b, s, thr, dict(type='nms', iou_threshold=0.65), 300, return_inds=True)
     np.testing.assert_array_equal(d.numpy(), g[f'{tag}_dets'])
     np.testing.assert_array_equal(l.numpy(), g[f'{tag}_labels'])
+    np.testing.assert_array_equal(inds.numpy(), g[f'{tag}_inds'])
     if tag == 'empty':
         assert tuple(d.shape) == (0, 4) and l.dtype == torch.int64  # Q7
 
