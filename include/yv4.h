@@ -116,6 +116,10 @@ typedef struct yv4_conv_desc {
 #define YV4_TILE_128x64 2
 #define YV4_TILE_64x64 3
 #define YV4_TILE_64x128 4
+/* LDS-DMA kernels (need Cin % 32 == 0 and tensors below 4 GiB) */
+#define YV4_TILE_DMA_64x64 5
+#define YV4_TILE_DMA_128x64 6
+#define YV4_TILE_DMA_128x128 7
 
 int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const float* w,
                         const float* scale1, const float* shift1,

@@ -236,6 +236,281 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_kernel(ConvArgs p) 
   }
 }
 
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA wave-instruction: lane l's 16 bytes at (descriptor base + voff + soff) land at
+// LDS byte address lds_addr + 16*l.  Issued through inline asm on purpose: hipcc would
+// otherwise wait vmcnt(0) before the next ds_read of ANY LDS address (it cannot tell the two
+// halves of the double buffer apart), exposing the whole memory latency every K step.  The
+// kernel counts these loads itself: s_waitcnt vmcnt(0) + s_barrier before the slice is read.
+__device__ __forceinline__ void lds_dma16(u32x4_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+
+__device__ __forceinline__ u32x4_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  u32x4_t v;
+  v.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  v.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+  v.z = __builtin_amdgcn_readfirstlane(bytes);
+  v.w = 0x00020000u;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------
+// Fast path (Cin % 32 == 0): LDS-DMA staging.  The next K slice goes global -> LDS directly
+// (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, no VGPR round trip and no
+// ds_write: in the register-staged kernel above the VGPR->LDS store path is the largest
+// non-MFMA cost, ~12 % in an ablation).
+// An LDS-DMA instruction writes lane l at base + 16*l, so the LDS image is unpadded
+// [row][32 floats] with 128-byte rows; ds_read_b128 conflicts are avoided by an XOR
+// swizzle of the 16-byte chunk index with (row>>1)&7, applied on the SOURCE side (which
+// global chunk a lane fetches) and on the read side.  Out-of-range buffer offsets deliver
+// zeros, which implements conv padding, the M tail and the Cout tail.
+// ---------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
+__global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes) {
+  static_assert(NBUF >= 2 && NBUF <= 4, "ring of 2..4 slices");
+  constexpr int D = NBUF - 1;           // prefetch distance in K slices
+  constexpr int kDmaPerSlice = BM / 32 + BN / 32;   // LDS-DMA instructions per wave per slice
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  constexpr int PA = BM / 32;   // DMA passes over A: 32 rows per pass (8 rows per wave-instruction)
+  constexpr int PB = BN / 32;
+  constexpr int kRow = kBK;     // floats per LDS row (128 B, unpadded)
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                      // [NBUF][BM][32]
+  float* Bs = smem + NBUF * BM * kRow;   // [NBUF][BN][32]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  const unsigned nwg = gridDim.x;
+  const unsigned bid = blockIdx.x;
+  const unsigned xcd = bid & 7u, q8 = nwg >> 3, rem8 = nwg & 7u;
+  const unsigned tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (bid >> 3);
+  const int tile_n = tile % p.tiles_n;
+  const int tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const u32x4_t rsA = make_rsrc(p.x, x_bytes);
+  const u32x4_t rsB = make_rsrc(p.w, w_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem;   // LDS byte address of the carve
+
+  // staging: this lane fills LDS row (32*q + 8*wave + lane/8), physical chunk lane%8
+  const int srow = 8 * wave + (lane >> 3);
+  const int pc = lane & 7;
+  unsigned a_off[PA];
+  unsigned long long a_mask[PA];
+#pragma unroll
+  for (int q = 0; q < PA; ++q) {
+    const int row = srow + 32 * q;
+    const int lc = pc ^ ((row >> 1) & 7);    // logical chunk this lane must fetch
+    const int m = m0 + row;
+    unsigned long long mk = 0ull;
+    unsigned off = 0u;
+    if (m < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int n = m / hw;
+      const int rm = m - n * hw;
+      const int ho = rm / p.Wo;
+      const int wo = rm - ho * p.Wo;
+      const int hi0 = ho * p.stride - p.pad;
+      const int wi0 = wo * p.stride - p.pad;
+      off = (unsigned)((((int64_t)(n * p.H + hi0) * p.W + wi0) * p.x_cs + p.x_co + lc * 4) * 4);
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw)
+          if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
+            mk |= 1ull << (kh * p.KW + kw);
+    }
+    a_off[q] = off;
+    a_mask[q] = mk;
+  }
+  unsigned b_off[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int row = srow + 32 * q;
+    const int lc = pc ^ ((row >> 1) & 7);
+    const int co = n0 + row;
+    b_off[q] = co < p.Cout ? (unsigned)(((int64_t)co * p.Kw + lc * 4) * 4) : kOOB;
+  }
+
+  int s_tap = 0, s_c0 = 0, s_kh = 0, s_kw = 0;
+  unsigned s_kb = 0;
+
+#define YV4_V3_DMA(BUF)                                                             \
+  {                                                                                 \
+    const unsigned step = (unsigned)((((int64_t)s_kh * p.W + s_kw) * p.x_cs + s_c0) * 4); \
+    const unsigned la_ = lds_base + (unsigned)(((BUF) * BM + 8 * wave) * kRow * 4);  \
+    const unsigned lb_ = lds_base + (unsigned)((NBUF * BM + (BUF) * BN + 8 * wave) * kRow * 4); \
+    _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                \
+      const bool ok = (a_mask[q] >> s_tap) & 1ull;                                  \
+      lds_dma16(rsA, la_ + 32 * q * kRow * 4, ok ? a_off[q] + step : kOOB, 0u);      \
+    }                                                                               \
+    _Pragma("unroll") for (int q = 0; q < PB; ++q)                                  \
+      lds_dma16(rsB, lb_ + 32 * q * kRow * 4, b_off[q], s_kb);                       \
+    s_kb += kBK * 4;                                                                \
+    s_c0 += kBK;                                                                    \
+    const int wrap_c = s_c0 >= p.Cin ? 1 : 0;                                       \
+    s_c0 = wrap_c ? 0 : s_c0;                                                       \
+    s_tap += wrap_c;                                                                \
+    s_kw += wrap_c;                                                                 \
+    const int wrap_w = s_kw == p.KW ? 1 : 0;                                        \
+    s_kw = wrap_w ? 0 : s_kw;                                                       \
+    s_kh += wrap_w;                                                                 \
+  }
+
+  // fragment read addresses: row*128 B + ((chunk ^ swz) << 4); chunk = 2j + h
+  unsigned a_rd[TM], b_rd[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = wm * TM * 32 + i * 32 + r;
+    a_rd[i] = (unsigned)(row * kRow * 4 + ((((row >> 1) & 7) ^ h) << 4));
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int row = wn * TN * 32 + i * 32 + r;
+    b_rd[i] = (unsigned)(row * kRow * 4 + ((((row >> 1) & 7) ^ h) << 4));
+  }
+
+#define YV4_V3_COMPUTE(BUF)                                                         \
+  {                                                                                 \
+    const char* as_ = reinterpret_cast<const char*>(As + (BUF) * BM * kRow);        \
+    const char* bs_ = reinterpret_cast<const char*>(Bs + (BUF) * BN * kRow);        \
+    _Pragma("unroll") for (int j = 0; j < kBK / 8; ++j) {                           \
+      float4 fa[TM], fb[TN];                                                        \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                \
+          fa[i] = *reinterpret_cast<const float4*>(as_ + (a_rd[i] ^ (unsigned)(j << 5))); \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i)                                \
+          fb[i] = *reinterpret_cast<const float4*>(bs_ + (b_rd[i] ^ (unsigned)(j << 5))); \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                \
+        _Pragma("unroll") for (int jn = 0; jn < TN; ++jn) {                         \
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[jn].x, acc[i][jn], 0, 0, 0); \
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[jn].y, acc[i][jn], 0, 0, 0); \
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[jn].z, acc[i][jn], 0, 0, 0); \
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[jn].w, acc[i][jn], 0, 0, 0); \
+        }                                                                           \
+    }                                                                               \
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // wait until at most `newer` later slices of this wave's DMAs are still in flight
+#define YV4_V3_WAIT(NEWER)                                                          \
+  {                                                                                 \
+    if ((NEWER) >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * kDmaPerSlice) : "memory"); \
+    else if ((NEWER) == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * kDmaPerSlice) : "memory"); \
+    else if ((NEWER) == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 * kDmaPerSlice) : "memory"); \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                 \
+  }
+
+  const int nk = p.K / kBK;
+  int issued = 0;        // slices whose DMA has been issued
+  int wbuf = 0;          // ring slot the next DMA goes to
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (d < nk) {
+      YV4_V3_DMA(wbuf);
+      ++issued;
+      wbuf = wbuf + 1 == NBUF ? 0 : wbuf + 1;
+    }
+  }
+  YV4_V3_WAIT(issued - 1);             // slice 0 landed (this wave's part) ...
+  __builtin_amdgcn_s_barrier();        // ... and everybody else's
+
+  int rbuf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (issued < nk) {                 // slot wbuf was last read before the previous barrier
+      YV4_V3_DMA(wbuf);
+      ++issued;
+      wbuf = wbuf + 1 == NBUF ? 0 : wbuf + 1;
+    }
+    YV4_V3_COMPUTE(rbuf);
+    rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
+    if (kt + 1 < nk) {
+      // fragment reads of this slot returned (lgkmcnt(0)), slice kt+1 landed (counted
+      // vmcnt: slices kt+2.. may stay in flight), then the workgroup moves on.
+      YV4_V3_WAIT(issued - (kt + 2));
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+#undef YV4_V3_WAIT
+#undef YV4_V3_DMA
+#undef YV4_V3_COMPUTE
+
+  const bool has2 = p.s2 != nullptr;
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int co = n0 + wn * TN * 32 + jn * 32 + r;
+    const bool cok = co < p.Cout;
+    const float s1 = cok ? p.s1[co] : 0.f;
+    const float t1 = cok ? p.t1[co] : 0.f;
+    const float s2 = (cok && has2) ? p.s2[co] : 1.f;
+    const float t2 = (cok && has2) ? p.t2[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (cok && m < p.M) {
+          float v = acc[i][jn][e] * s1 + t1;
+          v = apply_act(v, p.act1, p.slope1);
+          if (p.res) v += p.res[(int64_t)m * p.r_cs + p.r_co + co];
+          if (has2) v = apply_act(v * s2 + t2, p.act2, p.slope2);
+          p.y[(int64_t)m * p.y_cs + p.y_co + co] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
+static int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
+  constexpr size_t lds = (size_t)NBUF * (BM + BN) * kBK * sizeof(float);
+  ConvArgs p = a;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.Cout + BN - 1) / BN;
+  const long long tiles = (long long)tiles_m * p.tiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffLL) {
+    set_error("conv: grid of %lld tiles out of range", tiles);
+    return YV4_E_INVALID;
+  }
+  const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 4, wb = (long long)p.Cout * p.Kw * 4;
+  if (xb >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) {
+    set_error("conv dma: tensors of 4 GiB or more are not addressable through a buffer descriptor");
+    return YV4_E_UNSUPPORTED;
+  }
+  auto kern = conv_mfma_f32_dma_kernel<BM, BN, WAVES_M, WAVES_N, NBUF>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kThreads), lds, stream, p, (unsigned)xb, (unsigned)wb);
+  YV4_CHECK_LAUNCH("conv_mfma_f32_dma");
+  return YV4_OK;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_conv(const ConvArgs& a, bool uniform_tap, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * (BM + BN) * kLDK * sizeof(float);
@@ -265,7 +540,10 @@ static int launch_conv(const ConvArgs& a, bool uniform_tap, hipStream_t stream) 
   return YV4_OK;
 }
 
-static int pick_tile(long long M, int Cout) {
+static int pick_tile(long long M, int Cout, bool fast_ok) {
+  // Measured on MI355X (tools/conv_bench.py, batch 32 YOLOv4-L shapes): the 64x64 LDS-DMA
+  // kernel at 5 workgroups per CU is the best or within 2 % of the best on every layer.
+  if (fast_ok) return YV4_TILE_DMA_64x64;
   // 256 CUs x 2 resident workgroups.  Prefer the biggest tile that still gives the
   // chip >= 2 full rounds of workgroups; small maps (19x19) fall to smaller tiles.
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
@@ -290,7 +568,9 @@ extern "C" double yv4_conv_flops(const yv4_conv_desc* d) {
 
 extern "C" int yv4_conv_pick_tile(const yv4_conv_desc* d) {
   if (!d) return YV4_TILE_AUTO;
-  return pick_tile((long long)d->N * d->Ho * d->Wo, d->Cout);
+  const bool fast_ok = d->Cin % kBK == 0 && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL &&
+                       (long long)d->Cout * d->KH * d->KW * d->Cin * 4 < 0xFFFFFFF0LL;
+  return pick_tile((long long)d->N * d->Ho * d->Wo, d->Cout, fast_ok);
 }
 
 extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const float* w,
@@ -301,6 +581,7 @@ extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const
   YV4_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), "conv: scale2/shift2 must come together");
   YV4_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: empty shape");
   YV4_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv: bad kernel/stride/pad");
+  YV4_REQUIRE(d->KH * d->KW <= 64, "conv: kernels above 64 taps are not supported");
   YV4_REQUIRE(d->Cin % 4 == 0 && d->x_cstride % 4 == 0 && d->x_coff % 4 == 0,
               "conv: Cin (%d), x_cstride (%d), x_coff (%d) must be multiples of 4", d->Cin,
               d->x_cstride, d->x_coff);
@@ -330,15 +611,22 @@ extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.Kw = a.K; a.tiles_n = 0;
 
   const bool uniform = (d->Cin % kBK) == 0;
-  int tile = d->tile == YV4_TILE_AUTO ? pick_tile(M, d->Cout) : d->tile;
+  // the LDS-DMA kernels address x and w through 32-bit buffer descriptors
+  const bool fast_ok = uniform && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL &&
+                       (long long)d->Cout * a.K * 4 < 0xFFFFFFF0LL;
+  int tile = d->tile == YV4_TILE_AUTO ? pick_tile(M, d->Cout, fast_ok) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (tile) {
     case YV4_TILE_128x128: return launch_conv<128, 128, 2, 2>(a, uniform, s);
     case YV4_TILE_128x64: return launch_conv<128, 64, 2, 2>(a, uniform, s);
     case YV4_TILE_64x128: return launch_conv<64, 128, 2, 2>(a, uniform, s);
     case YV4_TILE_64x64: return launch_conv<64, 64, 2, 2>(a, uniform, s);
+    case YV4_TILE_DMA_64x64: if (fast_ok) return launch_conv_dma<64, 64, 2, 2, 2>(a, s); break;
+    case YV4_TILE_DMA_128x64: if (fast_ok) return launch_conv_dma<128, 64, 2, 2, 2>(a, s); break;
+    case YV4_TILE_DMA_128x128: if (fast_ok) return launch_conv_dma<128, 128, 2, 2, 2>(a, s); break;
     default:
-      set_error("conv: unknown tile id %d", tile);
-      return YV4_E_INVALID;
+      break;
   }
+  set_error("conv: unknown or inapplicable tile id %d", tile);
+  return YV4_E_INVALID;
 }
