@@ -87,25 +87,43 @@ def init_head(det, plan, img, target_per_img, logit_std=2.0):
     return count
 
 
+def host_cpu_budget():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(det, size, budget_s=25.0):
-    """The CPU oracle (oracle/: the reference's graph in torch CPU ops + C NMS) on this box."""
+    """The CPU oracle (oracle/: the reference's graph in torch CPU ops + C NMS) on this box.
+    Test infrastructure used as a yardstick only; never on the product path."""
     from oracle import yolov4_oracle as O
     sd = {k: v.detach().cpu().clone() for k, v in det.state_dict().items()}
     stages, reps = O.ARCH[det_scale(det)]
     img = synthetic_images(1, size, 99, 'cpu')
     sf = [[1.0, 1.0, 1.0, 1.0]]
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = host_cpu_budget()
+    torch.set_num_threads(threads)
     n, t_total = 0, 0.0
     with torch.no_grad():
+        t0 = time.perf_counter()
         O.simple_test(img, sd, stages, reps, [3, 4, 5], sf, 80)      # warm-up (oneDNN primitive cache)
-        while t_total < budget_s and n < 8:
+        warm = time.perf_counter() - t0
+        while t_total + warm < budget_s and n < 16:
             t0 = time.perf_counter()
             O.simple_test(img, sd, stages, reps, [3, 4, 5], sf, 80)
             t_total += time.perf_counter() - t0
             n += 1
-    return dict(value=round(n / t_total, 4), unit='images/sec', cores=torch.get_num_threads(), kind='port',
-                sample=f'{n} single-image 608x608 forwards+decode+NMS of the CPU oracle after 1 warm-up '
-                       f'({t_total:.1f} s), same weights as the GPU run')
+        if n == 0:      # a single forward already exceeds the budget: report the warm-up run
+            n, t_total = 1, warm
+    return dict(value=round(n / t_total, 4), unit='images/sec', cores=threads, kind='port',
+                sample=f'{n} single-image {size}x{size} forward+decode+NMS runs of the CPU oracle '
+                       f'({t_total:.1f} s, {threads} torch threads = cgroup CPU quota), same weights as the GPU run')
 
 
 def det_scale(det):

@@ -1,0 +1,30 @@
+// Device helpers shared by the NMS kernels (postproc.hip, nms_split.hip).
+// Translation units including this header must be built with -ffp-contract=off.
+#pragma once
+#include "yv4_common.h"
+
+namespace yv4 {
+
+// ---- order-preserving float <-> uint32 (descending score = ascending key) ---------
+__device__ __forceinline__ uint32_t score_to_key(float s) {
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending order of floats
+  return ~u;                                       // descending
+}
+__device__ __forceinline__ float key_to_score(uint32_t k) {
+  uint32_t u = ~k;
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+
+__device__ __forceinline__ bool iou_gt(const float4 bi, const float ai, const float4 bj, const float aj, const float thr) {
+  const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+  const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+  const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+  const float inter = w * h;
+  const float ovr = inter / (ai + aj - inter);
+  return ovr > thr;
+}
+
+
+}  // namespace yv4

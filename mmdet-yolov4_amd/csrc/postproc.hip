@@ -17,20 +17,9 @@
 //            inter / (area_i + area_j - inter) > iou_threshold, offset = 0.
 //            Tie-break (unspecified by mmcv): lower flat candidate index first.
 #include "yv4_common.h"
+#include "nms_common.h"
 
 namespace yv4 {
-
-// ---- order-preserving float <-> uint32 (descending score = ascending key) ---------
-__device__ __forceinline__ uint32_t score_to_key(float s) {
-  uint32_t u = __float_as_uint(s);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending order of floats
-  return ~u;                                       // descending
-}
-__device__ __forceinline__ float key_to_score(uint32_t k) {
-  uint32_t u = ~k;
-  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-  return __uint_as_float(u);
-}
 
 __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
   // valid for any mix of signs when *addr starts at -inf
@@ -177,15 +166,6 @@ struct NmsArgs {
   int64_t* out_index;
   int32_t* out_count;
 };
-
-__device__ __forceinline__ bool iou_gt(const float4 bi, const float ai, const float4 bj, const float aj, const float thr) {
-  const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-  const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-  const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
-  const float inter = w * h;
-  const float ovr = inter / (ai + aj - inter);
-  return ovr > thr;
-}
 
 __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -489,19 +469,4 @@ extern "C" int yv4_nms_prepare(const float* boxes, const float* scores, int64_t 
   }
   YV4_CHECK_LAUNCH("nms_prepare");
   return YV4_OK;
-}
-
-extern "C" size_t yv4_nms_split_work(int64_t n) {
-  (void)n;
-  return 0;
-}
-
-extern "C" int yv4_nms_split(const uint64_t* keys, int64_t n, float max_coord, const float* boxes,
-                             const int32_t* labels, int fused_classes, float iou_thr, int max_out, void* work,
-                             float* out_dets, int32_t* out_labels, int64_t* out_index, int32_t* out_count,
-                             void* stream) {
-  (void)keys; (void)n; (void)max_coord; (void)boxes; (void)labels; (void)fused_classes; (void)iou_thr;
-  (void)max_out; (void)work; (void)out_dets; (void)out_labels; (void)out_index; (void)out_count; (void)stream;
-  set_error("nms_split: the n >= split_thr per-class path is not built yet");
-  return YV4_E_UNSUPPORTED;
 }

@@ -101,8 +101,12 @@ def nhwc_to_nchw(src, dst, C_, H, W, src_cstride, src_coff=0):
 SPLIT_THR_DEFAULT = 10000
 
 
-def _nms_single(boxes, scores, labels, iou_threshold, max_out, split_thr):
-    """One image through yv4_nms_prepare + yv4_nms_images.  Returns (dets(k,5), keep(k,))."""
+FAST_NMS_CAP = 16384   # candidates one workgroup sorts in LDS (csrc/postproc.hip kSortCap)
+
+
+def _nms_single(boxes, scores, labels, iou_threshold, max_out, split_thr, class_agnostic=False):
+    """One image through yv4_nms_prepare + yv4_nms_images (n < split_thr) or yv4_nms_split.
+    Returns (dets(k,5), keep(k,))."""
     n = boxes.shape[0]
     dev = boxes.device
     L = _lib.lib()
@@ -117,15 +121,21 @@ def _nms_single(boxes, scores, labels, iou_threshold, max_out, split_thr):
     olab = torch.empty(cap, dtype=torch.int32, device=dev)
     oidx = torch.empty(cap, dtype=torch.int64, device=dev)
     ocnt = torch.empty(1, dtype=torch.int32, device=dev)
-    if n < split_thr and n <= 16384:
+    if n < split_thr:
+        if n > FAST_NMS_CAP:
+            raise NotImplementedError(
+                f'single-call NMS over {n} > {FAST_NMS_CAP} candidates is not built '
+                "(mmcv's default split_thr=10000 switches to the per-class path before that)")
         check(L.yv4_nms_images(_ptr(keys), n, _ptr(counts), _ptr(maxc), _ptr(boxes), n,
-                               _ptr(labels), n, 0, 1, float(iou_threshold), cap, split_thr,
-                               _ptr(dets), _ptr(olab), _ptr(oidx), _ptr(ocnt), stream_ptr()),
+                               None if class_agnostic else _ptr(labels), n, 0, 1, float(iou_threshold), cap,
+                               split_thr, _ptr(dets), _ptr(olab), _ptr(oidx), _ptr(ocnt), stream_ptr()),
               'yv4_nms_images')
     else:
-        work_bytes = L.yv4_nms_split_work(n)
-        work = torch.empty(max(work_bytes, 16), dtype=torch.uint8, device=dev)
-        check(L.yv4_nms_split(_ptr(keys), n, float(maxc.item()), _ptr(boxes), _ptr(labels), 0,
+        # mmcv's split branch loops over unique(idxs) even when class_agnostic (then without the
+        # coordinate offset): max_coord = -1 makes the offset unit zero.
+        work = torch.empty(max(L.yv4_nms_split_work(n), 256), dtype=torch.uint8, device=dev)
+        mc = -1.0 if class_agnostic else float(maxc.item())
+        check(L.yv4_nms_split(_ptr(keys), n, mc, _ptr(boxes), _ptr(labels), 0,
                               float(iou_threshold), cap, _ptr(work), _ptr(dets), _ptr(olab),
                               _ptr(oidx), _ptr(ocnt), stream_ptr()), 'yv4_nms_split')
     k = int(ocnt.item())
@@ -152,7 +162,7 @@ def nms(boxes, scores, iou_threshold, offset=0, score_threshold=0, max_num=-1):
         boxes, scores = boxes[inds].contiguous(), scores[inds].contiguous()
     if boxes.shape[0] == 0:
         return boxes.new_zeros((0, 5)), torch.zeros((0,), dtype=torch.int64, device=boxes.device)
-    dets, keep = _nms_single(boxes, scores, None, iou_threshold, max_num, 1 << 30)
+    dets, keep = _nms_single(boxes, scores, None, iou_threshold, max_num, 1 << 30, True)
     if inds is not None:
         keep = inds[keep]
     return dets, keep
@@ -182,7 +192,7 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
     n = boxes.shape[0]
     if n == 0:
         return boxes.new_zeros((0, 5)), torch.zeros((0,), dtype=torch.int64, device=boxes.device)
-    labels = None if class_agnostic else idxs.to(device=boxes.device, dtype=torch.int32).contiguous()
+    labels = idxs.to(device=boxes.device, dtype=torch.int32).contiguous()
     inds = None
     if score_threshold > 0:
         inds = (scores > score_threshold).nonzero(as_tuple=False).squeeze(1)
@@ -191,7 +201,7 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
             labels = labels[inds].contiguous()
         if boxes.shape[0] == 0:
             return boxes.new_zeros((0, 5)), torch.zeros((0,), dtype=torch.int64, device=boxes.device)
-    dets, keep = _nms_single(boxes, scores, labels, iou_threshold, max_num, split_thr)
+    dets, keep = _nms_single(boxes, scores, labels, iou_threshold, max_num, split_thr, class_agnostic)
     if inds is not None:
         keep = inds[keep]
     return dets, keep

@@ -330,7 +330,7 @@ def test_decode_filter_against_oracle(golden, gpu_device, name):
         assert abs(float(post['max_coord'][n]) - float(cand_boxes.max())) < 1e-3
 
 
-@pytest.mark.parametrize('tag', ['small', 'mid', 'empty'])
+@pytest.mark.parametrize('tag', ['small', 'mid', 'split', 'empty'])
 def test_batched_nms_bit_exact_vs_oracle(golden, gpu_device, tag):
     g = golden('nms')
     b = torch.from_numpy(g[f'{tag}_boxes']); s = torch.from_numpy(g[f'{tag}_scores']); thr = float(g[f'{tag}_thr'])
@@ -347,7 +347,7 @@ def test_batched_nms_bit_exact_vs_oracle(golden, gpu_device, tag):
         np.testing.assert_array_equal(inds.cpu().numpy(), ro[2].numpy())
 
 
-@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 255, 256, 257, 1000, 5000, 9999])
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 255, 256, 257, 1000, 5000, 9999, 10000, 30000])
 def test_nms_sizes_and_ties_bit_exact(gpu_device, n):
     rng = np.random.RandomState(n)
     c = rng.rand(max(n // 20, 1), 2) * 200
@@ -401,3 +401,30 @@ def test_fused_postprocess_bit_exact_selection(golden, gpu_device, name):
         np.testing.assert_array_equal(post['index'][n, :k].cpu().numpy(), rinds.numpy())
         np.testing.assert_array_equal(post['dets'][n, :k].cpu().numpy(), rd.numpy())
         np.testing.assert_array_equal(post['labels'][n, :k].cpu().numpy(), rl.numpy().astype(np.int32))
+
+
+def test_fused_postprocess_split_path(golden, gpu_device):
+    """>= 10000 candidates per image: mmcv's per-class branch (yv4_nms_split)."""
+    from mmdet_yolov4_amd.yolocsp_head import collect_results
+    g = golden('tiny_v4')
+    preds = []
+    for i in range(3):
+        p = torch.from_numpy(g[f'pred{i}']).clone()
+        v = p.view(2, 3, 85, *p.shape[-2:])
+        v[:, :, 4:] += 3.5                      # raise objectness and class logits
+        preds.append(p)
+    sf = g['scale_factors']
+    post = _run_post(gpu_device, preds, sf)
+    counts = post['counts'].cpu().numpy()
+    assert (counts >= 10000).all(), counts
+    assert (post['count'].cpu().numpy() == -1).all()
+    res = collect_results(post, with_nms=True)
+    for n in range(2):
+        boxes = post['boxes'][n].cpu()
+        score = (post['cls'][n] * post['conf'][n][:, None]).cpu()
+        mb = torch.cat([score, score.new_zeros(score.shape[0], 1)], 1)
+        rd, rl, rflat = O.multiclass_nms(boxes, mb, 0.001, dict(type='nms', iou_threshold=0.65), 300, return_flat=True)
+        d, l = res[n]
+        np.testing.assert_array_equal(d.cpu().numpy(), rd.numpy())
+        np.testing.assert_array_equal(l.cpu().numpy(), rl.numpy())
+        np.testing.assert_array_equal(post['index'][n, :d.shape[0]].cpu().numpy(), rflat.numpy())
