@@ -143,18 +143,14 @@ def main():
     ap.add_argument('--layers', default='', help='write a per-conv timing table (JSON) to this path')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    import mmdet_yolov4_amd as pkg
+    from mmdet_yolov4_amd import dist as D
+    rank, local_rank, world = D.env_world()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+    D.init(backend='nccl', device=dev)              # RCCL; a no-op for a single process
 
-    import mmdet_yolov4_amd as pkg
     from mmdet_yolov4_amd.calibrate import calibrate_bn
     pkg._lib.lib()                                  # fail loudly if the HIP extension is missing
 
@@ -193,26 +189,15 @@ def main():
         host_labels.copy_(post['labels'], non_blocking=True)
         host_count.copy_(post['count'], non_blocking=True)
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    barrier()
+    D.barrier()
     events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(events)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev)
     assert int(host_count.min()) >= 0, 'an image took the split NMS path; lower --candidates'
 
     # ---- roofline of the dominant kernel (the fused MFMA conv), from the timed region ------
@@ -271,9 +256,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    D.finalize()
 
 
 if __name__ == '__main__':

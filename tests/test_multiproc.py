@@ -1,0 +1,85 @@
+"""The N>1 launch path on CPU: 2 ranks, gloo backend, 127.0.0.1 rendezvous.
+
+Covers what bench.py does around the timed region (join the group from the launcher's
+environment, shard the work, barrier, MAX-reduce the elapsed time, rank 0 reports) and that the
+ranks build identical weights while drawing different synthetic batches."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import torch
+    import mmdet_yolov4_amd as pkg
+    from mmdet_yolov4_amd import dist as D
+    rank, local_rank, world = D.init(backend='gloo')
+    torch.manual_seed(0)                                  # same recipe as bench.py
+    det = pkg.build_detector(dict(
+        type='SingleStageDetector',
+        backbone=dict(type='DarknetCSP', scale=[['conv', 'bottleneck', 'csp', 'sppv4'], [None, 1, 1, 1], [4, 8, 16, 16]],
+                      out_indices=[1, 2, 3]),
+        neck=dict(type='YOLOV4Neck', in_channels=[8, 16, 16], out_channels=[8, 16, 32], csp_repetition=1),
+        bbox_head=dict(type='YOLOCSPHead', num_classes=3, in_channels=[8, 16, 32], featmap_strides=[4, 8, 16],
+                       anchor_generator=dict(type='YOLOV4AnchorGenerator', strides=[4, 8, 16],
+                                             base_sizes=[[(4, 4)] * 3, [(8, 8)] * 3, [(16, 16)] * 3])),
+        test_cfg=dict(nms_pre=-1, score_thr=0.001, nms=dict(type='nms', iou_threshold=0.65), max_per_img=10)))
+    wsum = float(sum(p.double().sum() for p in det.parameters()))
+    g = torch.Generator().manual_seed(1000 + rank)
+    batch = torch.randint(0, 256, (2, 3, 8, 8), generator=g)
+    lo, hi = D.shard(11, rank, world)
+    D.barrier(sync_device=False)
+    elapsed = 0.25 * (rank + 1)                           # pretend rank r took 0.25*(r+1) s
+    worst = D.max_over_ranks(elapsed)
+    D.barrier(sync_device=False)
+    out = dict(rank=rank, world=world, wsum=wsum, bsum=int(batch.sum()), lo=lo, hi=hi, worst=worst)
+    print('RESULT ' + json.dumps(out), flush=True)
+    D.finalize()
+''')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out
+        outs.append(json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][0][7:]))
+    outs.sort(key=lambda o: o['rank'])
+    assert [o['world'] for o in outs] == [2, 2]
+    assert outs[0]['wsum'] == outs[1]['wsum']             # replicated weights
+    assert outs[0]['bsum'] != outs[1]['bsum']             # different shards of synthetic data
+    assert (outs[0]['lo'], outs[0]['hi'], outs[1]['lo'], outs[1]['hi']) == (0, 6, 6, 11)
+    assert outs[0]['worst'] == outs[1]['worst'] == 0.5    # max over ranks, seen by every rank
+
+
+def test_shard_covers_everything():
+    from mmdet_yolov4_amd import dist as D
+    for n in (0, 1, 7, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 CSVs into small summaries.  Usage: summarize_prof.py <raw_dir> <out_dir>"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+raw, out = sys.argv[1], sys.argv[2]
+os.makedirs(out, exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'(yv4::[A-Za-z0-9_]+(<[^>]*>)?)', name)
+    if m:
+        return m.group(1)
+    return name.split('(')[0][:70]
+
+
+# 1. kernel stats
+for f in glob.glob(os.path.join(raw, 'trace', '*', '*_kernel_stats.csv')):
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(out, 'kernel_stats.csv'), 'w', newline='') as g:
+        w = csv.writer(g)
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+        for r in rows:
+            w.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'],
+                        r['MinNs'], r['MaxNs']])
+
+# 2. PMC per kernel (mean per launch)
+pm = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
+    for f in glob.glob(os.path.join(raw, d, '*', '*_counter_collection.csv')):
+        for r in csv.DictReader(open(f)):
+            if 'yv4::' not in r['Kernel_Name']:
+                continue
+            pm[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+res = {}
+for k, cs in pm.items():
+    e = {c: sum(v) / len(v) for c, v in cs.items()}
+    e['launches_sampled'] = max(len(v) for v in cs.values())
+    if 'FETCH_SIZE' in e:
+        # MI355X_MICROARCH.md, HBM: FETCH_SIZE (KiB) counts 64 B per 128-B request on gfx950 -> x2
+        e['hbm_read_bytes_per_launch'] = e['FETCH_SIZE'] * 1024 * 2
+    if 'WRITE_SIZE' in e:
+        e['hbm_write_bytes_per_launch'] = e['WRITE_SIZE'] * 1024
+    if 'hbm_read_bytes_per_launch' in e and 'hbm_write_bytes_per_launch' in e:
+        e['hbm_bytes_per_launch'] = e['hbm_read_bytes_per_launch'] + e['hbm_write_bytes_per_launch']
+    if 'TCC_HIT_sum' in e:
+        e['l2_hit_rate'] = e['TCC_HIT_sum'] / max(e['TCC_HIT_sum'] + e['TCC_MISS_sum'], 1)
+    res[k] = e
+json.dump(res, open(os.path.join(out, 'pmc_per_kernel.json'), 'w'), indent=1, sort_keys=True)
+for name in ('conv_shapes.txt', 'bench.json', 'layers.json'):
+    p = os.path.join(raw, name)
+    if os.path.exists(p):
+        open(os.path.join(out, name), 'w').write(open(p).read())
+print('summary written to', out)
