@@ -87,6 +87,25 @@ def init_head(det, plan, img, target_per_img, logit_std=2.0):
     return count
 
 
+def pmc_traffic(tile_name):
+    """HBM bytes per launch of the dominant conv kernel from the committed rocprofv3 --pmc summary of
+    this same command (profiles/rNN_pmc_per_kernel.json; counters cannot be read from inside the bench)."""
+    import glob
+    kern = {'dma64x64': 'yv4::conv_mfma_f32_dma_kernel<64, 64, 2, 2, 2>',
+            'dma128x64': 'yv4::conv_mfma_f32_dma_kernel<128, 64, 2, 2, 2>',
+            'dma128x128': 'yv4::conv_mfma_f32_dma_kernel<128, 128, 2, 2, 2>'}.get(tile_name)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel.json')))
+    if not kern or not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1])).get(kern, {})
+        if 'hbm_bytes_per_launch' in d:
+            return round(d['hbm_bytes_per_launch']), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def host_cpu_budget():
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -114,7 +133,7 @@ def cpu_baseline(det, size, budget_s=25.0):
         t0 = time.perf_counter()
         O.simple_test(img, sd, stages, reps, [3, 4, 5], sf, 80)      # warm-up (oneDNN primitive cache)
         warm = time.perf_counter() - t0
-        while t_total + warm < budget_s and n < 16:
+        while t_total + warm < budget_s and n < 64:
             t0 = time.perf_counter()
             O.simple_test(img, sd, stages, reps, [3, 4, 5], sf, 80)
             t_total += time.perf_counter() - t0
@@ -203,9 +222,13 @@ def main():
     # ---- roofline of the dominant kernel (the fused MFMA conv), from the timed region ------
     per_tile = {}
     per_layer = {}
+
+    def tile_of(op):
+        return pkg._lib.TILE_NAMES[pkg._lib.lib().yv4_conv_pick_tile(__import__('ctypes').byref(op.info['desc']))]
+
     for op, e0, e1 in events:
         ms = e0.elapsed_time(e1)
-        tile = pkg._lib.TILE_NAMES[pkg._lib.lib().yv4_conv_pick_tile(__import__('ctypes').byref(op.info['desc']))]
+        tile = tile_of(op)
         a = per_tile.setdefault(tile, [0.0, 0.0, 0])
         a[0] += op.flops
         a[1] += ms * 1e-3
@@ -217,9 +240,13 @@ def main():
     conv_time = sum(v[1] for v in per_tile.values())
     dom = max(per_tile, key=lambda k: per_tile[k][1])
     dflops, dtime, dn = per_tile[dom]
+    traffic, traffic_src = pmc_traffic(dom)
     roofline = dict(bound='mfma', kernel=f'conv_mfma_f32_kernel<{dom}>',
                     achieved=round(dflops / dtime / 1e12, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(dflops / dtime / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                    frac=round(dflops / dtime / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                    traffic_source=traffic_src,
+                    algorithmic_bytes_per_launch=round(sum(o.bytes for o, _, _ in events
+                                                           if tile_of(o) == dom) / dn),
                     launches=dn, avg_launch_us=round(dtime / dn * 1e6, 2),
                     gflop_per_launch=round(dflops / dn / 1e9, 3),
                     all_convs_tflops=round(conv_flops / conv_time / 1e12, 2),
