@@ -120,6 +120,8 @@ typedef struct yv4_conv_desc {
 #define YV4_TILE_DMA_64x64 5
 #define YV4_TILE_DMA_128x64 6
 #define YV4_TILE_DMA_128x128 7
+/* register-only kernel for the 3x3/s1/p1 stem (Cin padded to 4, Cout <= 64) */
+#define YV4_TILE_STEM 8
 
 int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const float* w,
                         const float* scale1, const float* shift1,

@@ -19,9 +19,9 @@ ABI_VERSION = 1
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_MISH, ACT_LEAKY, ACT_SWISH = 0, 1, 2, 3
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
-TILE_DMA_64x64, TILE_DMA_128x64, TILE_DMA_128x128 = 5, 6, 7
+TILE_DMA_64x64, TILE_DMA_128x64, TILE_DMA_128x128, TILE_STEM = 5, 6, 7, 8
 TILE_NAMES = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '64x128', 5: 'dma64x64', 6: 'dma128x64',
-              7: 'dma128x128'}
+              7: 'dma128x128', 8: 'stem3x3'}
 
 
 class ConvDesc(C.Structure):

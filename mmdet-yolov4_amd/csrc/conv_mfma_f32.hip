@@ -511,6 +511,109 @@ static int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
   return YV4_OK;
 }
 
+
+// ---------------------------------------------------------------------------------
+// Stem: 3x3 / stride 1 / pad 1 convolution of the 3-channel image (stored NHWC with C padded to
+// 4), Cout <= 64.  K = 9 taps x 4 channels = 36 is too shallow for the LDS-staged kernels (they
+// spend their time in prologue/epilogue) and the layer is bound by its own OUTPUT
+// (N*H*W*Cout*4 B = 1.5 GB at batch 32, 608^2, Cout 32), so this kernel keeps everything in
+// registers: a wave owns 32 consecutive pixels of one image row x 32 output channels
+// (one 32x32 MFMA tile), fetches its 9 x 8-byte input taps straight into the MFMA A operand
+// (lane (r,h): pixel r, channels 2h,2h+1 of each tap; out-of-image taps come back as zeros from
+// the buffer descriptor), holds the 18 weight values it needs for the whole kernel, issues
+// 18 MFMAs per tile and streams the epilogue to HBM in 128-byte rows.
+// ---------------------------------------------------------------------------------
+template <int TN>
+__global__ __launch_bounds__(kThreads) void conv_stem3x3_kernel(ConvArgs p, unsigned x_bytes, int tiles_w, long long ntiles) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, x_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+
+  // weights: B[k][cout r] with k = (tap, ci = 2h + j)
+  float wv[TN][9][2];
+  float s1[TN], t1[TN];
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int co = jn * 32 + r;
+    const bool cok = co < p.Cout;
+    s1[jn] = cok ? p.s1[co] : 0.f;
+    t1[jn] = cok ? p.t1[co] : 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wv[jn][tap][j] = cok ? p.w[(size_t)co * p.Kw + tap * 4 + 2 * h + j] : 0.f;
+  }
+
+  const long long wave_id = (long long)blockIdx.x * 4 + (tid >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long t = wave_id; t < ntiles; t += nwaves) {
+    const int tx = (int)(t % tiles_w);
+    const long long ty = t / tiles_w;       // n*H + y
+    const int y = (int)(ty % p.H);
+    const int x = tx * 32 + r;
+    // byte offset of x[n, y, x, x_co + 2h]
+    const unsigned base = (unsigned)(((ty * p.W + x) * p.x_cs + p.x_co + 2 * h) * 4);
+    u32x2 a[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const bool rok = (unsigned)(y + kh - 1) < (unsigned)p.H;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const bool ok = rok && (unsigned)(x + kw - 1) < (unsigned)p.W;
+        const unsigned off = base + (unsigned)((((kh - 1) * p.W + (kw - 1)) * p.x_cs) * 4);
+        a[kh * 3 + kw] = __builtin_amdgcn_raw_buffer_load_b64(rsA, ok ? off : kOOB, 0, 0);
+      }
+    }
+    f32x16 acc[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[jn][e] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[tap].x), wv[jn][tap][0], acc[jn], 0, 0, 0);
+        acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[tap].y), wv[jn][tap][1], acc[jn], 0, 0, 0);
+      }
+    const long long mrow = ty * p.W + tx * 32;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      const int co = jn * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (co < p.Cout && tx * 32 + row < p.W) {
+          const float v = apply_act(acc[jn][e] * s1[jn] + t1[jn], p.act1, p.slope1);
+          p.y[(mrow + row) * p.y_cs + p.y_co + co] = v;
+        }
+      }
+    }
+  }
+}
+
+static int launch_conv_stem(const ConvArgs& a, hipStream_t stream) {
+  const long long xb = (long long)a.N * a.H * a.W * a.x_cs * 4;
+  if (xb >= 0xFFFFFFF0LL) {
+    set_error("conv stem: input of 4 GiB or more is not addressable through a buffer descriptor");
+    return YV4_E_UNSUPPORTED;
+  }
+  const int tiles_w = (a.W + 31) / 32;
+  const long long ntiles = (long long)a.N * a.H * tiles_w;
+  long long blocks = (ntiles + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;   // 8 workgroups per CU, grid-stride over the tiles
+  if (a.Cout <= 32)
+    hipLaunchKernelGGL(conv_stem3x3_kernel<1>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, (unsigned)xb, tiles_w, ntiles);
+  else
+    hipLaunchKernelGGL(conv_stem3x3_kernel<2>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, (unsigned)xb, tiles_w, ntiles);
+  YV4_CHECK_LAUNCH("conv_stem3x3");
+  return YV4_OK;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_conv(const ConvArgs& a, bool uniform_tap, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * (BM + BN) * kLDK * sizeof(float);
@@ -538,6 +641,11 @@ static int launch_conv(const ConvArgs& a, bool uniform_tap, hipStream_t stream) 
     hipLaunchKernelGGL(kern_g, dim3((unsigned)tiles), dim3(kThreads), lds, stream, p);
   YV4_CHECK_LAUNCH("conv_mfma_f32");
   return YV4_OK;
+}
+
+static bool stem_ok(const yv4_conv_desc* d, bool has_res, bool has2) {
+  return d->Cin == 4 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cout <= 64 && !has_res &&
+         !has2 && d->x_coff % 2 == 0 && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL;
 }
 
 static int pick_tile(long long M, int Cout, bool fast_ok) {
@@ -570,6 +678,7 @@ extern "C" int yv4_conv_pick_tile(const yv4_conv_desc* d) {
   if (!d) return YV4_TILE_AUTO;
   const bool fast_ok = d->Cin % kBK == 0 && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL &&
                        (long long)d->Cout * d->KH * d->KW * d->Cin * 4 < 0xFFFFFFF0LL;
+  if (stem_ok(d, false, false)) return YV4_TILE_STEM;
   return pick_tile((long long)d->N * d->Ho * d->Wo, d->Cout, fast_ok);
 }
 
@@ -614,13 +723,15 @@ extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const
   // the LDS-DMA kernels address x and w through 32-bit buffer descriptors
   const bool fast_ok = uniform && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL &&
                        (long long)d->Cout * a.K * 4 < 0xFFFFFFF0LL;
-  int tile = d->tile == YV4_TILE_AUTO ? pick_tile(M, d->Cout, fast_ok) : d->tile;
+  const bool can_stem = stem_ok(d, residual != nullptr, scale2 != nullptr);
+  int tile = d->tile == YV4_TILE_AUTO ? (can_stem ? YV4_TILE_STEM : pick_tile(M, d->Cout, fast_ok)) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (tile) {
     case YV4_TILE_128x128: return launch_conv<128, 128, 2, 2>(a, uniform, s);
     case YV4_TILE_128x64: return launch_conv<128, 64, 2, 2>(a, uniform, s);
     case YV4_TILE_64x128: return launch_conv<64, 128, 2, 2>(a, uniform, s);
     case YV4_TILE_64x64: return launch_conv<64, 64, 2, 2>(a, uniform, s);
+    case YV4_TILE_STEM: if (can_stem) return launch_conv_stem(a, s); break;
     case YV4_TILE_DMA_64x64: if (fast_ok) return launch_conv_dma<64, 64, 2, 2, 2>(a, s); break;
     case YV4_TILE_DMA_128x64: if (fast_ok) return launch_conv_dma<128, 64, 2, 2, 2>(a, s); break;
     case YV4_TILE_DMA_128x128: if (fast_ok) return launch_conv_dma<128, 128, 2, 2, 2>(a, s); break;

@@ -116,7 +116,7 @@ def _conv_case(dev, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=Fals
     return close(got, ref, 1e-4, f'conv {N}x{Cin}x{H}x{W}->{Cout} k{k}s{stride} tile{tile}')
 
 
-@pytest.mark.parametrize('tile', [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64, L.TILE_DMA_64x64, L.TILE_DMA_128x64, L.TILE_DMA_128x128])
+@pytest.mark.parametrize('tile', [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64, L.TILE_DMA_64x64, L.TILE_DMA_128x64, L.TILE_DMA_128x128, L.TILE_STEM])
 @pytest.mark.parametrize('shape', [
     # N, H, W, Cin, Cout, k, stride, pad
     (2, 19, 19, 64, 128, 3, 1, 1),     # uniform-tap path, ragged M (722 rows)
@@ -125,9 +125,14 @@ def _conv_case(dev, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=Fals
     (1, 12, 12, 24, 40, 3, 1, 1),      # Cin % 32 != 0 -> per-chunk tap decode
     (2, 32, 32, 3, 32, 3, 1, 1),       # stem: Cin 3 padded to 4, K = 36
     (1, 24, 24, 3, 16, 6, 2, 2),       # Focus conv k=6 s=2 p=2
+    (1, 9, 37, 3, 16, 3, 1, 1),        # stem, W not a multiple of 32, Cout 16 (v4s)
+    (1, 8, 70, 3, 40, 3, 1, 1),        # stem, Cout 40 (v4x): two column tiles
 ])
 def test_conv_shapes_and_tiles(gpu_device, shape, tile):
-    if tile >= L.TILE_DMA_64x64 and shape[3] % 32 != 0:
+    stem_shape = shape[3] == 3 and shape[5:] == (3, 1, 1)
+    if tile == L.TILE_STEM and not stem_shape:
+        pytest.skip('stem kernel: 3x3 s1 p1 on the 3-channel image only')
+    if L.TILE_DMA_64x64 <= tile <= L.TILE_DMA_128x128 and shape[3] % 32 != 0:
         pytest.skip('fast-path kernels need Cin % 32 == 0')
     _conv_case(gpu_device, *shape, act=1, tile=tile)
 
