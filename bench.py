@@ -160,6 +160,9 @@ def main():
     ap.add_argument('--candidates', type=float, default=2000.0, help='target NMS candidates per image')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layers', default='', help='write a per-conv timing table (JSON) to this path')
+    ap.add_argument('--no-autotune', action='store_true', help='keep the static conv tile choice')
+    ap.add_argument('--event-every', type=int, default=4,
+                    help='bracket the conv launches with HIP events in every n-th timed step (events cost ~2 %)')
     args = ap.parse_args()
 
     import mmdet_yolov4_amd as pkg
@@ -183,6 +186,8 @@ def main():
     plan = det.compile(args.batch, args.size, args.size, device=dev, rescale=True)
     calibrate_bn(plan, img)
     ncand = init_head(det, plan, img, args.candidates)
+    if not args.no_autotune:
+        plan.autotune()
 
     conv_ops = [o for o in plan.ops if o.kind == 'conv']
     stream = torch.cuda.current_stream()
@@ -213,8 +218,8 @@ def main():
     D.barrier()
     events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(events)
+    for i in range(args.steps):
+        step(events if i % max(args.event_every, 1) == 0 else None)
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev)
     assert int(host_count.min()) >= 0, 'an image took the split NMS path; lower --candidates'
@@ -224,7 +229,9 @@ def main():
     per_layer = {}
 
     def tile_of(op):
-        return pkg._lib.TILE_NAMES[pkg._lib.lib().yv4_conv_pick_tile(__import__('ctypes').byref(op.info['desc']))]
+        d = op.info['desc']
+        t = d.tile if d.tile else pkg._lib.lib().yv4_conv_pick_tile(__import__('ctypes').byref(d))
+        return pkg._lib.TILE_NAMES[t]
 
     for op, e0, e1 in events:
         ms = e0.elapsed_time(e1)
@@ -251,7 +258,9 @@ def main():
                     gflop_per_launch=round(dflops / dn / 1e9, 3),
                     all_convs_tflops=round(conv_flops / conv_time / 1e12, 2),
                     all_convs_frac=round(conv_flops / conv_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    conv_share_of_step=round(conv_time / args.steps / (elapsed / args.steps), 4))
+                    conv_share_of_step=round(conv_time / max(len(events) // len(conv_ops), 1) /
+                                             (elapsed / args.steps), 4),
+                    instrumented_steps=len(events) // len(conv_ops))
     if args.layers and rank == 0:
         rows = []
         for op, tsum, n, tile in per_layer.values():

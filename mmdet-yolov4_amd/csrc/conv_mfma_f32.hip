@@ -614,6 +614,7 @@ static int launch_conv_stem(const ConvArgs& a, hipStream_t stream) {
   return YV4_OK;
 }
 
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_conv(const ConvArgs& a, bool uniform_tap, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * (BM + BN) * kLDK * sizeof(float);

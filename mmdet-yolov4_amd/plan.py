@@ -304,6 +304,44 @@ class Plan:
         self.finalized = True
         return self
 
+    def autotune(self, candidates=None, reps=3):
+        """Pick the conv tile per layer by timing the candidates on the plan's own buffers
+        (device-to-device spread on MI355X is larger than the gap between tile shapes, so a static
+        table is not robust).  Inputs must be set (run the plan once first).  Returns a dict
+        layer-index -> chosen tile id."""
+        assert self.finalized and self.graph is None and self.device.type == 'cuda'
+        cands = candidates or (_lib.TILE_DMA_64x64, _lib.TILE_DMA_128x64, _lib.TILE_DMA_128x128)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        chosen = {}
+        for idx, op in enumerate(self.ops):
+            if op.kind != 'conv':
+                continue
+            d = op.info['desc']
+            auto = _lib.lib().yv4_conv_pick_tile(C.byref(d))
+            if auto not in cands:          # stem / generic path: nothing to choose from
+                continue
+            best, best_t = auto, None
+            for t in cands:
+                d.tile = t
+                try:
+                    op.fn(stream)          # warm-up + applicability check
+                except _lib.Yv4Error:
+                    continue
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    op.fn(stream)
+                e1.record()
+                torch.cuda.synchronize()
+                dt = e0.elapsed_time(e1)
+                if best_t is None or dt < best_t:
+                    best, best_t = t, dt
+            d.tile = best
+            op.info['tile'] = best
+            chosen[idx] = best
+        return chosen
+
     def total_flops(self):
         return sum(o.flops for o in self.ops)
 
