@@ -261,6 +261,73 @@ __device__ __forceinline__ u32x4_t make_rsrc(const void* base, unsigned bytes) {
   return v;
 }
 
+// Epilogue of one 32x32 accumulator tile through a wave-private LDS patch: the MFMA result has
+// the output channel on the lane and 16 pixels in registers, which stores as 16 dword
+// instructions touching 2 x 128 B each; transposed through LDS every lane owns 4 consecutive
+// channels of one pixel, so the tile leaves (and the residual arrives) in 4 dwordx4
+// instructions per lane and the per-channel scale/shift become vector loads.
+// `vec_ok` (uniform): all views are 16-byte aligned per pixel (false for the 255-channel heads).
+__device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const f32x16& acc, float* ep, int lane, int m_base,
+                                              int co_base, bool vec_ok, bool has2) {
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int kPitch = 36;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + 4 * h) * kPitch + r] = acc[e];
+  const int c4 = (lane & 7) * 4;
+  const int co = co_base + c4;
+  if (vec_ok && co + 3 < p.Cout) {
+    const float4 s1 = *reinterpret_cast<const float4*>(p.s1 + co);
+    const float4 t1 = *reinterpret_cast<const float4*>(p.t1 + co);
+    float4 s2 = make_float4(1.f, 1.f, 1.f, 1.f), t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has2) {
+      s2 = *reinterpret_cast<const float4*>(p.s2 + co);
+      t2 = *reinterpret_cast<const float4*>(p.t2 + co);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = (lane >> 3) + 8 * k;
+      const int m = m_base + row;
+      const float4 a = *reinterpret_cast<const float4*>(ep + row * kPitch + c4);
+      if (m < p.M) {
+        float4 v;
+        v.x = apply_act(a.x * s1.x + t1.x, p.act1, p.slope1);
+        v.y = apply_act(a.y * s1.y + t1.y, p.act1, p.slope1);
+        v.z = apply_act(a.z * s1.z + t1.z, p.act1, p.slope1);
+        v.w = apply_act(a.w * s1.w + t1.w, p.act1, p.slope1);
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + (int64_t)m * p.r_cs + p.r_co + co);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (has2) {
+          v.x = apply_act(v.x * s2.x + t2.x, p.act2, p.slope2);
+          v.y = apply_act(v.y * s2.y + t2.y, p.act2, p.slope2);
+          v.z = apply_act(v.z * s2.z + t2.z, p.act2, p.slope2);
+          v.w = apply_act(v.w * s2.w + t2.w, p.act2, p.slope2);
+        }
+        *reinterpret_cast<float4*>(p.y + (int64_t)m * p.y_cs + p.y_co + co) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = (lane >> 3) + 8 * k;
+      const int m = m_base + row;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = co + u;
+        if (c < p.Cout) {
+          float v = ep[row * kPitch + c4 + u] * p.s1[c] + p.t1[c];
+          v = apply_act(v, p.act1, p.slope1);
+          if (p.res) v += p.res[(int64_t)m * p.r_cs + p.r_co + c];
+          if (has2) v = apply_act(v * p.s2[c] + p.t2[c], p.act2, p.slope2);
+          p.y[(int64_t)m * p.y_cs + p.y_co + c] = v;
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // Fast path (Cin % 32 == 0): LDS-DMA staging.  The next K slice goes global -> LDS directly
 // (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, no VGPR round trip and no
@@ -445,7 +512,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
       ++issued;
       wbuf = wbuf + 1 == NBUF ? 0 : wbuf + 1;
     }
+    __builtin_amdgcn_s_setprio(1);   // keep the MFMA cluster ahead of the other resident waves' setup code
     YV4_V3_COMPUTE(rbuf);
+    __builtin_amdgcn_s_setprio(0);
     rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
     if (kt + 1 < nk) {
       // fragment reads of this slot returned (lgkmcnt(0)), slice kt+1 landed (counted
@@ -458,30 +527,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
 #undef YV4_V3_DMA
 #undef YV4_V3_COMPUTE
 
+  // ---- epilogue: transposed through a wave-private LDS patch (the K-loop buffers are free
+  // once every wave has issued its last fragment reads: one more barrier) ----
   const bool has2 = p.s2 != nullptr;
+  const bool vec_ok = ((p.y_cs | p.y_co) & 3) == 0 && (p.res == nullptr || ((p.r_cs | p.r_co) & 3) == 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  float* ep = smem + wave * (32 * 36);
 #pragma unroll
-  for (int jn = 0; jn < TN; ++jn) {
-    const int co = n0 + wn * TN * 32 + jn * 32 + r;
-    const bool cok = co < p.Cout;
-    const float s1 = cok ? p.s1[co] : 0.f;
-    const float t1 = cok ? p.t1[co] : 0.f;
-    const float s2 = (cok && has2) ? p.s2[co] : 1.f;
-    const float t2 = (cok && has2) ? p.t2[co] : 0.f;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (cok && m < p.M) {
-          float v = acc[i][jn][e] * s1 + t1;
-          v = apply_act(v, p.act1, p.slope1);
-          if (p.res) v += p.res[(int64_t)m * p.r_cs + p.r_co + co];
-          if (has2) v = apply_act(v * s2 + t2, p.act2, p.slope2);
-          p.y[(int64_t)m * p.y_cs + p.y_co + co] = v;
-        }
-      }
-    }
-  }
+    for (int jn = 0; jn < TN; ++jn)
+      epilogue_tile(p, acc[i][jn], ep, lane, m0 + wm * TM * 32 + i * 32, n0 + wn * TN * 32 + jn * 32, vec_ok, has2);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NBUF>
