@@ -194,6 +194,96 @@ def make_nms(ref, out):
     print('nms', out)
 
 
+
+def make_train(ref, out):
+    """One training-mode forward + backward of the reference on a tiny v4 detector: loss dict,
+    gradients (full for selected tensors, 3 checksums for every parameter), BN running statistics
+    after the step, and responsible_indices for hand-placed ground truths."""
+    gen = torch.Generator().manual_seed(11)
+    dk, nk, hd = ref.darknetcsp, ref.neck, ref.head
+    scale = [['conv', 'bottleneck', 'csp', 'csp', 'csp', 'sppv4'], [None, 1, 1, 2, 1, 1], [4, 8, 16, 32, 64, 64]]
+    backbone = dk.DarknetCSP(scale=scale, out_indices=[3, 4, 5])
+    neck = nk.YOLOV4Neck(in_channels=[32, 64, 64], out_channels=[32, 64, 128], csp_repetition=1)
+    head = hd.YOLOCSPHead(num_classes=80, in_channels=[32, 64, 128], train_cfg=None,
+                          test_cfg=ref.ConfigDict(nms_pre=-1, score_thr=0.001, nms=dict(type='nms', iou_threshold=0.65),
+                                                  max_per_img=300))
+    for m in (backbone, neck, head):
+        randomize(m, gen)
+    with torch.no_grad():
+        for conv in head.convs_pred:
+            conv.weight.normal_(0, 0.05, generator=gen)
+            conv.bias.normal_(-2.0, 0.5, generator=gen)
+    for m in (backbone, neck, head):
+        quantize_fp16(m)
+        torch.nn.Module.train(m, True)
+    N = 2
+    img = (torch.randint(0, 256, (N, 3, 64, 96), generator=gen).float() - 114.0) / 255.0
+    gt_bboxes = [torch.tensor([[8.0, 10.0, 40.0, 44.0], [50.5, 5.0, 95.0, 30.0], [20.0, 30.0, 28.0, 62.0]]),
+                 torch.tensor([[0.0, 0.0, 30.0, 20.0], [60.0, 20.0, 90.0, 63.5]])]
+    gt_labels = [torch.tensor([3, 17, 79]), torch.tensor([0, 41])]
+    metas = [dict() for _ in range(N)]
+    data = {'img': img.numpy()}
+    sd_before = {}
+    for pre, m in (('backbone', backbone), ('neck', neck), ('bbox_head', head)):
+        sd_before.update(sd_np(pre, m))
+    feats = backbone(img)
+    nouts = neck(feats)
+    preds = head(nouts)[0]
+    losses = head.loss(preds, gt_bboxes, gt_labels, metas)
+    total = sum(sum(x.mean() for x in v) for k, v in losses.items() if 'loss' in k)
+    total.backward()
+    for k, v in losses.items():
+        data['loss/' + k] = (torch.stack([x.reshape(()) for x in v]).detach().numpy() if isinstance(v, list)
+                             else v.detach().numpy())
+    data['loss_total'] = total.detach().numpy()
+    for i, f in enumerate(preds):
+        data[f'pred{i}'] = f.detach().numpy()
+    names, sums = [], []
+    keep_full = ('backbone.conv0.conv.weight', 'backbone.conv0.bn.weight', 'backbone.conv0.bn.bias',
+                 'backbone.csp3.conv_csp.bn.weight', 'backbone.csp3.conv_csp.conv3.weight',
+                 'backbone.csp2.conv_downscale.conv.weight', 'backbone.sppv45.spp.conv5.conv.weight',
+                 'neck.downsample_convs.0.conv.weight', 'neck.out_convs.1.bn.bias',
+                 'bbox_head.convs_pred.0.weight', 'bbox_head.convs_pred.2.bias')
+    for pre, m in (('backbone', backbone), ('neck', neck), ('bbox_head', head)):
+        for n, prm in m.named_parameters():
+            full = f'{pre}.{n}'
+            g = prm.grad
+            assert g is not None, full
+            names.append(full)
+            sums.append([float(g.double().sum()), float(g.double().abs().sum()), float(g.double().pow(2).sum().sqrt())])
+            if full in keep_full:
+                data['grad/' + full] = g.numpy()
+        for n, b in m.named_buffers():
+            if n.endswith('running_mean') or n.endswith('running_var'):
+                full = f'{pre}.{n}'
+                if full.split('.running')[0] in ('backbone.conv0.bn', 'backbone.sppv45.spp.conv1.bn',
+                                                 'backbone.csp3.conv_csp.bn', 'neck.out_convs.2.bn'):
+                    data['after/' + full] = b.detach().numpy()
+    data['grad_names'] = np.array(names)
+    data['grad_sums'] = np.array(sums)
+    data.update(sd_before)
+    for i, (b, l) in enumerate(zip(gt_bboxes, gt_labels)):
+        data[f'gt_bboxes{i}'] = b.numpy()
+        data[f'gt_labels{i}'] = l.numpy()
+    data['meta_stages'] = np.array(scale[0])
+    data['meta_reps'] = np.array([-1 if r is None else r for r in scale[1]])
+    data['meta_channels'] = np.array(scale[2])
+    # responsible_indices on hand-placed gts: cell centres, cell edges, image borders, extreme aspect
+    ag = head.anchor_generator
+    gts = [torch.tensor([[12.0, 12.0, 20.0, 20.0], [0.0, 0.0, 7.9, 8.1], [88.0, 56.0, 96.0, 64.0], [30.0, 2.0, 34.0, 62.0],
+                         [15.9, 16.0, 48.1, 47.9]]),
+           torch.tensor([[40.0, 24.0, 56.0, 40.0], [1.0, 30.0, 95.0, 34.0]])]
+    sizes = [(8, 12), (4, 6), (2, 3)]
+    for nb in (0, 2, 3):
+        res = ag.responsible_indices(sizes, gts, neighbor=nb, shape_match_thres=4., device='cpu')
+        for lvl, (a, b, c) in enumerate(res):
+            data[f'resp/n{nb}/l{lvl}'] = torch.stack([a, b, c]).numpy()
+    for i, gbox in enumerate(gts):
+        data[f'resp_gt{i}'] = gbox.numpy()
+    np.savez_compressed(out, **data)
+    print('train', out, f'{os.path.getsize(out) / 1e6:.2f} MB', 'loss', float(total))
+
+
 def main():
     if not _ref_import.available():
         print('reference not present: nothing to do')
@@ -209,6 +299,7 @@ def main():
     run_detector(ref, 'tiny_v5', v5, [2, 3, 4], 'v5', [32, 64, 128], [32, 64, 128], 1, (64, 64), 5,
                  os.path.join(HERE, 'tiny_v5.npz'), obj_bias=-3.5, cls_bias=-4.0, head_std=12000)
     make_nms(ref, os.path.join(HERE, 'nms.npz'))
+    make_train(ref, os.path.join(HERE, 'train_v4.npz'))
 
 
 if __name__ == '__main__':
