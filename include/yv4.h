@@ -226,6 +226,38 @@ int yv4_nms_prepare(const float* boxes, const float* scores, int64_t n,
                     uint64_t* keys, int32_t* counts, float* max_coord,
                     void* stream);
 
+/* ---- training side (fp32) -----------------------------------------------------
+ * Replaces the autograd of mmcv ConvModule in training mode (cuDNN backward-filter /
+ * backward-data, ATen batch_norm fwd/bwd with batch statistics, MishCudaFunction.backward,
+ * mmdet/ops/mish_cuda/mish.py:27-36) for the blocks of mmdet/models/backbones/darknetcsp.py.
+ *
+ * yv4_conv_wgrad: dW[co][(kh,kw,ci)] += sum_m dY[m][co] * x[n, ho*s-p+kh, wo*s-p+kw, ci];
+ *   `d` is the FORWARD descriptor; the y_* fields describe the dY view; dW has the packed
+ *   forward layout (Cout, KH*KW*Cin) and must be zero on entry (partial sums are added with
+ *   float atomics).  Cin, Cout and all view strides/offsets must be multiples of 4.
+ * The data gradient is yv4_conv_bn_act_fwd on dY with the weights transposed+flipped (pad
+ *   K-1-p); for stride 2 dY is zero-dilated first:
+ * yv4_dilate2_fwd: dst (N,2H,2W,C dense) [n,2y,2x,c] = src[n,y,x,c], zeros elsewhere.
+ * yv4_bn_train_stats: per-channel batch mean / 1/sqrt(biased var + eps) of an NHWC view with M
+ *   rows; updates running_mean/var (unbiased var, `momentum`) when given. work: 2*C doubles.
+ * yv4_bn_act_fwd:  y = act((x-mean)*invstd*gamma+beta) (+ residual).
+ * yv4_bn_act_bwd:  from dy (gradient w.r.t. y), the saved conv output x and the batch
+ *   statistics: dx, dgamma, dbeta (the activation is recomputed, nothing else is saved).  */
+int yv4_conv_wgrad(const yv4_conv_desc* d, const float* x, const float* dy, float* dw, void* stream);
+int yv4_dilate2_fwd(const float* src, float* dst, int N, int H, int W, int C, int src_cstride,
+                    int src_coff, void* stream);
+int yv4_bn_train_stats(const float* x, int64_t M, int C, int x_cstride, int x_coff, float eps,
+                       float momentum, double* work, float* mean, float* invstd,
+                       float* running_mean, float* running_var, void* stream);
+int yv4_bn_act_fwd(const float* x, int x_cstride, int x_coff, const float* mean,
+                   const float* invstd, const float* gamma, const float* beta,
+                   const float* residual, int r_cstride, int r_coff, float* y, int y_cstride,
+                   int y_coff, int64_t M, int C, int act, float slope, void* stream);
+int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, int dy_cstride,
+                   int dy_coff, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, float* dx, int dx_cstride, int dx_coff, float* dgamma,
+                   float* dbeta, double* work, int64_t M, int C, int act, float slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

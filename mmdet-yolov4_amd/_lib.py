@@ -68,6 +68,12 @@ SIGNATURES = {
     'yv4_nms_split': (C.c_int, [_vp, _i64, _f, _vp, _vp, _i, _f, _i, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
     'yv4_nms_prepare': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'yv4_conv_wgrad': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    'yv4_dilate2_fwd': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'yv4_bn_train_stats': (C.c_int, [_vp, _i64, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'yv4_bn_act_fwd': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i64, _i, _i, _f, _vp]),
+    'yv4_bn_act_bwd': (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i,
+                                 _i, _f, _vp]),
 }
 
 _lock = threading.Lock()

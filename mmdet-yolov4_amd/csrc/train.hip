@@ -1,0 +1,487 @@
+// Training-side kernels of the YOLOv4 path on gfx950 (fp32): convolution weight gradient,
+// zero-dilation for the data gradient of strided convolutions, and train-mode BatchNorm
+// (+ activation, + residual) forward / backward.
+//
+// What they replace in the reference's training step:
+//   cuDNN conv backward-filter / backward-data  (autograd of mmcv ConvModule, darknetcsp.py:15-35)
+//   ATen batch_norm forward/backward in training mode + MishCudaFunction.backward (mish.py:27-36)
+// The data gradient itself is the forward kernel again (conv_mfma_f32.hip) on dY with the
+// weights transposed and flipped; for stride 2 dY is first zero-dilated (yv4_dilate2_fwd).
+#include "yv4_common.h"
+
+namespace yv4 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_dma16_t(u32x4_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+__device__ __forceinline__ u32x4_t make_rsrc_t(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  u32x4_t v;
+  v.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  v.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+  v.z = __builtin_amdgcn_readfirstlane(bytes);
+  v.w = 0x00020000u;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------
+// Weight gradient:  dW[co][k] += sum_m dY[m][co] * A[m][k],  A = im2col(x), k = (kh,kw,ci).
+// A workgroup owns a 64 (co) x 64 (k) tile of dW and one chunk of the M = N*Ho*Wo reduction;
+// slices of 32 rows of dY and of A go global -> LDS by LDS-DMA (rows of 64 floats, read back
+// with ds_read_b32 along the row, so no swizzle is needed), each wave accumulates a 32x32 tile
+// on v_mfma_f32_32x32x2_f32 with the reduction index m as the MFMA K dimension, and the
+// chunk's partial tile is added to dW with float atomics (dW must be zero on entry).
+// ---------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* dw;
+  int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+  int x_cs, x_co, dy_cs, dy_co;
+  int M, K;
+  int tiles_k, rows_per_chunk;
+};
+
+constexpr int kWgRows = 32;   // reduction rows per slice
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // [2][32][64] dY slice, [2][32][64] A slice
+  float* Ds = smem;
+  float* As = smem + 2 * kWgRows * 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int tile_k = blockIdx.x % p.tiles_k;
+  const int tile_c = blockIdx.x / p.tiles_k;
+  const int co0 = tile_c * 64;
+  const int k0 = tile_k * 64;
+  const int m_lo = blockIdx.y * p.rows_per_chunk;
+  const int m_hi = min(m_lo + p.rows_per_chunk, p.M);
+  if (m_lo >= m_hi) return;
+
+  const u32x4_t rsX = make_rsrc_t(p.x, x_bytes);
+  const u32x4_t rsD = make_rsrc_t(p.dy, dy_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem;
+
+  // staging: one DMA instruction of a wave covers 4 rows x 256 B; lane -> (row = lane/16, chunk = lane%16)
+  // per slice each wave issues 2 instructions for dY (rows 8*wave + {0..3, 4..7}) and 2 for A.
+  const int srow = lane >> 4;     // 0..3
+  const int chunk = lane & 15;    // 16-byte chunk inside the 64-float row
+  // dY column validity / offset (fixed per lane)
+  const int dco = co0 + chunk * 4;
+  const bool dco_ok = dco < p.Cout;          // Cout % 4 == 0 is required by the host
+  // A column: k = k0 + chunk*4 -> (tap, ci): fixed per lane
+  const int kk = k0 + chunk * 4;
+  const bool k_ok = kk < p.K;
+  const int tap = k_ok ? kk / p.Cin : 0;
+  const int ci = kk - tap * p.Cin;
+  const int kh = tap / p.KW;
+  const int kw = tap - kh * p.KW;
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+  auto issue = [&](int m_base, int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = 8 * wave + 4 * q + srow;          // 0..31 within the slice
+      const int m = m_base + row;
+      unsigned doff = kOOB, aoff = kOOB;
+      if (m < m_hi) {
+        if (dco_ok) doff = (unsigned)((((int64_t)m * p.dy_cs) + p.dy_co + dco) * 4);
+        if (k_ok) {
+          const int hw = p.Ho * p.Wo;
+          const int n = m / hw;
+          const int rm = m - n * hw;
+          const int ho = rm / p.Wo;
+          const int wo = rm - ho * p.Wo;
+          const int hi = ho * p.stride - p.pad + kh;
+          const int wi = wo * p.stride - p.pad + kw;
+          if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+            aoff = (unsigned)(((((int64_t)n * p.H + hi) * p.W + wi) * p.x_cs + p.x_co + ci) * 4);
+        }
+      }
+      const unsigned lrow = (unsigned)((buf * kWgRows + 8 * wave + 4 * q) * 64 * 4);
+      lds_dma16_t(rsD, lds_base + lrow, doff, 0u);
+      lds_dma16_t(rsX, lds_base + (unsigned)(2 * kWgRows * 64 * 4) + lrow, aoff, 0u);
+    }
+  };
+
+  const int nslices = (m_hi - m_lo + kWgRows - 1) / kWgRows;
+  issue(m_lo, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int s = 0; s < nslices; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslices) issue(m_lo + (s + 1) * kWgRows, buf ^ 1);
+    const float* ds = Ds + buf * kWgRows * 64 + wm * 32 + r;   // dY^T operand: [m][co]
+    const float* as = As + buf * kWgRows * 64 + wn * 32 + r;   // A operand:    [m][k]
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = 0; t < kWgRows / 2; ++t) {
+      const float a = ds[(2 * t + h) * 64];
+      const float b = as[(2 * t + h) * 64];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // D[row = co][col = k]: row = (e&3) + 8*(e>>2) + 4*h, col = r
+  const int kcol = k0 + wn * 32 + r;
+  if (kcol < p.K) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (co < p.Cout) atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[e]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// dst[n, 2y, 2x, c] = src[n, y, x, c], everything else 0  (dst is (N, 2H, 2W, C) dense NHWC).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H,
+                                                      int W, int C4, int src_cs, int src_co) {
+  const size_t total = (size_t)N * 2 * H * 2 * W * C4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    const int x = (int)(t % (2 * W));
+    t /= 2 * W;
+    const int y = (int)(t % (2 * H));
+    const int n = (int)(t / (2 * H));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (((x | y) & 1) == 0)
+      v = *reinterpret_cast<const float4*>(src + ((size_t)(n * H + (y >> 1)) * W + (x >> 1)) * src_cs + src_co + c4 * 4);
+    reinterpret_cast<float4*>(dst)[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Train-mode BatchNorm.  x is an NHWC view (M rows, C channels).
+//   stats:   per-channel sum and sum of squares, fp64 partials per workgroup -> atomics (double)
+//   fwd:     z = (x - mean) * invstd * gamma + beta;  y = act(z) (+ residual)
+//   bwd:     g = dy * act'(z);  dbeta = sum g;  dgamma = sum g * xhat;
+//            dx = gamma * invstd * (g - dbeta/M - xhat * dgamma/M)
+// act in {none, Mish, LeakyReLU, Swish}; Mish' as mmdet/ops/mish_cuda/src/mish.h:21-29.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float z, int act, float slope) {
+  switch (act) {
+    case YV4_ACT_MISH: {
+      const float sp = z < 20.f ? log1pf(expf(z)) : z;
+      const float grad_sp = 1.f - expf(-sp);
+      const float tsp = tanhf(sp);
+      return z * (1.f - tsp * tsp) * grad_sp + tsp;
+    }
+    case YV4_ACT_LEAKY: return z >= 0.f ? 1.f : slope;
+    case YV4_ACT_SWISH: {
+      const float s = 1.f / (1.f + expf(-z));
+      return s + z * s * (1.f - s);
+    }
+    default: return 1.f;
+  }
+}
+__device__ __forceinline__ float act_fwd_exact(float z, int act, float slope) {
+  switch (act) {
+    case YV4_ACT_MISH: return mish_f32(z);
+    case YV4_ACT_LEAKY: return z >= 0.f ? z : z * slope;
+    case YV4_ACT_SWISH: return z * sigmoid_f32(z);
+    default: return z;
+  }
+}
+
+constexpr int kBnRows = 256;   // rows per workgroup in the reductions
+
+// sums[c] += sum x, sums[C + c] += sum x^2   (double)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t M, int C, int cs, int co,
+                                                       double* __restrict__ sums) {
+  // thread -> channel quad cq = tid % C4 ... handled by looping over channel quads in the outer grid dim
+  const int C4 = C >> 2;
+  const int cq = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rsub = threadIdx.x >> 6;          // 4 row lanes per channel quad
+  const int64_t r0 = (int64_t)blockIdx.x * kBnRows;
+  const int64_t r1 = r0 + kBnRows < M ? r0 + kBnRows : M;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (cq < C4) {
+    float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
+    for (int64_t rr = r0 + rsub; rr < r1; rr += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(x + rr * cs + co + cq * 4);
+      fs[0] += v.x; fs[1] += v.y; fs[2] += v.z; fs[3] += v.w;
+      fq[0] += v.x * v.x; fq[1] += v.y * v.y; fq[2] += v.z * v.z; fq[3] += v.w * v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s[k] = fs[k]; q[k] = fq[k]; }
+  }
+  __shared__ double red[4][64][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[rsub][threadIdx.x & 63][k] = s[k]; red[rsub][threadIdx.x & 63][4 + k] = q[k]; }
+  __syncthreads();
+  if (rsub == 0 && cq < C4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double ss = red[0][threadIdx.x][k] + red[1][threadIdx.x][k] + red[2][threadIdx.x][k] + red[3][threadIdx.x][k];
+      const double qq = red[0][threadIdx.x][4 + k] + red[1][threadIdx.x][4 + k] + red[2][threadIdx.x][4 + k] +
+                        red[3][threadIdx.x][4 + k];
+      atomicAdd(&sums[cq * 4 + k], ss);
+      atomicAdd(&sums[C + cq * 4 + k], qq);
+    }
+  }
+}
+
+// mean / biased var / invstd from the sums; running stats update (unbiased var, momentum)
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M, int C, float eps, float momentum,
+                                   float* mean, float* invstd, float* running_mean, float* running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[c] / (double)M;
+  double var = sums[C + c] / (double)M - m * m;
+  if (var < 0) var = 0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+struct BnArgs {
+  const float* x; int x_cs, x_co;
+  const float* mean; const float* invstd; const float* gamma; const float* beta;
+  const float* res; int r_cs, r_co;
+  float* y; int y_cs, y_co;
+  const float* dy; int dy_cs, dy_co;
+  float* dx; int dx_cs, dx_co;
+  double* sums;      // bwd: [dbeta (C) | dgamma (C)]
+  int64_t M; int C; int act; float slope;
+};
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnArgs p) {
+  const int C4 = p.C >> 2;
+  const size_t total = (size_t)p.M * C4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cq = (int)(i % C4);
+    const size_t m = i / C4;
+    const int c = cq * 4;
+    const float4 v = *reinterpret_cast<const float4*>(p.x + m * p.x_cs + p.x_co + c);
+    const float4 mu = *reinterpret_cast<const float4*>(p.mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(p.invstd + c);
+    const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c);
+    const float4 be = *reinterpret_cast<const float4*>(p.beta + c);
+    float4 o;
+    o.x = act_fwd_exact((v.x - mu.x) * is.x * ga.x + be.x, p.act, p.slope);
+    o.y = act_fwd_exact((v.y - mu.y) * is.y * ga.y + be.y, p.act, p.slope);
+    o.z = act_fwd_exact((v.z - mu.z) * is.z * ga.z + be.z, p.act, p.slope);
+    o.w = act_fwd_exact((v.w - mu.w) * is.w * ga.w + be.w, p.act, p.slope);
+    if (p.res) {
+      const float4 rr = *reinterpret_cast<const float4*>(p.res + m * p.r_cs + p.r_co + c);
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    }
+    *reinterpret_cast<float4*>(p.y + m * p.y_cs + p.y_co + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
+  const int C4 = p.C >> 2;
+  const int cq = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rsub = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * kBnRows;
+  const int64_t r1 = r0 + kBnRows < p.M ? r0 + kBnRows : p.M;
+  float db[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0};
+  if (cq < C4) {
+    const int c = cq * 4;
+    const float mu[4] = {p.mean[c], p.mean[c + 1], p.mean[c + 2], p.mean[c + 3]};
+    const float is[4] = {p.invstd[c], p.invstd[c + 1], p.invstd[c + 2], p.invstd[c + 3]};
+    const float ga[4] = {p.gamma[c], p.gamma[c + 1], p.gamma[c + 2], p.gamma[c + 3]};
+    const float be[4] = {p.beta[c], p.beta[c + 1], p.beta[c + 2], p.beta[c + 3]};
+    for (int64_t rr = r0 + rsub; rr < r1; rr += 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(p.x + rr * p.x_cs + p.x_co + c);
+      const float4 gv = *reinterpret_cast<const float4*>(p.dy + rr * p.dy_cs + p.dy_co + c);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xhat = (xs[k] - mu[k]) * is[k];
+        const float g = gs[k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
+        db[k] += g;
+        dg[k] += g * xhat;
+      }
+    }
+  }
+  __shared__ double red[4][64][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[rsub][threadIdx.x & 63][k] = db[k]; red[rsub][threadIdx.x & 63][4 + k] = dg[k]; }
+  __syncthreads();
+  if (rsub == 0 && cq < C4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double b = red[0][threadIdx.x][k] + red[1][threadIdx.x][k] + red[2][threadIdx.x][k] + red[3][threadIdx.x][k];
+      const double g = red[0][threadIdx.x][4 + k] + red[1][threadIdx.x][4 + k] + red[2][threadIdx.x][4 + k] +
+                       red[3][threadIdx.x][4 + k];
+      atomicAdd(&p.sums[cq * 4 + k], b);
+      atomicAdd(&p.sums[p.C + cq * 4 + k], g);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
+  const int C4 = p.C >> 2;
+  const size_t total = (size_t)p.M * C4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const double invM = 1.0 / (double)p.M;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cq = (int)(i % C4);
+    const size_t m = i / C4;
+    const int c = cq * 4;
+    const float4 xv = *reinterpret_cast<const float4*>(p.x + m * p.x_cs + p.x_co + c);
+    const float4 gv = *reinterpret_cast<const float4*>(p.dy + m * p.dy_cs + p.dy_co + c);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float mu = p.mean[c + k], is = p.invstd[c + k], ga = p.gamma[c + k], be = p.beta[c + k];
+      const float xhat = (xs[k] - mu) * is;
+      const float g = gs[k] * act_grad(xhat * ga + be, p.act, p.slope);
+      const float dbm = (float)(p.sums[c + k] * invM);
+      const float dgm = (float)(p.sums[p.C + c + k] * invM);
+      o[k] = ga * is * (g - dbm - xhat * dgm);
+    }
+    *reinterpret_cast<float4*>(p.dx + m * p.dx_cs + p.dx_co + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__global__ void sums_to_float_kernel(const double* __restrict__ sums, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)sums[i];
+}
+
+static inline unsigned ew_grid_t(size_t work_items) {
+  size_t g = (work_items + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (unsigned)g;
+}
+
+}  // namespace yv4
+
+using namespace yv4;
+
+extern "C" int yv4_conv_wgrad(const yv4_conv_desc* d, const float* x, const float* dy, float* dw, void* stream) {
+  YV4_REQUIRE(d && x && dy && dw, "wgrad: null argument");
+  YV4_REQUIRE(d->Cin % 4 == 0 && d->x_cstride % 4 == 0 && d->x_coff % 4 == 0, "wgrad: input channels/stride/offset must be multiples of 4");
+  YV4_REQUIRE(d->Cout % 4 == 0 && d->y_cstride % 4 == 0 && d->y_coff % 4 == 0, "wgrad: dY channels/stride/offset must be multiples of 4");
+  YV4_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 64 && d->stride > 0, "wgrad: bad kernel/stride");
+  const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  const int Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  YV4_REQUIRE(Ho == d->Ho && Wo == d->Wo, "wgrad: Ho/Wo do not match the geometry");
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const long long xb = (long long)d->N * d->H * d->W * d->x_cstride * 4, db = M * d->y_cstride * 4;
+  YV4_REQUIRE(M < (1LL << 31) && xb < 0xFFFFFFF0LL && db < 0xFFFFFFF0LL, "wgrad: tensors of 4 GiB or more are not supported");
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.dy_cs = d->y_cstride; a.dy_co = d->y_coff;
+  a.M = (int)M; a.K = d->KH * d->KW * d->Cin;
+  a.tiles_k = (a.K + 63) / 64;
+  const int tiles_c = (a.Cout + 63) / 64;
+  const long long tiles = (long long)a.tiles_k * tiles_c;
+  // enough chunks of the reduction to fill ~4 workgroups per CU, at least 8 slices each
+  long long chunks = (256 * 4 + tiles - 1) / tiles;
+  const long long max_chunks = (M + 8 * kWgRows - 1) / (8 * kWgRows);
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  if (chunks > 65535) chunks = 65535;
+  long long rows = (M + chunks - 1) / chunks;
+  rows = (rows + kWgRows - 1) / kWgRows * kWgRows;
+  a.rows_per_chunk = (int)rows;
+  chunks = (M + rows - 1) / rows;
+  const size_t lds = (size_t)4 * kWgRows * 64 * sizeof(float);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds,
+                     reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
+  YV4_CHECK_LAUNCH("conv_wgrad");
+  return YV4_OK;
+}
+
+extern "C" int yv4_dilate2_fwd(const float* src, float* dst, int N, int H, int W, int C, int src_cstride, int src_coff,
+                               void* stream) {
+  YV4_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && C > 0, "dilate2: bad argument");
+  YV4_REQUIRE(C % 4 == 0 && src_cstride % 4 == 0 && src_coff % 4 == 0, "dilate2: channels must be multiples of 4");
+  const size_t total = (size_t)N * 2 * H * 2 * W * (C / 4);
+  hipLaunchKernelGGL(dilate2_kernel, dim3(ew_grid_t(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst,
+                     N, H, W, C / 4, src_cstride, src_coff);
+  YV4_CHECK_LAUNCH("dilate2");
+  return YV4_OK;
+}
+
+extern "C" int yv4_bn_train_stats(const float* x, int64_t M, int C, int x_cstride, int x_coff, float eps, float momentum,
+                                  double* work /* 2*C doubles */, float* mean, float* invstd, float* running_mean,
+                                  float* running_var, void* stream) {
+  YV4_REQUIRE(x && work && mean && invstd && M > 0 && C > 0, "bn_train_stats: bad argument");
+  YV4_REQUIRE(C % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0, "bn_train_stats: channels must be multiples of 4");
+  YV4_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_stats: running stats come together");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) { set_error("bn_train_stats: memset failed"); return YV4_E_LAUNCH; }
+  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows), (unsigned)((C / 4 + 63) / 64));
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, x, M, C, x_cstride, x_coff, work);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, M, C, eps, momentum, mean, invstd,
+                     running_mean, running_var);
+  YV4_CHECK_LAUNCH("bn_train_stats");
+  return YV4_OK;
+}
+
+extern "C" int yv4_bn_act_fwd(const float* x, int x_cstride, int x_coff, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, const float* residual, int r_cstride, int r_coff,
+                              float* y, int y_cstride, int y_coff, int64_t M, int C, int act, float slope, void* stream) {
+  YV4_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0, "bn_act_fwd: bad argument");
+  YV4_REQUIRE(((C | x_cstride | x_coff | y_cstride | y_coff) & 3) == 0, "bn_act_fwd: channels must be multiples of 4");
+  YV4_REQUIRE(!residual || ((r_cstride | r_coff) & 3) == 0, "bn_act_fwd: residual channels must be multiples of 4");
+  BnArgs a = {};
+  a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
+  a.res = residual; a.r_cs = r_cstride; a.r_co = r_coff; a.y = y; a.y_cs = y_cstride; a.y_co = y_coff;
+  a.M = M; a.C = C; a.act = act; a.slope = slope;
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid_t((size_t)M * (C / 4))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  YV4_CHECK_LAUNCH("bn_act_fwd");
+  return YV4_OK;
+}
+
+extern "C" int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, int dy_cstride, int dy_coff,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              float* dx, int dx_cstride, int dx_coff, float* dgamma, float* dbeta,
+                              double* work /* 2*C doubles */, int64_t M, int C, int act, float slope, void* stream) {
+  YV4_REQUIRE(x && dy && mean && invstd && gamma && beta && dx && dgamma && dbeta && work && M > 0 && C > 0,
+              "bn_act_bwd: bad argument");
+  YV4_REQUIRE(((C | x_cstride | x_coff | dy_cstride | dy_coff | dx_cstride | dx_coff) & 3) == 0,
+              "bn_act_bwd: channels must be multiples of 4");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) { set_error("bn_act_bwd: memset failed"); return YV4_E_LAUNCH; }
+  BnArgs a = {};
+  a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.dy = dy; a.dy_cs = dy_cstride; a.dy_co = dy_coff;
+  a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dx_cs = dx_cstride; a.dx_co = dx_coff;
+  a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope;
+  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows), (unsigned)((C / 4 + 63) / 64));
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid_t((size_t)M * (C / 4))), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
+  hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
+  YV4_CHECK_LAUNCH("bn_act_bwd");
+  return YV4_OK;
+}

@@ -1,0 +1,187 @@
+"""Autograd front ends of the training-side HIP kernels (``csrc/train.hip`` + the forward conv).
+
+Training does not go through launch plans: modules build an ordinary autograd graph out of
+the two Functions below, on ``torch.channels_last`` tensors (logical NCHW, physical NHWC --
+exactly the layout the kernels use, so nothing is converted).  What they replace in the
+reference: the autograd of mmcv ``ConvModule`` in train mode (cuDNN conv fwd / backward-data /
+backward-filter, ATen batch_norm with batch statistics, ``MishCudaFunction``,
+mmdet/models/backbones/darknetcsp.py:15-64, mmdet/ops/mish_cuda/mish.py:18-36).
+
+  ConvFunction    y = conv(x, w)                       fwd: fused conv kernel with an identity
+                                                       epilogue; bwd: dX = the same kernel on dY
+                                                       (zero-dilated for stride 2) with flipped,
+                                                       transposed weights, dW = yv4_conv_wgrad
+  BNActFunction   y = act(BN_batchstats(x)) (+ res)    saves only x and the batch statistics; the
+                                                       activation is recomputed in backward (the
+                                                       reference keeps conv-out, BN-out and the Mish
+                                                       input: SURVEY Q17)
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+from .ops import _need_cuda, stream_ptr
+from .plan import pack_conv_weight
+
+
+def to_nhwc(x):
+    """Logical NCHW tensor whose storage is dense NHWC."""
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _is_nhwc(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out):
+    N, _, H, W = x.shape
+    Ho, Wo = out.shape[2], out.shape[3]
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin_p, Ho, Wo, Cout
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    d.x_cstride, d.y_cstride = Cin_p, Cout
+    ones = torch.ones(Cout, device=x.device)
+    zeros = torch.zeros(Cout, device=x.device)
+    check(_lib.lib().yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w_packed.data_ptr(), ones.data_ptr(),
+                                         zeros.data_ptr(), None, None, None, out.data_ptr(), stream_ptr()),
+          'yv4_conv_bn_act_fwd')
+    return d
+
+
+class ConvFunction(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        _need_cuda(x, 'x')
+        Cout, Cin, KH, KW = weight.shape
+        assert x.shape[1] == Cin and Cin % 4 == 0 and Cout % 4 == 0, \
+            f'training conv needs channel counts that are multiples of 4 (got {Cin}->{Cout})'
+        x = to_nhwc(x.float())
+        N, _, H, W = x.shape
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W + 2 * pad - KW) // stride + 1
+        wp, cp = pack_conv_weight(weight)
+        y = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=torch.float32,
+                        memory_format=torch.channels_last)
+        _conv_launch(x, wp, cp, Cout, KH, KW, stride, pad, y)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad = ctx.geom
+        Cout, Cin, KH, KW = weight.shape
+        N, _, H, W = x.shape
+        dy = to_nhwc(dy.float())
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        L = _lib.lib()
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros((Cout, KH * KW * Cin), device=x.device, dtype=torch.float32)
+            d = ConvDesc()
+            d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
+            d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+            d.x_cstride, d.y_cstride = Cin, Cout
+            check(L.yv4_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), stream_ptr()),
+                  'yv4_conv_wgrad')
+            dw = dwp.view(Cout, KH, KW, Cin).permute(0, 3, 1, 2).contiguous()
+        if ctx.needs_input_grad[0]:
+            # dX = correlate(dY (zero-dilated by `stride`), W flipped in (kh,kw) and transposed in (co,ci))
+            wt = weight.detach().flip(2, 3).transpose(0, 1)          # (Cin, Cout, KH, KW)
+            wtp, _ = pack_conv_weight(wt)
+            if stride == 1:
+                src = dy
+            elif stride == 2:
+                src = torch.empty((N, Cout, 2 * Ho, 2 * Wo), device=x.device, dtype=torch.float32,
+                                  memory_format=torch.channels_last)
+                check(L.yv4_dilate2_fwd(dy.data_ptr(), src.data_ptr(), N, Ho, Wo, Cout, Cout, 0, stream_ptr()),
+                      'yv4_dilate2_fwd')
+            else:
+                raise NotImplementedError('conv backward: stride must be 1 or 2')
+            p2 = KH - 1 - pad
+            Hs, Ws = src.shape[2], src.shape[3]
+            Hx = Hs + 2 * p2 - KH + 1
+            Wx = Ws + 2 * p2 - KW + 1
+            dxf = torch.empty((N, Cin, Hx, Wx), device=x.device, dtype=torch.float32,
+                              memory_format=torch.channels_last)
+            _conv_launch(src, wtp, Cout, Cin, KH, KW, 1, p2, dxf)
+            if (Hx, Wx) != (H, W):
+                # stride 2 with odd input size: the dilated grid is one row/column larger or smaller
+                dx = torch.empty((N, Cin, H, W), device=x.device, dtype=torch.float32,
+                                 memory_format=torch.channels_last).zero_()
+                hh, ww = min(H, Hx), min(W, Wx)
+                dx[:, :, :hh, :ww] = dxf[:, :, :hh, :ww]
+            else:
+                dx = dxf
+        return dx, dw, None, None
+
+
+def conv2d(x, weight, stride=1, pad=0):
+    return ConvFunction.apply(x, weight, stride, pad)
+
+
+class BNActFunction(torch.autograd.Function):
+    """Train-mode BatchNorm2d + activation (+ residual add) as one forward and one backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual):
+        _need_cuda(x, 'x')
+        x = to_nhwc(x.float())
+        N, Cc, H, W = x.shape
+        assert Cc % 4 == 0, 'BatchNorm kernels need a channel count that is a multiple of 4'
+        M = N * H * W
+        dev = x.device
+        L = _lib.lib()
+        work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+        mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+        invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+        check(L.yv4_bn_train_stats(x.data_ptr(), M, Cc, Cc, 0, float(eps), float(momentum), work.data_ptr(),
+                                   mean.data_ptr(), invstd.data_ptr(),
+                                   running_mean.data_ptr() if running_mean is not None else None,
+                                   running_var.data_ptr() if running_var is not None else None, stream_ptr()),
+              'yv4_bn_train_stats')
+        res = to_nhwc(residual.float()) if residual is not None else None
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        g = gamma.detach().float().contiguous()
+        b = beta.detach().float().contiguous()
+        check(L.yv4_bn_act_fwd(x.data_ptr(), Cc, 0, mean.data_ptr(), invstd.data_ptr(), g.data_ptr(), b.data_ptr(),
+                               res.data_ptr() if res is not None else None, Cc, 0, y.data_ptr(), Cc, 0, M, Cc,
+                               int(act), float(slope), stream_ptr()), 'yv4_bn_act_fwd')
+        ctx.save_for_backward(x, mean, invstd, g, b)
+        ctx.act = (int(act), float(slope))
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, invstd, g, b = ctx.saved_tensors
+        act, slope = ctx.act
+        dy = to_nhwc(dy.float())
+        N, Cc, H, W = x.shape
+        M = N * H * W
+        dev = x.device
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
+        work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+        check(_lib.lib().yv4_bn_act_bwd(x.data_ptr(), Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(), invstd.data_ptr(),
+                                        g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0, dgamma.data_ptr(),
+                                        dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope, stream_ptr()),
+              'yv4_bn_act_bwd')
+        dres = dy if ctx.has_res else None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres
+
+
+def bn_act(x, bn, act=(0, 0.0), residual=None):
+    """``bn`` is a torch BatchNorm2d in training mode; act = (YV4_ACT_*, slope)."""
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    out = BNActFunction.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                              bn.running_var if bn.track_running_stats else None, bn.eps, mom, act[0], act[1],
+                              residual)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return out

@@ -1,0 +1,100 @@
+"""Training-side HIP ops (conv backward-data / backward-filter, train-mode BN+act) through their
+autograd front ends, against torch CPU autograd in fp64.  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mmdet_yolov4_amd as pkg
+from mmdet_yolov4_amd import train_ops as T
+from oracle import yolov4_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(got, ref):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize('shape', [
+    # N, Cin, H, W, Cout, k, stride, pad
+    (2, 32, 13, 17, 64, 3, 1, 1),
+    (2, 64, 9, 9, 32, 1, 1, 0),
+    (2, 32, 16, 20, 64, 3, 2, 1),      # stride 2, even size
+    (1, 32, 15, 19, 32, 3, 2, 1),      # stride 2, odd size (dilated grid cropped)
+    (2, 24, 10, 10, 40, 3, 1, 1),      # Cin, Cout not multiples of 32/64
+    (2, 4, 12, 12, 16, 3, 1, 1),       # stem-like (padded image), weight gradient only
+    (3, 128, 19, 19, 128, 3, 1, 1),    # several reduction chunks
+])
+def test_conv_forward_backward(gpu_device, shape):
+    N, Cin, H, W, Cout, k, s, p = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    need_dx = Cin != 4
+    xr = x.double().requires_grad_(need_dx)
+    wr = w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, s, p)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+
+    xd = x.to(gpu_device).requires_grad_(need_dx)
+    wd = w.to(gpu_device).requires_grad_(True)
+    y = T.conv2d(xd, wd, s, p)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy.to(gpu_device))
+    assert rel(y, yr) < 2e-5
+    assert rel(wd.grad, wr.grad) < 5e-5, 'dW'
+    if need_dx:
+        assert rel(xd.grad, xr.grad) < 5e-5, 'dX'
+
+
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_bn_act_forward_backward(gpu_device, act, with_res):
+    g = torch.Generator().manual_seed(act * 2 + int(with_res))
+    N, Cc, H, W = 3, 24, 7, 9
+    x = torch.randn(N, Cc, H, W, generator=g) * 1.5 + 0.3
+    res = torch.randn(N, Cc, H, W, generator=g) if with_res else None
+    gy = torch.randn(N, Cc, H, W, generator=g)
+    acts = {0: lambda v: v, 1: O.mish, 2: lambda v: F.leaky_relu(v, 0.1), 3: lambda v: v * torch.sigmoid(v)}
+
+    bn_ref = torch.nn.BatchNorm2d(Cc, eps=1e-3, momentum=0.03).double()
+    bn = torch.nn.BatchNorm2d(Cc, eps=1e-3, momentum=0.03).to(gpu_device)
+    with torch.no_grad():
+        wv = torch.rand(Cc, generator=g) + 0.5
+        bv = torch.randn(Cc, generator=g) * 0.2
+        for m in (bn_ref, bn):
+            m.weight.copy_(wv); m.bias.copy_(bv)
+    xr = x.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_res else None
+    yr = acts[act](bn_ref(xr))
+    if with_res:
+        yr = yr + rr
+    yr.backward(gy.double())
+
+    xd = x.to(gpu_device).requires_grad_(True)
+    rd = res.to(gpu_device).requires_grad_(True) if with_res else None
+    y = T.bn_act(xd, bn, (act, 0.1), rd)
+    y.backward(gy.to(gpu_device))
+    assert rel(y, yr) < 1e-5
+    assert rel(xd.grad, xr.grad) < 1e-4, 'dx'
+    assert rel(bn.weight.grad, bn_ref.weight.grad) < 1e-4, 'dgamma'
+    assert rel(bn.bias.grad, bn_ref.bias.grad) < 1e-4, 'dbeta'
+    if with_res:
+        assert rel(rd.grad, rr.grad) < 1e-6
+    assert rel(bn.running_mean, bn_ref.running_mean) < 1e-5 and rel(bn.running_var, bn_ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_wgrad_rejects_unaligned(gpu_device):
+    import ctypes
+    lib = pkg._lib.lib()
+    d = pkg._lib.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad = 1, 8, 8, 8, 8, 8, 255, 1, 1, 1, 0
+    d.x_cstride, d.y_cstride = 8, 255
+    t = torch.zeros(1 << 16, device=gpu_device)
+    assert lib.yv4_conv_wgrad(ctypes.byref(d), t.data_ptr(), t.data_ptr(), t.data_ptr(), None) == -1
