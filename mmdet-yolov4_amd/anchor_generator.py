@@ -68,11 +68,59 @@ class YOLOAnchorGenerator:
 
 @ANCHOR_GENERATORS.register_module()
 class YOLOV4AnchorGenerator(YOLOAnchorGenerator):
-    """yolov4_anchor_generator.py:8.  ``responsible_indices`` (training target
-    assignment, :12-134) belongs to the training row of the scope table and is not
-    built yet."""
+    """yolov4_anchor_generator.py:8 (+ training target assignment, :12-134)."""
+
+    _NEIGHBOR_OFFSET = [[0, 0], [-1, 0], [0, -1], [1, 0], [0, 1], [-1, -1], [1, -1], [1, 1], [-1, 1]]
 
     def responsible_indices(self, featmap_sizes, gt_bboxes_list, neighbor=3, shape_match_thres=4.,
                             device='cuda'):
-        raise NotImplementedError(
-            'YOLOV4AnchorGenerator.responsible_indices (training) is not built yet: see DESIGN.md scope')
+        """yolov4_anchor_generator.py:12-134: per level ``(img_idx, anchor_idx, gt_idx)`` of the
+        anchors made responsible for each ground truth: shape test ``max(r, 1/r).max() < thres`` between
+        the level's base anchors and the gt, then the gt's own cell plus the neighbour cells selected by
+        ``neighbor`` (0 none, 1 nearest, 2 the two nearest as in YOLOv5, 3 all eight candidates)."""
+        img_id = [g.new_full((g.shape[0],), i, dtype=torch.long) for i, g in enumerate(gt_bboxes_list)]
+        gt = torch.cat(gt_bboxes_list, dim=0)
+        img_id = torch.cat(img_id, dim=0).to(device)
+        if gt.shape[0] == 0:
+            e = torch.tensor([], device=device, dtype=torch.long)
+            return [(e, e.clone(), e.clone()) for _ in range(self.num_levels)]
+        gt_xy = (0.5 * (gt[:, 2:4] + gt[:, :2])).to(device)
+        gt_wh = (gt[:, 2:4] - gt[:, :2]).to(device)
+        noff = gt_xy.new_tensor(self._NEIGHBOR_OFFSET)
+        out = []
+        for i in range(self.num_levels):
+            fh, fw = featmap_sizes[i]
+            A = self.num_base_anchors[i]
+            base = self.base_anchors[i].to(device)
+            base_wh = base[:, 2:] - base[:, :2]
+            dev = gt_wh[None, :, :] / base_wh[:, None, :]
+            dev = torch.max(dev, 1. / dev).max(dim=2).values
+            a_ind, g_ind = (dev < shape_match_thres).nonzero(as_tuple=True)
+            feat = gt_xy.new_tensor([[fw, fh]])
+            xy = gt_xy[g_ind] / gt_xy.new_tensor([self.strides[i]])
+            inv = feat - xy
+            if neighbor == 0:
+                px, py = xy.long().T
+                anchor = (py * fw + px) * A + a_ind
+            else:
+                left, up = ((xy % 1. < 0.5) & (xy > 1.)).T
+                right, down = ((inv % 1. < 0.5) & (inv > 1.)).T
+                rows = [torch.ones_like(left), left, up, right, down]
+                if neighbor == 1:
+                    ok = torch.stack(rows)
+                    if ok.numel() > 0:
+                        dist = torch.cat((xy, inv), dim=-1) % 1.
+                        ok[1:] = ok[1:] & (dist == dist.min(dim=-1).values[:, None]).T
+                elif neighbor == 2:
+                    ok = torch.stack(rows)
+                elif neighbor == 3:
+                    ok = torch.stack(rows + [left & up, right & up, right & down, left & down])
+                else:
+                    raise NotImplementedError
+                n = ok.shape[0]
+                g_ind = g_ind.repeat((n, 1))[ok]
+                a_ind = a_ind.repeat((n, 1))[ok]
+                px, py = (xy[None, :, :] + noff[:n, None, :])[ok].long().T
+                anchor = (py * fw + px) * A + a_ind
+            out.append((img_id[g_ind], anchor, g_ind))
+        return out

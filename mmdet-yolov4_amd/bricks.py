@@ -143,10 +143,10 @@ def apply_init_cfg(module, init_cfg):
 
 # ---- plan-backed module base -------------------------------------------------------------
 class HipModule(nn.Module):
-    """Base of every registered module.  ``forward`` compiles (once per input geometry and
-    parameter version) the module's own launch plan via ``emit`` and replays it; NCHW in,
-    NCHW out, like the reference's modules.  Training-mode forward (batch-statistics BN,
-    autograd) is the next scope row and raises."""
+    """Base of every registered module.  In eval mode ``forward`` compiles (once per input
+    geometry and parameter version) the module's own launch plan via ``emit`` and replays it;
+    in training mode it runs ``fwd``: an autograd graph over the HIP training ops
+    (``train_ops.py``).  NCHW in, NCHW out, like the reference's modules."""
 
     def __init__(self, init_cfg=None):
         super().__init__()
@@ -166,6 +166,17 @@ class HipModule(nn.Module):
 
     def emit(self, plan, *xs):  # pragma: no cover - abstract
         raise NotImplementedError
+
+    def fwd(self, *xs):  # pragma: no cover - abstract
+        """Training-mode forward on channels_last tensors through the autograd HIP ops."""
+        raise NotImplementedError
+
+    def _dispatch(self, args, structure):
+        """forward() of every registered module: training mode -> autograd graph over the HIP
+        training ops (batch-statistics BN); eval mode -> fused launch plan."""
+        if self.training:
+            return self.fwd(*args)
+        return self._run_plan(args, structure)
 
     def _param_version(self):
         v = 0
@@ -193,11 +204,10 @@ class HipModule(nn.Module):
             ops._need_cuda(t, 'input')
             if t.dtype != torch.float32:
                 raise RuntimeError(f'{type(self).__name__}: the HIP path computes in fp32; got {t.dtype}')
-        if self.training and any(isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training
-                                 for m in self.modules()):
+        if torch.is_grad_enabled() and any(t.requires_grad for t in flat):
             raise NotImplementedError(
-                f'{type(self).__name__}.forward in training mode (batch-statistics BN + autograd) is '
-                'not built yet; call .eval() -- see DESIGN.md "out of scope this round"')
+                f'{type(self).__name__}: the eval-mode (fused launch plan) path has no autograd; call .train() '
+                'to differentiate through the HIP training ops')
         key = (tuple(tuple(t.shape) for t in flat), str(flat[0].device), self._param_version())
         plan = self._plan_cache.get(key)
         if plan is None:

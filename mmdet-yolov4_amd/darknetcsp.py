@@ -18,9 +18,11 @@ import warnings
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.modules.batchnorm import _BatchNorm
 
 from .bricks import (HipModule, build_activation_layer, build_norm_layer, _NO_INPLACE)
+from . import train_ops as T
 from .plan import act_id, bn_affine
 from .registry import BACKBONES
 
@@ -87,8 +89,30 @@ class Conv(HipModule):
                          name=name or f'conv{self.kernel_size}x{self.kernel_size}',
                          bn1=(self.norm, 0, self.out_channels) if self.with_norm else None, bn2=bn2)
 
+    def fwd(self, x, residual=None):
+        w = self.conv.weight
+        if x.shape[1] % 4:           # the 3-channel image: zero-pad x and the weight to 4 input channels
+            padc = 4 - x.shape[1] % 4
+            x = F.pad(x, (0, 0, 0, 0, 0, padc))
+            w = F.pad(w, (0, 0, 0, 0, 0, padc))
+        y = T.conv2d(x, w, self.stride, self.padding)
+        if self.with_norm:
+            if not self.norm.training:
+                raise NotImplementedError('eval-mode BatchNorm inside a training graph (norm_eval / frozen '
+                                          'stages) is not built')
+            return T.bn_act(y, self.norm, act_id(self.activate), residual)
+        if self.conv.bias is not None:
+            y = y + self.conv.bias.view(1, -1, 1, 1)
+        if self.activate is not None:
+            y = self.activate(y)
+        return y if residual is None else y + residual
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
+
+
+def bare_conv_fwd(conv, x):
+    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0])
 
 
 def emit_bare_conv(plan, conv, x, stage, out=None, name='conv1x1_bare'):
@@ -121,8 +145,11 @@ class Bottleneck(HipModule):
         y = self.conv1.emit(plan, x)
         return self.conv2.emit(plan, y, out=out, residual=x if self.shortcut else None, post=post)
 
+    def fwd(self, x):
+        return self.conv2.fwd(self.conv1.fwd(x), residual=x if self.shortcut else None)
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
 
 def _emit_chain(plan, bottlenecks, x, out=None, post=None):
@@ -167,8 +194,15 @@ class BottleneckCSP(HipModule):
         emit_bare_conv(plan, self.conv2, x, half1, out=cat.slice(h, h), name='csp_conv2')
         return self.conv4.emit(plan, cat, out=out)
 
+    def fwd(self, x):
+        y = self.conv1.fwd(x)
+        for b in self.bottlenecks:
+            y = b.fwd(y)
+        z = torch.cat((bare_conv_fwd(self.conv3, y), bare_conv_fwd(self.conv2, x)), dim=1)
+        return self.conv4.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
 
 class BottleneckCSP2(HipModule):
@@ -202,8 +236,16 @@ class BottleneckCSP2(HipModule):
         emit_bare_conv(plan, self.conv2, x1, half1, out=cat.slice(h, h), name='csp2_conv2')
         return self.conv3.emit(plan, cat, out=out)
 
+    def fwd(self, x):
+        x1 = self.conv1.fwd(x)
+        y1 = x1
+        for b in self.bottlenecks:
+            y1 = b.fwd(y1)
+        z = torch.cat((y1, bare_conv_fwd(self.conv2, x1)), dim=1)
+        return self.conv3.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
 
 class SPPV5(HipModule):
@@ -227,8 +269,12 @@ class SPPV5(HipModule):
         plan.spp(cat, h)
         return self.conv2.emit(plan, cat, out=out)
 
+    def fwd(self, x):
+        x = self.conv1.fwd(x)
+        return self.conv2.fwd(torch.cat([x] + [mp(x) for mp in self.maxpools], 1))
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
 
 class SPPV4(HipModule):
@@ -268,8 +314,14 @@ class SPPV4(HipModule):
         emit_bare_conv(plan, self.conv2, x, half1, out=cat.slice(h, h), name='sppv4_conv2')
         return self.conv7.emit(plan, cat, out=out)
 
+    def fwd(self, x):
+        x1 = self.conv4.fwd(self.conv3.fwd(self.conv1.fwd(x)))
+        y1 = self.conv6.fwd(self.conv5.fwd(torch.cat([x1] + [mp(x1) for mp in self.maxpools], 1)))
+        z = torch.cat((y1, bare_conv_fwd(self.conv2, x)), dim=1)
+        return self.conv7.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
 
 class Focus(HipModule):
@@ -284,8 +336,11 @@ class Focus(HipModule):
     def emit(self, plan, x, out=None):
         return self.conv.emit(plan, x, out=out)
 
+    def fwd(self, x):
+        return self.conv.fwd(x)
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
 
 class CSPStage(HipModule):
@@ -299,8 +354,11 @@ class CSPStage(HipModule):
     def emit(self, plan, x, out=None):
         return self.conv_csp.emit(plan, self.conv_downscale.emit(plan, x), out=out)
 
+    def fwd(self, x):
+        return self.conv_csp.fwd(self.conv_downscale.fwd(x))
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
 
 class SPPV5Stage(HipModule):
@@ -316,8 +374,11 @@ class SPPV5Stage(HipModule):
         y = self.conv_downscale.emit(plan, x)
         return self.conv_csp.emit(plan, self.spp.emit(plan, y), out=out)
 
+    def fwd(self, x):
+        return self.conv_csp.fwd(self.spp.fwd(self.conv_downscale.fwd(x)))
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
 
 class SPPV4Stage(HipModule):
@@ -333,8 +394,11 @@ class SPPV4Stage(HipModule):
         y = self.conv_csp.emit(plan, self.conv_downscale.emit(plan, x))
         return self.spp.emit(plan, y, out=out)
 
+    def fwd(self, x):
+        return self.spp.fwd(self.conv_csp.fwd(self.conv_downscale.fwd(x)))
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
 
 class BottleneckStage(HipModule):
@@ -349,8 +413,11 @@ class BottleneckStage(HipModule):
     def emit(self, plan, x, out=None):
         return self.conv_bottleneck.emit(plan, self.conv_downscale.emit(plan, x), out=out)
 
+    def fwd(self, x):
+        return self.conv_bottleneck.fwd(self.conv_downscale.fwd(x))
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
 
 _STAGES = dict(bottleneck=BottleneckStage, csp=CSPStage, sppv4=SPPV4Stage, sppv5=SPPV5Stage)
@@ -429,8 +496,16 @@ class DarknetCSP(HipModule):
                 outs.append(x)
         return tuple(outs)
 
+    def fwd(self, x):
+        outs = []
+        for i, layer_name in enumerate(self.layers):
+            x = getattr(self, layer_name).fwd(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
     def forward(self, x):
-        return self._run_plan((x,), 'flat')
+        return self._dispatch((x,), 'flat')
 
     def _freeze_stages(self):
         if self.frozen_stages >= 0:

@@ -10,8 +10,11 @@ SPP, 2 upsamples, decode+filter, NMS -- built once per (batch, height, width) by
 ``compile``; the host touches the device twice per batch (scale factors in, detections
 out).
 """
+from collections import OrderedDict
+
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from .bricks import HipModule
 from .plan import Plan
@@ -126,4 +129,32 @@ class SingleStageDetector(HipModule):
         return self.forward_test(img, img_metas, **kwargs)
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
-        raise NotImplementedError('SingleStageDetector.forward_train is not built yet: see DESIGN.md scope')
+        """single_stage.py:51-79: features through the HIP training ops, then the head's losses."""
+        x = self.extract_feat(img)
+        return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore)
+
+    def _parse_losses(self, losses):
+        """detectors/base.py:171-204: total = sum of the entries whose key contains 'loss'; every
+        log variable is averaged over ranks (one small all-reduce each, as the reference does)."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        for name, value in log_vars.items():
+            if dist.is_available() and dist.is_initialized():
+                value = value.data.clone()
+                dist.all_reduce(value.div_(dist.get_world_size()))
+            log_vars[name] = value.item()
+        return loss, log_vars
+
+    def train_step(self, data, optimizer):
+        """detectors/base.py:206-239."""
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))

@@ -6,7 +6,9 @@ writing the upsampled half of the concat buffer while the lateral 1x1 conv write
 other half directly; the bottom-up ``cat`` (:229) is a strided conv writing half 0 and a
 channel-slice copy of the saved top-down tensor into half 1.
 """
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .bricks import HipModule
 from .darknetcsp import BottleneckCSP, BottleneckCSP2, Conv
@@ -46,8 +48,13 @@ class _PANBase(HipModule):
             return int(x.H * sf), int(x.W * sf)
         return bottom.H, bottom.W
 
+    def _up(self, x, bottom):
+        if 'scale_factor' in self.upsample_cfg:
+            return F.interpolate(x, **self.upsample_cfg)
+        return F.interpolate(x, size=bottom.shape[2:], **self.upsample_cfg)
+
     def forward(self, inputs):
-        return self._run_plan((tuple(inputs),), 'tuple')
+        return self._dispatch((tuple(inputs),), 'tuple')
 
 
 @NECKS.register_module()
@@ -138,6 +145,23 @@ class YOLOV4Neck(_PANBase):
             outs.append(x)
         return tuple(self.out_convs[i].emit(plan, outs[i]) for i in range(len(outs)))
 
+    def fwd(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        used = self.backbone_end_level - self.start_level
+        x = inputs[self.backbone_end_level - 1]
+        merge = []
+        for i in range(used - 1, 0, -1):
+            bottom = self.backbone_pre_concat_convs[i - 1].fwd(inputs[self.start_level + i - 1])
+            merge.append(x)
+            x = self._up(self.pre_upsample_convs[i - 1].fwd(x), bottom)
+            x = self.post_upsample_concat_csp[i - 1].fwd(torch.cat((bottom, x), dim=1))
+        outs = [x]
+        for i in range(used - 1):
+            x = torch.cat((self.downsample_convs[i].fwd(x), merge.pop(-1)), dim=1)
+            x = self.post_downsample_concat_csp[i].fwd(x)
+            outs.append(x)
+        return tuple(self.out_convs[i].fwd(outs[i]) for i in range(len(outs)))
+
 
 @NECKS.register_module()
 class YOLOV5Neck(_PANBase):
@@ -214,5 +238,22 @@ class YOLOV5Neck(_PANBase):
             down.emit(plan, x, out=cat.slice(0, c))
             plan.resample(top, cat.slice(c, c), name='concat_copy')
             x = csp.emit(plan, cat)
+            outs.append(x)
+        return tuple(outs)
+
+    def fwd(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        used = self.backbone_end_level - self.start_level
+        x = inputs[self.backbone_end_level - 1]
+        merge = []
+        for i in range(used - 1, 0, -1):
+            bottom = inputs[self.start_level + i - 1]
+            x = self.pre_upsample_convs[i - 1].fwd(x)
+            merge.append(x)
+            x = self.post_upsample_concat_csp[i - 1].fwd(torch.cat((bottom, self._up(x, bottom)), dim=1))
+        outs = [x]
+        for i in range(used - 1):
+            x = torch.cat((self.downsample_convs[i].fwd(x), merge.pop(-1)), dim=1)
+            x = self.post_downsample_concat_csp[i].fwd(x)
             outs.append(x)
         return tuple(outs)

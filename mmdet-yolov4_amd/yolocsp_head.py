@@ -16,8 +16,11 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from . import losses as _losses  # noqa: F401  (registers GIoULoss / CrossEntropyLoss / SoftFocalLoss)
 from . import ops
+from . import train_ops as T
 from .bricks import HipModule, normal_init
 from .plan import Plan
 from .registry import HEADS, LOSSES, ConfigDict, build_anchor_generator, build_bbox_coder, build_loss
@@ -67,9 +70,11 @@ class YOLOCSPHead(HipModule):
         self.class_agnostic = class_agnostic
         if class_agnostic:
             raise NotImplementedError('class_agnostic heads have no fused decode kernel yet')
-        # loss configs are kept for the training row of the scope table (not built yet)
-        self.loss_cls_cfg, self.loss_conf_cfg, self.loss_bbox_cfg = loss_cls, loss_conf, loss_bbox
-        self.loss_bbox_weight = dict(loss_bbox).get('loss_weight', 1.0)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_conf = build_loss(loss_conf)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.loss_bbox_weight = self.loss_bbox.loss_weight      # yolocsp_head.py:160-162
+        self.loss_bbox.loss_weight = 1.
         self.num_anchors = self.anchor_generator.num_base_anchors
         self._init_layers()
         self.fp16_enabled = False
@@ -132,8 +137,23 @@ class YOLOCSPHead(HipModule):
             rescale=rescale, want_cls=want_cls)
 
     # ---- reference API ----------------------------------------------------------------------
+    def fwd(self, feats):
+        """Training-mode head forward: biased 1x1 convs through the HIP conv (output channels padded
+        255 -> 256 so that the gradient w.r.t. the pred map is a 16-byte aligned NHWC tensor)."""
+        assert len(feats) == self.num_levels
+        outs = []
+        for conv, x in zip(self.convs_pred, feats):
+            co = conv.out_channels
+            w = conv.weight
+            padc = (-co) % 4
+            if padc:
+                w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, padc))
+            y = T.conv2d(x, w, 1, 0)[:, :co]
+            outs.append(y + conv.bias.view(1, -1, 1, 1))
+        return tuple(outs)
+
     def forward(self, feats):
-        return self._run_plan((tuple(feats),), 'tuple'),
+        return self._dispatch((tuple(feats),), 'tuple'),
 
     def get_bboxes(self, pred_maps, img_metas, cfg=None, rescale=False, with_nms=True):
         """pred_maps: NCHW tensors as returned by ``forward``.  Returns
@@ -158,11 +178,79 @@ class YOLOCSPHead(HipModule):
         plan.run(*[p.float() for p in pred_maps])
         return collect_results(plan.post, with_nms=with_nms, head=self)
 
-    def loss(self, *args, **kwargs):
-        raise NotImplementedError('YOLOCSPHead.loss (training) is not built yet: see DESIGN.md scope')
+    # ---- training (yolocsp_head.py:384-575) -------------------------------------------------------
+    def loss(self, pred_maps, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
+        num_gts = pred_maps[0].new_tensor([g.size(0) for g in gt_bboxes]).mean()
+        pred_maps = [p.float() for p in pred_maps]
+        device = pred_maps[0].device
+        featmap_sizes = [pred_maps[i].shape[-2:] for i in range(self.num_levels)]
+        if self.assigner is not None:
+            raise NotImplementedError
+        resp = self.anchor_generator.responsible_indices(
+            featmap_sizes, gt_bboxes, neighbor=2, shape_match_thres=self.shape_match_thres, device=device)
+        pos, tb, tl = self.get_targets_no_assigner(resp, gt_bboxes, gt_labels)
+        anchors = self.anchor_generator.grid_anchors(featmap_sizes, device)
+        l_cls, l_conf, l_box = [], [], []
+        for lvl in range(self.num_levels):
+            c, f, b = self.loss_single_no_assigner(pred_maps[lvl], anchors[lvl], self.featmap_strides[lvl],
+                                                   pos[lvl], tb[lvl], tl[lvl])
+            l_cls.append(c)
+            l_conf.append(f * self.conf_level_balance_weight[lvl])
+            l_box.append(b)
+        if not self.class_agnostic:
+            return dict(loss_cls=l_cls, loss_conf=l_conf, loss_bbox=l_box, num_gts=num_gts)
+        return dict(loss_conf=l_conf, loss_bbox=l_box, num_gts=num_gts)
 
-    def forward_train(self, *args, **kwargs):
-        raise NotImplementedError('YOLOCSPHead.forward_train (training) is not built yet: see DESIGN.md scope')
+    def loss_single_no_assigner(self, pred_map, anchors, stride, pos_indices, target_bboxes, target_labels):
+        num_imgs = len(pred_map)
+        pred_map = pred_map.permute(0, 2, 3, 1).reshape(num_imgs, -1, self.num_attrib)
+        img_ind, anchor_ind = pos_indices
+        pred_conf = pred_map[..., 4]
+        target_conf = torch.zeros_like(pred_conf, requires_grad=False)
+        loss_bbox = pred_map.new_zeros((1,))
+        loss_cls = pred_map.new_zeros((1,))
+        if anchor_ind.numel():
+            pos = pred_map[img_ind, anchor_ind]
+            pb = pos[..., :4].sigmoid()
+            xy = pb[..., :2] * 2. - 1.
+            wh = (pb[..., 2:] * 2.) ** 2.
+            box = self.bbox_coder.decode(anchors[anchor_ind], torch.cat((xy, wh), dim=-1), stride)
+            giou_loss = self.loss_bbox(box, target_bboxes, reduction_override='none')
+            loss_bbox = loss_bbox + _losses.reduce_loss(giou_loss, self.loss_bbox.reduction)
+            if not self.class_agnostic:
+                loss_cls = loss_cls + self.loss_cls(pos[..., 5:], target_labels)
+            r = self.conf_iou_loss_ratio
+            conf_t = (1 - r) + r * (1 - giou_loss).detach().clamp(0.0, 1.0)
+            target_conf[img_ind, anchor_ind] = conf_t.type(target_conf.dtype)
+        loss_conf = self.loss_conf(pred_conf, target_conf)
+        return loss_cls, loss_conf, loss_bbox * self.loss_bbox_weight
+
+    def get_targets_no_assigner(self, responsible_indices_list, gt_bboxes_list, gt_labels_list):
+        gt_bboxes = torch.cat(gt_bboxes_list, dim=0)
+        gt_labels = torch.cat(gt_labels_list, dim=0)
+        pos, tb, tl = [], [], []
+        for lvl in range(self.num_levels):
+            img_ind, anchor_ind, gt_ind = responsible_indices_list[lvl]
+            pos.append((img_ind, anchor_ind))
+            tb.append(gt_bboxes[gt_ind])
+            t = F.one_hot(gt_labels[gt_ind], num_classes=self.num_classes).float()
+            if self.one_hot_smoother != 0:
+                t = t * (1 - self.one_hot_smoother) + self.one_hot_smoother / self.num_classes
+            tl.append(t)
+        return pos, tb, tl
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
+                      **kwargs):
+        """base_dense_head.py:22-59."""
+        outs = self(x)
+        if gt_labels is None:
+            loss_inputs = outs + (gt_bboxes, img_metas)
+        else:
+            loss_inputs = outs + (gt_bboxes, gt_labels, img_metas)
+        losses = self.loss(*loss_inputs, gt_bboxes_ignore=gt_bboxes_ignore)
+        if proposal_cfg is None:
+            return losses
+        return losses, self.get_bboxes(*outs, img_metas, cfg=proposal_cfg)
 
 
 def set_scale_factors(post, img_metas, rescale):

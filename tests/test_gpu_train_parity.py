@@ -1,0 +1,91 @@
+"""One training-mode forward + backward of the registered detector on the HIP training ops vs the
+golden vectors the REFERENCE produced for the same weights, batch and ground truth
+(tests/golden/train_v4.npz): losses, gradients of every parameter, BN running statistics.
+
+Tolerances: losses 1e-4 relative; gradients are compared per tensor on |g|_1 and |g|_2 (1 %) and,
+for the stored tensors, elementwise with an absolute tolerance of 0.2 % of the tensor's max (the
+weights in front of a batch-stat BN receive differences of large sums)."""
+import numpy as np
+import pytest
+import torch
+
+import mmdet_yolov4_amd as pkg
+from conftest import arch_from, state_dict_from
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(g, dev):
+    stages, reps, chans = arch_from(g)
+    cfg = dict(type='SingleStageDetector',
+               backbone=dict(type='DarknetCSP', scale=[stages, reps, chans], out_indices=[3, 4, 5]),
+               neck=dict(type='YOLOV4Neck', in_channels=[32, 64, 64], out_channels=[32, 64, 128], csp_repetition=1),
+               bbox_head=dict(type='YOLOCSPHead', num_classes=80, in_channels=[32, 64, 128]),
+               train_cfg=None,
+               test_cfg=dict(nms_pre=-1, score_thr=0.001, nms=dict(type='nms', iou_threshold=0.65), max_per_img=300))
+    det = pkg.build_detector(cfg)
+    det.load_state_dict(state_dict_from(g), strict=True)
+    return det.to(dev)
+
+
+def test_train_step_matches_reference(golden, gpu_device):
+    g = golden('train_v4')
+    det = _build(g, gpu_device).train()
+    img = torch.from_numpy(g['img']).to(gpu_device)
+    gtb = [torch.from_numpy(g['gt_bboxes0']).to(gpu_device), torch.from_numpy(g['gt_bboxes1']).to(gpu_device)]
+    gtl = [torch.from_numpy(g['gt_labels0']).to(gpu_device), torch.from_numpy(g['gt_labels1']).to(gpu_device)]
+    metas = [dict(), dict()]
+    out = det.train_step(dict(img=img, img_metas=metas, gt_bboxes=gtb, gt_labels=gtl), None)
+    assert out['num_samples'] == 2
+    np.testing.assert_allclose(out['log_vars']['loss'], float(g['loss_total']), rtol=1e-4)
+    np.testing.assert_allclose(out['log_vars']['loss_cls'], float(g['loss/loss_cls'].sum()), rtol=1e-4)
+    np.testing.assert_allclose(out['log_vars']['loss_conf'], float(g['loss/loss_conf'].sum()), rtol=1e-4)
+    np.testing.assert_allclose(out['log_vars']['loss_bbox'], float(g['loss/loss_bbox'].sum()), rtol=1e-4)
+    out['loss'].backward()
+    params = dict(det.named_parameters())
+    names = [str(n) for n in g['grad_names']]
+    assert names == list(params)
+    sums = g['grad_sums']
+    for i, n in enumerate(names):
+        gr = params[n].grad
+        assert gr is not None, n
+        gr = gr.double()
+        got = np.array([float(gr.abs().sum()), float(gr.pow(2).sum().sqrt())])
+        np.testing.assert_allclose(got, sums[i][1:], rtol=1e-2, atol=1e-5, err_msg=n)
+    for k in g.files:
+        if k.startswith('grad/'):
+            ref = g[k]
+            np.testing.assert_allclose(params[k[5:]].grad.cpu().numpy(), ref, rtol=1e-2,
+                                       atol=2e-3 * float(np.abs(ref).max()) + 2e-5, err_msg=k)
+        if k.startswith('after/'):
+            got = dict(det.named_buffers())[k[6:]].cpu().numpy()
+            np.testing.assert_allclose(got, g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_eval_path_has_no_autograd(gpu_device):
+    conv = pkg.Conv(8, 8, 3).to(gpu_device).eval()
+    x = torch.randn(1, 8, 6, 6, device=gpu_device, requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        conv(x)
+    y = conv.train()(x)               # training mode differentiates
+    y.sum().backward()
+    assert x.grad is not None and conv.conv.weight.grad is not None
+
+
+def test_sgd_steps_reduce_the_loss(golden, gpu_device):
+    """A few SGD steps on one batch through the HIP training ops must drive the loss down."""
+    g = golden('train_v4')
+    det = _build(g, gpu_device).train()
+    img = torch.from_numpy(g['img']).to(gpu_device)
+    gtb = [torch.from_numpy(g['gt_bboxes0']).to(gpu_device), torch.from_numpy(g['gt_bboxes1']).to(gpu_device)]
+    gtl = [torch.from_numpy(g['gt_labels0']).to(gpu_device), torch.from_numpy(g['gt_labels1']).to(gpu_device)]
+    opt = torch.optim.SGD(det.parameters(), lr=1e-3, momentum=0.9, nesterov=True)
+    hist = []
+    for _ in range(8):
+        opt.zero_grad()
+        out = det.train_step(dict(img=img, img_metas=[dict(), dict()], gt_bboxes=gtb, gt_labels=gtl), opt)
+        out['loss'].backward()
+        torch.nn.utils.clip_grad_norm_(det.parameters(), 35)
+        opt.step()
+        hist.append(out['log_vars']['loss'])
+    assert hist[-1] < 0.7 * hist[0], hist

@@ -136,9 +136,16 @@ def test_config_fromfile_base_and_delete(tmp_path):
     assert sum(p.numel() for p in det.backbone.parameters()) + sum(p.numel() for p in det.neck.parameters()) > 9e6
 
 
-def test_training_entry_points_say_not_built():
-    det = pkg.build_detector(V4L)
-    with pytest.raises(NotImplementedError):
-        det.forward_train(None, None, None, None)
-    with pytest.raises(NotImplementedError):
-        det.bbox_head.loss()
+def test_head_loss_on_cpu_tensors_matches_oracle(golden):
+    """The loss side is tensor ops (like the reference's): check it against the oracle on the
+    reference's pred maps without a GPU."""
+    g = golden('train_v4')
+    head = pkg.YOLOCSPHead(num_classes=80, in_channels=[32, 64, 128])
+    preds = [torch.from_numpy(g[f'pred{i}']) for i in range(3)]
+    gtb = [torch.from_numpy(g['gt_bboxes0']), torch.from_numpy(g['gt_bboxes1'])]
+    gtl = [torch.from_numpy(g['gt_labels0']), torch.from_numpy(g['gt_labels1'])]
+    L = head.loss(preds, gtb, gtl, [dict(), dict()])
+    for k in ('loss_cls', 'loss_conf', 'loss_bbox'):
+        got = torch.stack([x.reshape(()) for x in L[k]]).numpy()
+        np.testing.assert_allclose(got, g['loss/' + k], rtol=1e-6, atol=1e-7)
+    assert float(L['num_gts']) == 2.5
