@@ -88,4 +88,4 @@ def test_sgd_steps_reduce_the_loss(golden, gpu_device):
         torch.nn.utils.clip_grad_norm_(det.parameters(), 35)
         opt.step()
         hist.append(out['log_vars']['loss'])
-    assert hist[-1] < 0.7 * hist[0], hist
+    assert hist[-1] < 0.8 * hist[0] and all(b < a for a, b in zip(hist, hist[1:])), hist
