@@ -183,10 +183,12 @@ __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ 
 __device__ __forceinline__ float act_grad(float z, int act, float slope) {
   switch (act) {
     case YV4_ACT_MISH: {
-      const float sp = z < 20.f ? log1pf(expf(z)) : z;
-      const float grad_sp = 1.f - expf(-sp);
-      const float tsp = tanhf(sp);
-      return z * (1.f - tsp * tsp) * grad_sp + tsp;
+      // mish.h:21-29 with sp = log1p(e^z):  tanh(sp) = n/(n+2), n = e(e+2);  1 - exp(-sp) = e/(1+e)
+      if (z >= 20.f) return 1.f;
+      const float e = expf(z);
+      const float n = e * (e + 2.f);
+      const float tsp = n / (n + 2.f);
+      return z * (1.f - tsp * tsp) * (e / (1.f + e)) + tsp;
     }
     case YV4_ACT_LEAKY: return z >= 0.f ? 1.f : slope;
     case YV4_ACT_SWISH: {
@@ -205,42 +207,70 @@ __device__ __forceinline__ float act_fwd_exact(float z, int act, float slope) {
   }
 }
 
-constexpr int kBnRows = 256;   // rows per workgroup in the reductions
+constexpr int kBnRows = 512;   // rows per workgroup in the reductions
+
+// Thread map of the per-channel reductions: a row of the NHWC view is C4 = C/4 float4s; the
+// workgroup's 256 threads cover rows_per_pass = 256 / C4 rows at a time (all threads busy and
+// perfectly coalesced for every C4 <= 256; wider rows are walked in passes of 256 float4s).
+struct RedMap {
+  int cq0, cq_step, rsub, rstep;
+  bool active;
+};
+__device__ __forceinline__ RedMap red_map(int C4) {
+  RedMap m;
+  if (C4 <= 256) {
+    const int rpp = 256 / C4;
+    m.active = (int)threadIdx.x < rpp * C4;
+    m.cq0 = threadIdx.x % C4;
+    m.cq_step = C4;          // one quad per thread
+    m.rsub = threadIdx.x / C4;
+    m.rstep = rpp;
+  } else {
+    m.active = true;
+    m.cq0 = threadIdx.x;
+    m.cq_step = 256;
+    m.rsub = 0;
+    m.rstep = 1;
+  }
+  return m;
+}
+
+// Block-level combine of per-thread partials (a: first C values, b: second C values) and one
+// double atomic per channel per workgroup.  part[] lives in LDS: [2][C] doubles.
+__device__ __forceinline__ void red_flush(double* part, int C, int c, const float (&a)[4], const float (&b)[4],
+                                          bool active) {
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&part[c + k], (double)a[k]);
+      atomicAdd(&part[C + c + k], (double)b[k]);
+    }
+  }
+}
 
 // sums[c] += sum x, sums[C + c] += sum x^2   (double)
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t M, int C, int cs, int co,
                                                        double* __restrict__ sums) {
-  // thread -> channel quad cq = tid % C4 ... handled by looping over channel quads in the outer grid dim
+  extern __shared__ double part[];   // [2][C]
   const int C4 = C >> 2;
-  const int cq = blockIdx.y * 64 + (threadIdx.x & 63);
-  const int rsub = threadIdx.x >> 6;          // 4 row lanes per channel quad
+  for (int i = threadIdx.x; i < 2 * C; i += 256) part[i] = 0.0;
+  __syncthreads();
+  const RedMap mp = red_map(C4);
   const int64_t r0 = (int64_t)blockIdx.x * kBnRows;
   const int64_t r1 = r0 + kBnRows < M ? r0 + kBnRows : M;
-  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  if (cq < C4) {
-    float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
-    for (int64_t rr = r0 + rsub; rr < r1; rr += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(x + rr * cs + co + cq * 4);
-      fs[0] += v.x; fs[1] += v.y; fs[2] += v.z; fs[3] += v.w;
-      fq[0] += v.x * v.x; fq[1] += v.y * v.y; fq[2] += v.z * v.z; fq[3] += v.w * v.w;
+  if (mp.active) {
+    for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
+      float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
+      for (int64_t rr = r0 + mp.rsub; rr < r1; rr += mp.rstep) {
+        const float4 v = *reinterpret_cast<const float4*>(x + rr * cs + co + cq * 4);
+        fs[0] += v.x; fs[1] += v.y; fs[2] += v.z; fs[3] += v.w;
+        fq[0] += v.x * v.x; fq[1] += v.y * v.y; fq[2] += v.z * v.z; fq[3] += v.w * v.w;
+      }
+      red_flush(part, C, cq * 4, fs, fq, true);
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { s[k] = fs[k]; q[k] = fq[k]; }
   }
-  __shared__ double red[4][64][8];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { red[rsub][threadIdx.x & 63][k] = s[k]; red[rsub][threadIdx.x & 63][4 + k] = q[k]; }
   __syncthreads();
-  if (rsub == 0 && cq < C4) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double ss = red[0][threadIdx.x][k] + red[1][threadIdx.x][k] + red[2][threadIdx.x][k] + red[3][threadIdx.x][k];
-      const double qq = red[0][threadIdx.x][4 + k] + red[1][threadIdx.x][4 + k] + red[2][threadIdx.x][4 + k] +
-                        red[3][threadIdx.x][4 + k];
-      atomicAdd(&sums[cq * 4 + k], ss);
-      atomicAdd(&sums[C + cq * 4 + k], qq);
-    }
-  }
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[i], part[i]);
 }
 
 // mean / biased var / invstd from the sums; running stats update (unbiased var, momentum)
@@ -298,46 +328,39 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnArgs p) {
 }
 
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
+  extern __shared__ double part[];   // [2][C]: dbeta | dgamma
   const int C4 = p.C >> 2;
-  const int cq = blockIdx.y * 64 + (threadIdx.x & 63);
-  const int rsub = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 2 * p.C; i += 256) part[i] = 0.0;
+  __syncthreads();
+  const RedMap mp = red_map(C4);
   const int64_t r0 = (int64_t)blockIdx.x * kBnRows;
   const int64_t r1 = r0 + kBnRows < p.M ? r0 + kBnRows : p.M;
-  float db[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0};
-  if (cq < C4) {
-    const int c = cq * 4;
-    const float mu[4] = {p.mean[c], p.mean[c + 1], p.mean[c + 2], p.mean[c + 3]};
-    const float is[4] = {p.invstd[c], p.invstd[c + 1], p.invstd[c + 2], p.invstd[c + 3]};
-    const float ga[4] = {p.gamma[c], p.gamma[c + 1], p.gamma[c + 2], p.gamma[c + 3]};
-    const float be[4] = {p.beta[c], p.beta[c + 1], p.beta[c + 2], p.beta[c + 3]};
-    for (int64_t rr = r0 + rsub; rr < r1; rr += 4) {
-      const float4 xv = *reinterpret_cast<const float4*>(p.x + rr * p.x_cs + p.x_co + c);
-      const float4 gv = *reinterpret_cast<const float4*>(p.dy + rr * p.dy_cs + p.dy_co + c);
-      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-      const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+  if (mp.active) {
+    for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
+      const int c = cq * 4;
+      const float mu[4] = {p.mean[c], p.mean[c + 1], p.mean[c + 2], p.mean[c + 3]};
+      const float is[4] = {p.invstd[c], p.invstd[c + 1], p.invstd[c + 2], p.invstd[c + 3]};
+      const float ga[4] = {p.gamma[c], p.gamma[c + 1], p.gamma[c + 2], p.gamma[c + 3]};
+      const float be[4] = {p.beta[c], p.beta[c + 1], p.beta[c + 2], p.beta[c + 3]};
+      float db[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0};
+      for (int64_t rr = r0 + mp.rsub; rr < r1; rr += mp.rstep) {
+        const float4 xv = *reinterpret_cast<const float4*>(p.x + rr * p.x_cs + p.x_co + c);
+        const float4 gv = *reinterpret_cast<const float4*>(p.dy + rr * p.dy_cs + p.dy_co + c);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float xhat = (xs[k] - mu[k]) * is[k];
-        const float g = gs[k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
-        db[k] += g;
-        dg[k] += g * xhat;
+        for (int k = 0; k < 4; ++k) {
+          const float xhat = (xs[k] - mu[k]) * is[k];
+          const float g = gs[k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
+          db[k] += g;
+          dg[k] += g * xhat;
+        }
       }
+      red_flush(part, p.C, c, db, dg, true);
     }
   }
-  __shared__ double red[4][64][8];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { red[rsub][threadIdx.x & 63][k] = db[k]; red[rsub][threadIdx.x & 63][4 + k] = dg[k]; }
   __syncthreads();
-  if (rsub == 0 && cq < C4) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double b = red[0][threadIdx.x][k] + red[1][threadIdx.x][k] + red[2][threadIdx.x][k] + red[3][threadIdx.x][k];
-      const double g = red[0][threadIdx.x][4 + k] + red[1][threadIdx.x][4 + k] + red[2][threadIdx.x][4 + k] +
-                       red[3][threadIdx.x][4 + k];
-      atomicAdd(&p.sums[cq * 4 + k], b);
-      atomicAdd(&p.sums[p.C + cq * 4 + k], g);
-    }
-  }
+  for (int i = threadIdx.x; i < 2 * p.C; i += 256) atomicAdd(&p.sums[i], part[i]);
 }
 
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
@@ -439,8 +462,9 @@ extern "C" int yv4_bn_train_stats(const float* x, int64_t M, int C, int x_cstrid
   YV4_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_stats: running stats come together");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) { set_error("bn_train_stats: memset failed"); return YV4_E_LAUNCH; }
-  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows), (unsigned)((C / 4 + 63) / 64));
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, x, M, C, x_cstride, x_coff, work);
+  YV4_REQUIRE(C <= 4096, "bn_train_stats: more than 4096 channels");
+  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows));
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), sizeof(double) * 2 * C, s, x, M, C, x_cstride, x_coff, work);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, M, C, eps, momentum, mean, invstd,
                      running_mean, running_var);
   YV4_CHECK_LAUNCH("bn_train_stats");
@@ -477,8 +501,9 @@ extern "C" int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const f
   a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.dy = dy; a.dy_cs = dy_cstride; a.dy_co = dy_coff;
   a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dx_cs = dx_cstride; a.dx_co = dx_coff;
   a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope;
-  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows), (unsigned)((C / 4 + 63) / 64));
-  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, s, a);
+  YV4_REQUIRE(C <= 4096, "bn_act_bwd: more than 4096 channels");
+  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows));
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), sizeof(double) * 2 * C, s, a);
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid_t((size_t)M * (C / 4))), dim3(256), 0, s, a);
   hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
   hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
