@@ -35,6 +35,17 @@ def _is_nhwc(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
 
+_IDENTITY = {}
+
+
+def _identity_affine(device, C_):
+    """(ones, zeros) of length C_, cached per device: the identity epilogue of a training conv."""
+    key = (str(device), C_)
+    if key not in _IDENTITY:
+        _IDENTITY[key] = (torch.ones(C_, device=device), torch.zeros(C_, device=device))
+    return _IDENTITY[key]
+
+
 def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out):
     N, _, H, W = x.shape
     Ho, Wo = out.shape[2], out.shape[3]
@@ -42,8 +53,7 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out):
     d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin_p, Ho, Wo, Cout
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.x_cstride, d.y_cstride = Cin_p, Cout
-    ones = torch.ones(Cout, device=x.device)
-    zeros = torch.zeros(Cout, device=x.device)
+    ones, zeros = _identity_affine(x.device, Cout)
     check(_lib.lib().yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w_packed.data_ptr(), ones.data_ptr(),
                                          zeros.data_ptr(), None, None, None, out.data_ptr(), stream_ptr()),
           'yv4_conv_bn_act_fwd')
