@@ -16,5 +16,10 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_B
 python3 tools/conv_bench.py --tiles 3,5,6,7 > $OUT/conv_shapes.txt 2>&1
 python3 bench.py --steps 20 --warmup 5 --layers $OUT/layers.json > $OUT/bench.json 2> $OUT/bench.err
 tail -2 $OUT/bench.json
+# 4. training step (row f-1): per-kernel time + the un-profiled train-step line
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python3 tools/train_bench.py --batch 32 --steps 2 --warmup 1 > $OUT/trace_train.log 2>&1
+python3 tools/train_bench.py --batch 32 --steps 5 2> $OUT/train_bench.err | tail -1 > $OUT/train_bench.json
 python3 tools/summarize_prof.py $OUT $OUT/summary
 ls -la $OUT/summary
+# raw per-dispatch traces are large and already condensed: keep the pull small
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete

@@ -20,10 +20,11 @@ def short(name):
     return name.split('(')[0][:70]
 
 
-# 1. kernel stats
-for f in glob.glob(os.path.join(raw, 'trace', '*', '*_kernel_stats.csv')):
+# 1. kernel stats (inference bench, training step)
+for sub, dst in (('trace', 'kernel_stats.csv'), ('trace_train', 'train_kernel_stats.csv')):
+  for f in glob.glob(os.path.join(raw, sub, '*', '*_kernel_stats.csv')):
     rows = list(csv.DictReader(open(f)))
-    with open(os.path.join(out, 'kernel_stats.csv'), 'w', newline='') as g:
+    with open(os.path.join(out, dst), 'w', newline='') as g:
         w = csv.writer(g)
         w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
         for r in rows:
@@ -53,7 +54,7 @@ for k, cs in pm.items():
         e['l2_hit_rate'] = e['TCC_HIT_sum'] / max(e['TCC_HIT_sum'] + e['TCC_MISS_sum'], 1)
     res[k] = e
 json.dump(res, open(os.path.join(out, 'pmc_per_kernel.json'), 'w'), indent=1, sort_keys=True)
-for name in ('conv_shapes.txt', 'bench.json', 'layers.json'):
+for name in ('conv_shapes.txt', 'bench.json', 'layers.json', 'train_bench.json'):
     p = os.path.join(raw, name)
     if os.path.exists(p):
         open(os.path.join(out, name), 'w').write(open(p).read())
