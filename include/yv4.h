@@ -258,6 +258,35 @@ int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, i
                    const float* beta, float* dx, int dx_cstride, int dx_coff, float* dgamma,
                    float* dbeta, double* work, int64_t M, int C, int act, float slope, void* stream);
 
+/* ---- optimizer side of the training step (flat fp32 arenas) -------------------------
+ * The reference steps torch.optim.SGD(nesterov) with one param group per parameter
+ * (core/custom_hooks/warmup_hooks.py:24-32 requires that), un-scales and clips gradients in
+ * Fp16GradAccumulateOptimizerHook.after_train_iter (core/custom_hooks/accum_optim_hooks.py:37-60)
+ * and averages all 658 state entries in a Python loop (StateEMAHook.after_train_iter,
+ * core/custom_hooks/ema_hooks.py:80-98).  Here parameters, gradients, momentum buffers and EMA
+ * copies are slices of four flat arenas and each of those steps is one streaming kernel; every
+ * decision (clip coefficient, skip on overflow, loss-scale growth) stays on the device.
+ *
+ * yv4_grad_prepare: GradScaler.unscale_ + clip_grad_norm_(max_norm, 2) folded into one
+ *   multiplier.  scale_state = {scale, growth_tracker} on the device or NULL (scale 1);
+ *   max_norm <= 0 disables clipping; work: 2 doubles; ctrl (4 floats, device) receives
+ *   {grad multiplier = clip_coef/scale, total L2 norm of the unscaled gradients,
+ *    found_inf (0/1), 1/scale}.
+ * yv4_sgd_step: p -= lr*(nesterov ? g + m*b : b), b = m*b + g, g = grad*ctrl[0] + wd*p, with
+ *   (lr, momentum, weight_decay, nesterov) per segment: seg_off has nseg+1 entries (float
+ *   offsets, multiples of 4, seg_off[0] = 0, seg_off[nseg] = n), seg_hyper nseg*4 floats.
+ *   No-op when ctrl[2] != 0 (GradScaler.step semantics).  ctrl may be NULL (multiplier 1).
+ * yv4_loss_scale_update: GradScaler.update for the dynamic loss scale.
+ * yv4_ema_update: ema = momentum*ema + (1-momentum)*online over n floats.                */
+int yv4_grad_prepare(const float* grad, int64_t n, const float* scale_state, float max_norm,
+                     double* work, float* ctrl, void* stream);
+int yv4_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
+                 const int64_t* seg_off, const float* seg_hyper, int nseg, const float* ctrl,
+                 void* stream);
+int yv4_loss_scale_update(float* scale_state, const float* ctrl, float growth_factor,
+                          float backoff_factor, int growth_interval, void* stream);
+int yv4_ema_update(float* ema, const float* online, int64_t n, float momentum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

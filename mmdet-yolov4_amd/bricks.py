@@ -164,6 +164,15 @@ class HipModule(nn.Module):
                     m.init_weights()
             self._is_init = True
 
+    def zero_grad(self, set_to_none=True):
+        """With a FlatState attached (training through the flat arenas) gradients are zeroed by one
+        memset and stay views of the gradient arena; otherwise ``nn.Module.zero_grad``."""
+        fs = getattr(self, '_flat_state', None)
+        if fs is not None:
+            fs.zero_grad()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
     def emit(self, plan, *xs):  # pragma: no cover - abstract
         raise NotImplementedError
 

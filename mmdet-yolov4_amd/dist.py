@@ -1,4 +1,5 @@
-"""One-process-per-GPU plumbing for the sharded inference path.
+"""One-process-per-GPU plumbing: the sharded inference path and the gradient exchange of the
+training step.
 
 The path has no data-path collective (images are independent: per-image NMS, eval-mode BN,
 SURVEY 8e); ``torch.distributed`` (backend 'nccl' = RCCL on ROCm, 'gloo' in CPU tests) is
@@ -51,6 +52,94 @@ def max_over_ranks(value, device='cpu'):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class GradReducer:
+    """The one exchange step of data-parallel training: SUM all-reduce of the
+    gradients, then divide by the world size -- what the reference gets from
+    ``MMDistributedDataParallel`` (``mmdet/apis/train.py:96-103``), which copies ~430 gradient
+    tensors into 25 MB buckets and back.
+
+    Here the gradients already ARE one contiguous arena (``FlatState.grads``), so a bucket is a
+    slice of it: no copy-in/copy-out, and few large collectives (xGMI is point-to-point, a ring
+    all-reduce is per-link bound, so larger messages amortise the per-step latency better; 64 MB
+    default -> 4 collectives for YOLOv4-L's 212 MB).  Buckets are launched asynchronously from
+    post-accumulate-grad hooks as soon as every gradient inside is final, i.e. overlapped with the
+    rest of backward: arena order is registration order, backward produces the tail first, so
+    the last bucket goes out first.
+
+    ``arm()`` before the backward whose gradients are to be exchanged (the last micro-batch of an
+    accumulation window -- earlier micro-batches only accumulate locally), ``finish()`` after it.
+    """
+
+    def __init__(self, flat, bucket_mb=64, group=None):
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        cap = max(4, int(bucket_mb * (1 << 20) // 4))
+        self.buckets = []          # [lo, hi, [segment indices]]
+        cur = None
+        for si, seg in enumerate(flat.param_segments):
+            end = flat.param_segments[si + 1].offset if si + 1 < len(flat.param_segments) else flat.n_param
+            if cur is None or (end - cur[0]) > cap and cur[2]:
+                cur = [seg.offset, end, []]
+                self.buckets.append(cur)
+            cur[1] = end
+            cur[2].append(si)
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for si in b[2]:
+                self._bucket_of[si] = bi
+        self._armed = False
+        self._pending = []
+        self._launched = []
+        self._handles = []
+        self._hooks = []
+        for si, p in enumerate(flat._params):
+            if p.requires_grad:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(si)))
+
+    def _make_hook(self, si):
+        def hook(_p):
+            if self._armed:
+                bi = self._bucket_of[si]
+                self._pending[bi] -= 1
+                if self._pending[bi] == 0:
+                    self._launch(bi)
+        return hook
+
+    def arm(self):
+        self._armed = True
+        self._pending = [sum(1 for si in b[2] if self.flat._params[si].requires_grad) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+
+    def _launch(self, bi):
+        if self._launched[bi]:
+            return
+        self._launched[bi] = True
+        if self.world > 1:
+            lo, hi, _ = self.buckets[bi]
+            self._handles.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True))
+
+    def finish(self):
+        """Exchange whatever backward has not triggered (unused parameters), wait, average."""
+        if not self._armed:
+            raise RuntimeError('GradReducer.finish() without arm()')
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self._armed = False
+        if self.world > 1:
+            self.flat.grads.mul_(1.0 / self.world)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
 
 def finalize():

@@ -83,3 +83,61 @@ def test_shard_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- training exchange step: GradReducer over the flat gradient arena, 2 ranks ------------------
+REDUCE_WORKER = textwrap.dedent('''
+    import json, os, sys
+    sys.path.insert(0, %r)
+    sys.path.insert(0, os.path.join(%r, 'tests', 'golden'))
+    import torch
+    from toy_model import Toy
+    from mmdet_yolov4_amd import dist as D
+    from mmdet_yolov4_amd.flat_state import FlatState
+    rank, local_rank, world = D.init(backend='gloo')
+    torch.manual_seed(0)
+    model = Toy()                                         # identical weights on both ranks
+    fs = FlatState(model)
+    red = D.GradReducer(fs, bucket_mb=200 * 4 / (1 << 20))
+    g = torch.Generator().manual_seed(100)
+    xs = [torch.randn(2, 4, 6, 6, generator=g) for _ in range(4)]   # 2 ranks x 2 micro-batches
+    mine = xs[2 * rank: 2 * rank + 2]
+    # accumulation window of 2 micro-batches: only the last one is exchanged
+    fs.zero_grad()
+    model(mine[0]).square().mean().backward()
+    red.arm()
+    model(mine[1]).square().mean().backward()
+    launched_in_backward = all(red._launched)
+    red.finish()
+    # what the exchange must produce: mean over ranks of the per-rank SUM of micro-batch gradients
+    ref = Toy(); ref.load_state_dict({k: v for k, v in model.state_dict().items()})
+    for r in range(2):
+        for x in xs[2 * r: 2 * r + 2]:
+            (ref(x).square().mean() / 2).backward()
+    err = max(float((p.grad - q.grad).abs().max()) for p, q in zip(model.parameters(), ref.parameters()))
+    out = dict(rank=rank, nb=len(red.buckets), launched=launched_in_backward, err=err,
+               gsum=float(fs.grads.double().sum()))
+    print('RESULT ' + json.dumps(out), flush=True)
+    D.finalize()
+''')
+
+
+def test_grad_reducer_two_ranks_gloo(tmp_path):
+    script = tmp_path / 'reduce_worker.py'
+    script.write_text(REDUCE_WORKER % (ROOT, ROOT))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out
+        outs.append(json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][0][7:]))
+    outs.sort(key=lambda o: o['rank'])
+    assert outs[0]['nb'] >= 2 and all(o['launched'] for o in outs)
+    assert all(o['err'] < 1e-6 for o in outs), outs      # averaged sum of both ranks' gradients
+    assert outs[0]['gsum'] == outs[1]['gsum']            # bit-identical arenas after the exchange
