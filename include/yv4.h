@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YV4_ABI_VERSION 1
+#define YV4_ABI_VERSION 2
 
 /* error codes */
 #define YV4_OK 0
@@ -160,6 +160,11 @@ int yv4_resample_nearest_fwd(const float* src, float* dst, int N, int Hs, int Ws
  *   for each class c with s_{5+c}*s4 > score_thr: append the candidate key
  *       (~bits(score) << 32 | (j*num_classes + c)) to keys[n*key_cap + ...],
  *       and fold the box into max_coord[n] (the per-image boxes.max()).
+ * num_classes == 0 is the class-agnostic head (yolocsp_head.py:155-178,357-360:
+ * 5 attributes per box, one score column = conf, flat index = j).
+ * topk_keys (N device values from yv4_conf_topk, or NULL) implements `nms_pre`
+ * (yolocsp_head.py:349-355): boxes whose (conf, index) key ranks behind the
+ * image's k-th are decoded but produce no candidates.
  * counts[n] / max_coord[n] must be zero / -inf-initialised by
  * yv4_decode_reset().  If more than key_cap candidates pass for an image the
  * count keeps counting (so the caller can see the overflow) but keys beyond the
@@ -182,7 +187,18 @@ int yv4_decode_filter(const yv4_level_desc* levels, int num_levels, int N, int A
                       float* conf /* (N, total_anchors) or NULL */,
                       float* cls /* (N, total_anchors, num_classes) sigmoid, or NULL */,
                       uint64_t* keys, int64_t key_cap, int32_t* counts,
-                      float* max_coord, void* stream);
+                      float* max_coord, const uint64_t* topk_keys /* (N) or NULL */,
+                      void* stream);
+
+/* nms_pre pre-selection: topk_keys[n] = the k-th smallest key
+ * (~order(conf) << 32 | anchor index) of image n, i.e. the admission threshold of
+ * `conf_pred.topk(k)` with ties broken towards the lower anchor index.  Requires
+ * 0 < k < anchors per image (the reference applies top-k only then).  work:
+ * yv4_conf_topk_work(N, anchors per image) bytes of device memory. */
+size_t yv4_conf_topk_work(int N, int64_t total_anchors);
+int yv4_conf_topk(const yv4_level_desc* levels, int num_levels, int N, int A,
+                  int num_classes, int k, void* work, uint64_t* topk_keys,
+                  void* stream);
 
 /* ---- batched NMS -----------------------------------------------------------
  * Per image n (one workgroup each): sort its counts[n] candidate keys by

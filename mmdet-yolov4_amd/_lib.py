@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(LIB_DIR, 'libyv4_hip.so')
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 # ---- constants mirrored from include/yv4.h -------------------------------------
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_MISH, ACT_LEAKY, ACT_SWISH = 0, 1, 2, 3
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
@@ -61,7 +61,9 @@ SIGNATURES = {
     'yv4_decode_reset': (C.c_int, [_vp, _vp, _i, _vp]),
     'yv4_decode_filter': (C.c_int, [C.POINTER(LevelDesc), _i, _i, _i, _i, _f,
                                     _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
-                                    _vp]),
+                                    _vp, _vp]),
+    'yv4_conf_topk_work': (_sz, [_i, _i64]),
+    'yv4_conf_topk': (C.c_int, [C.POINTER(LevelDesc), _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'yv4_nms_images': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i,
                                  _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'yv4_nms_split_work': (_sz, [_i64]),

@@ -62,6 +62,7 @@ struct DecodeArgs {
   int64_t key_cap;
   int32_t* counts;
   float* max_coord;
+  const uint64_t* topk;   // per image: largest admissible (conf key << 32 | anchor) or NULL
 };
 
 __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
@@ -115,7 +116,17 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
     reinterpret_cast<float4*>(p.boxes)[gj] = make_float4(x1, y1, x2, y2);
     if (p.conf) p.conf[gj] = cf;
   }
+  // nms_pre (yolocsp_head.py:349-355): only the top-k anchors by conf stay candidates; the
+  // k-th (conf, anchor) key of the image was selected by yv4_conf_topk
+  if (p.topk && (((uint64_t)score_to_key(cf) << 32) | (uint32_t)j) > p.topk[n]) return;
   bool any = false;
+  if (p.C == 0) {                 // class_agnostic (yolocsp_head.py:357-360): one column, score = conf
+    if (part == 0 && cf > p.score_thr) {
+      any = true;
+      const int slot = atomicAdd(&p.counts[n], 1);
+      if (slot < p.key_cap) p.keys[(size_t)n * p.key_cap + slot] = ((uint64_t)score_to_key(cf) << 32) | (uint32_t)j;
+    }
+  }
   for (int c = part; c < p.C; c += 4) {
     const float sc = s[5 + c];
     if (p.cls) p.cls[gj * p.C + c] = sc;
@@ -391,10 +402,12 @@ extern "C" int yv4_decode_reset(int32_t* counts, float* max_coord, int N, void* 
 
 extern "C" int yv4_decode_filter(const yv4_level_desc* levels, int num_levels, int N, int A, int num_classes,
                                  float score_thr, const float* scale_factor, float* boxes, float* conf, float* cls,
-                                 uint64_t* keys, int64_t key_cap, int32_t* counts, float* max_coord, void* stream) {
+                                 uint64_t* keys, int64_t key_cap, int32_t* counts, float* max_coord,
+                                 const uint64_t* topk_keys, void* stream) {
   YV4_REQUIRE(levels && boxes && keys && counts && max_coord, "decode_filter: null pointer");
   YV4_REQUIRE(num_levels > 0 && num_levels <= kMaxLevels, "decode_filter: 1..%d levels supported", kMaxLevels);
-  YV4_REQUIRE(N > 0 && N <= 65535 && A > 0 && A <= 8 && num_classes > 0, "decode_filter: bad N/A/num_classes");
+  YV4_REQUIRE(N > 0 && N <= 65535 && A > 0 && A <= 8 && num_classes >= 0, "decode_filter: bad N/A/num_classes");
+  YV4_REQUIRE(num_classes > 0 || cls == nullptr, "decode_filter: a class-agnostic head has no class scores to return");
   YV4_REQUIRE(key_cap > 0, "decode_filter: key_cap must be positive");
   YV4_REQUIRE(((uintptr_t)boxes & 15) == 0, "decode_filter: boxes must be 16-byte aligned");
   DecodeArgs a;
@@ -416,11 +429,12 @@ extern "C" int yv4_decode_filter(const yv4_level_desc* levels, int num_levels, i
     blocks += (int)((nb + kDecBoxes - 1) / kDecBoxes);
   }
   a.block_base[num_levels] = blocks;
-  YV4_REQUIRE(total * num_classes < (1LL << 32), "decode_filter: anchors*classes = %lld overflows the 32-bit flat index",
-              total * num_classes);
+  YV4_REQUIRE(total * (num_classes > 0 ? num_classes : 1) < (1LL << 32),
+              "decode_filter: anchors*classes = %lld overflows the 32-bit flat index", total * num_classes);
   a.num_levels = num_levels; a.N = N; a.A = A; a.C = num_classes; a.total_anchors = (int)total;
   a.score_thr = score_thr; a.scale_factor = scale_factor; a.boxes = boxes; a.conf = conf; a.cls = cls;
   a.keys = keys; a.key_cap = key_cap; a.counts = counts; a.max_coord = max_coord;
+  a.topk = topk_keys;
   const size_t lds = (size_t)kDecBoxes * (5 + num_classes) * sizeof(float);
   YV4_REQUIRE(lds <= 64 * 1024, "decode_filter: num_classes %d too large for the LDS tile", num_classes);
   hipLaunchKernelGGL(decode_filter_kernel, dim3(blocks, N), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);

@@ -232,13 +232,17 @@ class Plan:
         return len(self.outputs) - 1
 
     def postprocess(self, pred_views, strides, base_anchors, num_classes, score_thr, iou_thr, max_per_img,
-                    split_thr=10000, rescale=True, want_cls=False):
+                    split_thr=10000, rescale=True, want_cls=False, nms_pre=-1, class_agnostic=False):
         """decode+filter and per-image NMS over the head's NHWC pred maps.
         base_anchors: list (per level) of (A,4) float tensors.  Returns a dict of result
-        tensors (allocated at finalize)."""
+        tensors (allocated at finalize).  ``class_agnostic``: 5 attributes per box, the score is the
+        objectness (one pseudo-class); ``nms_pre`` > 0: only the top-k boxes by objectness are
+        candidates (yolocsp_head.py:349-360)."""
         N = pred_views[0].N
         A = base_anchors[0].shape[0]
-        attr = 5 + num_classes
+        kclasses = 0 if class_agnostic else num_classes          # what the kernels see
+        num_classes = 1 if class_agnostic else num_classes       # columns of the score matrix
+        attr = 5 + kclasses
         total = 0
         for v in pred_views:
             assert v.C == A * attr and v.coff == 0 and v.cstride == v.C, 'pred maps must be dense NHWC'
@@ -246,7 +250,9 @@ class Plan:
         levels = (LevelDesc * len(pred_views))()
         res = dict(N=N, total_anchors=total, num_classes=num_classes, max_per_img=max_per_img,
                    key_cap=total * num_classes, want_cls=want_cls, rescale=rescale,
-                   iou_thr=iou_thr, split_thr=split_thr, score_thr=score_thr)
+                   iou_thr=iou_thr, split_thr=split_thr, score_thr=score_thr, class_agnostic=class_agnostic)
+        use_topk = 0 < nms_pre < total
+        res['nms_pre'] = nms_pre if use_topk else -1
         self.post = res
         self.params.append(levels)
 
@@ -254,7 +260,14 @@ class Plan:
             dev = self.device
             res['boxes'] = torch.empty((N, total, 4), dtype=torch.float32, device=dev)
             res['conf'] = torch.empty((N, total), dtype=torch.float32, device=dev)
-            res['cls'] = torch.empty((N, total, num_classes), dtype=torch.float32, device=dev) if want_cls else None
+            res['cls'] = (torch.empty((N, total, num_classes), dtype=torch.float32, device=dev)
+                          if want_cls and not class_agnostic else None)
+            if use_topk:
+                nbytes = _lib.lib().yv4_conf_topk_work(N, total)
+                if nbytes == 0:
+                    raise RuntimeError('yv4_conf_topk_work: batch * anchors too large for the top-k pre-selection')
+                res['topk_work'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                res['topk_keys'] = torch.zeros(N, dtype=torch.int64, device=dev)
             res['keys'] = torch.empty((N, res['key_cap']), dtype=torch.int64, device=dev)
             res['counts'] = torch.zeros(N, dtype=torch.int32, device=dev)
             res['max_coord'] = torch.zeros(N, dtype=torch.float32, device=dev)
@@ -276,13 +289,19 @@ class Plan:
             check(_lib.lib().yv4_decode_reset(res['counts'].data_ptr(), res['max_coord'].data_ptr(), N, stream),
                   'yv4_decode_reset')
 
+        def topk(stream):
+            check(_lib.lib().yv4_conf_topk(levels, len(pred_views), N, A, kclasses, int(nms_pre),
+                                           res['topk_work'].data_ptr(), res['topk_keys'].data_ptr(), stream),
+                  'yv4_conf_topk')
+
         def decode(stream):
             check(_lib.lib().yv4_decode_filter(
-                levels, len(pred_views), N, A, num_classes, float(score_thr),
+                levels, len(pred_views), N, A, kclasses, float(score_thr),
                 res['scale_factor'].data_ptr() if rescale else None, res['boxes'].data_ptr(),
-                res['conf'].data_ptr(), res['cls'].data_ptr() if want_cls else None,
+                res['conf'].data_ptr(), res['cls'].data_ptr() if res['cls'] is not None else None,
                 res['keys'].data_ptr(), res['key_cap'], res['counts'].data_ptr(),
-                res['max_coord'].data_ptr(), stream), 'yv4_decode_filter')
+                res['max_coord'].data_ptr(), res['topk_keys'].data_ptr() if use_topk else None, stream),
+                'yv4_decode_filter')
 
         def nms(stream):
             check(_lib.lib().yv4_nms_images(
@@ -291,6 +310,8 @@ class Plan:
                 int(split_thr), res['dets'].data_ptr(), res['labels'].data_ptr(), res['index'].data_ptr(),
                 res['count'].data_ptr(), stream), 'yv4_nms_images')
         self.ops.append(Op('reset', 'decode_reset', reset))
+        if use_topk:
+            self.ops.append(Op('topk', 'conf_topk', topk))
         self.ops.append(Op('decode', 'decode_filter', decode, nbytes=4.0 * N * total * attr))
         self.ops.append(Op('nms', 'nms_images', nms))
         return res

@@ -68,9 +68,8 @@ class YOLOCSPHead(HipModule):
         self.bbox_coder = build_bbox_coder(bbox_coder)
         self.anchor_generator = build_anchor_generator(anchor_generator)
         self.class_agnostic = class_agnostic
-        if class_agnostic:
-            raise NotImplementedError('class_agnostic heads have no fused decode kernel yet')
-        self.loss_cls = build_loss(loss_cls)
+        if not self.class_agnostic:                              # yolocsp_head.py:155-156
+            self.loss_cls = build_loss(loss_cls)
         self.loss_conf = build_loss(loss_conf)
         self.loss_bbox = build_loss(loss_bbox)
         self.loss_bbox_weight = self.loss_bbox.loss_weight      # yolocsp_head.py:160-162
@@ -127,14 +126,11 @@ class YOLOCSPHead(HipModule):
         if nms_cfg.get('type', 'nms') != 'nms':
             raise NotImplementedError('only nms type "nms" is built')
         nms_pre = cfg.get('nms_pre', -1)
-        total = sum(v.H * v.W * self.num_anchors[i] for i, v in enumerate(pred_views))
-        if 0 < nms_pre < total:
-            raise NotImplementedError('nms_pre top-k pre-selection is not built (the configs use nms_pre=-1)')
         return plan.postprocess(
             pred_views, self.featmap_strides, self.anchor_generator.base_anchors, self.num_classes,
             score_thr=cfg['score_thr'], iou_thr=nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr')),
             max_per_img=cfg['max_per_img'], split_thr=nms_cfg.get('split_thr', ops.SPLIT_THR_DEFAULT),
-            rescale=rescale, want_cls=want_cls)
+            rescale=rescale, want_cls=want_cls, nms_pre=nms_pre, class_agnostic=self.class_agnostic)
 
     # ---- reference API ----------------------------------------------------------------------
     def fwd(self, feats):
@@ -266,8 +262,15 @@ def collect_results(post, with_nms=True, head=None):
     N = post['N']
     if not with_nms:
         # aug_test branch, yolocsp_head.py:377-382 (class score multiplied by conf twice, Q8)
+        if post.get('nms_pre', -1) > 0:
+            raise NotImplementedError('get_bboxes(with_nms=False) with nms_pre > 0 (aug_test only) is not built')
         out = []
         for n in range(N):
+            if post.get('class_agnostic'):
+                cls = post['conf'][n][:, None] * post['conf'][n][:, None]    # yolocsp_head.py:360,378
+                score, cid = cls.max(dim=-1)
+                out.append((torch.cat((post['boxes'][n], score[:, None]), dim=-1), cid))
+                continue
             cls = post['cls'][n] * post['conf'][n][:, None]
             cls = cls * post['conf'][n][:, None]
             score, cid = cls.max(dim=-1)

@@ -284,6 +284,39 @@ def make_train(ref, out):
     print('train', out, f'{os.path.getsize(out) / 1e6:.2f} MB', 'loss', float(total))
 
 
+def make_post(ref, out):
+    """get_bboxes variants the YOLOv4 configs leave at their defaults but the head supports
+    (yolocsp_head.py:349-360): nms_pre top-k pre-selection and the class-agnostic head, on
+    seeded random pred maps (N=2, featmaps 8x12 / 4x6 / 2x3)."""
+    hd = ref.head
+    gen = torch.Generator().manual_seed(21)
+    sizes = [(8, 12), (4, 6), (2, 3)]
+    data = {}
+    metas = [dict(scale_factor=np.array([1.25, 1.5, 1.25, 1.5], dtype=np.float32)),
+             dict(scale_factor=np.array([0.75, 0.75, 0.75, 0.75], dtype=np.float32))]
+    data['scale_factors'] = np.stack([m['scale_factor'] for m in metas])
+    for tag, agnostic, ncls in (('aware', False, 6), ('agnostic', True, 6)):
+        attr = 5 if agnostic else 5 + ncls
+        preds = []
+        for (h, w) in sizes:
+            p = torch.randn(2, 3 * attr, h, w, generator=gen) * 1.5
+            p.view(2, 3, attr, h, w)[:, :, 4] += 1.0           # objectness well above the threshold
+            preds.append(p)
+            data[f'{tag}/pred{len(preds) - 1}'] = p.numpy()
+        for nms_pre in (-1, 60, 250):
+            head = hd.YOLOCSPHead(num_classes=ncls, in_channels=[8, 8, 8], class_agnostic=agnostic, train_cfg=None,
+                                  test_cfg=ref.ConfigDict(nms_pre=nms_pre, score_thr=0.05,
+                                                          nms=dict(type='nms', iou_threshold=0.5), max_per_img=50))
+            res = head.get_bboxes([p.clone() for p in preds], metas, rescale=True)
+            for i, (d, l) in enumerate(res):
+                data[f'{tag}/pre{nms_pre}/dets{i}'] = d.numpy()
+                data[f'{tag}/pre{nms_pre}/labels{i}'] = l.numpy()
+    data['num_classes'] = np.array(6)
+    np.savez_compressed(out, **data)
+    print('post', out, f'{os.path.getsize(out) / 1e3:.1f} kB',
+          {k: v.shape for k, v in data.items() if k.endswith('dets0')})
+
+
 def main():
     if not _ref_import.available():
         print('reference not present: nothing to do')
@@ -291,6 +324,9 @@ def main():
     ext = build_ref.load_ext()
     ref = _ref_import.install_shim(ext)
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'post':      # only the newest fixture
+        make_post(ref, os.path.join(HERE, 'post_variants.npz'))
+        return
     make_mish(ref, os.path.join(HERE, 'mish.npz'))
     v4 = [['conv', 'bottleneck', 'csp', 'csp', 'csp', 'sppv4'], [None, 1, 1, 2, 2, 1], [4, 8, 16, 32, 64, 64]]
     run_detector(ref, 'tiny_v4', v4, [3, 4, 5], 'v4', [32, 64, 64], [32, 64, 128], 2, (64, 96), 3,
@@ -300,6 +336,7 @@ def main():
                  os.path.join(HERE, 'tiny_v5.npz'), obj_bias=-3.5, cls_bias=-4.0, head_std=12000)
     make_nms(ref, os.path.join(HERE, 'nms.npz'))
     make_train(ref, os.path.join(HERE, 'train_v4.npz'))
+    make_post(ref, os.path.join(HERE, 'post_variants.npz'))
 
 
 if __name__ == '__main__':

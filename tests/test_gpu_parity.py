@@ -433,3 +433,65 @@ def test_fused_postprocess_split_path(golden, gpu_device):
         np.testing.assert_array_equal(d.cpu().numpy(), rd.numpy())
         np.testing.assert_array_equal(l.cpu().numpy(), rl.numpy())
         np.testing.assert_array_equal(post['index'][n, :d.shape[0]].cpu().numpy(), rflat.numpy())
+
+
+# ---------------------------------------------------------------------------------------------
+# get_bboxes variants: nms_pre top-k pre-selection, class-agnostic head (yolocsp_head.py:349-360)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,agnostic', [('aware', False), ('agnostic', True)])
+@pytest.mark.parametrize('nms_pre', [-1, 60, 250])
+def test_get_bboxes_nms_pre_and_class_agnostic(golden, gpu_device, tag, agnostic, nms_pre):
+    g = golden('post_variants')
+    ncls = int(g['num_classes'])
+    head = pkg.build_head(dict(type='YOLOCSPHead', num_classes=ncls, in_channels=[8, 8, 8], class_agnostic=agnostic,
+                               train_cfg=None,
+                               test_cfg=dict(nms_pre=nms_pre, score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5),
+                                             max_per_img=50))).to(gpu_device)
+    assert head.num_attrib == (5 if agnostic else 5 + ncls)
+    assert head.convs_pred[0].out_channels == 3 * head.num_attrib
+    assert hasattr(head, 'loss_cls') != agnostic                 # yolocsp_head.py:155-156
+    preds = [torch.from_numpy(g[f'{tag}/pred{i}']).to(gpu_device) for i in range(3)]
+    metas = [dict(scale_factor=g['scale_factors'][i]) for i in range(2)]
+    res = head.get_bboxes(preds, metas, rescale=True)
+    for n in range(2):
+        d, l = res[n]
+        rd, rl = g[f'{tag}/pre{nms_pre}/dets{n}'], g[f'{tag}/pre{nms_pre}/labels{n}']
+        assert l.dtype == torch.int64
+        # identical inputs: same selection in the same order, boxes/scores within 1e-4
+        np.testing.assert_array_equal(l.cpu().numpy(), rl)
+        np.testing.assert_allclose(d.cpu().numpy(), rd, rtol=1e-4, atol=1e-4)
+    # bit-exact against the oracle restatement on the same inputs (indices, boxes and scores)
+    ores = O.get_bboxes([p.cpu() for p in preds], g['scale_factors'], ncls, score_thr=0.05, iou_threshold=0.5,
+                        max_per_img=50, rescale=True, nms_pre=nms_pre, class_agnostic=agnostic)
+    for n in range(2):
+        np.testing.assert_array_equal(res[n][1].cpu().numpy(), ores[n][1].numpy())
+        np.testing.assert_allclose(res[n][0].cpu().numpy(), ores[n][0].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_conf_topk_threshold_keys(gpu_device):
+    """yv4_conf_topk: the k-th (conf desc, index asc) key per image, ties included."""
+    import ctypes as C
+    from mmdet_yolov4_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(3)
+    N, A, ncls = 3, 3, 4
+    sizes = [(6, 5), (3, 3)]
+    preds = [torch.randn(N, h, w, A * (5 + ncls), device=gpu_device) for h, w in sizes]
+    preds[0].view(N, -1, 5 + ncls)[:, :40, 4] = 0.25            # a block of exact ties
+    levels = (_lib.LevelDesc * 2)()
+    for i, (p, (h, w)) in enumerate(zip(preds, sizes)):
+        levels[i].pred = p.data_ptr()
+        levels[i].H, levels[i].W, levels[i].stride = h, w, 8 * (i + 1)
+    total = sum(h * w * A for h, w in sizes)
+    conf = torch.cat([p.view(N, -1, 5 + ncls)[:, :, 4] for p in preds], 1).sigmoid().cpu().numpy()
+    work = torch.empty(L.yv4_conf_topk_work(N, total), dtype=torch.uint8, device=gpu_device)
+    out = torch.zeros(N, dtype=torch.int64, device=gpu_device)
+    for k in (1, 17, 50, total - 1):
+        _lib.check(L.yv4_conf_topk(levels, 2, N, A, ncls, k, work.data_ptr(), out.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream), 'topk')
+        got = out.cpu().numpy().astype(np.uint64)
+        for n in range(N):
+            order = np.lexsort((np.arange(total), -conf[n].astype(np.float64)))
+            assert int(got[n] & np.uint64(0xffffffff)) == order[k - 1], (k, n)
+    assert L.yv4_conf_topk(levels, 2, N, A, ncls, total, work.data_ptr(), out.data_ptr(), None) != 0
+    assert L.yv4_conf_topk(levels, 2, N, A, ncls, 0, work.data_ptr(), out.data_ptr(), None) != 0

@@ -131,3 +131,18 @@ def test_base_anchor_known_answers():
         assert torch.equal(a, e)
     v4 = O.base_anchors()
     assert torch.equal(v4[0], torch.tensor([[-2., -4., 10., 12.], [-5.5, -14., 13.5, 22.], [-16., -10., 24., 18.]]))
+
+
+@pytest.mark.parametrize('tag,agnostic', [('aware', False), ('agnostic', True)])
+@pytest.mark.parametrize('nms_pre', [-1, 60, 250])
+def test_get_bboxes_nms_pre_and_class_agnostic(golden, tag, agnostic, nms_pre):
+    """yolocsp_head.py:349-360 variants (top-k by objectness, class-agnostic score) vs the reference."""
+    g = golden('post_variants')
+    preds = [torch.from_numpy(g[f'{tag}/pred{i}']) for i in range(3)]
+    res = O.get_bboxes(preds, g['scale_factors'], int(g['num_classes']), score_thr=0.05, iou_threshold=0.5,
+                       max_per_img=50, rescale=True, nms_pre=nms_pre, class_agnostic=agnostic)
+    for n in range(2):
+        np.testing.assert_array_equal(res[n][0].numpy(), g[f'{tag}/pre{nms_pre}/dets{n}'])
+        np.testing.assert_array_equal(res[n][1].numpy(), g[f'{tag}/pre{nms_pre}/labels{n}'])
+    if nms_pre == 60 and not agnostic:      # the pre-selection really changes the result
+        assert not np.array_equal(g[f'{tag}/pre60/dets0'], g[f'{tag}/pre-1/dets0'])

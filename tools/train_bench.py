@@ -32,6 +32,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--model', default='yolov4l')
+    ap.add_argument('--accumulation', type=int, default=1)
+    ap.add_argument('--torch-optim', action='store_true')
     a = ap.parse_args()
     rank, local_rank, world = D.env_world()
     dev = torch.device('cuda', local_rank)
@@ -41,22 +43,57 @@ def main():
     det = pkg.build_detector(bench.model_cfg(a.model))
     det.init_weights()
     det.train().to(dev)
-    model = det
-    if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(det, device_ids=[local_rank], broadcast_buffers=False)
-    opt = torch.optim.SGD(det.parameters(), lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
+    # the recipe of configs/yolov4/yolov4l_coco_mosaic.py:108-147: SGD-Nesterov with one group per
+    # parameter, grad clip 35, dynamic loss scale, per-parameter warm-up, EMA of the whole state --
+    # all through the flat arenas; --torch-optim switches to torch.optim.SGD + DDP for comparison
+    metas = [dict() for _ in range(a.batch)]
     img = bench.synthetic_images(a.batch, a.size, 1000 + rank, dev)
     gtb, gtl = synthetic_gts(a.batch, a.size, 2000 + rank, dev)
-    metas = [dict() for _ in range(a.batch)]
+    data = dict(img=img, img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
+    if a.torch_optim:
+        model = det
+        if world > 1:
+            model = torch.nn.parallel.DistributedDataParallel(det, device_ids=[local_rank], broadcast_buffers=False)
+        opt = torch.optim.SGD(det.parameters(), lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        losses = model(img=img, img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
-        loss, log_vars = det._parse_losses(losses)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(det.parameters(), 35)
-        opt.step()
-        return log_vars['loss']
+        def step():
+            opt.zero_grad(set_to_none=True)
+            losses = model(**data)
+            loss, log_vars = det._parse_losses(losses)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(det.parameters(), 35)
+            opt.step()
+            return log_vars['loss']
+    else:
+        from mmdet_yolov4_amd import hooks as H
+        from mmdet_yolov4_amd.optim import build_optimizer
+        opt = build_optimizer(det, dict(type='SGD', lr=0.01, momentum=0.937, weight_decay=0.0005, nesterov=True,
+                                        paramwise_cfg=dict(bias_decay_mult=0., norm_decay_mult=0.)))
+        runner = H.Runner(det, opt, max_epochs=1)
+        runner.log_buffer = None                                      # no per-step grad-norm readback
+        runner.register_hook_from_cfg(dict(type='DetailedLinearWarmUpHook', warmup_iters=10000, priority='NORMAL'))
+        runner.register_hook_from_cfg(dict(type='StateEMAHook', momentum=0.9999, interval=1, warm_up=10000,
+                                           priority='HIGH'))
+        runner.register_hook(H.Fp16GradAccumulateOptimizerHook(accumulation=a.accumulation,
+                                                               grad_clip=dict(max_norm=35, norm_type=2),
+                                                               loss_scale='dynamic'), 'ABOVE_NORMAL')
+        runner.data_loader = H.BatchSource([data], a.batch)
+        runner.call_hook('before_run')
+        runner.call_hook('before_train_epoch')
+        last = {}
+
+        def step():
+            runner.call_hook('before_train_iter')
+            losses = det(**data)
+            # keep the loss on the device inside the timed loop (the reference's _parse_losses does
+            # one .item() per logged value = a host sync per step)
+            loss = sum(sum(x.mean() for x in v) if isinstance(v, (list, tuple)) else v.mean()
+                       for k, v in losses.items() if 'loss' in k)
+            runner.outputs = dict(loss=loss, num_samples=a.batch)
+            runner.call_hook('after_train_iter')
+            runner.iter += 1
+            last['loss'] = loss.detach()
+            return last['loss']
 
     for _ in range(a.warmup):
         l0 = step()
@@ -70,7 +107,8 @@ def main():
         fl = 3 * 108.516e9 * (a.size / 608.0) ** 2 if a.model == 'yolov4l' else float('nan')
         print(json.dumps(dict(metric='images/sec (train step) ' + a.model, value=round(a.batch * world * a.steps / el, 2),
                               n_gpus=world, ms_per_step=round(el / a.steps * 1e3, 1), batch_per_gpu=a.batch,
-                              dtype='f32', loss_first=round(l0, 3), loss_last=round(l1, 3),
+                              dtype='f32', loss_first=round(float(l0), 3), loss_last=round(float(l1), 3),
+                              optimizer='torch SGD + DDP' if a.torch_optim else 'flat arenas + recipe hooks',
                               approx_conv_tflops=round(fl * a.batch * a.steps / el / 1e12, 1),
                               peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))))
     D.finalize()
