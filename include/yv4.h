@@ -274,6 +274,23 @@ int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, i
                    const float* beta, float* dx, int dx_cstride, int dx_coff, float* dgamma,
                    float* dbeta, double* work, int64_t M, int C, int act, float slope, void* stream);
 
+/* ---- 16-bit operand convolution (fp16 / bf16 in, fp32 accumulate) ---------------------
+ * The reduced-precision form of yv4_conv_bn_act_fwd (BASELINE configs[2..4]; the reference
+ * runs its ConvModules in half under mmcv's wrap_fp16_model / autocast, darknetcsp.py:15-35):
+ * x, w, residual and (unless out_dtype == YV4_F32) y are NHWC / packed tensors of `dtype`
+ * (YV4_F16 or YV4_BF16); scale/shift stay fp32; the epilogue runs in fp32 and rounds once.
+ * Same descriptor as the fp32 entry; channel counts, strides and offsets of the 16-bit views
+ * must be multiples of 8 (16-byte pixel chunks), w is (Cout, KH*KW*Cin) with Cin padded to 8.
+ * desc->tile: YV4_TILE_AUTO or one of YV4_HTILE_*. */
+#define YV4_HTILE_128x128 1
+#define YV4_HTILE_128x64 2
+#define YV4_HTILE_64x64 3
+int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x,
+                            const void* w, const float* scale1, const float* shift1,
+                            const float* scale2, const float* shift2, const void* residual,
+                            void* y, void* stream);
+int yv4_conv_h16_pick_tile(const yv4_conv_desc* d);
+
 /* ---- optimizer side of the training step (flat fp32 arenas) -------------------------
  * The reference steps torch.optim.SGD(nesterov) with one param group per parameter
  * (core/custom_hooks/warmup_hooks.py:24-32 requires that), un-scales and clips gradients in

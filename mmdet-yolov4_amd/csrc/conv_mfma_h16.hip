@@ -1,0 +1,452 @@
+// Fused implicit-GEMM convolution for gfx950 with 16-bit operands (fp16 or bf16 activations and
+// weights, fp32 accumulate on v_mfma_f32_32x32x16_{f16,bf16}, fp32 epilogue, 16-bit or fp32 store).
+//
+// The reduced-precision form of conv_mfma_f32.hip, for BASELINE.json configs[2..4] (bf16 training,
+// fp16 inference): same GEMM view (M = N*Ho*Wo pixels, Ncol = Cout, K = KH*KW*Cin ordered
+// (kh,kw,ci)), same fused epilogue (affine1 -> act1 -> +residual -> affine2 -> act2 -> store at a
+// channel offset), same LDS image -- a K slice is 64 elements = 128-byte rows, 16-byte chunks XOR-
+// swizzled with (row>>1)&7, filled by LDS-DMA (buffer_load_dwordx4 ... lds; out-of-range offsets
+// deliver zeros = conv padding, M tail, Cout tail, K tail).  One ds_read_b128 is exactly one
+// lane's 8-element operand of a 32x32x16 MFMA (lane (r,h): row r, k = 8h..8h+7 of the step), so a
+// slice is 4 MFMA steps per accumulator tile.  The MFMA runs 16x the fp32 rate, so tiles are larger
+// (a wave owns up to 64x64 outputs) to keep LDS reads (mt+nt per mt*nt MFMAs) under the array's
+// bandwidth.
+//
+// What the reference does at this precision (mmcv wrap_fp16_model / autocast around ConvModule,
+// darknetcsp.py:15-35): conv in half with fp32 accumulation -> round -> BN in fp32 -> round -> Mish ->
+// round.  Here the chain after the accumulator stays in fp32 and is rounded once.
+#include "yv4_common.h"
+
+namespace yv4 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kHBK = 64;        // K slice in elements (128 bytes)
+constexpr int kHThreads = 256;
+
+struct ConvArgsH {
+  const void* x;
+  const void* w;
+  const float* s1;
+  const float* t1;
+  const float* s2;
+  const float* t2;
+  const void* res;
+  void* y;
+  int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+  int x_cs, x_co, y_cs, y_co, r_cs, r_co;
+  int act1, act2;
+  float slope1, slope2;
+  int M, K, Kw;
+  int tiles_n;
+  int out_f32;    // store fp32 instead of the operand type (pred maps feeding the fp32 decode kernel)
+};
+
+__device__ __forceinline__ void lds_dma16_h(u32x4_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+__device__ __forceinline__ u32x4_t make_rsrc_h(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  u32x4_t v;
+  v.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  v.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+  v.z = __builtin_amdgcn_readfirstlane(bytes);
+  v.w = 0x00020000u;
+  return v;
+}
+
+template <bool BF16>
+struct Elem;
+template <>
+struct Elem<true> {
+  typedef __bf16 T;
+  typedef bf16x8 V8;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Elem<false> {
+  typedef _Float16 T;
+  typedef f16x8 V8;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// Epilogue of one 32x32 accumulator tile through a wave-private LDS patch (fp32, pitch 36):
+// afterwards lane l owns 8 consecutive channels of rows (l>>2) and (l>>2)+16, i.e. one 16-byte
+// store of 16-bit outputs per row (two dwordx4 when the output is fp32).
+template <bool BF16>
+__device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16& acc, float* ep, int lane, int m_base,
+                                                int co_base, bool vec_ok, bool has2) {
+  typedef typename Elem<BF16>::T T;
+  typedef typename Elem<BF16>::V8 V8;
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int kPitch = 36;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + 4 * h) * kPitch + r] = acc[e];
+  const int c8 = (lane & 3) * 8;
+  const int co = co_base + c8;
+  if (vec_ok && co + 7 < p.Cout) {
+    float s1[8], t1[8], s2[8], t2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s1[u] = p.s1[co + u];
+      t1[u] = p.t1[co + u];
+      s2[u] = has2 ? p.s2[co + u] : 1.f;
+      t2[u] = has2 ? p.t2[co + u] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = (lane >> 2) + 16 * k;
+      const int m = m_base + row;
+      const float4 a0 = *reinterpret_cast<const float4*>(ep + row * kPitch + c8);
+      const float4 a1 = *reinterpret_cast<const float4*>(ep + row * kPitch + c8 + 4);
+      if (m < p.M) {
+        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = apply_act(v[u] * s1[u] + t1[u], p.act1, p.slope1);
+        if (p.res) {
+          const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.r_cs + p.r_co + co);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] += (float)rr[u];
+        }
+        if (has2) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = apply_act(v[u] * s2[u] + t2[u], p.act2, p.slope2);
+        }
+        if (p.out_f32) {
+          float* dst = reinterpret_cast<float*>(p.y) + (int64_t)m * p.y_cs + p.y_co + co;
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          V8 o;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) o[u] = (T)v[u];
+          *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.y) + (int64_t)m * p.y_cs + p.y_co + co) = o;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = (lane >> 2) + 16 * k;
+      const int m = m_base + row;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = co + u;
+        if (c < p.Cout) {
+          float v = ep[row * kPitch + c8 + u] * p.s1[c] + p.t1[c];
+          v = apply_act(v, p.act1, p.slope1);
+          if (p.res) v += (float)reinterpret_cast<const T*>(p.res)[(int64_t)m * p.r_cs + p.r_co + c];
+          if (has2) v = apply_act(v * p.s2[c] + p.t2[c], p.act2, p.slope2);
+          if (p.out_f32)
+            reinterpret_cast<float*>(p.y)[(int64_t)m * p.y_cs + p.y_co + c] = v;
+          else
+            reinterpret_cast<T*>(p.y)[(int64_t)m * p.y_cs + p.y_co + c] = (T)v;
+        }
+      }
+    }
+  }
+}
+
+// GENERAL_K = false: Cin % 64 == 0, a slice lies inside one (kh,kw) tap and the (tap, channel)
+//   walk is scalar.  GENERAL_K = true: Cin % 8 == 0 only (stem with C padded to 8, Cin = 32
+//   layers, tiny models): every lane derives (tap, channel) of its own 8-element chunk per slice;
+//   chunks beyond K read zeros on both operands.
+template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, bool GENERAL_K>
+__global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes) {
+  typedef typename Elem<BF16>::V8 V8;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  constexpr int PA = BM / 32;
+  constexpr int PB = BN / 32;
+  constexpr int kDmaPerSlice = PA + PB;
+  constexpr int kRowB = 128;    // bytes per LDS row
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_h[];
+  char* As = smem_h;                      // [2][BM][128 B]
+  char* Bs = smem_h + 2 * BM * kRowB;     // [2][BN][128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  const unsigned nwg = gridDim.x;
+  const unsigned bid = blockIdx.x;
+  const unsigned xcd = bid & 7u, q8 = nwg >> 3, rem8 = nwg & 7u;
+  const unsigned tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (bid >> 3);
+  const int tile_n = tile % p.tiles_n;
+  const int tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const u32x4_t rsA = make_rsrc_h(p.x, x_bytes);
+  const u32x4_t rsB = make_rsrc_h(p.w, w_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_h;
+
+  // staging: this lane fills LDS row (32*q + 8*wave + lane/8), physical chunk lane%8; the logical
+  // chunk it must fetch is the same for every pass q ((row>>1)&7 does not change with +32)
+  const int srow = 8 * wave + (lane >> 3);
+  const int pc = lane & 7;
+  const int lc = pc ^ ((srow >> 1) & 7);
+  unsigned a_off[PA];
+  unsigned long long a_mask[PA];
+#pragma unroll
+  for (int q = 0; q < PA; ++q) {
+    const int m = m0 + srow + 32 * q;
+    unsigned long long mk = 0ull;
+    unsigned off = 0u;
+    if (m < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int n = m / hw;
+      const int rm = m - n * hw;
+      const int ho = rm / p.Wo;
+      const int wo = rm - ho * p.Wo;
+      const int hi0 = ho * p.stride - p.pad;
+      const int wi0 = wo * p.stride - p.pad;
+      off = (unsigned)((((int64_t)(n * p.H + hi0) * p.W + wi0) * p.x_cs + p.x_co + (GENERAL_K ? 0 : lc * 8)) * 2);
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw)
+          if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
+            mk |= 1ull << (kh * p.KW + kw);
+    }
+    a_off[q] = off;
+    a_mask[q] = mk;
+  }
+  unsigned b_off[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int co = n0 + srow + 32 * q;
+    b_off[q] = co < p.Cout ? (unsigned)(((int64_t)co * p.Kw + (GENERAL_K ? 0 : lc * 8)) * 2) : kOOB;
+  }
+
+  int s_tap = 0, s_c0 = 0, s_kh = 0, s_kw = 0;
+  unsigned s_kb = 0;
+  int g_k = lc * 8;     // GENERAL_K: first K index of this lane's chunk in the next slice
+
+#define YV4_H_DMA(BUF)                                                                           \
+  {                                                                                              \
+    const unsigned la_ = lds_base + (unsigned)(((BUF) * BM + 8 * wave) * kRowB);                  \
+    const unsigned lb_ = lds_base + (unsigned)((2 * BM + (BUF) * BN + 8 * wave) * kRowB);         \
+    if (GENERAL_K) {                                                                             \
+      const bool kin = g_k < p.K;                                                                \
+      const int tap = kin ? g_k / p.Cin : 0;                                                     \
+      const int c = g_k - tap * p.Cin;                                                           \
+      const int kh = tap / p.KW;                                                                 \
+      const int kw = tap - kh * p.KW;                                                            \
+      const unsigned step = (unsigned)((((int64_t)kh * p.W + kw) * p.x_cs + c) * 2);             \
+      _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                           \
+        const bool ok = kin && ((a_mask[q] >> tap) & 1ull);                                      \
+        lds_dma16_h(rsA, la_ + 32 * q * kRowB, ok ? a_off[q] + step : kOOB, 0u);                  \
+      }                                                                                          \
+      _Pragma("unroll") for (int q = 0; q < PB; ++q)                                             \
+        lds_dma16_h(rsB, lb_ + 32 * q * kRowB, (kin && b_off[q] != kOOB) ? b_off[q] + (unsigned)(g_k * 2) : kOOB, 0u); \
+      g_k += kHBK;                                                                               \
+    } else {                                                                                     \
+      const unsigned step = (unsigned)((((int64_t)s_kh * p.W + s_kw) * p.x_cs + s_c0) * 2);      \
+      _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                           \
+        const bool ok = (a_mask[q] >> s_tap) & 1ull;                                             \
+        lds_dma16_h(rsA, la_ + 32 * q * kRowB, ok ? a_off[q] + step : kOOB, 0u);                  \
+      }                                                                                          \
+      _Pragma("unroll") for (int q = 0; q < PB; ++q)                                             \
+        lds_dma16_h(rsB, lb_ + 32 * q * kRowB, b_off[q], s_kb);                                   \
+      s_kb += kHBK * 2;                                                                          \
+      s_c0 += kHBK;                                                                              \
+      const int wrap_c = s_c0 >= p.Cin ? 1 : 0;                                                  \
+      s_c0 = wrap_c ? 0 : s_c0;                                                                  \
+      s_tap += wrap_c;                                                                           \
+      s_kw += wrap_c;                                                                            \
+      const int wrap_w = s_kw == p.KW ? 1 : 0;                                                   \
+      s_kw = wrap_w ? 0 : s_kw;                                                                  \
+      s_kh += wrap_w;                                                                            \
+    }                                                                                            \
+  }
+
+  // fragment read addresses: row*128 B + ((chunk ^ swz) << 4); MFMA step j reads chunk 2j + h
+  unsigned a_rd[TM], b_rd[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = wm * TM * 32 + i * 32 + r;
+    a_rd[i] = (unsigned)(row * kRowB + ((((row >> 1) & 7) ^ h) << 4));
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int row = wn * TN * 32 + i * 32 + r;
+    b_rd[i] = (unsigned)(row * kRowB + ((((row >> 1) & 7) ^ h) << 4));
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#define YV4_H_COMPUTE(BUF)                                                                       \
+  {                                                                                              \
+    const char* as_ = As + (BUF) * BM * kRowB;                                                   \
+    const char* bs_ = Bs + (BUF) * BN * kRowB;                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
+      V8 fa[TM], fb[TN];                                                                         \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+          fa[i] = *reinterpret_cast<const V8*>(as_ + (a_rd[i] ^ (unsigned)(j << 5)));            \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i)                                             \
+          fb[i] = *reinterpret_cast<const V8*>(bs_ + (b_rd[i] ^ (unsigned)(j << 5)));            \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+        _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                        \
+            acc[i][jn] = Elem<BF16>::mfma(fa[i], fb[jn], acc[i][jn]);                            \
+    }                                                                                            \
+  }
+
+  const int nk = (p.K + kHBK - 1) / kHBK;
+  YV4_H_DMA(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) YV4_H_DMA(buf ^ 1);     // slot buf^1 was last read before the previous barrier
+    __builtin_amdgcn_s_setprio(1);
+    YV4_H_COMPUTE(buf);
+    __builtin_amdgcn_s_setprio(0);
+    if (kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+#undef YV4_H_DMA
+#undef YV4_H_COMPUTE
+  (void)kDmaPerSlice;
+
+  const bool has2 = p.s2 != nullptr;
+  const int ymask = p.out_f32 ? 3 : 7;
+  const bool vec_ok = ((p.y_cs | p.y_co) & ymask) == 0 && (p.res == nullptr || ((p.r_cs | p.r_co) & 7) == 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  float* ep = reinterpret_cast<float*>(smem_h) + wave * (32 * 36);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+      epilogue_tile_h<BF16>(p, acc[i][jn], ep, lane, m0 + wm * TM * 32 + i * 32, n0 + wn * TN * 32 + jn * 32, vec_ok,
+                            has2);
+}
+
+template <bool BF16, int BM, int BN, bool GENERAL_K>
+static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
+  constexpr size_t lds = (size_t)2 * (BM + BN) * 128;
+  static_assert(lds >= 4 * 32 * 36 * 4, "epilogue patches must fit the K-loop carve");
+  ConvArgsH p = a;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.Cout + BN - 1) / BN;
+  const long long tiles = (long long)tiles_m * p.tiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffLL) {
+    set_error("conv h16: grid of %lld tiles out of range", tiles);
+    return YV4_E_INVALID;
+  }
+  const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 2, wb = (long long)p.Cout * p.Kw * 2;
+  auto kern = conv_mfma_h16_kernel<BF16, BM, BN, 2, 2, GENERAL_K>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kHThreads), lds, stream, p, (unsigned)xb, (unsigned)wb);
+  YV4_CHECK_LAUNCH("conv_mfma_h16");
+  return YV4_OK;
+}
+
+template <bool BF16>
+static int dispatch_h16(const ConvArgsH& a, int tile, bool general, hipStream_t s) {
+  switch (tile) {
+    case YV4_HTILE_128x128:
+      return general ? launch_h16<BF16, 128, 128, true>(a, s) : launch_h16<BF16, 128, 128, false>(a, s);
+    case YV4_HTILE_128x64:
+      return general ? launch_h16<BF16, 128, 64, true>(a, s) : launch_h16<BF16, 128, 64, false>(a, s);
+    case YV4_HTILE_64x64:
+      return general ? launch_h16<BF16, 64, 64, true>(a, s) : launch_h16<BF16, 64, 64, false>(a, s);
+    default:
+      break;
+  }
+  set_error("conv h16: unknown tile id %d", tile);
+  return YV4_E_INVALID;
+}
+
+static int pick_tile_h16(long long M, int Cout) {
+  // 256 CUs x 2 resident workgroups: the biggest tile that still fills the chip twice
+  auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
+  if (Cout > 64 && tiles(128, 128) >= 1024) return YV4_HTILE_128x128;
+  if (tiles(128, 64) >= 1024) return YV4_HTILE_128x64;
+  return YV4_HTILE_64x64;
+}
+
+}  // namespace yv4
+
+using namespace yv4;
+
+extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
+  if (!d) return YV4_TILE_AUTO;
+  return pick_tile_h16((long long)d->N * d->Ho * d->Wo, d->Cout);
+}
+
+extern "C" int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x, const void* w,
+                                       const float* scale1, const float* shift1, const float* scale2,
+                                       const float* shift2, const void* residual, void* y, void* stream) {
+  YV4_REQUIRE(d && x && w && scale1 && shift1 && y, "conv h16: null argument");
+  YV4_REQUIRE(dtype == YV4_F16 || dtype == YV4_BF16, "conv h16: dtype must be YV4_F16 or YV4_BF16");
+  YV4_REQUIRE(out_dtype == dtype || out_dtype == YV4_F32, "conv h16: out_dtype must be the operand type or YV4_F32");
+  YV4_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), "conv h16: scale2/shift2 must come together");
+  YV4_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv h16: empty shape");
+  YV4_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv h16: bad kernel/stride/pad");
+  YV4_REQUIRE(d->KH * d->KW <= 64, "conv h16: kernels above 64 taps are not supported");
+  YV4_REQUIRE(d->Cin % 8 == 0 && d->x_cstride % 8 == 0 && d->x_coff % 8 == 0,
+              "conv h16: Cin (%d), x_cstride (%d), x_coff (%d) must be multiples of 8", d->Cin, d->x_cstride, d->x_coff);
+  YV4_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "conv h16: x / w must be 16-byte aligned");
+  YV4_REQUIRE(d->x_coff + d->Cin <= d->x_cstride, "conv h16: input view exceeds its pixel stride");
+  YV4_REQUIRE(d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_cstride, "conv h16: output view exceeds its pixel stride");
+  const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  const int Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  YV4_REQUIRE(Ho == d->Ho && Wo == d->Wo, "conv h16: Ho/Wo (%d,%d) do not match the geometry (%d,%d)", d->Ho, d->Wo, Ho,
+              Wo);
+  if (residual)
+    YV4_REQUIRE(d->r_coff >= 0 && d->r_coff + d->Cout <= d->r_cstride, "conv h16: residual view exceeds its pixel stride");
+  YV4_REQUIRE(d->act1 >= 0 && d->act1 <= YV4_ACT_SWISH && d->act2 >= 0 && d->act2 <= YV4_ACT_SWISH,
+              "conv h16: unknown activation id");
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  YV4_REQUIRE(M < (1LL << 31), "conv h16: N*Ho*Wo = %lld does not fit 31 bits", M);
+  YV4_REQUIRE((long long)d->N * d->H * d->W < (1LL << 31), "conv h16: N*H*W does not fit 31 bits");
+  const long long K = (long long)d->KH * d->KW * d->Cin;
+  YV4_REQUIRE((long long)d->N * d->H * d->W * d->x_cstride * 2 < 0xFFFFFFF0LL && (long long)d->Cout * K * 2 < 0xFFFFFFF0LL,
+              "conv h16: tensors of 4 GiB or more are not addressable through a buffer descriptor");
+
+  ConvArgsH a;
+  a.x = x; a.w = w; a.s1 = scale1; a.t1 = shift1; a.s2 = scale2; a.t2 = shift2;
+  a.res = residual; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff;
+  a.r_cs = d->r_cstride; a.r_co = d->r_coff;
+  a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
+  a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0;
+  a.out_f32 = out_dtype == YV4_F32 ? 1 : 0;
+  const bool general = (d->Cin % kHBK) != 0;
+  const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout) : d->tile;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);
+}

@@ -1,0 +1,133 @@
+"""16-bit operand convolution (fp16 / bf16 in, fp32 accumulate) through the C ABI vs a float64
+convolution of the SAME rounded operands + the same epilogue in float64.
+
+Tolerance: the only differences are fp32 accumulation order (~1e-6 relative to the sum of
+|products|) and the final rounding of the output to the 16-bit type (half an ulp: 2^-9 relative for
+bf16, 2^-12 for fp16); fp32 outputs (`out_dtype = YV4_F32`) are held to 2e-5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mmdet_yolov4_amd as pkg
+from mmdet_yolov4_amd import _lib as L
+from oracle import yolov4_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+HT = dict(t128x128=1, t128x64=2, t64x64=3)
+
+
+def _h16_conv(dev, dtype, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=False, two_stage=False, x_off=0,
+              y_off=0, out_f32=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    cp = (Cin + 7) // 8 * 8
+    x = torch.randn(N, H, W, Cin, generator=g).to(dtype)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) * (1.0 / (Cin * k * k)) ** 0.5).to(dtype)
+    s1 = torch.rand(Cout, generator=g) + 0.5
+    t1 = torch.randn(Cout, generator=g) * 0.1
+    s2 = torch.rand(Cout, generator=g) + 0.5
+    t2 = torch.randn(Cout, generator=g) * 0.1
+    Ho = (H + 2 * pad - k) // stride + 1
+    Wo = (W + 2 * pad - k) // stride + 1
+    res = torch.randn(N, Ho, Wo, Cout, generator=g).to(dtype) if residual else None
+    acts = {0: lambda v: v, 1: lambda v: v * torch.tanh(F.softplus(v)), 2: lambda v: F.leaky_relu(v, 0.1),
+            3: lambda v: v * torch.sigmoid(v)}
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None, stride, pad)
+    ref = acts[act](ref * s1.double()[None, :, None, None] + t1.double()[None, :, None, None])
+    if residual:
+        ref = ref + res.double().permute(0, 3, 1, 2)
+    if two_stage:
+        ref = acts[act](ref * s2.double()[None, :, None, None] + t2.double()[None, :, None, None])
+    ref = ref.permute(0, 2, 3, 1)                                   # NHWC
+
+    xs = cp + x_off + (8 if x_off else 0)
+    xbuf = torch.zeros(N, H, W, xs, dtype=dtype, device=dev)
+    xbuf[..., x_off:x_off + Cin] = x.to(dev)
+    wbuf = torch.zeros(Cout, k, k, cp, dtype=dtype, device=dev)
+    wbuf[..., :Cin] = w.to(dev)
+    odt = torch.float32 if out_f32 else dtype
+    ys = Cout + y_off + (8 if y_off else 0)
+    if not out_f32 and ys % 8:
+        ys = (ys + 7) // 8 * 8
+    ybuf = torch.full((N, Ho, Wo, ys), 7.0, dtype=odt, device=dev)
+    rbuf = res.to(dev).contiguous() if residual else None
+    d = L.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, cp, Ho, Wo, Cout
+    d.KH, d.KW, d.stride, d.pad = k, k, stride, pad
+    d.x_cstride, d.x_coff, d.y_cstride, d.y_coff = xs, x_off, ys, y_off
+    d.r_cstride, d.r_coff = Cout, 0
+    d.act1, d.act2, d.slope1, d.slope2 = act, act if two_stage else 0, 0.1, 0.1
+    d.tile = tile
+    dev_f = lambda t: t.to(dev).float().contiguous()
+    s1d, t1d, s2d, t2d = dev_f(s1), dev_f(t1), dev_f(s2), dev_f(t2)
+    rc = L.lib().yv4_conv_bn_act_fwd_h16(C.byref(d), 1 if dtype == torch.float16 else 2, 0 if out_f32 else
+                                         (1 if dtype == torch.float16 else 2), xbuf.data_ptr(), wbuf.data_ptr(),
+                                         s1d.data_ptr(), t1d.data_ptr(), s2d.data_ptr() if two_stage else None,
+                                         t2d.data_ptr() if two_stage else None,
+                                         rbuf.data_ptr() if residual else None, ybuf.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+    L.check(rc, 'yv4_conv_bn_act_fwd_h16')
+    torch.cuda.synchronize()
+    got = ybuf[..., y_off:y_off + Cout].double().cpu()
+    assert bool((ybuf[..., :y_off] == 7.0).all()) and bool((ybuf[..., y_off + Cout:] == 7.0).all())
+    ulp = 2e-5 if out_f32 else (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11)
+    err = (got - ref).abs()
+    bound = ulp * ref.abs() + 3e-5 + (0 if out_f32 else ulp * 1e-2)
+    bad = err > bound
+    assert not bool(bad.any()), (f'{int(bad.sum())} of {bad.numel()} outside tolerance; worst '
+                                 f'{float((err / (ref.abs() + 1e-3)).max()):.3e} rel')
+
+
+SHAPES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (2, 19, 19, 64, 128, 3, 1, 1),     # uniform-tap path, ragged M (722 rows)
+    (1, 16, 20, 64, 255, 1, 1, 0),     # head-like: Cout 255 not a tile multiple
+    (2, 17, 23, 128, 64, 3, 2, 1),     # stride 2, odd sizes
+    (1, 12, 12, 32, 40, 3, 1, 1),      # Cin % 64 != 0 -> per-lane tap decode, K tail
+    (2, 32, 32, 3, 32, 3, 1, 1),       # stem: Cin 3 padded to 8, K = 72
+    (1, 24, 24, 3, 16, 6, 2, 2),       # Focus conv k=6 s=2 p=2
+    (1, 10, 10, 192, 96, 1, 1, 0),     # 1x1, K = 3 slices
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_h16_conv_shapes_and_tiles(gpu_device, dtype, tile, shape):
+    _h16_conv(gpu_device, dtype, *shape, act=1, tile=tile)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+def test_h16_conv_epilogues(gpu_device, dtype, act):
+    _h16_conv(gpu_device, dtype, 2, 13, 13, 64, 72, 3, 1, 1, act, 0, residual=True, two_stage=True, x_off=8, y_off=16)
+    _h16_conv(gpu_device, dtype, 1, 9, 11, 64, 255, 1, 1, 0, act, 0, out_f32=True)           # pred maps in fp32
+    _h16_conv(gpu_device, dtype, 1, 9, 11, 40, 64, 3, 1, 1, act, 3, out_f32=True, y_off=4)
+
+
+def test_h16_conv_big_k(gpu_device):
+    _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 512, 64, 3, 1, 1, 1, 1)       # K = 4608
+
+
+def test_h16_conv_rejects_bad_arguments(gpu_device):
+    d = L.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 1, 8, 8, 12, 8, 8, 16
+    d.KH = d.KW = 1
+    d.stride, d.pad = 1, 0
+    d.x_cstride, d.y_cstride = 12, 16
+    t = torch.zeros(4096, device=gpu_device)
+    f = L.lib().yv4_conv_bn_act_fwd_h16
+    p = t.data_ptr()
+    assert f(C.byref(d), 2, 2, p, p, p, p, None, None, None, p, None) != 0          # Cin % 8
+    d.Cin = d.x_cstride = 16
+    assert f(C.byref(d), 0, 0, p, p, p, p, None, None, None, p, None) != 0          # fp32 is the other entry
+    assert f(C.byref(d), 2, 1, p, p, p, p, None, None, None, p, None) != 0          # bf16 in, fp16 out
+    assert f(C.byref(d), 2, 2, p, p, p, p, p, None, None, p, None) != 0             # scale2 without shift2
+    assert f(C.byref(d), 2, 2, p + 2, p, p, p, None, None, None, p, None) != 0      # misaligned x
+    d.tile = 9
+    assert f(C.byref(d), 2, 2, p, p, p, p, None, None, None, p, None) != 0
+    assert b'tile' in L.lib().yv4_last_error()
