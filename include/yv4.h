@@ -291,6 +291,17 @@ int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int out_dtype, co
                             void* y, void* stream);
 int yv4_conv_h16_pick_tile(const yv4_conv_desc* d);
 
+/* 16-bit forms of the layout adaptors and the SPP pools (same argument meaning as the fp32
+ * entries; the boundary tensors stay fp32 NCHW like the reference's, the NHWC side is `dtype`).
+ * The nearest resample / concat copy has no 16-bit entry: call yv4_resample_nearest_fwd with the
+ * channel arguments halved (a 16-bit view with C % 8 == 0 is an fp32 view with C/2 channels). */
+int yv4_nchw_to_nhwc_h16(const float* src, void* dst, int N, int C, int H, int W,
+                         int dst_cstride, int dst_coff, int zero_pad, int dtype, void* stream);
+int yv4_nhwc_to_nchw_h16(const void* src, float* dst, int N, int C, int H, int W,
+                         int src_cstride, int src_coff, int dtype, void* stream);
+int yv4_spp_pool_fwd_h16(void* buf, int N, int H, int W, int C, int cstride, int coff,
+                         int dtype, void* stream);
+
 /* ---- optimizer side of the training step (flat fp32 arenas) -------------------------
  * The reference steps torch.optim.SGD(nesterov) with one param group per parameter
  * (core/custom_hooks/warmup_hooks.py:24-32 requires that), un-scales and clips gradients in

@@ -9,7 +9,7 @@ from . import _lib
 from .registry import (ACTIVATION_LAYERS, ANCHOR_GENERATORS, BACKBONES, BBOX_CODERS, DETECTORS, HEADS, LOSSES,
                        MODELS, NECKS, Config, ConfigDict, Registry, build_anchor_generator, build_backbone,
                        build_bbox_coder, build_detector, build_from_cfg, build_head, build_neck)
-from .bricks import Mish, build_activation_layer, build_norm_layer
+from .bricks import Mish, build_activation_layer, build_norm_layer, wrap_fp16_model
 from .ops import MishFunction, batched_nms, mish_backward, mish_forward, multiclass_nms, nms
 from .anchor_generator import YOLOAnchorGenerator, YOLOV4AnchorGenerator
 from .bbox_coder import YOLOV4BBoxCoder

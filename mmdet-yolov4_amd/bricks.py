@@ -217,11 +217,12 @@ class HipModule(nn.Module):
             raise NotImplementedError(
                 f'{type(self).__name__}: the eval-mode (fused launch plan) path has no autograd; call .train() '
                 'to differentiate through the HIP training ops')
-        key = (tuple(tuple(t.shape) for t in flat), str(flat[0].device), self._param_version())
+        dtype = getattr(self, 'compute_dtype', torch.float32)
+        key = (tuple(tuple(t.shape) for t in flat), str(flat[0].device), self._param_version(), dtype)
         plan = self._plan_cache.get(key)
         if plan is None:
             self._plan_cache.clear()
-            plan = Plan(flat[0].device)
+            plan = Plan(flat[0].device, dtype)
             views = [plan.add_input_nchw(*t.shape, name=f'in{i}') for i, t in enumerate(flat)]
             outs = self.emit(plan, *(views if structure == 'flat' else [views]))
             outs_l = list(outs) if isinstance(outs, (tuple, list)) else [outs]
@@ -232,6 +233,25 @@ class HipModule(nn.Module):
             self._plan_cache[key] = plan
         res = plan.run(*flat)
         return res[0] if plan.single else tuple(res)
+
+
+def wrap_fp16_model(model, dtype=torch.float16):
+    """mmcv ``wrap_fp16_model`` for the eval-mode fused path (what ``tools/test.py:175-177`` calls
+    when the config has an ``fp16`` field): every plan-backed module computes its convs on 16-bit
+    operands (fp32 accumulate, fp32 BN/activation epilogue) from then on; parameters stay fp32 master
+    copies and are packed to ``dtype`` when a plan is built.  ``dtype`` may be ``torch.bfloat16``.
+    Module boundaries keep the reference's fp32 NCHW tensors."""
+    if dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        raise ValueError('wrap_fp16_model: dtype must be float16, bfloat16 or float32')
+    for m in model.modules():
+        if isinstance(m, HipModule):
+            m.compute_dtype = dtype
+            m._plan_cache.clear()
+            if hasattr(m, '_engines'):
+                m._engines.clear()
+        if hasattr(m, 'fp16_enabled'):
+            m.fp16_enabled = dtype != torch.float32
+    return model
 
 
 def conv_bn_stage(conv_module):

@@ -23,11 +23,13 @@ from ._lib import ConvDesc, LevelDesc, check
 
 
 class Buf:
-    """One NHWC fp32 allocation: (N, H, W, C) with C floats per pixel."""
+    """One NHWC allocation: (N, H, W, C) with C elements per pixel (fp32, or fp16 / bf16 in a
+    16-bit plan)."""
 
-    def __init__(self, N, H, W, C_, name=''):
+    def __init__(self, N, H, W, C_, name='', dtype=torch.float32):
         self.N, self.H, self.W, self.C = int(N), int(H), int(W), int(C_)
         self.name = name
+        self.dtype = dtype
         self.tensor = None
 
     @property
@@ -97,20 +99,35 @@ def bn_affine(bn):
     return s.contiguous(), t.contiguous()
 
 
-def pack_conv_weight(weight, cin_pad=None):
+def pack_conv_weight(weight, cin_pad=None, align=4):
     """(Cout, Cin, KH, KW) -> (Cout, KH*KW*Cin_pad) with K ordered (kh, kw, ci), the order
-    the kernel's NHWC gather walks; Cin is zero-padded to a multiple of 4."""
+    the kernel's NHWC gather walks; Cin is zero-padded to a multiple of ``align`` (4 floats or
+    8 sixteen-bit elements = one 16-byte chunk)."""
     Cout, Cin, KH, KW = weight.shape
-    cp = cin_pad if cin_pad is not None else (Cin + 3) // 4 * 4
+    cp = cin_pad if cin_pad is not None else (Cin + align - 1) // align * align
     w = weight.detach().float().permute(0, 2, 3, 1)  # Cout, KH, KW, Cin
     if cp != Cin:
         w = torch.nn.functional.pad(w, (0, cp - Cin))
     return w.reshape(Cout, KH * KW * cp).contiguous(), cp
 
 
+_DCODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}      # YV4_F32 / YV4_F16 / YV4_BF16
+
+
 class Plan:
-    def __init__(self, device):
+    """``dtype``: torch.float32 (the parity dtype) or torch.float16 / torch.bfloat16: activations and
+    weights are stored in that type, convs accumulate in fp32 (``yv4_conv_bn_act_fwd_h16``), folded BN
+    scale/shift and the pred maps handed to decode stay fp32."""
+
+    def __init__(self, device, dtype=torch.float32):
         self.device = torch.device(device)
+        if dtype not in _DCODE:
+            raise ValueError(f'Plan dtype must be float32, float16 or bfloat16 (got {dtype})')
+        self.dtype = dtype
+        self.h16 = dtype != torch.float32
+        self.dcode = _DCODE[dtype]
+        self.calign = 8 if self.h16 else 4       # channels per 16-byte chunk
+        self.esize = 2 if self.h16 else 4
         self.bufs = []
         self.ops = []
         self.params = []      # device tensors kept alive (packed weights, scales, descs)
@@ -120,8 +137,8 @@ class Plan:
         self._static_inputs = None
 
     # ---- buffers -----------------------------------------------------------------
-    def new_buf(self, N, H, W, C_, name=''):
-        b = Buf(N, H, W, C_, name or f'b{len(self.bufs)}')
+    def new_buf(self, N, H, W, C_, name='', dtype=None):
+        b = Buf(N, H, W, C_, name or f'b{len(self.bufs)}', dtype or self.dtype)
         self.bufs.append(b)
         return View(b, 0, C_)
 
@@ -131,36 +148,52 @@ class Plan:
         return t
 
     def add_input_nchw(self, N, C_, H, W, name='input', pad4=True):
-        """Declare an NCHW fp32 input; returns its NHWC view (channels zero-padded to a
-        multiple of 4 unless pad4=False, which keeps the buffer dense)."""
-        cp = (C_ + 3) // 4 * 4 if pad4 else C_
+        """Declare an NCHW fp32 input; returns its NHWC view in the plan's dtype (channels
+        zero-padded to one 16-byte chunk -- 4 floats / 8 halves -- unless pad4=False, which keeps
+        the buffer dense)."""
+        al = self.calign
+        cp = (C_ + al - 1) // al * al if pad4 else C_
         v = self.new_buf(N, H, W, cp, name)
         slot = {'view': v, 'C': C_, 'src': None}
         self.inputs.append(slot)
-
-        def fn(stream, slot=slot, v=v, C_=C_, cp=cp):
-            src = slot['src']
-            check(_lib.lib().yv4_nchw_to_nhwc(src.data_ptr(), v.buf.ptr(), v.N, C_, v.H, v.W, cp, 0,
-                                              cp - C_, stream), 'yv4_nchw_to_nhwc')
-        self.ops.append(Op('to_nhwc', name, fn, nbytes=2.0 * 4 * N * C_ * H * W))
+        if self.h16:
+            def fn(stream, slot=slot, v=v, C_=C_, cp=cp):
+                check(_lib.lib().yv4_nchw_to_nhwc_h16(slot['src'].data_ptr(), v.buf.ptr(), v.N, C_, v.H, v.W, cp, 0,
+                                                      cp - C_, self.dcode, stream), 'yv4_nchw_to_nhwc_h16')
+        else:
+            def fn(stream, slot=slot, v=v, C_=C_, cp=cp):
+                src = slot['src']
+                check(_lib.lib().yv4_nchw_to_nhwc(src.data_ptr(), v.buf.ptr(), v.N, C_, v.H, v.W, cp, 0,
+                                                  cp - C_, stream), 'yv4_nchw_to_nhwc')
+        self.ops.append(Op('to_nhwc', name, fn, nbytes=(4.0 + self.esize) * N * C_ * H * W))
         return v
 
     # ---- ops ---------------------------------------------------------------------
     def conv(self, x, weight, s1, t1, act1=(0, 0.0), stride=1, pad=None, residual=None, s2=None,
-             t2=None, act2=(0, 0.0), out=None, name='conv', tile=0, bn1=None, bn2=None):
+             t2=None, act2=(0, 0.0), out=None, name='conv', tile=0, bn1=None, bn2=None, out_f32=False):
         """Fused conv launch.  weight: (Cout, Cin, KH, KW) torch tensor (any device).
         bn1 / bn2: optional (BatchNorm module, lo, hi) naming the BN channels that stage 1 /
-        stage 2 of the epilogue were folded from (used by calibrate.py only)."""
+        stage 2 of the epilogue were folded from (used by calibrate.py only).
+        out_f32: in a 16-bit plan, store this conv's output in fp32 (pred maps feeding decode)."""
         Cout, Cin, KH, KW = weight.shape
-        wp, cp = pack_conv_weight(weight)
-        assert x.C == cp or (x.C == Cin and Cin % 4 == 0), f'{name}: input view has {x.C} channels, conv wants {Cin}'
+        wp, cp = pack_conv_weight(weight, align=self.calign)
+        if self.h16:
+            wp = wp.to(self.dtype)
+            assert x.buf.dtype == self.dtype, f'{name}: a 16-bit plan convolves {self.dtype} inputs, got {x.buf.dtype}'
+            assert x.coff % 8 == 0 and x.cstride % 8 == 0, \
+                f'{name}: 16-bit views need channel offsets / strides that are multiples of 8 ({x})'
+        assert x.C == cp or (x.C == Cin and Cin % self.calign == 0), \
+            f'{name}: input view has {x.C} channels, conv wants {Cin} (padded {cp})'
         if pad is None:
             pad = KH // 2
         Ho = (x.H + 2 * pad - KH) // stride + 1
         Wo = (x.W + 2 * pad - KW) // stride + 1
         if out is None:
-            out = self.new_buf(x.N, Ho, Wo, Cout, name)
+            out = self.new_buf(x.N, Ho, Wo, Cout, name, dtype=torch.float32 if out_f32 else None)
         assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, Cout), f'{name}: output view mismatch {out} vs {(x.N, Ho, Wo, Cout)}'
+        out_code = _DCODE[out.buf.dtype]
+        if self.h16 and out_code != 0:
+            assert out.coff % 8 == 0 and out.cstride % 8 == 0, f'{name}: 16-bit output view must be 8-channel aligned ({out})'
         if residual is not None:
             assert (residual.N, residual.H, residual.W, residual.C) == (x.N, Ho, Wo, Cout), f'{name}: residual mismatch'
         d = ConvDesc()
@@ -180,17 +213,27 @@ class Plan:
                  t2=self._dev(t2.float()) if s2 is not None else None)
         self.params.append(d)
 
-        def fn(stream, L=L):
-            check(_lib.lib().yv4_conv_bn_act_fwd(
-                C.byref(L['d']), L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(), L['t1'].data_ptr(),
-                L['s2'].data_ptr() if L['s2'] is not None else None,
-                L['t2'].data_ptr() if L['t2'] is not None else None,
-                L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), stream), 'yv4_conv_bn_act_fwd')
+        if self.h16:
+            def fn(stream, L=L, out_code=out_code):
+                check(_lib.lib().yv4_conv_bn_act_fwd_h16(
+                    C.byref(L['d']), self.dcode, out_code, L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(),
+                    L['t1'].data_ptr(), L['s2'].data_ptr() if L['s2'] is not None else None,
+                    L['t2'].data_ptr() if L['t2'] is not None else None,
+                    L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), stream),
+                    'yv4_conv_bn_act_fwd_h16')
+        else:
+            def fn(stream, L=L):
+                check(_lib.lib().yv4_conv_bn_act_fwd(
+                    C.byref(L['d']), L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(), L['t1'].data_ptr(),
+                    L['s2'].data_ptr() if L['s2'] is not None else None,
+                    L['t2'].data_ptr() if L['t2'] is not None else None,
+                    L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), stream), 'yv4_conv_bn_act_fwd')
         M = x.N * Ho * Wo
         flops = 2.0 * M * Cout * KH * KW * Cin          # algorithmic: real Cin, not the padded one
-        nbytes = 4.0 * (x.N * x.H * x.W * Cin + M * Cout + Cout * KH * KW * Cin)
+        es = float(self.esize)
+        nbytes = es * (x.N * x.H * x.W * Cin + Cout * KH * KW * Cin) + (4.0 if out_code == 0 else es) * M * Cout
         if residual is not None:
-            nbytes += 4.0 * M * Cout
+            nbytes += es * M * Cout
         self.ops.append(Op('conv', name, fn, flops, nbytes,
                            dict(Cin=Cin, Cout=Cout, k=KH, stride=stride, H=x.H, W=x.W, Ho=Ho, Wo=Wo,
                                 N=x.N, desc=d, launch=L, out=out, bn1=bn1, bn2=bn2)))
@@ -201,32 +244,47 @@ class Plan:
         assert cat_view.C == 4 * C_
         b = cat_view.buf
 
-        def fn(stream, b=b, v=cat_view, C_=C_):
-            check(_lib.lib().yv4_spp_pool_fwd(b.ptr(), v.N, v.H, v.W, C_, v.cstride, v.coff, stream),
-                  'yv4_spp_pool_fwd')
-        self.ops.append(Op('spp', name, fn, nbytes=4.0 * 4 * cat_view.N * cat_view.H * cat_view.W * C_))
+        if self.h16:
+            def fn(stream, b=b, v=cat_view, C_=C_):
+                check(_lib.lib().yv4_spp_pool_fwd_h16(b.ptr(), v.N, v.H, v.W, C_, v.cstride, v.coff, self.dcode,
+                                                      stream), 'yv4_spp_pool_fwd_h16')
+        else:
+            def fn(stream, b=b, v=cat_view, C_=C_):
+                check(_lib.lib().yv4_spp_pool_fwd(b.ptr(), v.N, v.H, v.W, C_, v.cstride, v.coff, stream),
+                      'yv4_spp_pool_fwd')
+        self.ops.append(Op('spp', name, fn, nbytes=self.esize * 4.0 * cat_view.N * cat_view.H * cat_view.W * C_))
         return cat_view
 
     def resample(self, src, dst, name='resample'):
         """Nearest resample src -> dst (same N and C; dst's H/W are the target size)."""
-        assert src.N == dst.N and src.C == dst.C
+        assert src.N == dst.N and src.C == dst.C and src.buf.dtype == dst.buf.dtype
+        # a 16-bit view with C % 8 == 0 is byte-identical to an fp32 view with C/2 channels
+        k = 2 if src.buf.dtype != torch.float32 else 1
+        if k == 2:
+            assert all(v % 8 == 0 for v in (src.C, src.cstride, src.coff, dst.cstride, dst.coff)), \
+                f'{name}: 16-bit resample needs 8-channel aligned views'
 
-        def fn(stream, s=src, d=dst):
+        def fn(stream, s=src, d=dst, k=k):
             check(_lib.lib().yv4_resample_nearest_fwd(s.buf.ptr(), d.buf.ptr(), s.N, s.H, s.W, d.H, d.W,
-                                                      s.C, s.cstride, s.coff, d.cstride, d.coff, stream),
-                  'yv4_resample_nearest_fwd')
+                                                      s.C // k, s.cstride // k, s.coff // k, d.cstride // k,
+                                                      d.coff // k, stream), 'yv4_resample_nearest_fwd')
         self.ops.append(Op('resample', name, fn,
-                           nbytes=4.0 * src.C * src.N * (src.H * src.W + dst.H * dst.W)))
+                           nbytes=(4.0 / k) * src.C * src.N * (src.H * src.W + dst.H * dst.W)))
         return dst
 
     def add_output_nchw(self, view, name='out'):
         """Materialise a view as a fresh NCHW tensor on every run; returns the slot index."""
         slot = {'view': view, 'dst': None}
 
-        def fn(stream, slot=slot, v=view):
-            check(_lib.lib().yv4_nhwc_to_nchw(v.buf.ptr(), slot['dst'].data_ptr(), v.N, v.C, v.H, v.W,
-                                              v.cstride, v.coff, stream), 'yv4_nhwc_to_nchw')
-        self.ops.append(Op('to_nchw', name, fn, nbytes=2.0 * 4 * view.N * view.C * view.H * view.W))
+        if view.buf.dtype != torch.float32:
+            def fn(stream, slot=slot, v=view, code=_DCODE[view.buf.dtype]):
+                check(_lib.lib().yv4_nhwc_to_nchw_h16(v.buf.ptr(), slot['dst'].data_ptr(), v.N, v.C, v.H, v.W,
+                                                      v.cstride, v.coff, code, stream), 'yv4_nhwc_to_nchw_h16')
+        else:
+            def fn(stream, slot=slot, v=view):
+                check(_lib.lib().yv4_nhwc_to_nchw(v.buf.ptr(), slot['dst'].data_ptr(), v.N, v.C, v.H, v.W,
+                                                  v.cstride, v.coff, stream), 'yv4_nhwc_to_nchw')
+        self.ops.append(Op('to_nchw', name, fn, nbytes=(4.0 + self.esize) * view.N * view.C * view.H * view.W))
         self.outputs = getattr(self, 'outputs', [])
         self.outputs.append(slot)
         return len(self.outputs) - 1
@@ -245,6 +303,8 @@ class Plan:
         attr = 5 + kclasses
         total = 0
         for v in pred_views:
+            assert v.buf.dtype == torch.float32, 'decode reads fp32 pred maps (emit the head convs with out_f32)'
+            assert v.buf.dtype == torch.float32, 'decode reads fp32 pred maps (emit the head convs with out_f32)'
             assert v.C == A * attr and v.coff == 0 and v.cstride == v.C, 'pred maps must be dense NHWC'
             total += v.H * v.W * A
         levels = (LevelDesc * len(pred_views))()
@@ -319,7 +379,7 @@ class Plan:
     # ---- lifecycle ---------------------------------------------------------------
     def finalize(self):
         for b in self.bufs:
-            b.tensor = torch.empty(b.numel, dtype=torch.float32, device=self.device)
+            b.tensor = torch.empty(b.numel, dtype=b.dtype, device=self.device)
         if getattr(self, 'post', None) is not None:
             self.post['_alloc']()
         self.finalized = True
@@ -331,14 +391,17 @@ class Plan:
         table is not robust).  Inputs must be set (run the plan once first).  Returns a dict
         layer-index -> chosen tile id."""
         assert self.finalized and self.graph is None and self.device.type == 'cuda'
-        cands = candidates or (_lib.TILE_DMA_64x64, _lib.TILE_DMA_128x64, _lib.TILE_DMA_128x128)
+        if self.h16:
+            cands = candidates or (1, 2, 3)            # YV4_HTILE_128x128 / 128x64 / 64x64
+        else:
+            cands = candidates or (_lib.TILE_DMA_64x64, _lib.TILE_DMA_128x64, _lib.TILE_DMA_128x128)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         chosen = {}
         for idx, op in enumerate(self.ops):
             if op.kind != 'conv':
                 continue
             d = op.info['desc']
-            auto = _lib.lib().yv4_conv_pick_tile(C.byref(d))
+            auto = (_lib.lib().yv4_conv_h16_pick_tile if self.h16 else _lib.lib().yv4_conv_pick_tile)(C.byref(d))
             if auto not in cands:          # stem / generic path: nothing to choose from
                 continue
             best, best_t = auto, None
@@ -367,7 +430,7 @@ class Plan:
         return sum(o.flops for o in self.ops)
 
     def activation_bytes(self):
-        return sum(b.numel for b in self.bufs) * 4
+        return sum(b.numel * (4 if b.dtype == torch.float32 else 2) for b in self.bufs)
 
     def _launch_all(self, stream):
         for op in self.ops:

@@ -65,16 +65,18 @@ class SingleStageDetector(HipModule):
         """forward_dummy graph: image -> NHWC pred maps."""
         return self.bbox_head.emit(plan, self.emit_feat(plan, x))
 
-    def compile(self, batch, height, width, device='cuda', rescale=True, graph=False, autotune=False):
+    def compile(self, batch, height, width, device='cuda', rescale=True, graph=False, autotune=False, dtype=None):
         """Build (and cache) the end-to-end inference plan for one input geometry.
         graph=True records the launch list into a hipGraph (one replay per call; the
         reference's batch-1 protocol is otherwise bound by ~124 host launches);
-        autotune=True times the candidate conv tiles per layer first."""
-        key = (batch, height, width, str(device), bool(rescale), bool(graph), self._param_version())
+        autotune=True times the candidate conv tiles per layer first; dtype: torch.float32 (default,
+        the parity dtype), torch.float16 or torch.bfloat16 (``wrap_fp16_model`` sets the default)."""
+        dtype = dtype or getattr(self, 'compute_dtype', torch.float32)
+        key = (batch, height, width, str(device), bool(rescale), bool(graph), self._param_version(), dtype)
         eng = self._engines.get(key)
         if eng is None:
             self._engines.clear()
-            plan = Plan(device)
+            plan = Plan(device, dtype)
             x = plan.add_input_nchw(batch, 3, height, width, name='img')
             preds = self.emit(plan, x)
             self.bbox_head.emit_postprocess(plan, preds, rescale=rescale)

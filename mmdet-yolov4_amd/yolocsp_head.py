@@ -117,7 +117,8 @@ class YOLOCSPHead(HipModule):
             conv = self.convs_pred[i]
             s = torch.ones(conv.out_channels)
             t = conv.bias.detach().float()
-            outs.append(plan.conv(x, conv.weight, s, t, (0, 0.0), stride=1, pad=0, name=f'pred_conv{i}'))
+            outs.append(plan.conv(x, conv.weight, s, t, (0, 0.0), stride=1, pad=0, name=f'pred_conv{i}',
+                                  out_f32=plan.h16))      # decode reads fp32 pred maps
         return tuple(outs)
 
     def emit_postprocess(self, plan, pred_views, cfg=None, rescale=True, want_cls=False):

@@ -131,3 +131,83 @@ def test_h16_conv_rejects_bad_arguments(gpu_device):
     d.tile = 9
     assert f(C.byref(d), 2, 2, p, p, p, p, None, None, None, p, None) != 0
     assert b'tile' in L.lib().yv4_last_error()
+
+
+# ---------------------------------------------------------------------------------------------
+# whole detector in fp16 / bf16 (wrap_fp16_model) vs the oracle's reduced-precision emulation
+# ---------------------------------------------------------------------------------------------
+def _build_v5(golden, dev):
+    from conftest import arch_from, state_dict_from
+    g = golden('tiny_v5')
+    stages, reps, chans = arch_from(g)
+    det = pkg.build_detector(dict(
+        type='SingleStageDetector',
+        backbone=dict(type='DarknetCSP', scale=[stages, reps, chans], out_indices=[2, 3, 4]),
+        neck=dict(type='YOLOV5Neck', in_channels=[32, 64, 128], out_channels=[32, 64, 128], csp_repetition=1),
+        bbox_head=dict(type='YOLOCSPHead', num_classes=80, in_channels=[32, 64, 128]), train_cfg=None,
+        test_cfg=dict(min_bbox_size=0, nms_pre=-1, score_thr=0.001, nms=dict(type='nms', iou_threshold=0.65),
+                      max_per_img=300)))
+    det.load_state_dict(state_dict_from(g), strict=True)
+    return g, det.to(dev).eval(), (stages, reps)
+
+
+@pytest.mark.parametrize('dtype,tol_fused,tol_ref', [(torch.float16, 1.2e-2, 2e-2), (torch.bfloat16, 8e-2, 2e-1)])
+def test_detector_in_16_bit_vs_oracle_emulation(golden, gpu_device, dtype, tol_fused, tol_ref):
+    """Pred maps of the fused 16-bit path vs (a) the oracle rounding where a single-rounding fused
+    kernel rounds, (b) the oracle rounding where the reference's wrap_fp16_model rounds (conv out, BN
+    out, activation out), (c) the fp32 golden.  Tolerances are absolute on logits of magnitude ~5:
+    a few ulps of the 16-bit type accumulated over ~60 layers."""
+    g, det, (stages, reps) = _build_v5(golden, gpu_device)
+    img = torch.from_numpy(g['img']).to(gpu_device)
+    sd = {k: v.detach().cpu() for k, v in det.state_dict().items()}
+    with torch.no_grad():
+        p32 = [p.cpu() for p in det.forward_dummy(img)[0]]
+    pkg.wrap_fp16_model(det, dtype)
+    assert det.bbox_head.fp16_enabled
+    with torch.no_grad():
+        p16 = [p.cpu() for p in det.forward_dummy(img)[0]]
+    assert all(p.dtype == torch.float32 for p in p16)              # module boundaries stay fp32 NCHW
+    with O.precision(dtype, 'fused'):
+        of, _ = O.forward_pred_maps(img.cpu(), sd, stages, reps, [2, 3, 4], neck='v5')
+    with O.precision(dtype, 'reference'):
+        orf, _ = O.forward_pred_maps(img.cpu(), sd, stages, reps, [2, 3, 4], neck='v5')
+    for i in range(3):
+        scale = 1.0 + p32[i].abs()
+        e_f = float(((p16[i] - of[i]).abs() / scale).max())
+        e_r = float(((p16[i] - orf[i]).abs() / scale).max())
+        e_32 = float(((p16[i] - p32[i]).abs() / scale).max())
+        print(f'{dtype} level {i}: vs fused-emulation {e_f:.2e}, vs reference-emulation {e_r:.2e}, vs fp32 {e_32:.2e}')
+        assert e_f <= tol_fused, (i, e_f)
+        assert e_r <= tol_ref and e_32 <= tol_ref, (i, e_r, e_32)
+        assert e_32 > 0                                            # it really ran in reduced precision
+    # end to end: detections of the 16-bit plan are close to the fp32 ones
+    metas = [dict(scale_factor=g['scale_factors'][i]) for i in range(2)]
+    res = det.simple_test(img, metas, rescale=True)
+    n16 = sum(len(r) for r in res[0])
+    assert abs(n16 - len(g['dets0'])) <= max(6, len(g['dets0']) // 8)
+    pkg.wrap_fp16_model(det, torch.float32)
+    with torch.no_grad():
+        back = [p.cpu() for p in det.forward_dummy(img)[0]]
+    for a, b in zip(back, p32):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_h16_layout_and_spp_kernels(gpu_device, dtype):
+    torch.manual_seed(0)
+    plan = pkg.Plan(gpu_device, dtype)
+    x = plan.add_input_nchw(2, 16, 13, 11)
+    cat = plan.new_buf(2, 13, 11, 64, 'cat')
+    plan.resample(x, cat.slice(0, 16))
+    plan.spp(cat, 16)
+    up = plan.new_buf(2, 26, 22, 64, 'up')
+    plan.resample(cat, up)
+    plan.add_output_nchw(cat)
+    plan.add_output_nchw(up)
+    plan.finalize()
+    inp = torch.randn(2, 16, 13, 11, device=gpu_device)
+    got_cat, got_up = plan.run(inp)
+    xr = inp.to(dtype).float()
+    ref = torch.cat([xr] + [F.max_pool2d(xr, k, 1, k // 2) for k in (5, 9, 13)], 1)
+    assert torch.equal(got_cat, ref)
+    assert torch.equal(got_up, F.interpolate(ref, size=(26, 22), mode='nearest'))

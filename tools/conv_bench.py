@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--filter', default='')
     ap.add_argument('--json', default='')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'])
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(',')]
     dev = torch.device('cuda:0')
@@ -47,19 +48,22 @@ def main():
         tag = f'{cin}->{cout} k{k}s{s} @{h}'
         if a.filter and a.filter not in tag:
             continue
-        cp = (cin + 3) // 4 * 4
+        h16 = a.dtype != 'f32'
+        tdt = dict(f32=torch.float32, f16=torch.float16, bf16=torch.bfloat16)[a.dtype]
+        cp = (cin + 7) // 8 * 8 if h16 else (cin + 3) // 4 * 4
         pad = k // 2
         ho = (h + 2 * pad - k) // s + 1
-        x = torch.randn(a.batch * h * h * cp, device=dev)
-        w = torch.randn(cout * k * k * cp, device=dev) * 0.05
-        y = torch.empty(a.batch * ho * ho * cout, device=dev)
+        x = torch.randn(a.batch * h * h * cp, device=dev).to(tdt)
+        w = (torch.randn(cout * k * k * cp, device=dev) * 0.05).to(tdt)
+        ycs = (cout + 7) // 8 * 8 if h16 else cout
+        y = torch.empty(a.batch * ho * ho * ycs, device=dev, dtype=tdt)
         sc = torch.ones(cout, device=dev)
         sh = torch.zeros(cout, device=dev)
         d = ConvDesc()
         d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = a.batch, h, h, cp, ho, ho, cout
         d.KH = d.KW = k
         d.stride, d.pad = s, pad
-        d.x_cstride, d.y_cstride = cp, cout
+        d.x_cstride, d.y_cstride = cp, (ycs if h16 else cout)
         d.act1 = 1
         flops = 2.0 * a.batch * ho * ho * cout * k * k * cin
         res = {}
@@ -70,8 +74,13 @@ def main():
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-                rc = lib.yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                                             None, None, None, y.data_ptr(), stream)
+                if h16:
+                    code = 1 if a.dtype == 'f16' else 2
+                    rc = lib.yv4_conv_bn_act_fwd_h16(C.byref(d), code, code, x.data_ptr(), w.data_ptr(), sc.data_ptr(),
+                                                     sh.data_ptr(), None, None, None, y.data_ptr(), stream)
+                else:
+                    rc = lib.yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                                 None, None, None, y.data_ptr(), stream)
                 e1.record()
                 torch.cuda.synchronize()
                 if rc != 0:
@@ -82,7 +91,7 @@ def main():
             res[t] = ts[len(ts) // 2] if ts else float('inf')
             tot[t] += res[t] * cnt
         d.tile = 0
-        auto = lib.yv4_conv_pick_tile(C.byref(d))
+        auto = (lib.yv4_conv_h16_pick_tile if h16 else lib.yv4_conv_pick_tile)(C.byref(d))
         best = min(res, key=res.get)
         best_tot += res[best] * cnt
         line = f'{tag:28s} x{cnt:2d} ' + ' '.join(
