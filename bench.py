@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_H16_MFMA_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, same guide (not the 2:1-sparsity figure)
 
 MODELS = {
     'yolov4l': dict(scale='v4l5p', neck_in=[256, 512, 512], neck_out=[256, 512, 1024], csp_rep=2),
@@ -161,6 +162,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layers', default='', help='write a per-conv timing table (JSON) to this path')
     ap.add_argument('--no-autotune', action='store_true', help='keep the static conv tile choice')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'],
+                    help='operand type of the convs (f32 = the headline / parity configuration)')
     ap.add_argument('--event-every', type=int, default=4,
                     help='bracket the conv launches with HIP events in every n-th timed step (events cost ~2 %)')
     args = ap.parse_args()
@@ -186,6 +189,18 @@ def main():
     plan = det.compile(args.batch, args.size, args.size, device=dev, rescale=True)
     calibrate_bn(plan, img)
     ncand = init_head(det, plan, img, args.candidates)
+    h16 = args.dtype != 'f32'
+    if h16:
+        # BN statistics and the head were fitted through the fp32 plan (they live in the modules);
+        # rebuild the plan on 16-bit operands
+        del plan
+        det._engines.clear()
+        torch.cuda.empty_cache()
+        plan = det.compile(args.batch, args.size, args.size, device=dev, rescale=True,
+                           dtype=torch.float16 if args.dtype == 'f16' else torch.bfloat16)
+        plan.run(img)
+        torch.cuda.synchronize()
+        ncand = float(plan.post['counts'].float().mean())
     if not args.no_autotune:
         plan.autotune()
 
@@ -230,6 +245,11 @@ def main():
 
     def tile_of(op):
         d = op.info['desc']
+        if op.info.get('stem32'):
+            return 'stem3x3'
+        if h16:
+            t = d.tile if d.tile else pkg._lib.lib().yv4_conv_h16_pick_tile(__import__('ctypes').byref(d))
+            return {1: 'h16_128x128', 2: 'h16_128x64', 3: 'h16_64x64'}[t]
         t = d.tile if d.tile else pkg._lib.lib().yv4_conv_pick_tile(__import__('ctypes').byref(d))
         return pkg._lib.TILE_NAMES[t]
 
@@ -248,16 +268,17 @@ def main():
     dom = max(per_tile, key=lambda k: per_tile[k][1])
     dflops, dtime, dn = per_tile[dom]
     traffic, traffic_src = pmc_traffic(dom)
-    roofline = dict(bound='mfma', kernel=f'conv_mfma_f32_kernel<{dom}>',
-                    achieved=round(dflops / dtime / 1e12, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(dflops / dtime / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+    peak = PEAK_H16_MFMA_TFLOPS if h16 else PEAK_FP32_MFMA_TFLOPS
+    roofline = dict(bound='mfma', kernel=f'conv_mfma_{"h16" if h16 else "f32"}_kernel<{dom}>',
+                    achieved=round(dflops / dtime / 1e12, 2), peak=peak, unit='TFLOP/s',
+                    frac=round(dflops / dtime / 1e12 / peak, 4), traffic=traffic,
                     traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=round(sum(o.bytes for o, _, _ in events
                                                            if tile_of(o) == dom) / dn),
                     launches=dn, avg_launch_us=round(dtime / dn * 1e6, 2),
                     gflop_per_launch=round(dflops / dn / 1e9, 3),
                     all_convs_tflops=round(conv_flops / conv_time / 1e12, 2),
-                    all_convs_frac=round(conv_flops / conv_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    all_convs_frac=round(conv_flops / conv_time / 1e12 / peak, 4),
                     conv_share_of_step=round(conv_time / max(len(events) // len(conv_ops), 1) /
                                              (elapsed / args.steps), 4),
                     instrumented_steps=len(events) // len(conv_ops))
@@ -277,11 +298,11 @@ def main():
             metric='images/sec (inference) YOLOv4 608x608', value=round(total_images / elapsed, 2),
             unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
-            vs_baseline=None, dtype='f32', data='synthetic',
+            vs_baseline=None, dtype=args.dtype, data='synthetic',
             config=dict(workload=f'{args.model} (DarknetCSP v4l5p + YOLOV4Neck + YOLOCSPHead, 80 classes) '
-                                 f'{args.size}x{args.size} fp32 inference, batch {args.batch}/GPU: image -> '
+                                 f'{args.size}x{args.size} {dict(f32="fp32", f16="fp16", bf16="bf16")[args.dtype]} inference, batch {args.batch}/GPU: image -> '
                                  'fused conv path -> decode -> per-class NMS -> detections on host '
-                                 '(BASELINE.json configs[1])',
+                                 '(BASELINE.json configs[1]' + ('' if args.dtype == 'f32' else '; NOT the headline dtype') + ')',
                         global_batch=args.batch * world, per_gpu_batch=args.batch, input=f'{args.size}x{args.size}',
                         weights='random init (seed 0), BN statistics fitted on the batch, head bias set for '
                                 f'~{ncand:.0f} NMS candidates/image', parallelism=f'replicated weights, batch '

@@ -290,6 +290,11 @@ int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int out_dtype, co
                             const float* scale2, const float* shift2, const void* residual,
                             void* y, void* stream);
 int yv4_conv_h16_pick_tile(const yv4_conv_desc* d);
+/* Stem of the 16-bit path (3-channel image, 3x3 s1 p1, Cout <= 64): x and w are fp32 exactly as
+ * for yv4_conv_bn_act_fwd's stem tile, the arithmetic is fp32, only y is `out_dtype`. */
+int yv4_conv_stem_fwd(const yv4_conv_desc* d, const float* x, const float* w,
+                      const float* scale1, const float* shift1, void* y, int out_dtype,
+                      void* stream);
 
 /* 16-bit forms of the layout adaptors and the SPP pools (same argument meaning as the fp32
  * entries; the boundary tensors stay fp32 NCHW like the reference's, the NHWC side is `dtype`).

@@ -77,6 +77,7 @@ SIGNATURES = {
     'yv4_bn_act_bwd': (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i,
                                  _i, _f, _vp]),
     'yv4_conv_bn_act_fwd_h16': (C.c_int, [C.POINTER(ConvDesc), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'yv4_conv_stem_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'yv4_conv_h16_pick_tile': (C.c_int, [C.POINTER(ConvDesc)]),
     'yv4_nchw_to_nhwc_h16': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_nhwc_to_nchw_h16': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -580,7 +580,9 @@ static int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
 // the buffer descriptor), holds the 18 weight values it needs for the whole kernel, issues
 // 18 MFMAs per tile and streams the epilogue to HBM in 128-byte rows.
 // ---------------------------------------------------------------------------------
-template <int TN>
+// OUT: 0 fp32 (p.y), 1 fp16, 2 bf16 (p.y reinterpreted; the 16-bit inference path keeps the image
+// and this layer's arithmetic in fp32 and only rounds the layer's output).
+template <int TN, int OUT>
 __global__ __launch_bounds__(kThreads) void conv_stem3x3_kernel(ConvArgs p, unsigned x_bytes, int tiles_w, long long ntiles) {
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x;
@@ -646,13 +648,17 @@ __global__ __launch_bounds__(kThreads) void conv_stem3x3_kernel(ConvArgs p, unsi
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
         if (co < p.Cout && tx * 32 + row < p.W) {
           const float v = apply_act(acc[jn][e] * s1[jn] + t1[jn], p.act1, p.slope1);
-          p.y[(mrow + row) * p.y_cs + p.y_co + co] = v;
+          const long long idx = (mrow + row) * p.y_cs + p.y_co + co;
+          if (OUT == 0) p.y[idx] = v;
+          else if (OUT == 1) reinterpret_cast<_Float16*>(p.y)[idx] = (_Float16)v;
+          else reinterpret_cast<__bf16*>(p.y)[idx] = (__bf16)v;
         }
       }
     }
   }
 }
 
+template <int OUT>
 static int launch_conv_stem(const ConvArgs& a, hipStream_t stream) {
   const long long xb = (long long)a.N * a.H * a.W * a.x_cs * 4;
   if (xb >= 0xFFFFFFF0LL) {
@@ -664,9 +670,11 @@ static int launch_conv_stem(const ConvArgs& a, hipStream_t stream) {
   long long blocks = (ntiles + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;   // 8 workgroups per CU, grid-stride over the tiles
   if (a.Cout <= 32)
-    hipLaunchKernelGGL(conv_stem3x3_kernel<1>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, (unsigned)xb, tiles_w, ntiles);
+    hipLaunchKernelGGL((conv_stem3x3_kernel<1, OUT>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, (unsigned)xb,
+                       tiles_w, ntiles);
   else
-    hipLaunchKernelGGL(conv_stem3x3_kernel<2>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, (unsigned)xb, tiles_w, ntiles);
+    hipLaunchKernelGGL((conv_stem3x3_kernel<2, OUT>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, (unsigned)xb,
+                       tiles_w, ntiles);
   YV4_CHECK_LAUNCH("conv_stem3x3");
   return YV4_OK;
 }
@@ -789,7 +797,7 @@ extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const
     case YV4_TILE_128x64: return launch_conv<128, 64, 2, 2>(a, uniform, s);
     case YV4_TILE_64x128: return launch_conv<64, 128, 2, 2>(a, uniform, s);
     case YV4_TILE_64x64: return launch_conv<64, 64, 2, 2>(a, uniform, s);
-    case YV4_TILE_STEM: if (can_stem) return launch_conv_stem(a, s); break;
+    case YV4_TILE_STEM: if (can_stem) return launch_conv_stem<0>(a, s); break;
     case YV4_TILE_DMA_64x64: if (fast_ok) return launch_conv_dma<64, 64, 2, 2, 2>(a, s); break;
     case YV4_TILE_DMA_128x64: if (fast_ok) return launch_conv_dma<128, 64, 2, 2, 2>(a, s); break;
     case YV4_TILE_DMA_128x128: if (fast_ok) return launch_conv_dma<128, 128, 2, 2, 2>(a, s); break;
@@ -798,4 +806,31 @@ extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const
   }
   set_error("conv: unknown or inapplicable tile id %d", tile);
   return YV4_E_INVALID;
+}
+
+// The stem of the 16-bit path: fp32 image (NHWC, C padded to 4) and fp32 weights in, fp32 MFMA,
+// output rounded to fp16 / bf16 (the layer is bound by its output bytes, which this halves).
+extern "C" int yv4_conv_stem_fwd(const yv4_conv_desc* d, const float* x, const float* w, const float* scale1,
+                                 const float* shift1, void* y, int out_dtype, void* stream) {
+  YV4_REQUIRE(d && x && w && scale1 && shift1 && y, "conv stem: null argument");
+  YV4_REQUIRE(out_dtype == YV4_F32 || out_dtype == YV4_F16 || out_dtype == YV4_BF16, "conv stem: bad out_dtype");
+  YV4_REQUIRE(stem_ok(d, false, false), "conv stem: needs Cin 4 (3 padded), 3x3, stride 1, pad 1, Cout <= 64");
+  YV4_REQUIRE(d->Ho == d->H && d->Wo == d->W, "conv stem: Ho/Wo must equal H/W");
+  YV4_REQUIRE(d->x_coff + d->Cin <= d->x_cstride && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_cstride,
+              "conv stem: view exceeds its pixel stride");
+  YV4_REQUIRE(d->act1 >= 0 && d->act1 <= YV4_ACT_SWISH, "conv stem: unknown activation id");
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  YV4_REQUIRE(M < (1LL << 31), "conv stem: N*Ho*Wo does not fit 31 bits");
+  ConvArgs a;
+  a.x = x; a.w = w; a.s1 = scale1; a.t1 = shift1; a.s2 = nullptr; a.t2 = nullptr; a.res = nullptr;
+  a.y = reinterpret_cast<float*>(y);
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1;
+  a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = 0; a.r_co = 0;
+  a.act1 = d->act1; a.act2 = 0; a.slope1 = d->slope1; a.slope2 = 0.f;
+  a.M = (int)M; a.K = 36; a.Kw = 36; a.tiles_n = 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (out_dtype == YV4_F16) return launch_conv_stem<1>(a, s);
+  if (out_dtype == YV4_BF16) return launch_conv_stem<2>(a, s);
+  return launch_conv_stem<0>(a, s);
 }

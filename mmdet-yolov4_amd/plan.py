@@ -147,16 +147,18 @@ class Plan:
         self.params.append(t)
         return t
 
-    def add_input_nchw(self, N, C_, H, W, name='input', pad4=True):
+    def add_input_nchw(self, N, C_, H, W, name='input', pad4=True, dtype=None):
         """Declare an NCHW fp32 input; returns its NHWC view in the plan's dtype (channels
         zero-padded to one 16-byte chunk -- 4 floats / 8 halves -- unless pad4=False, which keeps
         the buffer dense)."""
-        al = self.calign
+        dtype = dtype or self.dtype          # fp32 in a 16-bit plan: the image feeding the fp32 stem kernel
+        h16 = dtype != torch.float32
+        al = 8 if h16 else 4
         cp = (C_ + al - 1) // al * al if pad4 else C_
-        v = self.new_buf(N, H, W, cp, name)
+        v = self.new_buf(N, H, W, cp, name, dtype=dtype)
         slot = {'view': v, 'C': C_, 'src': None}
         self.inputs.append(slot)
-        if self.h16:
+        if h16:
             def fn(stream, slot=slot, v=v, C_=C_, cp=cp):
                 check(_lib.lib().yv4_nchw_to_nhwc_h16(slot['src'].data_ptr(), v.buf.ptr(), v.N, C_, v.H, v.W, cp, 0,
                                                       cp - C_, self.dcode, stream), 'yv4_nchw_to_nhwc_h16')
@@ -165,7 +167,7 @@ class Plan:
                 src = slot['src']
                 check(_lib.lib().yv4_nchw_to_nhwc(src.data_ptr(), v.buf.ptr(), v.N, C_, v.H, v.W, cp, 0,
                                                   cp - C_, stream), 'yv4_nchw_to_nhwc')
-        self.ops.append(Op('to_nhwc', name, fn, nbytes=(4.0 + self.esize) * N * C_ * H * W))
+        self.ops.append(Op('to_nhwc', name, fn, nbytes=(4.0 + (2 if h16 else 4)) * N * C_ * H * W))
         return v
 
     # ---- ops ---------------------------------------------------------------------
@@ -176,13 +178,19 @@ class Plan:
         stage 2 of the epilogue were folded from (used by calibrate.py only).
         out_f32: in a 16-bit plan, store this conv's output in fp32 (pred maps feeding decode)."""
         Cout, Cin, KH, KW = weight.shape
-        wp, cp = pack_conv_weight(weight, align=self.calign)
-        if self.h16:
+        stem32 = self.h16 and x.buf.dtype == torch.float32      # fp32 image -> fp32 stem kernel -> 16-bit output
+        if stem32:
+            assert (Cin, KH, KW, stride) == (3, 3, 3, 1) and pad in (None, 1) and Cout <= 64 and residual is None \
+                and s2 is None, f'{name}: an fp32 input in a 16-bit plan must feed the 3x3 stem'
+        wp, cp = pack_conv_weight(weight, align=4 if stem32 else self.calign)
+        if stem32:
+            pass
+        elif self.h16:
             wp = wp.to(self.dtype)
             assert x.buf.dtype == self.dtype, f'{name}: a 16-bit plan convolves {self.dtype} inputs, got {x.buf.dtype}'
             assert x.coff % 8 == 0 and x.cstride % 8 == 0, \
                 f'{name}: 16-bit views need channel offsets / strides that are multiples of 8 ({x})'
-        assert x.C == cp or (x.C == Cin and Cin % self.calign == 0), \
+        assert x.C == cp or (x.C == Cin and Cin % (4 if stem32 else self.calign) == 0), \
             f'{name}: input view has {x.C} channels, conv wants {Cin} (padded {cp})'
         if pad is None:
             pad = KH // 2
@@ -213,7 +221,12 @@ class Plan:
                  t2=self._dev(t2.float()) if s2 is not None else None)
         self.params.append(d)
 
-        if self.h16:
+        if stem32:
+            def fn(stream, L=L, out_code=out_code):
+                check(_lib.lib().yv4_conv_stem_fwd(C.byref(L['d']), L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(),
+                                                   L['t1'].data_ptr(), L['y'].ptr(), out_code, stream),
+                      'yv4_conv_stem_fwd')
+        elif self.h16:
             def fn(stream, L=L, out_code=out_code):
                 check(_lib.lib().yv4_conv_bn_act_fwd_h16(
                     C.byref(L['d']), self.dcode, out_code, L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(),
@@ -231,12 +244,13 @@ class Plan:
         M = x.N * Ho * Wo
         flops = 2.0 * M * Cout * KH * KW * Cin          # algorithmic: real Cin, not the padded one
         es = float(self.esize)
-        nbytes = es * (x.N * x.H * x.W * Cin + Cout * KH * KW * Cin) + (4.0 if out_code == 0 else es) * M * Cout
+        ies = 4.0 if stem32 else es
+        nbytes = ies * (x.N * x.H * x.W * Cin + Cout * KH * KW * Cin) + (4.0 if out_code == 0 else es) * M * Cout
         if residual is not None:
             nbytes += es * M * Cout
         self.ops.append(Op('conv', name, fn, flops, nbytes,
                            dict(Cin=Cin, Cout=Cout, k=KH, stride=stride, H=x.H, W=x.W, Ho=Ho, Wo=Wo,
-                                N=x.N, desc=d, launch=L, out=out, bn1=bn1, bn2=bn2)))
+                                N=x.N, desc=d, launch=L, out=out, bn1=bn1, bn2=bn2, stem32=stem32)))
         return out
 
     def spp(self, cat_view, C_, name='spp'):
@@ -401,6 +415,8 @@ class Plan:
             if op.kind != 'conv':
                 continue
             d = op.info['desc']
+            if op.info.get('stem32'):
+                continue
             auto = (_lib.lib().yv4_conv_h16_pick_tile if self.h16 else _lib.lib().yv4_conv_pick_tile)(C.byref(d))
             if auto not in cands:          # stem / generic path: nothing to choose from
                 continue

@@ -211,3 +211,33 @@ def test_h16_layout_and_spp_kernels(gpu_device, dtype):
     ref = torch.cat([xr] + [F.max_pool2d(xr, k, 1, k // 2) for k in (5, 9, 13)], 1)
     assert torch.equal(got_cat, ref)
     assert torch.equal(got_up, F.interpolate(ref, size=(26, 22), mode='nearest'))
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_h16_plan_with_fp32_stem(gpu_device, dtype):
+    """A detector whose backbone starts with the 3x3 stem keeps the image fp32 in a 16-bit plan
+    (yv4_conv_stem_fwd: fp32 arithmetic, 16-bit output)."""
+    torch.manual_seed(0)
+    det = pkg.build_detector(dict(
+        type='SingleStageDetector',
+        backbone=dict(type='DarknetCSP', scale=[['conv', 'bottleneck', 'csp', 'csp', 'csp', 'sppv4'],
+                                                [None, 1, 1, 1, 1, 1], [8, 16, 32, 64, 64, 64]], out_indices=[3, 4, 5]),
+        neck=dict(type='YOLOV4Neck', in_channels=[64, 64, 64], out_channels=[32, 64, 128], csp_repetition=1),
+        bbox_head=dict(type='YOLOCSPHead', num_classes=80, in_channels=[32, 64, 128]), train_cfg=None,
+        test_cfg=dict(nms_pre=-1, score_thr=0.001, nms=dict(type='nms', iou_threshold=0.65), max_per_img=300)))
+    det.init_weights()
+    det.to(gpu_device).eval()
+    img = torch.randn(2, 3, 64, 96, device=gpu_device)
+    p32 = det.compile(2, 64, 96, device=gpu_device, rescale=False)
+    p32.run(img)
+    ref = [v.buf.tensor.clone() for v in p32.pred_views]
+    p16 = det.compile(2, 64, 96, device=gpu_device, rescale=False, dtype=dtype)
+    convs = [o for o in p16.ops if o.kind == 'conv']
+    assert convs[0].info['stem32'] and not any(o.info['stem32'] for o in convs[1:])
+    assert p16.inputs[0]['view'].buf.dtype == torch.float32 and convs[0].info['out'].buf.dtype == dtype
+    p16.run(img)
+    tol = 2e-2 if dtype == torch.float16 else 2e-1
+    for a, b in zip(ref, [v.buf.tensor for v in p16.pred_views]):
+        assert float((a - b).abs().max()) <= tol * (1 + float(a.abs().max()))
+    p16.autotune()
+    p16.run(img)
