@@ -162,10 +162,12 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
 //   walk is scalar.  GENERAL_K = true: Cin % 8 == 0 only (stem with C padded to 8, Cin = 32
 //   layers, tiny models): every lane derives (tap, channel) of its own 8-element chunk per slice;
 //   chunks beyond K read zeros on both operands.
-template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, bool GENERAL_K>
+template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, bool GENERAL_K, int NBUF>
 __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes) {
   typedef typename Elem<BF16>::V8 V8;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(NBUF >= 2 && NBUF <= 4, "ring of 2..4 slices");
+  constexpr int D = NBUF - 1;   // prefetch distance in K slices
   constexpr int TM = BM / WAVES_M / 32;
   constexpr int TN = BN / WAVES_N / 32;
   constexpr int PA = BM / 32;
@@ -175,8 +177,8 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   extern __shared__ __attribute__((aligned(16))) char smem_h[];
-  char* As = smem_h;                      // [2][BM][128 B]
-  char* Bs = smem_h + 2 * BM * kRowB;     // [2][BN][128 B]
+  char* As = smem_h;                         // [NBUF][BM][128 B]
+  char* Bs = smem_h + NBUF * BM * kRowB;     // [NBUF][BN][128 B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
 #define YV4_H_DMA(BUF)                                                                           \
   {                                                                                              \
     const unsigned la_ = lds_base + (unsigned)(((BUF) * BM + 8 * wave) * kRowB);                  \
-    const unsigned lb_ = lds_base + (unsigned)((2 * BM + (BUF) * BN + 8 * wave) * kRowB);         \
+    const unsigned lb_ = lds_base + (unsigned)((NBUF * BM + (BUF) * BN + 8 * wave) * kRowB);      \
     if (GENERAL_K) {                                                                             \
       const bool kin = g_k < p.K;                                                                \
       const int tap = kin ? g_k / p.Cin : 0;                                                     \
@@ -315,24 +317,47 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
     }                                                                                            \
   }
 
+  // wait until at most NEWER later slices of this wave's DMAs are still in flight
+#define YV4_H_WAIT(NEWER)                                                                        \
+  {                                                                                              \
+    if ((NEWER) >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * kDmaPerSlice) : "memory"); \
+    else if ((NEWER) == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * kDmaPerSlice) : "memory"); \
+    else if ((NEWER) == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 * kDmaPerSlice) : "memory"); \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
+  }
+
   const int nk = (p.K + kHBK - 1) / kHBK;
-  YV4_H_DMA(0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  int issued = 0;        // slices whose DMA has been issued
+  int wbuf = 0;          // ring slot the next DMA goes to
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (d < nk) {
+      YV4_H_DMA(wbuf);
+      ++issued;
+      wbuf = wbuf + 1 == NBUF ? 0 : wbuf + 1;
+    }
+  }
+  YV4_H_WAIT(issued - 1);
   __builtin_amdgcn_s_barrier();
+  int rbuf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) YV4_H_DMA(buf ^ 1);     // slot buf^1 was last read before the previous barrier
+    if (issued < nk) {     // slot wbuf was last read before the previous barrier
+      YV4_H_DMA(wbuf);
+      ++issued;
+      wbuf = wbuf + 1 == NBUF ? 0 : wbuf + 1;
+    }
     __builtin_amdgcn_s_setprio(1);
-    YV4_H_COMPUTE(buf);
+    YV4_H_COMPUTE(rbuf);
     __builtin_amdgcn_s_setprio(0);
+    rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
     if (kt + 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      YV4_H_WAIT(issued - (kt + 2));
       __builtin_amdgcn_s_barrier();
     }
   }
+#undef YV4_H_WAIT
 #undef YV4_H_DMA
 #undef YV4_H_COMPUTE
-  (void)kDmaPerSlice;
 
   const bool has2 = p.s2 != nullptr;
   const int ymask = p.out_f32 ? 3 : 7;
@@ -348,9 +373,9 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
                             has2);
 }
 
-template <bool BF16, int BM, int BN, bool GENERAL_K>
+template <bool BF16, int BM, int BN, bool GENERAL_K, int NBUF>
 static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
-  constexpr size_t lds = (size_t)2 * (BM + BN) * 128;
+  constexpr size_t lds = (size_t)NBUF * (BM + BN) * 128;
   static_assert(lds >= 4 * 32 * 36 * 4, "epilogue patches must fit the K-loop carve");
   ConvArgsH p = a;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -361,7 +386,7 @@ static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
     return YV4_E_INVALID;
   }
   const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 2, wb = (long long)p.Cout * p.Kw * 2;
-  auto kern = conv_mfma_h16_kernel<BF16, BM, BN, 2, 2, GENERAL_K>;
+  auto kern = conv_mfma_h16_kernel<BF16, BM, BN, 2, 2, GENERAL_K, NBUF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -372,20 +397,28 @@ static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
   return YV4_OK;
 }
 
-template <bool BF16>
-static int dispatch_h16(const ConvArgsH& a, int tile, bool general, hipStream_t s) {
-  switch (tile) {
+template <bool BF16, int NBUF>
+static int dispatch_h16_n(const ConvArgsH& a, int shape, bool general, hipStream_t s) {
+  switch (shape) {
     case YV4_HTILE_128x128:
-      return general ? launch_h16<BF16, 128, 128, true>(a, s) : launch_h16<BF16, 128, 128, false>(a, s);
+      return general ? launch_h16<BF16, 128, 128, true, NBUF>(a, s) : launch_h16<BF16, 128, 128, false, NBUF>(a, s);
     case YV4_HTILE_128x64:
-      return general ? launch_h16<BF16, 128, 64, true>(a, s) : launch_h16<BF16, 128, 64, false>(a, s);
+      return general ? launch_h16<BF16, 128, 64, true, NBUF>(a, s) : launch_h16<BF16, 128, 64, false, NBUF>(a, s);
     case YV4_HTILE_64x64:
-      return general ? launch_h16<BF16, 64, 64, true>(a, s) : launch_h16<BF16, 64, 64, false>(a, s);
+      return general ? launch_h16<BF16, 64, 64, true, NBUF>(a, s) : launch_h16<BF16, 64, 64, false, NBUF>(a, s);
     default:
       break;
   }
-  set_error("conv h16: unknown tile id %d", tile);
+  set_error("conv h16: unknown tile id %d", shape);
   return YV4_E_INVALID;
+}
+
+// Deeper rings (NBUF 3: two slices in flight) were measured slower on every YOLOv4-L shape: a
+// slice costs ~1.3 us of memory latency against 0.2 us of MFMA, so throughput is set by the bytes in
+// flight per CU, and a third slot costs exactly the occupancy it buys (tools/conv_bench.py, round 1).
+template <bool BF16>
+static int dispatch_h16(const ConvArgsH& a, int tile, bool general, hipStream_t s) {
+  return dispatch_h16_n<BF16, 2>(a, tile, general, s);
 }
 
 static int pick_tile_h16(long long M, int Cout) {
