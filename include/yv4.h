@@ -307,6 +307,26 @@ int yv4_nhwc_to_nchw_h16(const void* src, float* dst, int N, int C, int H, int W
 int yv4_spp_pool_fwd_h16(void* buf, int N, int H, int W, int C, int cstride, int coff,
                          int dtype, void* stream);
 
+/* 16-bit forms of the training kernels (BASELINE configs[2], [4]: bf16 training): activations and
+ * their gradients are `dtype` (YV4_F16 / YV4_BF16) NHWC views, statistics / gamma / beta / dW stay
+ * fp32, reductions run in double.  Same argument meaning as the fp32 entries above.  The data
+ * gradient is yv4_conv_bn_act_fwd_h16 on dY; zero-dilation of a 16-bit map is yv4_dilate2_fwd
+ * with the channel arguments halved. */
+int yv4_conv_wgrad_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* dy,
+                       float* dw, void* stream);
+int yv4_bn_train_stats_h16(const void* x, int dtype, int64_t M, int C, int x_cstride, int x_coff,
+                           float eps, float momentum, double* work, float* mean, float* invstd,
+                           float* running_mean, float* running_var, void* stream);
+int yv4_bn_act_fwd_h16(const void* x, int dtype, int x_cstride, int x_coff, const float* mean,
+                       const float* invstd, const float* gamma, const float* beta,
+                       const void* residual, int r_cstride, int r_coff, void* y, int y_cstride,
+                       int y_coff, int64_t M, int C, int act, float slope, void* stream);
+int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
+                       int dy_cstride, int dy_coff, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, void* dx, int dx_cstride,
+                       int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C,
+                       int act, float slope, void* stream);
+
 /* ---- optimizer side of the training step (flat fp32 arenas) -------------------------
  * The reference steps torch.optim.SGD(nesterov) with one param group per parameter
  * (core/custom_hooks/warmup_hooks.py:24-32 requires that), un-scales and clips gradients in

@@ -38,9 +38,40 @@ __device__ __forceinline__ u32x4_t make_rsrc_t(const void* base, unsigned bytes)
 // on v_mfma_f32_32x32x2_f32 with the reduction index m as the MFMA K dimension, and the
 // chunk's partial tile is added to dW with float atomics (dW must be zero on entry).
 // ---------------------------------------------------------------------------------
+// ---- element access for the three operand types (fp32, fp16, bf16): 4 consecutive channels ----
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+template <typename T> struct El;
+template <> struct El<float> {
+  static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct El<_Float16> {
+  static __device__ __forceinline__ float4 ld4(const _Float16* p) {
+    const f16x4_t v = *reinterpret_cast<const f16x4_t*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  static __device__ __forceinline__ void st4(_Float16* p, float4 v) {
+    f16x4_t o;
+    o[0] = (_Float16)v.x; o[1] = (_Float16)v.y; o[2] = (_Float16)v.z; o[3] = (_Float16)v.w;
+    *reinterpret_cast<f16x4_t*>(p) = o;
+  }
+};
+template <> struct El<__bf16> {
+  static __device__ __forceinline__ float4 ld4(const __bf16* p) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  static __device__ __forceinline__ void st4(__bf16* p, float4 v) {
+    bf16x4_t o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4_t*>(p) = o;
+  }
+};
+
 struct WgradArgs {
-  const float* x;
-  const float* dy;
+  const void* x;
+  const void* dy;
   float* dw;
   int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
   int x_cs, x_co, dy_cs, dy_co;
@@ -50,12 +81,23 @@ struct WgradArgs {
 
 constexpr int kWgRows = 32;   // reduction rows per slice
 
+// T = float: rows of 64 floats (256 B), one LDS-DMA instruction of a wave covers 4 rows.
+// T = _Float16 / __bf16: rows of 64 elements (128 B), one instruction covers 8 rows; the operands are
+// widened to fp32 on the way from LDS to the MFMA (bf16 -> fp32 is a shift), so this form has the
+// fp32 kernel's arithmetic and half its memory traffic.  (A v_mfma_f32_32x32x16 form needs both
+// operands transposed on the way out of LDS -- ds_read_b64_tr_b16 -- and is next round's work.)
+template <typename T>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int ES = (int)sizeof(T);
+  constexpr int kChunkEl = 16 / ES;            // elements per 16-byte chunk: 4 or 8
+  constexpr int kChunksPerRow = 64 / kChunkEl; // 16 or 8
+  constexpr int kRowsPerDma = 64 / kChunksPerRow;   // rows covered by one wave-instruction: 4 or 8
+  constexpr int kDmaPerWave = kWgRows / 4 / kRowsPerDma;  // instructions per wave per operand per slice: 2 or 1
+  extern __shared__ __attribute__((aligned(16))) char smem_w[];
   // [2][32][64] dY slice, [2][32][64] A slice
-  float* Ds = smem;
-  float* As = smem + 2 * kWgRows * 64;
+  T* Ds = reinterpret_cast<T*>(smem_w);
+  T* As = Ds + 2 * kWgRows * 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,17 +115,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p, unsigne
   const u32x4_t rsX = make_rsrc_t(p.x, x_bytes);
   const u32x4_t rsD = make_rsrc_t(p.dy, dy_bytes);
   constexpr unsigned kOOB = 0xFFFFFFF0u;
-  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_w;
 
-  // staging: one DMA instruction of a wave covers 4 rows x 256 B; lane -> (row = lane/16, chunk = lane%16)
-  // per slice each wave issues 2 instructions for dY (rows 8*wave + {0..3, 4..7}) and 2 for A.
-  const int srow = lane >> 4;     // 0..3
-  const int chunk = lane & 15;    // 16-byte chunk inside the 64-float row
-  // dY column validity / offset (fixed per lane)
-  const int dco = co0 + chunk * 4;
-  const bool dco_ok = dco < p.Cout;          // Cout % 4 == 0 is required by the host
-  // A column: k = k0 + chunk*4 -> (tap, ci): fixed per lane
-  const int kk = k0 + chunk * 4;
+  // staging: lane -> (row within the instruction, 16-byte chunk of the 64-element row)
+  const int srow = lane / kChunksPerRow;
+  const int chunk = lane % kChunksPerRow;
+  const int dco = co0 + chunk * kChunkEl;
+  const bool dco_ok = dco < p.Cout;          // Cout % kChunkEl == 0 is required by the host
+  const int kk = k0 + chunk * kChunkEl;
   const bool k_ok = kk < p.K;
   const int tap = k_ok ? kk / p.Cin : 0;
   const int ci = kk - tap * p.Cin;
@@ -96,12 +135,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p, unsigne
 
   auto issue = [&](int m_base, int buf) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int row = 8 * wave + 4 * q + srow;          // 0..31 within the slice
-      const int m = m_base + row;
+    for (int q = 0; q < kDmaPerWave; ++q) {
+      const int row0 = 8 * wave + kRowsPerDma * q;      // first row of this instruction within the slice
+      const int m = m_base + row0 + srow;
       unsigned doff = kOOB, aoff = kOOB;
       if (m < m_hi) {
-        if (dco_ok) doff = (unsigned)((((int64_t)m * p.dy_cs) + p.dy_co + dco) * 4);
+        if (dco_ok) doff = (unsigned)((((int64_t)m * p.dy_cs) + p.dy_co + dco) * ES);
         if (k_ok) {
           const int hw = p.Ho * p.Wo;
           const int n = m / hw;
@@ -111,12 +150,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p, unsigne
           const int hi = ho * p.stride - p.pad + kh;
           const int wi = wo * p.stride - p.pad + kw;
           if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-            aoff = (unsigned)(((((int64_t)n * p.H + hi) * p.W + wi) * p.x_cs + p.x_co + ci) * 4);
+            aoff = (unsigned)(((((int64_t)n * p.H + hi) * p.W + wi) * p.x_cs + p.x_co + ci) * ES);
         }
       }
-      const unsigned lrow = (unsigned)((buf * kWgRows + 8 * wave + 4 * q) * 64 * 4);
+      const unsigned lrow = (unsigned)((buf * kWgRows + row0) * 64 * ES);
       lds_dma16_t(rsD, lds_base + lrow, doff, 0u);
-      lds_dma16_t(rsX, lds_base + (unsigned)(2 * kWgRows * 64 * 4) + lrow, aoff, 0u);
+      lds_dma16_t(rsX, lds_base + (unsigned)(2 * kWgRows * 64 * ES) + lrow, aoff, 0u);
     }
   };
 
@@ -127,13 +166,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p, unsigne
   for (int s = 0; s < nslices; ++s) {
     const int buf = s & 1;
     if (s + 1 < nslices) issue(m_lo + (s + 1) * kWgRows, buf ^ 1);
-    const float* ds = Ds + buf * kWgRows * 64 + wm * 32 + r;   // dY^T operand: [m][co]
-    const float* as = As + buf * kWgRows * 64 + wn * 32 + r;   // A operand:    [m][k]
+    const T* ds = Ds + buf * kWgRows * 64 + wm * 32 + r;   // dY^T operand: [m][co]
+    const T* as = As + buf * kWgRows * 64 + wn * 32 + r;   // A operand:    [m][k]
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < kWgRows / 2; ++t) {
-      const float a = ds[(2 * t + h) * 64];
-      const float b = as[(2 * t + h) * 64];
+      const float a = (float)ds[(2 * t + h) * 64];
+      const float b = (float)as[(2 * t + h) * 64];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -251,7 +290,8 @@ __device__ __forceinline__ void red_flush(double* part, int C, int c, const floa
 }
 
 // sums[c] += sum x, sums[C + c] += sum x^2   (double)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t M, int C, int cs, int co,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t M, int C, int cs, int co,
                                                        double* __restrict__ sums) {
   extern __shared__ double part[];   // [2][C]
   const int C4 = C >> 2;
@@ -264,7 +304,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
       float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
       for (int64_t rr = r0 + mp.rsub; rr < r1; rr += mp.rstep) {
-        const float4 v = *reinterpret_cast<const float4*>(x + rr * cs + co + cq * 4);
+        const float4 v = El<T>::ld4(x + rr * cs + co + cq * 4);
         fs[0] += v.x; fs[1] += v.y; fs[2] += v.z; fs[3] += v.w;
         fq[0] += v.x * v.x; fq[1] += v.y * v.y; fq[2] += v.z * v.z; fq[3] += v.w * v.w;
       }
@@ -293,17 +333,21 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M, i
 }
 
 struct BnArgs {
-  const float* x; int x_cs, x_co;
+  const void* x; int x_cs, x_co;
   const float* mean; const float* invstd; const float* gamma; const float* beta;
-  const float* res; int r_cs, r_co;
-  float* y; int y_cs, y_co;
-  const float* dy; int dy_cs, dy_co;
-  float* dx; int dx_cs, dx_co;
+  const void* res; int r_cs, r_co;
+  void* y; int y_cs, y_co;
+  const void* dy; int dy_cs, dy_co;
+  void* dx; int dx_cs, dx_co;
   double* sums;      // bwd: [dbeta (C) | dgamma (C)]
   int64_t M; int C; int act; float slope;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnArgs p) {
+  const T* px = reinterpret_cast<const T*>(p.x);
+  const T* pres = reinterpret_cast<const T*>(p.res);
+  T* py = reinterpret_cast<T*>(p.y);
   const int C4 = p.C >> 2;
   const size_t total = (size_t)p.M * C4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -311,7 +355,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnArgs p) {
     const int cq = (int)(i % C4);
     const size_t m = i / C4;
     const int c = cq * 4;
-    const float4 v = *reinterpret_cast<const float4*>(p.x + m * p.x_cs + p.x_co + c);
+    const float4 v = El<T>::ld4(px + m * p.x_cs + p.x_co + c);
     const float4 mu = *reinterpret_cast<const float4*>(p.mean + c);
     const float4 is = *reinterpret_cast<const float4*>(p.invstd + c);
     const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c);
@@ -321,16 +365,19 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnArgs p) {
     o.y = act_fwd_exact((v.y - mu.y) * is.y * ga.y + be.y, p.act, p.slope);
     o.z = act_fwd_exact((v.z - mu.z) * is.z * ga.z + be.z, p.act, p.slope);
     o.w = act_fwd_exact((v.w - mu.w) * is.w * ga.w + be.w, p.act, p.slope);
-    if (p.res) {
-      const float4 rr = *reinterpret_cast<const float4*>(p.res + m * p.r_cs + p.r_co + c);
+    if (pres) {
+      const float4 rr = El<T>::ld4(pres + m * p.r_cs + p.r_co + c);
       o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
     }
-    *reinterpret_cast<float4*>(p.y + m * p.y_cs + p.y_co + c) = o;
+    El<T>::st4(py + m * p.y_cs + p.y_co + c, o);
   }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
   extern __shared__ double part[];   // [2][C]: dbeta | dgamma
+  const T* px = reinterpret_cast<const T*>(p.x);
+  const T* pdy = reinterpret_cast<const T*>(p.dy);
   const int C4 = p.C >> 2;
   for (int i = threadIdx.x; i < 2 * p.C; i += 256) part[i] = 0.0;
   __syncthreads();
@@ -346,8 +393,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
       const float be[4] = {p.beta[c], p.beta[c + 1], p.beta[c + 2], p.beta[c + 3]};
       float db[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0};
       for (int64_t rr = r0 + mp.rsub; rr < r1; rr += mp.rstep) {
-        const float4 xv = *reinterpret_cast<const float4*>(p.x + rr * p.x_cs + p.x_co + c);
-        const float4 gv = *reinterpret_cast<const float4*>(p.dy + rr * p.dy_cs + p.dy_co + c);
+        const float4 xv = El<T>::ld4(px + rr * p.x_cs + p.x_co + c);
+        const float4 gv = El<T>::ld4(pdy + rr * p.dy_cs + p.dy_co + c);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
@@ -365,7 +412,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
   for (int i = threadIdx.x; i < 2 * p.C; i += 256) atomicAdd(&p.sums[i], part[i]);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
+  const T* px = reinterpret_cast<const T*>(p.x);
+  const T* pdy = reinterpret_cast<const T*>(p.dy);
+  T* pdx = reinterpret_cast<T*>(p.dx);
   const int C4 = p.C >> 2;
   const size_t total = (size_t)p.M * C4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -374,8 +425,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
     const int cq = (int)(i % C4);
     const size_t m = i / C4;
     const int c = cq * 4;
-    const float4 xv = *reinterpret_cast<const float4*>(p.x + m * p.x_cs + p.x_co + c);
-    const float4 gv = *reinterpret_cast<const float4*>(p.dy + m * p.dy_cs + p.dy_co + c);
+    const float4 xv = El<T>::ld4(px + m * p.x_cs + p.x_co + c);
+    const float4 gv = El<T>::ld4(pdy + m * p.dy_cs + p.dy_co + c);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
     const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
     float o[4];
@@ -388,7 +439,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
       const float dgm = (float)(p.sums[p.C + c + k] * invM);
       o[k] = ga * is * (g - dbm - xhat * dgm);
     }
-    *reinterpret_cast<float4*>(p.dx + m * p.dx_cs + p.dx_co + c) = make_float4(o[0], o[1], o[2], o[3]);
+    El<T>::st4(pdx + m * p.dx_cs + p.dx_co + c, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -408,16 +459,29 @@ static inline unsigned ew_grid_t(size_t work_items) {
 
 using namespace yv4;
 
-extern "C" int yv4_conv_wgrad(const yv4_conv_desc* d, const float* x, const float* dy, float* dw, void* stream) {
+// dtype-dispatching bodies shared by the fp32 entries and their _h16 forms ------------------------
+#define YV4_DISPATCH_T(dtype, CALL)                    \
+  switch (dtype) {                                     \
+    case YV4_F32: { typedef float T; CALL; } break;    \
+    case YV4_F16: { typedef _Float16 T; CALL; } break; \
+    default: { typedef __bf16 T; CALL; } break;        \
+  }
+
+static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const void* dy, float* dw, void* stream) {
   YV4_REQUIRE(d && x && dy && dw, "wgrad: null argument");
-  YV4_REQUIRE(d->Cin % 4 == 0 && d->x_cstride % 4 == 0 && d->x_coff % 4 == 0, "wgrad: input channels/stride/offset must be multiples of 4");
-  YV4_REQUIRE(d->Cout % 4 == 0 && d->y_cstride % 4 == 0 && d->y_coff % 4 == 0, "wgrad: dY channels/stride/offset must be multiples of 4");
+  YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "wgrad: dtype must be f32, f16 or bf16");
+  const int al = dtype == YV4_F32 ? 4 : 8;
+  const int es = dtype == YV4_F32 ? 4 : 2;
+  YV4_REQUIRE(d->Cin % al == 0 && d->x_cstride % al == 0 && d->x_coff % al == 0,
+              "wgrad: input channels/stride/offset must be multiples of %d", al);
+  YV4_REQUIRE(d->Cout % al == 0 && d->y_cstride % al == 0 && d->y_coff % al == 0,
+              "wgrad: dY channels/stride/offset must be multiples of %d", al);
   YV4_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 64 && d->stride > 0, "wgrad: bad kernel/stride");
   const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
   const int Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
   YV4_REQUIRE(Ho == d->Ho && Wo == d->Wo, "wgrad: Ho/Wo do not match the geometry");
   const long long M = (long long)d->N * d->Ho * d->Wo;
-  const long long xb = (long long)d->N * d->H * d->W * d->x_cstride * 4, db = M * d->y_cstride * 4;
+  const long long xb = (long long)d->N * d->H * d->W * d->x_cstride * es, db = M * d->y_cstride * es;
   YV4_REQUIRE(M < (1LL << 31) && xb < 0xFFFFFFF0LL && db < 0xFFFFFFF0LL, "wgrad: tensors of 4 GiB or more are not supported");
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = dw;
@@ -438,11 +502,82 @@ extern "C" int yv4_conv_wgrad(const yv4_conv_desc* d, const float* x, const floa
   rows = (rows + kWgRows - 1) / kWgRows * kWgRows;
   a.rows_per_chunk = (int)rows;
   chunks = (M + rows - 1) / rows;
-  const size_t lds = (size_t)4 * kWgRows * 64 * sizeof(float);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds,
-                     reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
+  const size_t lds = (size_t)4 * kWgRows * 64 * es;
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(conv_wgrad_kernel<T>, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds,
+                                           reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db));
   YV4_CHECK_LAUNCH("conv_wgrad");
   return YV4_OK;
+}
+
+static int bn_stats_impl(int dtype, const void* x, int64_t M, int C, int x_cstride, int x_coff, float eps, float momentum,
+                         double* work, float* mean, float* invstd, float* running_mean, float* running_var,
+                         void* stream) {
+  YV4_REQUIRE(x && work && mean && invstd && M > 0 && C > 0, "bn_train_stats: bad argument");
+  YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "bn_train_stats: dtype must be f32, f16 or bf16");
+  YV4_REQUIRE(C % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0, "bn_train_stats: channels must be multiples of 4");
+  YV4_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_stats: running stats come together");
+  YV4_REQUIRE(C <= 4096, "bn_train_stats: more than 4096 channels");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) { set_error("bn_train_stats: memset failed"); return YV4_E_LAUNCH; }
+  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows));
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s,
+                                           reinterpret_cast<const T*>(x), M, C, x_cstride, x_coff, work));
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, M, C, eps, momentum, mean, invstd,
+                     running_mean, running_var);
+  YV4_CHECK_LAUNCH("bn_train_stats");
+  return YV4_OK;
+}
+
+static int bn_fwd_impl(int dtype, const void* x, int x_cstride, int x_coff, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, const void* residual, int r_cstride, int r_coff, void* y,
+                       int y_cstride, int y_coff, int64_t M, int C, int act, float slope, void* stream) {
+  YV4_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0, "bn_act_fwd: bad argument");
+  YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "bn_act_fwd: dtype must be f32, f16 or bf16");
+  YV4_REQUIRE(((C | x_cstride | x_coff | y_cstride | y_coff) & 3) == 0, "bn_act_fwd: channels must be multiples of 4");
+  YV4_REQUIRE(!residual || ((r_cstride | r_coff) & 3) == 0, "bn_act_fwd: residual channels must be multiples of 4");
+  BnArgs a = {};
+  a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
+  a.res = residual; a.r_cs = r_cstride; a.r_co = r_coff; a.y = y; a.y_cs = y_cstride; a.y_co = y_coff;
+  a.M = M; a.C = C; a.act = act; a.slope = slope;
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid_t((size_t)M * (C / 4))), dim3(256), 0,
+                                           reinterpret_cast<hipStream_t>(stream), a));
+  YV4_CHECK_LAUNCH("bn_act_fwd");
+  return YV4_OK;
+}
+
+static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, const void* dy, int dy_cstride, int dy_coff,
+                       const float* mean, const float* invstd, const float* gamma, const float* beta, void* dx,
+                       int dx_cstride, int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C, int act,
+                       float slope, void* stream) {
+  YV4_REQUIRE(x && dy && mean && invstd && gamma && beta && dx && dgamma && dbeta && work && M > 0 && C > 0,
+              "bn_act_bwd: bad argument");
+  YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "bn_act_bwd: dtype must be f32, f16 or bf16");
+  YV4_REQUIRE(((C | x_cstride | x_coff | dy_cstride | dy_coff | dx_cstride | dx_coff) & 3) == 0,
+              "bn_act_bwd: channels must be multiples of 4");
+  YV4_REQUIRE(C <= 4096, "bn_act_bwd: more than 4096 channels");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) { set_error("bn_act_bwd: memset failed"); return YV4_E_LAUNCH; }
+  BnArgs a = {};
+  a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.dy = dy; a.dy_cs = dy_cstride; a.dy_co = dy_coff;
+  a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dx_cs = dx_cstride; a.dx_co = dx_coff;
+  a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope;
+  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows));
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s, a));
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(ew_grid_t((size_t)M * (C / 4))), dim3(256), 0,
+                                           s, a));
+  hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
+  hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
+  YV4_CHECK_LAUNCH("bn_act_bwd");
+  return YV4_OK;
+}
+
+extern "C" int yv4_conv_wgrad(const yv4_conv_desc* d, const float* x, const float* dy, float* dw, void* stream) {
+  return wgrad_impl(d, YV4_F32, x, dy, dw, stream);
+}
+extern "C" int yv4_conv_wgrad_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* dy, float* dw,
+                                  void* stream) {
+  YV4_REQUIRE(dtype == YV4_F16 || dtype == YV4_BF16, "wgrad_h16: dtype must be YV4_F16 or YV4_BF16");
+  return wgrad_impl(d, dtype, x, dy, dw, stream);
 }
 
 extern "C" int yv4_dilate2_fwd(const float* src, float* dst, int N, int H, int W, int C, int src_cstride, int src_coff,
@@ -459,56 +594,41 @@ extern "C" int yv4_dilate2_fwd(const float* src, float* dst, int N, int H, int W
 extern "C" int yv4_bn_train_stats(const float* x, int64_t M, int C, int x_cstride, int x_coff, float eps, float momentum,
                                   double* work /* 2*C doubles */, float* mean, float* invstd, float* running_mean,
                                   float* running_var, void* stream) {
-  YV4_REQUIRE(x && work && mean && invstd && M > 0 && C > 0, "bn_train_stats: bad argument");
-  YV4_REQUIRE(C % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0, "bn_train_stats: channels must be multiples of 4");
-  YV4_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_stats: running stats come together");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) { set_error("bn_train_stats: memset failed"); return YV4_E_LAUNCH; }
-  YV4_REQUIRE(C <= 4096, "bn_train_stats: more than 4096 channels");
-  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows));
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), sizeof(double) * 2 * C, s, x, M, C, x_cstride, x_coff, work);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, M, C, eps, momentum, mean, invstd,
-                     running_mean, running_var);
-  YV4_CHECK_LAUNCH("bn_train_stats");
-  return YV4_OK;
+  return bn_stats_impl(YV4_F32, x, M, C, x_cstride, x_coff, eps, momentum, work, mean, invstd, running_mean, running_var,
+                       stream);
+}
+extern "C" int yv4_bn_train_stats_h16(const void* x, int dtype, int64_t M, int C, int x_cstride, int x_coff, float eps,
+                                      float momentum, double* work, float* mean, float* invstd, float* running_mean,
+                                      float* running_var, void* stream) {
+  return bn_stats_impl(dtype, x, M, C, x_cstride, x_coff, eps, momentum, work, mean, invstd, running_mean, running_var,
+                       stream);
 }
 
 extern "C" int yv4_bn_act_fwd(const float* x, int x_cstride, int x_coff, const float* mean, const float* invstd,
                               const float* gamma, const float* beta, const float* residual, int r_cstride, int r_coff,
                               float* y, int y_cstride, int y_coff, int64_t M, int C, int act, float slope, void* stream) {
-  YV4_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0, "bn_act_fwd: bad argument");
-  YV4_REQUIRE(((C | x_cstride | x_coff | y_cstride | y_coff) & 3) == 0, "bn_act_fwd: channels must be multiples of 4");
-  YV4_REQUIRE(!residual || ((r_cstride | r_coff) & 3) == 0, "bn_act_fwd: residual channels must be multiples of 4");
-  BnArgs a = {};
-  a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
-  a.res = residual; a.r_cs = r_cstride; a.r_co = r_coff; a.y = y; a.y_cs = y_cstride; a.y_co = y_coff;
-  a.M = M; a.C = C; a.act = act; a.slope = slope;
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid_t((size_t)M * (C / 4))), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), a);
-  YV4_CHECK_LAUNCH("bn_act_fwd");
-  return YV4_OK;
+  return bn_fwd_impl(YV4_F32, x, x_cstride, x_coff, mean, invstd, gamma, beta, residual, r_cstride, r_coff, y, y_cstride,
+                     y_coff, M, C, act, slope, stream);
+}
+extern "C" int yv4_bn_act_fwd_h16(const void* x, int dtype, int x_cstride, int x_coff, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, const void* residual,
+                                  int r_cstride, int r_coff, void* y, int y_cstride, int y_coff, int64_t M, int C, int act,
+                                  float slope, void* stream) {
+  return bn_fwd_impl(dtype, x, x_cstride, x_coff, mean, invstd, gamma, beta, residual, r_cstride, r_coff, y, y_cstride,
+                     y_coff, M, C, act, slope, stream);
 }
 
 extern "C" int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, int dy_cstride, int dy_coff,
                               const float* mean, const float* invstd, const float* gamma, const float* beta,
                               float* dx, int dx_cstride, int dx_coff, float* dgamma, float* dbeta,
                               double* work /* 2*C doubles */, int64_t M, int C, int act, float slope, void* stream) {
-  YV4_REQUIRE(x && dy && mean && invstd && gamma && beta && dx && dgamma && dbeta && work && M > 0 && C > 0,
-              "bn_act_bwd: bad argument");
-  YV4_REQUIRE(((C | x_cstride | x_coff | dy_cstride | dy_coff | dx_cstride | dx_coff) & 3) == 0,
-              "bn_act_bwd: channels must be multiples of 4");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) { set_error("bn_act_bwd: memset failed"); return YV4_E_LAUNCH; }
-  BnArgs a = {};
-  a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.dy = dy; a.dy_cs = dy_cstride; a.dy_co = dy_coff;
-  a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dx_cs = dx_cstride; a.dx_co = dx_coff;
-  a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope;
-  YV4_REQUIRE(C <= 4096, "bn_act_bwd: more than 4096 channels");
-  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows));
-  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), sizeof(double) * 2 * C, s, a);
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid_t((size_t)M * (C / 4))), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
-  hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
-  YV4_CHECK_LAUNCH("bn_act_bwd");
-  return YV4_OK;
+  return bn_bwd_impl(YV4_F32, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
+                     dx_coff, dgamma, dbeta, work, M, C, act, slope, stream);
+}
+extern "C" int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,
+                                  int dy_coff, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, void* dx, int dx_cstride, int dx_coff, float* dgamma, float* dbeta,
+                                  double* work, int64_t M, int C, int act, float slope, void* stream) {
+  return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
+                     dx_coff, dgamma, dbeta, work, M, C, act, slope, stream);
 }

@@ -91,11 +91,13 @@ class Conv(HipModule):
 
     def fwd(self, x, residual=None):
         w = self.conv.weight
-        if x.shape[1] % 4:           # the 3-channel image: zero-pad x and the weight to 4 input channels
-            padc = 4 - x.shape[1] % 4
+        dt = T.train_dtype(self, x)
+        al = 4 if dt == torch.float32 else 8
+        if x.shape[1] % al:          # the 3-channel image: zero-pad x and the weight to one 16-byte chunk
+            padc = al - x.shape[1] % al
             x = F.pad(x, (0, 0, 0, 0, 0, padc))
             w = F.pad(w, (0, 0, 0, 0, 0, padc))
-        y = T.conv2d(x, w, self.stride, self.padding)
+        y = T.conv2d(x, w, self.stride, self.padding, dtype=dt)
         if self.with_norm:
             if not self.norm.training:
                 raise NotImplementedError('eval-mode BatchNorm inside a training graph (norm_eval / frozen '
@@ -112,7 +114,7 @@ class Conv(HipModule):
 
 
 def bare_conv_fwd(conv, x):
-    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0])
+    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0])      # follows x's dtype
 
 
 def emit_bare_conv(plan, conv, x, stage, out=None, name='conv1x1_bare'):

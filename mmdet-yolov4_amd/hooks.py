@@ -110,7 +110,13 @@ class Fp16GradAccumulateOptimizerHook(Hook):
     multiplier the step kernel applies (``ctrl[0]``), so ``p.grad`` is not rewritten in place."""
 
     def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, loss_scale=512., distributed=True,
-                 nominal_batch_size=None, accumulation=None):
+                 nominal_batch_size=None, accumulation=None, compute_dtype=None):
+        # compute_dtype: None leaves the model as it is (fp32 unless wrap_fp16_model was applied);
+        # 'fp16' / 'bf16' (or the torch dtypes) make before_run wrap the model like the reference's
+        # Fp16OptimizerHook.before_run does (mmcv wrap_fp16_model): 16-bit activations, fp32 master weights
+        self.compute_dtype = {None: None, 'fp16': torch.float16, 'bf16': torch.bfloat16, 'fp32': torch.float32,
+                              torch.float16: torch.float16, torch.bfloat16: torch.bfloat16,
+                              torch.float32: torch.float32}[compute_dtype]
         self.grad_clip = grad_clip
         self.coalesce = coalesce
         self.bucket_size_mb = bucket_size_mb
@@ -158,6 +164,9 @@ class Fp16GradAccumulateOptimizerHook(Hook):
 
     def before_run(self, runner):
         self._ensure_state(runner)
+        if self.compute_dtype is not None:
+            from .bricks import wrap_fp16_model
+            wrap_fp16_model(_unwrap(runner.model), self.compute_dtype)
         meta = getattr(runner, 'meta', None)
         if meta and 'fp16' in meta and 'loss_scaler' in meta['fp16']:
             sd = meta['fp16']['loss_scaler']

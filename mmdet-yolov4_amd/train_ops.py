@@ -46,7 +46,11 @@ def _identity_affine(device, C_):
     return _IDENTITY[key]
 
 
+_DCODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
 def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out):
+    """Identity-epilogue conv of a channels_last tensor; fp32, or fp16 / bf16 operands (fp32 accumulate)."""
     N, _, H, W = x.shape
     Ho, Wo = out.shape[2], out.shape[3]
     d = ConvDesc()
@@ -54,61 +58,80 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out):
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.x_cstride, d.y_cstride = Cin_p, Cout
     ones, zeros = _identity_affine(x.device, Cout)
-    check(_lib.lib().yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w_packed.data_ptr(), ones.data_ptr(),
-                                         zeros.data_ptr(), None, None, None, out.data_ptr(), stream_ptr()),
-          'yv4_conv_bn_act_fwd')
+    if x.dtype == torch.float32:
+        check(_lib.lib().yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w_packed.data_ptr(), ones.data_ptr(),
+                                             zeros.data_ptr(), None, None, None, out.data_ptr(), stream_ptr()),
+              'yv4_conv_bn_act_fwd')
+    else:
+        code = _DCODE[x.dtype]
+        check(_lib.lib().yv4_conv_bn_act_fwd_h16(C.byref(d), code, code, x.data_ptr(), w_packed.data_ptr(),
+                                                 ones.data_ptr(), zeros.data_ptr(), None, None, None, out.data_ptr(),
+                                                 stream_ptr()), 'yv4_conv_bn_act_fwd_h16')
     return d
 
 
 class ConvFunction(torch.autograd.Function):
+    """``dtype``: torch.float32, or torch.float16 / torch.bfloat16 -- then x, y and their gradients are
+    that type (fp32 accumulation in every kernel) while ``weight`` and its gradient stay fp32 (the
+    master copy the optimizer steps; autocast semantics of the reference's Fp16 hook)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad):
+    def forward(ctx, x, weight, stride, pad, dtype):
         _need_cuda(x, 'x')
         Cout, Cin, KH, KW = weight.shape
-        assert x.shape[1] == Cin and Cin % 4 == 0 and Cout % 4 == 0, \
-            f'training conv needs channel counts that are multiples of 4 (got {Cin}->{Cout})'
-        x = to_nhwc(x.float())
+        al = 4 if dtype == torch.float32 else 8
+        assert x.shape[1] == Cin and Cout % al == 0 and Cin % al == 0, \
+            f'training conv needs channel counts that are multiples of {al} (got {Cin}->{Cout})'
+        ctx.x_dtype = x.dtype
+        x = to_nhwc(x.to(dtype))
         N, _, H, W = x.shape
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        wp, cp = pack_conv_weight(weight)
-        y = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=torch.float32,
-                        memory_format=torch.channels_last)
-        _conv_launch(x, wp, cp, Cout, KH, KW, stride, pad, y)
+        wp, cp = pack_conv_weight(weight, align=al)
+        y = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=dtype, memory_format=torch.channels_last)
+        _conv_launch(x, wp.to(dtype), cp, Cout, KH, KW, stride, pad, y)
         ctx.save_for_backward(x, weight)
-        ctx.geom = (stride, pad)
+        ctx.geom = (stride, pad, dtype, cp)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        stride, pad = ctx.geom
+        stride, pad, dtype, cp = ctx.geom
         Cout, Cin, KH, KW = weight.shape
         N, _, H, W = x.shape
-        dy = to_nhwc(dy.float())
+        dy = to_nhwc(dy.to(dtype))
         Ho, Wo = dy.shape[2], dy.shape[3]
         L = _lib.lib()
+        h16 = dtype != torch.float32
+        code = _DCODE[dtype]
         dx = dw = None
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros((Cout, KH * KW * Cin), device=x.device, dtype=torch.float32)
+            dwp = torch.zeros((Cout, KH * KW * cp), device=x.device, dtype=torch.float32)
             d = ConvDesc()
-            d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
+            d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, cp, Ho, Wo, Cout
             d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-            d.x_cstride, d.y_cstride = Cin, Cout
-            check(L.yv4_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), stream_ptr()),
-                  'yv4_conv_wgrad')
-            dw = dwp.view(Cout, KH, KW, Cin).permute(0, 3, 1, 2).contiguous()
+            d.x_cstride, d.y_cstride = cp, Cout
+            if h16:
+                check(L.yv4_conv_wgrad_h16(C.byref(d), code, x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), stream_ptr()),
+                      'yv4_conv_wgrad_h16')
+            else:
+                check(L.yv4_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), stream_ptr()),
+                      'yv4_conv_wgrad')
+            dw = dwp.view(Cout, KH, KW, cp)[..., :Cin].permute(0, 3, 1, 2)
+            if cp != Cin:
+                dw = dw.contiguous()
         if ctx.needs_input_grad[0]:
             # dX = correlate(dY (zero-dilated by `stride`), W flipped in (kh,kw) and transposed in (co,ci))
             wt = weight.detach().flip(2, 3).transpose(0, 1)          # (Cin, Cout, KH, KW)
-            wtp, _ = pack_conv_weight(wt)
+            wtp, _ = pack_conv_weight(wt, align=4 if not h16 else 8)
             if stride == 1:
                 src = dy
             elif stride == 2:
-                src = torch.empty((N, Cout, 2 * Ho, 2 * Wo), device=x.device, dtype=torch.float32,
+                src = torch.empty((N, Cout, 2 * Ho, 2 * Wo), device=x.device, dtype=dtype,
                                   memory_format=torch.channels_last)
-                check(L.yv4_dilate2_fwd(dy.data_ptr(), src.data_ptr(), N, Ho, Wo, Cout, Cout, 0, stream_ptr()),
+                k = 2 if h16 else 1     # a 16-bit map with C % 8 == 0 is an fp32 map with C/2 channels
+                check(L.yv4_dilate2_fwd(dy.data_ptr(), src.data_ptr(), N, Ho, Wo, Cout // k, Cout // k, 0, stream_ptr()),
                       'yv4_dilate2_fwd')
             else:
                 raise NotImplementedError('conv backward: stride must be 1 or 2')
@@ -116,22 +139,34 @@ class ConvFunction(torch.autograd.Function):
             Hs, Ws = src.shape[2], src.shape[3]
             Hx = Hs + 2 * p2 - KH + 1
             Wx = Ws + 2 * p2 - KW + 1
-            dxf = torch.empty((N, Cin, Hx, Wx), device=x.device, dtype=torch.float32,
-                              memory_format=torch.channels_last)
-            _conv_launch(src, wtp, Cout, Cin, KH, KW, 1, p2, dxf)
+            dxf = torch.empty((N, Cin, Hx, Wx), device=x.device, dtype=dtype, memory_format=torch.channels_last)
+            _conv_launch(src, wtp.to(dtype), Cout, Cin, KH, KW, 1, p2, dxf)
             if (Hx, Wx) != (H, W):
                 # stride 2 with odd input size: the dilated grid is one row/column larger or smaller
-                dx = torch.empty((N, Cin, H, W), device=x.device, dtype=torch.float32,
+                dx = torch.empty((N, Cin, H, W), device=x.device, dtype=dtype,
                                  memory_format=torch.channels_last).zero_()
                 hh, ww = min(H, Hx), min(W, Wx)
                 dx[:, :, :hh, :ww] = dxf[:, :, :hh, :ww]
             else:
                 dx = dxf
-        return dx, dw, None, None
+            dx = dx.to(ctx.x_dtype)
+        return dx, dw, None, None, None
 
 
-def conv2d(x, weight, stride=1, pad=0):
-    return ConvFunction.apply(x, weight, stride, pad)
+def train_dtype(module, x):
+    """Operand type of a training-mode conv: the module's ``compute_dtype`` (``wrap_fp16_model``) if
+    it is a 16-bit type, else the type ``x`` already has (16-bit activations stay 16-bit), else fp32."""
+    dt = getattr(module, 'compute_dtype', None)
+    if dt in (torch.float16, torch.bfloat16):
+        return dt
+    return x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
+
+
+def conv2d(x, weight, stride=1, pad=0, dtype=None):
+    """``dtype`` None: follow ``x`` (a 16-bit activation keeps the path 16-bit, anything else is fp32)."""
+    if dtype is None:
+        dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
+    return ConvFunction.apply(x, weight, stride, pad, dtype)
 
 
 class BNActFunction(torch.autograd.Function):
@@ -140,7 +175,10 @@ class BNActFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual):
         _need_cuda(x, 'x')
-        x = to_nhwc(x.float())
+        if x.dtype not in _DCODE:
+            x = x.float()
+        x = to_nhwc(x)
+        code = _DCODE[x.dtype]
         N, Cc, H, W = x.shape
         assert Cc % 4 == 0, 'BatchNorm kernels need a channel count that is a multiple of 4'
         M = N * H * W
@@ -149,18 +187,18 @@ class BNActFunction(torch.autograd.Function):
         work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
         mean = torch.empty(Cc, dtype=torch.float32, device=dev)
         invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
-        check(L.yv4_bn_train_stats(x.data_ptr(), M, Cc, Cc, 0, float(eps), float(momentum), work.data_ptr(),
-                                   mean.data_ptr(), invstd.data_ptr(),
-                                   running_mean.data_ptr() if running_mean is not None else None,
-                                   running_var.data_ptr() if running_var is not None else None, stream_ptr()),
+        check(L.yv4_bn_train_stats_h16(x.data_ptr(), code, M, Cc, Cc, 0, float(eps), float(momentum), work.data_ptr(),
+                                       mean.data_ptr(), invstd.data_ptr(),
+                                       running_mean.data_ptr() if running_mean is not None else None,
+                                       running_var.data_ptr() if running_var is not None else None, stream_ptr()),
               'yv4_bn_train_stats')
-        res = to_nhwc(residual.float()) if residual is not None else None
+        res = to_nhwc(residual.to(x.dtype)) if residual is not None else None
         y = torch.empty_like(x, memory_format=torch.channels_last)
         g = gamma.detach().float().contiguous()
         b = beta.detach().float().contiguous()
-        check(L.yv4_bn_act_fwd(x.data_ptr(), Cc, 0, mean.data_ptr(), invstd.data_ptr(), g.data_ptr(), b.data_ptr(),
-                               res.data_ptr() if res is not None else None, Cc, 0, y.data_ptr(), Cc, 0, M, Cc,
-                               int(act), float(slope), stream_ptr()), 'yv4_bn_act_fwd')
+        check(L.yv4_bn_act_fwd_h16(x.data_ptr(), code, Cc, 0, mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),
+                                   b.data_ptr(), res.data_ptr() if res is not None else None, Cc, 0, y.data_ptr(), Cc,
+                                   0, M, Cc, int(act), float(slope), stream_ptr()), 'yv4_bn_act_fwd')
         ctx.save_for_backward(x, mean, invstd, g, b)
         ctx.act = (int(act), float(slope))
         ctx.has_res = residual is not None
@@ -170,7 +208,8 @@ class BNActFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x, mean, invstd, g, b = ctx.saved_tensors
         act, slope = ctx.act
-        dy = to_nhwc(dy.float())
+        dy = to_nhwc(dy.to(x.dtype))
+        code = _DCODE[x.dtype]
         N, Cc, H, W = x.shape
         M = N * H * W
         dev = x.device
@@ -178,10 +217,10 @@ class BNActFunction(torch.autograd.Function):
         dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
         dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
         work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
-        check(_lib.lib().yv4_bn_act_bwd(x.data_ptr(), Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(), invstd.data_ptr(),
-                                        g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0, dgamma.data_ptr(),
-                                        dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope, stream_ptr()),
-              'yv4_bn_act_bwd')
+        check(_lib.lib().yv4_bn_act_bwd_h16(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+                                            invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
+                                            dgamma.data_ptr(), dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope,
+                                            stream_ptr()), 'yv4_bn_act_bwd')
         dres = dy if ctx.has_res else None
         return dx, dgamma, dbeta, None, None, None, None, None, None, dres
 

@@ -142,11 +142,12 @@ class YOLOCSPHead(HipModule):
         for conv, x in zip(self.convs_pred, feats):
             co = conv.out_channels
             w = conv.weight
-            padc = (-co) % 4
+            dt = T.train_dtype(self, x)
+            padc = (-co) % (4 if dt == torch.float32 else 8)
             if padc:
                 w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, padc))
-            y = T.conv2d(x, w, 1, 0)[:, :co]
-            outs.append(y + conv.bias.view(1, -1, 1, 1))
+            y = T.conv2d(x, w, 1, 0, dtype=dt)[:, :co]
+            outs.append(y.float() + conv.bias.view(1, -1, 1, 1))     # losses are computed in fp32 (force_fp32)
         return tuple(outs)
 
     def forward(self, feats):

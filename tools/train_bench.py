@@ -34,6 +34,8 @@ def main():
     ap.add_argument('--model', default='yolov4l')
     ap.add_argument('--accumulation', type=int, default=1)
     ap.add_argument('--torch-optim', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'],
+                    help='activation / conv operand type (master weights, statistics and losses stay fp32)')
     a = ap.parse_args()
     rank, local_rank, world = D.env_world()
     dev = torch.device('cuda', local_rank)
@@ -43,6 +45,8 @@ def main():
     det = pkg.build_detector(bench.model_cfg(a.model))
     det.init_weights()
     det.train().to(dev)
+    if a.dtype != 'f32':
+        pkg.wrap_fp16_model(det, torch.float16 if a.dtype == 'f16' else torch.bfloat16)
     # the recipe of configs/yolov4/yolov4l_coco_mosaic.py:108-147: SGD-Nesterov with one group per
     # parameter, grad clip 35, dynamic loss scale, per-parameter warm-up, EMA of the whole state --
     # all through the flat arenas; --torch-optim switches to torch.optim.SGD + DDP for comparison
@@ -107,7 +111,7 @@ def main():
         fl = 3 * 108.516e9 * (a.size / 608.0) ** 2 if a.model == 'yolov4l' else float('nan')
         print(json.dumps(dict(metric='images/sec (train step) ' + a.model, value=round(a.batch * world * a.steps / el, 2),
                               n_gpus=world, ms_per_step=round(el / a.steps * 1e3, 1), batch_per_gpu=a.batch,
-                              dtype='f32', loss_first=round(float(l0), 3), loss_last=round(float(l1), 3),
+                              dtype=a.dtype, loss_first=round(float(l0), 3), loss_last=round(float(l1), 3),
                               optimizer='torch SGD + DDP' if a.torch_optim else 'flat arenas + recipe hooks',
                               approx_conv_tflops=round(fl * a.batch * a.steps / el / 1e12, 1),
                               peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))))
