@@ -191,6 +191,184 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p, unsigne
 }
 
 // ---------------------------------------------------------------------------------
+// Weight gradient on the 16-bit MFMA (v_mfma_f32_32x32x16_{f16,bf16}).
+// Both operands of  dW[co][k] = sum_m dY[m][co] * A[m][k]  have the reduction index m as their
+// SLOW memory dimension (NHWC: channels contiguous), while an MFMA lane needs 8 consecutive m of
+// one column.  The slices therefore go global -> LDS row-major by LDS-DMA ([m][128 columns], 256-byte
+// rows) and come out transposed through ds_read_b64_tr_b16: per 16-lane group a 4 (m) x 16 (column)
+// block, lane i receiving column i -- two such reads are one lane's 8-element MFMA operand.
+// Chunk swizzle (cdna_hip_programming.md T10, image (b)): the 16-byte chunk ch of row `row` lives at
+// ch ^ (((row&3)<<2) | ((row>>2)&3)), applied on the DMA source side and in the read addresses;
+// without it the four rows of a block share 16 banks.
+// A workgroup (4 waves, 2x2, each 64 co x 64 k = 4 accumulator tiles) owns a 128 x 128 tile of dW
+// and one chunk of the M reduction, 64 rows per slice, double-buffered (64 KB of LDS).
+// ---------------------------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_w __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_w __attribute__((ext_vector_type(8)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int kWhRows = 64;    // reduction rows per slice
+constexpr int kWhTile = 128;   // dW tile edge (co and k)
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_wh[];
+  constexpr int kRowB = 256;                                  // 128 columns x 2 bytes
+  constexpr int kOpBytes = kWhRows * kRowB;                   // one operand, one buffer: 16 KB
+  // layout: [buf][operand (0 = dY, 1 = A)][64 rows][256 B]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tile_k = blockIdx.x % p.tiles_k;
+  const int tile_c = blockIdx.x / p.tiles_k;
+  const int co0 = tile_c * kWhTile;
+  const int k0 = tile_k * kWhTile;
+  const int m_lo = blockIdx.y * p.rows_per_chunk;
+  const int m_hi = min(m_lo + p.rows_per_chunk, p.M);
+  if (m_lo >= m_hi) return;
+
+  const u32x4_t rsX = make_rsrc_t(p.x, x_bytes);
+  const u32x4_t rsD = make_rsrc_t(p.dy, dy_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_wh;
+
+  // ---- staging: instruction q of this wave fills rows 16*wave + 4q + lane/16, physical chunk lane%16
+  const int srow = lane >> 4;
+  const int pc = lane & 15;
+  int d_col[4];            // dY column offset (elements) of the logical chunk, or -1
+  int a_tap[4], a_kh[4], a_kw[4], a_ci[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int lc = pc ^ ((srow << 2) | q);                    // swizzle: row&3 = srow, (row>>2)&3 = q
+    const int co = co0 + lc * 8;
+    d_col[q] = co < p.Cout ? co : -1;                          // Cout % 8 == 0 (host)
+    const int kk = k0 + lc * 8;
+    if (kk < p.K) {
+      const int tap = kk / p.Cin;
+      a_tap[q] = tap;
+      a_ci[q] = kk - tap * p.Cin;
+      a_kh[q] = tap / p.KW;
+      a_kw[q] = tap - a_kh[q] * p.KW;
+    } else {
+      a_tap[q] = -1; a_ci[q] = 0; a_kh[q] = 0; a_kw[q] = 0;
+    }
+  }
+
+  auto issue = [&](int m_base, int buf) {
+    // first row of this lane in the slice, decoded once; rows of q = 1..3 follow by +4 pixels
+    int m = m_base + 16 * wave + srow;
+    const int hw = p.Ho * p.Wo;
+    int n = m / hw;
+    int rm = m - n * hw;
+    int ho = rm / p.Wo;
+    int wo = rm - ho * p.Wo;
+    const unsigned lrow0 = (unsigned)(buf * 2 * kOpBytes + (16 * wave) * kRowB);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned doff = kOOB, aoff = kOOB;
+      if (m < m_hi) {
+        if (d_col[q] >= 0) doff = (unsigned)((((int64_t)m * p.dy_cs) + p.dy_co + d_col[q]) * 2);
+        if (a_tap[q] >= 0) {
+          const int hi = ho * p.stride - p.pad + a_kh[q];
+          const int wi = wo * p.stride - p.pad + a_kw[q];
+          if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+            aoff = (unsigned)(((((int64_t)n * p.H + hi) * p.W + wi) * p.x_cs + p.x_co + a_ci[q]) * 2);
+        }
+      }
+      const unsigned lrow = lrow0 + (unsigned)(4 * q * kRowB);
+      lds_dma16_t(rsD, lds_base + lrow, doff, 0u);
+      lds_dma16_t(rsX, lds_base + (unsigned)kOpBytes + lrow, aoff, 0u);
+      // next instruction: 4 pixels further
+      m += 4;
+      wo += 4;
+      while (wo >= p.Wo) { wo -= p.Wo; ++ho; }
+      if (ho >= p.Ho) { ho -= p.Ho; ++n; }
+    }
+  };
+
+  // ---- transposed fragment reads ----
+  // lane = 16g + i: h = g>>1 (k half of the MFMA step), colhalf = g&1; inside the group lane 4q'+pp
+  // addresses row q' of the block, columns 4pp..4pp+3
+  const int g = lane >> 4, i16 = lane & 15;
+  const int hh = g >> 1, colhalf = g & 1;
+  const int qq = i16 >> 2, pp = i16 & 3;
+  // byte offset inside an operand buffer of (block row m0 + qq, column c0 + 4pp), m0 = 16s + 8hh + 4j:
+  //   256*(m0+qq) + 16*((c0/8 + (pp>>1)) ^ ((qq<<2) | ((2hh + j)&3))) + 8*(pp&1)
+  auto frag_addr = [&](int col_base, int s, int j) -> unsigned {
+    const int m0 = 16 * s + 8 * hh + 4 * j;
+    const int chunk = (col_base + 16 * colhalf) / 8 + (pp >> 1);
+    const int swz = (qq << 2) | ((2 * hh + j) & 3);
+    return (unsigned)(kRowB * (m0 + qq) + 16 * (chunk ^ swz) + 8 * (pp & 1));
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int nslices = (m_hi - m_lo + kWhRows - 1) / kWhRows;
+  issue(m_lo, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int sl = 0; sl < nslices; ++sl) {
+    const int buf = sl & 1;
+    if (sl + 1 < nslices) issue(m_lo + (sl + 1) * kWhRows, buf ^ 1);
+    char* dbuf = smem_wh + buf * 2 * kOpBytes;
+    char* abuf = dbuf + kOpBytes;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < kWhRows / 16; ++s) {
+      s16x8_t fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(dbuf + frag_addr(wm * 64 + t * 32, s, 0)));
+        const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(dbuf + frag_addr(wm * 64 + t * 32, s, 1)));
+        const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(abuf + frag_addr(wn * 64 + t * 32, s, 0)));
+        const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(abuf + frag_addr(wn * 64 + t * 32, s, 1)));
+        fa[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        fb[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (BF16)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, fa[a]),
+                                                                __builtin_bit_cast(bf16x8_w, fb[b]), acc[a][b], 0, 0, 0);
+          else
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_w, fa[a]),
+                                                               __builtin_bit_cast(f16x8_w, fb[b]), acc[a][b], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // D[row = co][col = k]: row = (e&3) + 8*(e>>2) + 4*(lane>>5), col = lane&31
+  const int r = lane & 31, h5 = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int kcol = k0 + wn * 64 + b * 32 + r;
+      if (kcol >= p.K) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h5;
+        if (co < p.Cout) atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[a][b][e]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // dst[n, 2y, 2x, c] = src[n, y, x, c], everything else 0  (dst is (N, 2H, 2W, C) dense NHWC).
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H,
@@ -467,6 +645,10 @@ using namespace yv4;
     default: { typedef __bf16 T; CALL; } break;        \
   }
 
+// test / ablation switch: route 16-bit inputs through the widening fp32-MFMA kernel instead of the
+// 16-bit MFMA one (YV4_WGRAD_WIDEN=1 in the environment)
+static const bool g_wgrad_widen = [] { const char* e = getenv("YV4_WGRAD_WIDEN"); return e && e[0] == '1'; }();
+
 static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const void* dy, float* dw, void* stream) {
   YV4_REQUIRE(d && x && dy && dw, "wgrad: null argument");
   YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "wgrad: dtype must be f32, f16 or bf16");
@@ -489,6 +671,38 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.dy_cs = d->y_cstride; a.dy_co = d->y_coff;
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin;
+  if (dtype != YV4_F32 && !g_wgrad_widen) {
+    // 16-bit MFMA form: 128 x 128 tiles of dW, 64-row slices
+    a.tiles_k = (a.K + kWhTile - 1) / kWhTile;
+    const int tc = (a.Cout + kWhTile - 1) / kWhTile;
+    const long long tl = (long long)a.tiles_k * tc;
+    long long ch = (256 * 2 * 2 + tl - 1) / tl;           // ~2 rounds of 2 workgroups per CU
+    const long long mx = (M + 4 * kWhRows - 1) / (4 * kWhRows);   // at least 4 slices per chunk
+    if (ch > mx) ch = mx;
+    if (ch < 1) ch = 1;
+    if (ch > 65535) ch = 65535;
+    long long rw = (M + ch - 1) / ch;
+    rw = (rw + kWhRows - 1) / kWhRows * kWhRows;
+    a.rows_per_chunk = (int)rw;
+    ch = (M + rw - 1) / rw;
+    const size_t ldsh = (size_t)2 * 2 * kWhRows * 256;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h16_kernel<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h16_kernel<false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh);
+      attr_done = true;
+    }
+    if (dtype == YV4_BF16)
+      hipLaunchKernelGGL(conv_wgrad_h16_kernel<true>, dim3((unsigned)tl, (unsigned)ch), dim3(256), ldsh,
+                         reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
+    else
+      hipLaunchKernelGGL(conv_wgrad_h16_kernel<false>, dim3((unsigned)tl, (unsigned)ch), dim3(256), ldsh,
+                         reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
+    YV4_CHECK_LAUNCH("conv_wgrad_h16");
+    return YV4_OK;
+  }
   a.tiles_k = (a.K + 63) / 64;
   const int tiles_c = (a.Cout + 63) / 64;
   const long long tiles = (long long)a.tiles_k * tiles_c;
