@@ -467,24 +467,43 @@ __device__ __forceinline__ void red_flush(double* part, int C, int c, const floa
   }
 }
 
+constexpr int kBnUnroll = 4;    // independent row loads in flight per thread (the loops are latency-bound otherwise)
+
+// rows per workgroup: enough workgroups to fill the chip (>= ~1024) but at most kBnRows rows each
+static inline int bn_rows_per_block(int64_t M) {
+  int64_t r = (M + 1023) / 1024;
+  if (r < 32) r = 32;
+  if (r > kBnRows) r = kBnRows;
+  return (int)r;
+}
+
 // sums[c] += sum x, sums[C + c] += sum x^2   (double)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t M, int C, int cs, int co,
-                                                       double* __restrict__ sums) {
+                                                       double* __restrict__ sums, int rows_per_block) {
   extern __shared__ double part[];   // [2][C]
   const int C4 = C >> 2;
   for (int i = threadIdx.x; i < 2 * C; i += 256) part[i] = 0.0;
   __syncthreads();
   const RedMap mp = red_map(C4);
-  const int64_t r0 = (int64_t)blockIdx.x * kBnRows;
-  const int64_t r1 = r0 + kBnRows < M ? r0 + kBnRows : M;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
   if (mp.active) {
     for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
       float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
-      for (int64_t rr = r0 + mp.rsub; rr < r1; rr += mp.rstep) {
-        const float4 v = El<T>::ld4(x + rr * cs + co + cq * 4);
-        fs[0] += v.x; fs[1] += v.y; fs[2] += v.z; fs[3] += v.w;
-        fq[0] += v.x * v.x; fq[1] += v.y * v.y; fq[2] += v.z * v.z; fq[3] += v.w * v.w;
+      const T* col = x + co + cq * 4;
+      for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnUnroll) {
+        float4 v[kBnUnroll];
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) {
+          const int64_t row = rr + (int64_t)u * mp.rstep;
+          v[u] = row < r1 ? El<T>::ld4(col + row * cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) {
+          fs[0] += v[u].x; fs[1] += v[u].y; fs[2] += v[u].z; fs[3] += v[u].w;
+          fq[0] += v[u].x * v[u].x; fq[1] += v[u].y * v[u].y; fq[2] += v[u].z * v[u].z; fq[3] += v[u].w * v[u].w;
+        }
       }
       red_flush(part, C, cq * 4, fs, fq, true);
     }
@@ -519,35 +538,51 @@ struct BnArgs {
   void* dx; int dx_cs, dx_co;
   double* sums;      // bwd: [dbeta (C) | dgamma (C)]
   int64_t M; int C; int act; float slope;
+  int rows_per_block;
 };
 
+// Elementwise passes use the reductions' thread map too: a thread keeps ONE channel quad (its
+// mean / invstd / gamma / beta live in registers) and walks rows -- no per-element index division,
+// kBnUnroll independent row loads in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnArgs p) {
   const T* px = reinterpret_cast<const T*>(p.x);
   const T* pres = reinterpret_cast<const T*>(p.res);
   T* py = reinterpret_cast<T*>(p.y);
   const int C4 = p.C >> 2;
-  const size_t total = (size_t)p.M * C4;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cq = (int)(i % C4);
-    const size_t m = i / C4;
+  const RedMap mp = red_map(C4);
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+  const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
+  if (!mp.active) return;
+  for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
     const int c = cq * 4;
-    const float4 v = El<T>::ld4(px + m * p.x_cs + p.x_co + c);
     const float4 mu = *reinterpret_cast<const float4*>(p.mean + c);
     const float4 is = *reinterpret_cast<const float4*>(p.invstd + c);
     const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c);
     const float4 be = *reinterpret_cast<const float4*>(p.beta + c);
-    float4 o;
-    o.x = act_fwd_exact((v.x - mu.x) * is.x * ga.x + be.x, p.act, p.slope);
-    o.y = act_fwd_exact((v.y - mu.y) * is.y * ga.y + be.y, p.act, p.slope);
-    o.z = act_fwd_exact((v.z - mu.z) * is.z * ga.z + be.z, p.act, p.slope);
-    o.w = act_fwd_exact((v.w - mu.w) * is.w * ga.w + be.w, p.act, p.slope);
-    if (pres) {
-      const float4 rr = El<T>::ld4(pres + m * p.r_cs + p.r_co + c);
-      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    // z = x * a + b
+    const float4 sa = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
+    for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnUnroll) {
+      float4 v[kBnUnroll], rs[kBnUnroll];
+#pragma unroll
+      for (int u = 0; u < kBnUnroll; ++u) {
+        const int64_t row = rr + (int64_t)u * mp.rstep;
+        const bool ok = row < r1;
+        v[u] = ok ? El<T>::ld4(px + row * p.x_cs + p.x_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rs[u] = (ok && pres) ? El<T>::ld4(pres + row * p.r_cs + p.r_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < kBnUnroll; ++u) {
+        const int64_t row = rr + (int64_t)u * mp.rstep;
+        if (row >= r1) continue;
+        float4 o;
+        o.x = act_fwd_exact((v[u].x - mu.x) * sa.x + be.x, p.act, p.slope) + rs[u].x;
+        o.y = act_fwd_exact((v[u].y - mu.y) * sa.y + be.y, p.act, p.slope) + rs[u].y;
+        o.z = act_fwd_exact((v[u].z - mu.z) * sa.z + be.z, p.act, p.slope) + rs[u].z;
+        o.w = act_fwd_exact((v[u].w - mu.w) * sa.w + be.w, p.act, p.slope) + rs[u].w;
+        El<T>::st4(py + row * p.y_cs + p.y_co + c, o);
+      }
     }
-    El<T>::st4(py + m * p.y_cs + p.y_co + c, o);
   }
 }
 
@@ -560,8 +595,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
   for (int i = threadIdx.x; i < 2 * p.C; i += 256) part[i] = 0.0;
   __syncthreads();
   const RedMap mp = red_map(C4);
-  const int64_t r0 = (int64_t)blockIdx.x * kBnRows;
-  const int64_t r1 = r0 + kBnRows < p.M ? r0 + kBnRows : p.M;
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+  const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
   if (mp.active) {
     for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
       const int c = cq * 4;
@@ -570,17 +605,26 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
       const float ga[4] = {p.gamma[c], p.gamma[c + 1], p.gamma[c + 2], p.gamma[c + 3]};
       const float be[4] = {p.beta[c], p.beta[c + 1], p.beta[c + 2], p.beta[c + 3]};
       float db[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0};
-      for (int64_t rr = r0 + mp.rsub; rr < r1; rr += mp.rstep) {
-        const float4 xv = El<T>::ld4(px + rr * p.x_cs + p.x_co + c);
-        const float4 gv = El<T>::ld4(pdy + rr * p.dy_cs + p.dy_co + c);
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+      for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnUnroll) {
+        float4 xv[kBnUnroll], gv[kBnUnroll];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float xhat = (xs[k] - mu[k]) * is[k];
-          const float g = gs[k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
-          db[k] += g;
-          dg[k] += g * xhat;
+        for (int u = 0; u < kBnUnroll; ++u) {
+          const int64_t row = rr + (int64_t)u * mp.rstep;
+          const bool ok = row < r1;
+          xv[u] = ok ? El<T>::ld4(px + row * p.x_cs + p.x_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          gv[u] = ok ? El<T>::ld4(pdy + row * p.dy_cs + p.dy_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) {
+          const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+          const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};   // zero beyond r1 -> contributes nothing
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float xhat = (xs[k] - mu[k]) * is[k];
+            const float g = gs[k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
+            db[k] += g;
+            dg[k] += g * xhat;
+          }
         }
       }
       red_flush(part, p.C, c, db, dg, true);
@@ -596,28 +640,45 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
   const T* pdy = reinterpret_cast<const T*>(p.dy);
   T* pdx = reinterpret_cast<T*>(p.dx);
   const int C4 = p.C >> 2;
-  const size_t total = (size_t)p.M * C4;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const RedMap mp = red_map(C4);
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+  const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
+  if (!mp.active) return;
   const double invM = 1.0 / (double)p.M;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cq = (int)(i % C4);
-    const size_t m = i / C4;
+  for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
     const int c = cq * 4;
-    const float4 xv = El<T>::ld4(px + m * p.x_cs + p.x_co + c);
-    const float4 gv = El<T>::ld4(pdy + m * p.dy_cs + p.dy_co + c);
-    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-    const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-    float o[4];
+    float mu[4], is[4], ga[4], be[4], dbm[4], dgm[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float mu = p.mean[c + k], is = p.invstd[c + k], ga = p.gamma[c + k], be = p.beta[c + k];
-      const float xhat = (xs[k] - mu) * is;
-      const float g = gs[k] * act_grad(xhat * ga + be, p.act, p.slope);
-      const float dbm = (float)(p.sums[c + k] * invM);
-      const float dgm = (float)(p.sums[p.C + c + k] * invM);
-      o[k] = ga * is * (g - dbm - xhat * dgm);
+      mu[k] = p.mean[c + k]; is[k] = p.invstd[c + k]; ga[k] = p.gamma[c + k]; be[k] = p.beta[c + k];
+      dbm[k] = (float)(p.sums[c + k] * invM);
+      dgm[k] = (float)(p.sums[p.C + c + k] * invM);
     }
-    El<T>::st4(pdx + m * p.dx_cs + p.dx_co + c, make_float4(o[0], o[1], o[2], o[3]));
+    for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnUnroll) {
+      float4 xv[kBnUnroll], gv[kBnUnroll];
+#pragma unroll
+      for (int u = 0; u < kBnUnroll; ++u) {
+        const int64_t row = rr + (int64_t)u * mp.rstep;
+        const bool ok = row < r1;
+        xv[u] = ok ? El<T>::ld4(px + row * p.x_cs + p.x_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gv[u] = ok ? El<T>::ld4(pdy + row * p.dy_cs + p.dy_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < kBnUnroll; ++u) {
+        const int64_t row = rr + (int64_t)u * mp.rstep;
+        if (row >= r1) continue;
+        const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+        const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xhat = (xs[k] - mu[k]) * is[k];
+          const float g = gs[k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
+          o[k] = ga[k] * is[k] * (g - dbm[k] - xhat * dgm[k]);
+        }
+        El<T>::st4(pdx + row * p.dx_cs + p.dx_co + c, make_float4(o[0], o[1], o[2], o[3]));
+      }
+    }
   }
 }
 
@@ -733,9 +794,10 @@ static int bn_stats_impl(int dtype, const void* x, int64_t M, int C, int x_cstri
   YV4_REQUIRE(C <= 4096, "bn_train_stats: more than 4096 channels");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) { set_error("bn_train_stats: memset failed"); return YV4_E_LAUNCH; }
-  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows));
+  const int rpb = bn_rows_per_block(M);
+  dim3 grid((unsigned)((M + rpb - 1) / rpb));
   YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s,
-                                           reinterpret_cast<const T*>(x), M, C, x_cstride, x_coff, work));
+                                           reinterpret_cast<const T*>(x), M, C, x_cstride, x_coff, work, rpb));
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, M, C, eps, momentum, mean, invstd,
                      running_mean, running_var);
   YV4_CHECK_LAUNCH("bn_train_stats");
@@ -753,8 +815,10 @@ static int bn_fwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
   a.res = residual; a.r_cs = r_cstride; a.r_co = r_coff; a.y = y; a.y_cs = y_cstride; a.y_co = y_coff;
   a.M = M; a.C = C; a.act = act; a.slope = slope;
-  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid_t((size_t)M * (C / 4))), dim3(256), 0,
-                                           reinterpret_cast<hipStream_t>(stream), a));
+  YV4_REQUIRE(C <= 4096, "bn_act_fwd: more than 4096 channels");
+  a.rows_per_block = bn_rows_per_block(M);
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block)),
+                                           dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a));
   YV4_CHECK_LAUNCH("bn_act_fwd");
   return YV4_OK;
 }
@@ -775,10 +839,10 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.dy = dy; a.dy_cs = dy_cstride; a.dy_co = dy_coff;
   a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dx_cs = dx_cstride; a.dx_co = dx_coff;
   a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope;
-  dim3 grid((unsigned)((M + kBnRows - 1) / kBnRows));
+  a.rows_per_block = bn_rows_per_block(M);
+  dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
   YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s, a));
-  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(ew_grid_t((size_t)M * (C / 4))), dim3(256), 0,
-                                           s, a));
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, grid, dim3(256), 0, s, a));
   hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
   hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
   YV4_CHECK_LAUNCH("bn_act_bwd");
