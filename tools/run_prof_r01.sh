@@ -19,6 +19,11 @@ tail -2 $OUT/bench.json
 # 4. training step (row f-1): per-kernel time + the un-profiled train-step line
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python3 tools/train_bench.py --batch 32 --steps 2 --warmup 1 > $OUT/trace_train.log 2>&1
 python3 tools/train_bench.py --batch 32 --steps 5 2> $OUT/train_bench.err | tail -1 > $OUT/train_bench.json
+# 5. 16-bit rows (configs[2], [3]): bf16 inference bench line, bf16 train step at batch 64 + its kernel stats
+python3 bench.py --dtype bf16 --no-cpu-baseline --layers $OUT/layers_bf16.json 2> $OUT/bench_bf16.err | tail -1 > $OUT/bench_bf16.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train_bf16 -- python3 tools/train_bench.py --batch 64 --steps 2 --warmup 1 --dtype bf16 > $OUT/trace_train_bf16.log 2>&1
+python3 tools/train_bench.py --batch 64 --steps 5 --dtype bf16 2> $OUT/train_bench_bf16.err | tail -1 > $OUT/train_bench_bf16.json
+python3 tools/conv_bench.py --dtype bf16 --tiles 1,2,3 > $OUT/conv_shapes_bf16.txt 2>&1
 python3 tools/summarize_prof.py $OUT $OUT/summary
 ls -la $OUT/summary
 # raw per-dispatch traces are large and already condensed: keep the pull small

@@ -14,6 +14,10 @@ os.makedirs(out, exist_ok=True)
 
 def short(name):
     name = re.sub(r'^void ', '', name)
+    m = re.match(r'_ZN3yv4(\d+)([A-Za-z0-9_]+?)I(DF16b|DF16_|f)E', name)     # templated on __bf16 / _Float16
+    if m:
+        base = m.group(2)[:int(m.group(1))]
+        return f"yv4::{base}<{ {'DF16b': '__bf16', 'DF16_': '_Float16', 'f': 'float'}[m.group(3)] }>"
     m = re.match(r'(yv4::[A-Za-z0-9_]+(<[^>]*>)?)', name)
     if m:
         return m.group(1)
@@ -21,7 +25,8 @@ def short(name):
 
 
 # 1. kernel stats (inference bench, training step)
-for sub, dst in (('trace', 'kernel_stats.csv'), ('trace_train', 'train_kernel_stats.csv')):
+for sub, dst in (('trace', 'kernel_stats.csv'), ('trace_train', 'train_kernel_stats.csv'),
+                 ('trace_train_bf16', 'train_bf16_kernel_stats.csv')):
   for f in glob.glob(os.path.join(raw, sub, '*', '*_kernel_stats.csv')):
     rows = list(csv.DictReader(open(f)))
     with open(os.path.join(out, dst), 'w', newline='') as g:
@@ -54,7 +59,8 @@ for k, cs in pm.items():
         e['l2_hit_rate'] = e['TCC_HIT_sum'] / max(e['TCC_HIT_sum'] + e['TCC_MISS_sum'], 1)
     res[k] = e
 json.dump(res, open(os.path.join(out, 'pmc_per_kernel.json'), 'w'), indent=1, sort_keys=True)
-for name in ('conv_shapes.txt', 'bench.json', 'layers.json', 'train_bench.json'):
+for name in ('conv_shapes.txt', 'bench.json', 'layers.json', 'train_bench.json', 'bench_bf16.json', 'layers_bf16.json',
+             'train_bench_bf16.json', 'conv_shapes_bf16.txt'):
     p = os.path.join(raw, name)
     if os.path.exists(p):
         open(os.path.join(out, name), 'w').write(open(p).read())
