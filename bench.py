@@ -32,6 +32,9 @@ PEAK_H16_MFMA_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, same guide (not the
 MODELS = {
     'yolov4l': dict(scale='v4l5p', neck_in=[256, 512, 512], neck_out=[256, 512, 1024], csp_rep=2),
     'yolov4s': dict(scale='v4s5p', neck_in=[128, 256, 256], neck_out=[128, 256, 512], csp_rep=1),
+    # configs/yolov5/yolov5l_coco_mosaic.py: _base_ yolov4l + backbone v5l5p (out 2,3,4) + YOLOV5Neck
+    'yolov5l': dict(scale='v5l5p', neck='YOLOV5Neck', neck_in=[256, 512, 1024], neck_out=[256, 512, 1024], csp_rep=2,
+                    out_indices=[2, 3, 4]),
 }
 
 
@@ -39,8 +42,8 @@ def model_cfg(name):
     m = MODELS[name]
     return dict(
         type='SingleStageDetector',
-        backbone=dict(type='DarknetCSP', scale=m['scale'], out_indices=[3, 4, 5]),
-        neck=dict(type='YOLOV4Neck', in_channels=m['neck_in'], out_channels=m['neck_out'],
+        backbone=dict(type='DarknetCSP', scale=m['scale'], out_indices=m.get('out_indices', [3, 4, 5])),
+        neck=dict(type=m.get('neck', 'YOLOV4Neck'), in_channels=m['neck_in'], out_channels=m['neck_out'],
                   csp_repetition=m['csp_rep']),
         bbox_head=dict(type='YOLOCSPHead', num_classes=80, in_channels=m['neck_out']),
         train_cfg=dict(),
@@ -165,7 +168,7 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'],
                     help='operand type of the convs (f32 = the headline / parity configuration)')
     ap.add_argument('--event-every', type=int, default=4,
-                    help='bracket the conv launches with HIP events in every n-th timed step (events cost ~2 %)')
+                    help='bracket the conv launches with HIP events in every n-th timed step (events cost ~2 %%)')
     args = ap.parse_args()
 
     import mmdet_yolov4_amd as pkg
@@ -295,14 +298,16 @@ def main():
     if rank == 0:
         total_images = args.batch * world * args.steps
         out = dict(
-            metric='images/sec (inference) YOLOv4 608x608', value=round(total_images / elapsed, 2),
+            metric=f'images/sec (inference) YOLOv4 {args.size}x{args.size}', value=round(total_images / elapsed, 2),
             unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
             vs_baseline=None, dtype=args.dtype, data='synthetic',
-            config=dict(workload=f'{args.model} (DarknetCSP v4l5p + YOLOV4Neck + YOLOCSPHead, 80 classes) '
+            config=dict(workload=f'{args.model} (DarknetCSP {MODELS[args.model]["scale"]} + '
+                                 f'{MODELS[args.model].get("neck", "YOLOV4Neck")} + YOLOCSPHead, 80 classes) '
                                  f'{args.size}x{args.size} {dict(f32="fp32", f16="fp16", bf16="bf16")[args.dtype]} inference, batch {args.batch}/GPU: image -> '
-                                 'fused conv path -> decode -> per-class NMS -> detections on host '
-                                 '(BASELINE.json configs[1]' + ('' if args.dtype == 'f32' else '; NOT the headline dtype') + ')',
+                                 'fused conv path -> decode -> per-class NMS -> detections on host ' +
+                                 ('(BASELINE.json configs[1])' if (args.model, args.size, args.batch, args.dtype) == ('yolov4l', 608, 32, 'f32')
+                                  else '(not the headline configuration)'),
                         global_batch=args.batch * world, per_gpu_batch=args.batch, input=f'{args.size}x{args.size}',
                         weights='random init (seed 0), BN statistics fitted on the batch, head bias set for '
                                 f'~{ncand:.0f} NMS candidates/image', parallelism=f'replicated weights, batch '

@@ -108,12 +108,13 @@ def main():
     D.barrier()
     el = D.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
-        fl = 3 * 108.516e9 * (a.size / 608.0) ** 2 if a.model == 'yolov4l' else float('nan')
+        per_img = {'yolov4l': 108.516e9 / 608.0 ** 2, 'yolov5l': 108.574e9 / 640.0 ** 2, 'yolov4s': 8.942e9 / 416.0 ** 2}
+        fl = 3 * per_img[a.model] * a.size ** 2      # fwd + dgrad + wgrad conv FLOPs
         print(json.dumps(dict(metric='images/sec (train step) ' + a.model, value=round(a.batch * world * a.steps / el, 2),
                               n_gpus=world, ms_per_step=round(el / a.steps * 1e3, 1), batch_per_gpu=a.batch,
                               dtype=a.dtype, loss_first=round(float(l0), 3), loss_last=round(float(l1), 3),
                               optimizer='torch SGD + DDP' if a.torch_optim else 'flat arenas + recipe hooks',
-                              approx_conv_tflops=round(fl * a.batch * a.steps / el / 1e12, 1),
+                              approx_conv_tflops=round(fl * a.batch * world * a.steps / el / 1e12, 1),
                               peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))))
     D.finalize()
 
