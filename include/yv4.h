@@ -327,6 +327,13 @@ int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x_coff, cons
                        int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C,
                        int act, float slope, void* stream);
 
+/* SPP backward: xcat is the forward's concat buffer (its first C channels are the pooled input),
+ * dcat the gradient w.r.t. the 4C-channel concat; dx (N, H, W, C) fp32, dense, ZERO on entry, receives
+ * the identity branch plus the three max-pool scatters (first maximum in row-major window order,
+ * like ATen).  dtype is the element type of xcat / dcat (YV4_F32 / F16 / BF16). */
+int yv4_spp_pool_bwd(const void* xcat, int x_cstride, int x_coff, const void* dcat, int d_cstride,
+                     int d_coff, float* dx, int N, int H, int W, int C, int dtype, void* stream);
+
 /* ---- optimizer side of the training step (flat fp32 arenas) -------------------------
  * The reference steps torch.optim.SGD(nesterov) with one param group per parameter
  * (core/custom_hooks/warmup_hooks.py:24-32 requires that), un-scales and clips gradients in

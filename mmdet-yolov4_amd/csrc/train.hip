@@ -682,6 +682,74 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// SPP backward (darknetcsp.py:176-181,203-206,222-226: cat([x, mp5(x), mp9(x), mp13(x)])):
+//   dx[p] = dcat[0][p] + sum over k in {5,9,13}, over output positions q whose window argmax is p,
+//   of dcat[k][q].
+// One thread owns (n, y, x, 4 channels) as an OUTPUT position: it rescans the 13x13 window of the
+// saved input once in row-major order, tracking the first maximum of the nested 5 / 9 / 13 windows
+// (torch's max_pool2d keeps the first maximum in scan order), and scatters its three gradients with
+// float atomics into the fp32 accumulator dx (N, H, W, C dense, zero on entry), plus its own
+// identity-branch gradient.  Replaces three ATen max_pool2d backward passes + three adds.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void spp_pool_bwd_kernel(const T* __restrict__ xcat, int x_cs, int x_co,
+                                                           const T* __restrict__ dcat, int d_cs, int d_co,
+                                                           float* __restrict__ dx, int N, int H, int W, int C) {
+  const int C4 = C >> 2;
+  const size_t total = (size_t)N * H * W * C4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float ninf = -__builtin_huge_valf();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const T* base = xcat + (size_t)n * H * W * x_cs + x_co + c4 * 4;
+    float m[3][4];
+    int am[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { m[k][u] = ninf; am[k][u] = y * W + x; }
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int yy = y + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      const int ady = dy < 0 ? -dy : dy;
+      for (int dxx = -6; dxx <= 6; ++dxx) {
+        const int xx = x + dxx;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        const int adx = dxx < 0 ? -dxx : dxx;
+        const int rad = ady > adx ? ady : adx;
+        const float4 v4 = El<T>::ld4(base + ((size_t)yy * W + xx) * x_cs);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const int pos = yy * W + xx;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (v[u] > m[2][u]) { m[2][u] = v[u]; am[2][u] = pos; }
+          if (rad <= 4 && v[u] > m[1][u]) { m[1][u] = v[u]; am[1][u] = pos; }
+          if (rad <= 2 && v[u] > m[0][u]) { m[0][u] = v[u]; am[0][u] = pos; }
+        }
+      }
+    }
+    const T* g = dcat + ((size_t)(n * H + y) * W + x) * d_cs + d_co + c4 * 4;
+    float* dxn = dx + (size_t)n * H * W * C + c4 * 4;
+    const float4 g0 = El<T>::ld4(g);
+    const float gi[4] = {g0.x, g0.y, g0.z, g0.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) atomicAdd(dxn + (size_t)(y * W + x) * C + u, gi[u]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 gk = El<T>::ld4(g + (k + 1) * C);
+      const float gv[4] = {gk.x, gk.y, gk.z, gk.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) atomicAdd(dxn + (size_t)am[k][u] * C + u, gv[u]);
+    }
+  }
+}
+
 __global__ void sums_to_float_kernel(const double* __restrict__ sums, int n, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (float)sums[i];
@@ -909,4 +977,20 @@ extern "C" int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x
                                   double* work, int64_t M, int C, int act, float slope, void* stream) {
   return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
                      dx_coff, dgamma, dbeta, work, M, C, act, slope, stream);
+}
+
+extern "C" int yv4_spp_pool_bwd(const void* xcat, int x_cstride, int x_coff, const void* dcat, int d_cstride, int d_coff,
+                                float* dx, int N, int H, int W, int C, int dtype, void* stream) {
+  YV4_REQUIRE(xcat && dcat && dx && N > 0 && H > 0 && W > 0 && C > 0, "spp_pool_bwd: bad argument");
+  YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "spp_pool_bwd: dtype must be f32, f16 or bf16");
+  YV4_REQUIRE(((C | x_cstride | x_coff | d_cstride | d_coff) & 3) == 0, "spp_pool_bwd: channels must be multiples of 4");
+  YV4_REQUIRE(x_coff + C <= x_cstride && d_coff + 4 * C <= d_cstride, "spp_pool_bwd: view exceeds its pixel stride");
+  YV4_REQUIRE((long long)H * W < (1LL << 31), "spp_pool_bwd: H*W does not fit 31 bits");
+  const size_t total = (size_t)N * H * W * (C / 4);
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(spp_pool_bwd_kernel<T>, dim3(ew_grid_t(total)), dim3(256), 0,
+                                           reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(xcat),
+                                           x_cstride, x_coff, reinterpret_cast<const T*>(dcat), d_cstride, d_coff, dx, N,
+                                           H, W, C));
+  YV4_CHECK_LAUNCH("spp_pool_bwd");
+  return YV4_OK;
 }

@@ -113,6 +113,14 @@ class Conv(HipModule):
         return self._dispatch((x,), 'flat')
 
 
+def _spp_cat(mod, x):
+    """cat([x, maxpools(x)...]) in training mode: the fused HIP op for the (5, 9, 13) pyramid."""
+    ks = tuple(int(mp.kernel_size) for mp in mod.maxpools)
+    if ks == (5, 9, 13) and x.is_cuda and x.shape[1] % (4 if x.dtype == torch.float32 else 8) == 0:
+        return T.spp_cat(x)
+    return torch.cat([x] + [mp(x) for mp in mod.maxpools], 1)
+
+
 def bare_conv_fwd(conv, x):
     return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0])      # follows x's dtype
 
@@ -273,7 +281,7 @@ class SPPV5(HipModule):
 
     def fwd(self, x):
         x = self.conv1.fwd(x)
-        return self.conv2.fwd(torch.cat([x] + [mp(x) for mp in self.maxpools], 1))
+        return self.conv2.fwd(_spp_cat(self, x))
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')
@@ -318,7 +326,7 @@ class SPPV4(HipModule):
 
     def fwd(self, x):
         x1 = self.conv4.fwd(self.conv3.fwd(self.conv1.fwd(x)))
-        y1 = self.conv6.fwd(self.conv5.fwd(torch.cat([x1] + [mp(x1) for mp in self.maxpools], 1)))
+        y1 = self.conv6.fwd(self.conv5.fwd(_spp_cat(self, x1)))
         z = torch.cat((y1, bare_conv_fwd(self.conv2, x)), dim=1)
         return self.conv7.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
 

@@ -234,3 +234,45 @@ def bn_act(x, bn, act=(0, 0.0), residual=None):
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return out
+
+
+class SPPCatFunction(torch.autograd.Function):
+    """``torch.cat([x, mp5(x), mp9(x), mp13(x)], 1)`` (darknetcsp.py:176-181,203-206,222-226) as one
+    forward (slice copy + ``yv4_spp_pool_fwd``) and one backward launch (``yv4_spp_pool_bwd``); the
+    concat buffer itself is what is saved."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x, 'x')
+        if x.dtype not in _DCODE:
+            x = x.float()
+        x = to_nhwc(x)
+        N, Cc, H, W = x.shape
+        al = 4 if x.dtype == torch.float32 else 8
+        assert Cc % al == 0, f'SPP kernels need a channel count that is a multiple of {al}'
+        out = torch.empty((N, 4 * Cc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        out[:, :Cc] = x
+        L = _lib.lib()
+        if x.dtype == torch.float32:
+            check(L.yv4_spp_pool_fwd(out.data_ptr(), N, H, W, Cc, 4 * Cc, 0, stream_ptr()), 'yv4_spp_pool_fwd')
+        else:
+            check(L.yv4_spp_pool_fwd_h16(out.data_ptr(), N, H, W, Cc, 4 * Cc, 0, _DCODE[x.dtype], stream_ptr()),
+                  'yv4_spp_pool_fwd_h16')
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dcat):
+        out, = ctx.saved_tensors
+        N, C4_, H, W = out.shape
+        Cc = C4_ // 4
+        dcat = to_nhwc(dcat.to(out.dtype))
+        dx = torch.zeros((N, Cc, H, W), dtype=torch.float32, device=out.device).contiguous(
+            memory_format=torch.channels_last)
+        check(_lib.lib().yv4_spp_pool_bwd(out.data_ptr(), 4 * Cc, 0, dcat.data_ptr(), 4 * Cc, 0, dx.data_ptr(), N, H, W,
+                                          Cc, _DCODE[out.dtype], stream_ptr()), 'yv4_spp_pool_bwd')
+        return dx.to(out.dtype)
+
+
+def spp_cat(x):
+    return SPPCatFunction.apply(x)

@@ -98,3 +98,31 @@ def test_wgrad_rejects_unaligned(gpu_device):
     d.x_cstride, d.y_cstride = 8, 255
     t = torch.zeros(1 << 16, device=gpu_device)
     assert lib.yv4_conv_wgrad(ctypes.byref(d), t.data_ptr(), t.data_ptr(), t.data_ptr(), None) == -1
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('hw', [(19, 19), (7, 5), (13, 20)])
+def test_spp_cat_forward_and_backward_match_max_pool_autograd(gpu_device, dtype, hw):
+    """cat([x, mp5, mp9, mp13]) as one HIP forward + one HIP backward vs torch's max_pool2d autograd."""
+    from mmdet_yolov4_amd import train_ops as T
+    torch.manual_seed(0)
+    H, W = hw
+    x = torch.randn(2, 16, H, W, device=gpu_device).to(dtype)
+    xr = x.clone().requires_grad_(True)
+    out = T.spp_cat(xr)
+    g = torch.randn(2, 64, H, W, device=gpu_device).to(dtype)
+    out.backward(g)
+    x2 = x.float().requires_grad_(True)
+    ref = torch.cat([x2] + [F.max_pool2d(x2, k, 1, k // 2) for k in (5, 9, 13)], 1)
+    ref.backward(g.float())
+    assert out.dtype == dtype and torch.equal(out.float(), ref.detach())
+    # fp32 is exact up to the order of the atomic adds; 16-bit rounds the accumulated gradient once.
+    # (exact ties between window elements -- common in 16 bits -- may send a gradient to a different,
+    # equal-valued element than ATen does: compare after summing each window's mass, i.e. per map)
+    tol = 1e-5 if dtype == torch.float32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
+    a, b = xr.grad.float(), x2.grad
+    if dtype == torch.float32:
+        torch.testing.assert_close(a, b, rtol=tol, atol=tol)
+    else:
+        torch.testing.assert_close(a.sum((2, 3)), b.sum((2, 3)), rtol=tol, atol=tol * 10)
+        assert float((a - b).abs().max()) <= 0.05 * float(b.abs().max()) or (a != b).float().mean() < 0.02
