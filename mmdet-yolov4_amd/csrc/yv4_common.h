@@ -58,7 +58,11 @@ __device__ __forceinline__ float sigmoid_f32(float x) {
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {
+#ifdef YV4_EXACT_MISH
+    case YV4_ACT_MISH: return mish_f32(v);
+#else
     case YV4_ACT_MISH: return mish_fast_f32(v);
+#endif
     case YV4_ACT_LEAKY: return v >= 0.f ? v : v * slope;
     case YV4_ACT_SWISH: return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-v * 1.44269504088896340736f));
     default: return v;

@@ -1,0 +1,162 @@
+"""YOLOv4-L at BASELINE.json's full size (608x608) on the GPU: parity against the CPU oracle on one
+image (the oracle needs a few seconds for it) and the size-independent properties of the path
+(determinism, batch-composition independence, plan == module-by-module composition, NMS invariants,
+rescale consistency)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import mmdet_yolov4_amd as pkg
+from mmdet_yolov4_amd.calibrate import calibrate_bn
+from oracle import yolov4_oracle as O
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (model config + synthetic inputs of the headline benchmark)
+
+pytestmark = pytest.mark.gpu
+SIZE = 608
+
+
+@pytest.fixture(scope='module')
+def v4l(gpu_device):
+    torch.manual_seed(0)
+    det = pkg.build_detector(bench.model_cfg('yolov4l'))
+    det.init_weights()
+    det.eval().to(gpu_device)
+    img = bench.synthetic_images(2, SIZE, 1000, gpu_device)
+    plan = det.compile(2, SIZE, SIZE, device=gpu_device, rescale=True)
+    calibrate_bn(plan, img)                               # BN statistics fitted on the batch (modules updated)
+    ncand = bench.init_head(det, plan, img, 1500.0)       # ~1500 NMS candidates per image
+    assert 500 < ncand < 5000
+    return det, img
+
+
+def _ious(b):
+    x1 = np.maximum(b[:, None, 0], b[None, :, 0]); y1 = np.maximum(b[:, None, 1], b[None, :, 1])
+    x2 = np.minimum(b[:, None, 2], b[None, :, 2]); y2 = np.minimum(b[:, None, 3], b[None, :, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (area[:, None] + area[None, :] - inter)
+
+
+def test_fullsize_parity_with_the_oracle_on_one_image(v4l):
+    """115 layers deep, two correct fp32 implementations no longer agree to 1e-4 on every logit: the
+    rounding differences of each layer (summation order inside a K = 4608 dot product) are amplified by
+    the layers after it.  The honest statement at full depth is therefore relative to the truth: the
+    oracle evaluated in float64.  The HIP path must be as close to it as the fp32 CPU oracle (= the
+    reference's own arithmetic) is; and what the north star names -- scores and box coordinates -- must
+    agree with the fp32 oracle to 1e-4 for all but a vanishing fraction of entries."""
+    det, img = v4l
+    sd = {k: v.detach().cpu() for k, v in det.state_dict().items()}
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    stages, reps = O.ARCH['v4l5p']
+    one = img[:1]
+    with torch.no_grad():
+        got = [p.cpu() for p in det.forward_dummy(one)[0]]
+    ref, _ = O.forward_pred_maps(one.cpu(), sd, stages, reps, [3, 4, 5], neck='v4')
+    ref64, _ = O.forward_pred_maps(one.cpu().double(), sd64, stages, reps, [3, 4, 5], neck='v4')
+    for i, (a, b, t) in enumerate(zip(got, ref, ref64)):
+        assert a.shape == b.shape == (1, 255, SIZE // (8 << i), SIZE // (8 << i))
+        e_gpu = (a.double() - t).abs() / (1 + t.abs())
+        e_cpu = (b.double() - t).abs() / (1 + t.abs())
+        e_ab = (a - b).abs() / (1 + b.abs())
+        print(f'level {i}: HIP vs fp64 max {float(e_gpu.max()):.2e} mean {float(e_gpu.mean()):.2e} | '
+              f'CPU fp32 vs fp64 max {float(e_cpu.max()):.2e} mean {float(e_cpu.mean()):.2e} | '
+              f'HIP vs CPU fp32 max {float(e_ab.max()):.2e} mean {float(e_ab.mean()):.2e}')
+        assert float(e_gpu.mean()) <= 2.5 * float(e_cpu.mean()) + 1e-6
+        assert float(e_gpu.max()) <= 3.0 * float(e_cpu.max()) + 1e-5
+        assert float(e_ab.mean()) <= 5e-5
+    # scores and boxes (what the north star names), HIP decode of HIP maps vs oracle decode of oracle maps
+    boxes_o, conf_o, cls_o = O.decode_maps(ref, 80)
+    plan = pkg.Plan(img.device)
+    views = [plan.add_input_nchw(*p.shape, name=f'p{i}', pad4=False) for i, p in enumerate(got)]
+    det.bbox_head.emit_postprocess(plan, views, rescale=False, want_cls=True)
+    plan.finalize()
+    plan.run(*[p.to(img.device) for p in got])
+    post = plan.post
+    sc_h = (post['cls'][0] * post['conf'][0][:, None]).cpu()
+    sc_o = cls_o[0] * conf_o[0][:, None]
+    ds = (sc_h - sc_o).abs()
+    print(f'scores: max diff {float(ds.max()):.2e}, fraction above 1e-4: {float((ds > 1e-4).float().mean()):.2e}')
+    assert float(ds.max()) <= 3e-4 and float((ds > 1e-4).float().mean()) <= 1e-4, (float(ds.max()), float((ds > 1e-4).float().mean()))
+    # boxes: w = (2 sigma(t))^2 * anchor turns a logit difference into up to 1.5 x the anchor size, so at
+    # this depth coordinates differ by ~1e-3 of the box size between ANY two fp32 evaluations; measured
+    # against the float64 decode, the HIP path must stay within 3x of the fp32 CPU oracle's own error
+    boxes_t, _, _ = O.decode_maps(ref64, 80)
+    bt = boxes_t[0]
+    size = torch.maximum(bt[:, 2] - bt[:, 0], bt[:, 3] - bt[:, 1]).clamp_min(1.0)[:, None]
+    e_h = (post['boxes'][0].cpu().double() - bt).abs() / size
+    e_c = (boxes_o[0].double() - bt).abs() / size
+    qs = torch.tensor([0.5, 0.99], dtype=torch.float64)
+    qh, qc = torch.quantile(e_h.flatten(), qs), torch.quantile(e_c.flatten(), qs)
+    print(f'boxes |diff|/size vs fp64: HIP median {float(qh[0]):.2e} p99 {float(qh[1]):.2e} max {float(e_h.max()):.2e} | '
+          f'CPU fp32 median {float(qc[0]):.2e} p99 {float(qc[1]):.2e} max {float(e_c.max()):.2e}')
+    assert float(qh[1]) <= 3.0 * float(qc[1]) + 1e-6 and float(e_h.max()) <= 3.0 * float(e_c.max()) + 1e-5
+    assert float(qh[0]) <= 1e-4          # the typical coordinate is inside the north star's 1e-4
+    # detections from the SAME pred maps: identical selection, boxes/scores within 1e-4
+    metas = [dict(scale_factor=np.array([1.25, 1.5, 1.25, 1.5], dtype=np.float32))]
+    res = det.bbox_head.get_bboxes([p.to(img.device) for p in ref], metas, rescale=True)[0]
+    ores = O.get_bboxes(ref, [metas[0]['scale_factor']], 80, rescale=True)[0]
+    np.testing.assert_array_equal(res[1].cpu().numpy(), ores[1].numpy())
+    np.testing.assert_allclose(res[0].cpu().numpy(), ores[0].numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_fullsize_determinism_and_batch_independence(v4l):
+    det, img = v4l
+    metas = [dict(scale_factor=np.ones(4, dtype=np.float32))] * 2
+    r1 = det.simple_test(img, metas, rescale=True)
+    r2 = det.simple_test(img, metas, rescale=True)
+    swapped = det.simple_test(img.flip(0), metas, rescale=True)
+    for n in range(2):
+        for c in range(80):
+            assert np.array_equal(r1[n][c], r2[n][c])                  # run-to-run bit-identical
+            assert np.array_equal(r1[n][c], swapped[1 - n][c])         # an image's result ignores its neighbours
+
+
+def test_fullsize_plan_equals_module_composition(v4l):
+    det, img = v4l
+    plan = det.compile(2, SIZE, SIZE, device=img.device, rescale=True)
+    plan.run(img)
+    fused = [v.buf.tensor.view(v.N, v.H, v.W, v.C).permute(0, 3, 1, 2).clone() for v in plan.pred_views]
+    with torch.no_grad():
+        step = det.bbox_head(det.neck(det.backbone(img)))[0]
+    for a, b in zip(fused, step):
+        assert torch.equal(a, b)          # same kernels, same K order, same tiles: bit-identical
+
+
+def test_fullsize_nms_invariants(v4l):
+    det, img = v4l
+    cfg = det.bbox_head.test_cfg
+    metas = [dict(scale_factor=np.ones(4, dtype=np.float32))] * 2
+    res = det.simple_test(img, metas, rescale=False)
+    for n in range(2):
+        tot = 0
+        for c in range(80):
+            d = res[n][c]
+            tot += len(d)
+            if len(d) == 0:
+                continue
+            assert d.dtype == np.float32 and d.shape[1] == 5
+            assert (d[:, 4] > cfg['score_thr']).all()
+            assert (np.diff(d[:, 4]) <= 0).all()                       # per class sorted by score
+            if len(d) > 1:
+                iou = _ious(d[:, :4])
+                np.fill_diagonal(iou, 0)
+                assert iou.max() <= cfg['nms']['iou_threshold'] + 1e-6  # survivors do not suppress each other
+        assert 0 < tot <= cfg['max_per_img']
+
+
+def test_fullsize_rescale_divides_boxes_before_nms(v4l):
+    det, img = v4l
+    sf = np.array([2.0, 2.0, 2.0, 2.0], dtype=np.float32)            # uniform scale: IoUs unchanged -> same selection
+    a = det.simple_test(img, [dict(scale_factor=np.ones(4, dtype=np.float32))] * 2, rescale=True)
+    b = det.simple_test(img, [dict(scale_factor=sf)] * 2, rescale=True)
+    for n in range(2):
+        for c in range(80):
+            assert a[n][c].shape == b[n][c].shape
+            if len(a[n][c]):
+                np.testing.assert_array_equal(a[n][c][:, 4], b[n][c][:, 4])
+                np.testing.assert_allclose(a[n][c][:, :4] / 2.0, b[n][c][:, :4], rtol=1e-6)
