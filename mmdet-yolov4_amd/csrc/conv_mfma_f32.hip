@@ -466,21 +466,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
           fb[i] = *reinterpret_cast<const float4*>(bs_ + (b_rd[i] ^ (unsigned)(j << 5))); \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                \
         _Pragma("unroll") for (int jn = 0; jn < TN; ++jn) {                         \
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[jn].x, acc[i][jn], 0, 0, 0); \
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[jn].y, acc[i][jn], 0, 0, 0); \
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[jn].z, acc[i][jn], 0, 0, 0); \
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[jn].w, acc[i][jn], 0, 0, 0); \
+          f32x16& ac_ = (j & 1) ? acc2[i][jn] : acc[i][jn];                         \
+          ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[jn].x, ac_, 0, 0, 0); \
+          ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[jn].y, ac_, 0, 0, 0); \
+          ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[jn].z, ac_, 0, 0, 0); \
+          ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[jn].w, ac_, 0, 0, 0); \
         }                                                                           \
     }                                                                               \
   }
 
-  f32x16 acc[TM][TN];
+  // Two accumulator sets, alternating every 8 K values: each fp32 chain is half as long (the
+  // sequential K = 4608 chain of a single set measured 1.7x the CPU reference's rounding error
+  // against float64 at full depth, tests/test_gpu_fullsize.py); summed once before the epilogue.
+  f32x16 acc[TM][TN], acc2[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; acc2[i][j][e] = 0.f; }
 
   // wait until at most `newer` later slices of this wave's DMAs are still in flight
 #define YV4_V3_WAIT(NEWER)                                                          \
@@ -529,6 +533,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
 
   // ---- epilogue: transposed through a wave-private LDS patch (the K-loop buffers are free
   // once every wave has issued its last fragment reads: one more barrier) ----
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
   const bool has2 = p.s2 != nullptr;
   const bool vec_ok = ((p.y_cs | p.y_co) & 3) == 0 && (p.res == nullptr || ((p.r_cs | p.r_co) & 3) == 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

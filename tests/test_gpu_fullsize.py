@@ -66,8 +66,8 @@ def test_fullsize_parity_with_the_oracle_on_one_image(v4l):
         print(f'level {i}: HIP vs fp64 max {float(e_gpu.max()):.2e} mean {float(e_gpu.mean()):.2e} | '
               f'CPU fp32 vs fp64 max {float(e_cpu.max()):.2e} mean {float(e_cpu.mean()):.2e} | '
               f'HIP vs CPU fp32 max {float(e_ab.max()):.2e} mean {float(e_ab.mean()):.2e}')
-        assert float(e_gpu.mean()) <= 2.5 * float(e_cpu.mean()) + 1e-6
-        assert float(e_gpu.max()) <= 3.0 * float(e_cpu.max()) + 1e-5
+        assert float(e_gpu.mean()) <= 1.5 * float(e_cpu.mean()) + 1e-6
+        assert float(e_gpu.max()) <= 2.5 * float(e_cpu.max()) + 1e-5
         assert float(e_ab.mean()) <= 5e-5
     # scores and boxes (what the north star names), HIP decode of HIP maps vs oracle decode of oracle maps
     boxes_o, conf_o, cls_o = O.decode_maps(ref, 80)
