@@ -327,6 +327,16 @@ int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x_coff, cons
                        int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C,
                        int act, float slope, void* stream);
 
+/* Backward of an EVAL-mode BatchNorm (+ activation) inside a training graph (frozen stages /
+ * norm_eval, darknetcsp.py:466-480): mean / invstd are the running statistics (constants), so
+ * dx = gamma * invstd * dy * act'(z); dgamma / dbeta as in yv4_bn_act_bwd.  The forward is
+ * yv4_bn_act_fwd(_h16) called with the running statistics. */
+int yv4_bn_eval_act_bwd(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
+                        int dy_cstride, int dy_coff, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, void* dx, int dx_cstride,
+                        int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C,
+                        int act, float slope, void* stream);
+
 /* SPP backward: xcat is the forward's concat buffer (its first C channels are the pooled input),
  * dcat the gradient w.r.t. the 4C-channel concat; dx (N, H, W, C) fp32, dense, ZERO on entry, receives
  * the identity branch plus the three max-pool scatters (first maximum in row-major window order,

@@ -88,6 +88,8 @@ SIGNATURES = {
                                      _vp]),
     'yv4_bn_act_bwd_h16': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i64,
                                      _i, _i, _f, _vp]),
+    'yv4_bn_eval_act_bwd': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i64,
+                                      _i, _i, _f, _vp]),
     'yv4_spp_pool_bwd': (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'yv4_grad_prepare': (C.c_int, [_vp, _i64, _vp, _f, _vp, _vp, _vp]),
     'yv4_sgd_step': (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _vp]),

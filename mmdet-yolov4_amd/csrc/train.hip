@@ -539,6 +539,7 @@ struct BnArgs {
   double* sums;      // bwd: [dbeta (C) | dgamma (C)]
   int64_t M; int C; int act; float slope;
   int rows_per_block;
+  int eval_mode;     // backward of an eval-mode BN (running statistics are constants): no mean/variance terms
 };
 
 // Elementwise passes use the reductions' thread map too: a thread keeps ONE channel quad (its
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
         for (int k = 0; k < 4; ++k) {
           const float xhat = (xs[k] - mu[k]) * is[k];
           const float g = gs[k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
-          o[k] = ga[k] * is[k] * (g - dbm[k] - xhat * dgm[k]);
+          o[k] = p.eval_mode ? ga[k] * is[k] * g : ga[k] * is[k] * (g - dbm[k] - xhat * dgm[k]);
         }
         El<T>::st4(pdx + row * p.dx_cs + p.dx_co + c, make_float4(o[0], o[1], o[2], o[3]));
       }
@@ -894,7 +895,7 @@ static int bn_fwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
 static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, const void* dy, int dy_cstride, int dy_coff,
                        const float* mean, const float* invstd, const float* gamma, const float* beta, void* dx,
                        int dx_cstride, int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C, int act,
-                       float slope, void* stream) {
+                       float slope, void* stream, int eval_mode = 0) {
   YV4_REQUIRE(x && dy && mean && invstd && gamma && beta && dx && dgamma && dbeta && work && M > 0 && C > 0,
               "bn_act_bwd: bad argument");
   YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "bn_act_bwd: dtype must be f32, f16 or bf16");
@@ -906,7 +907,7 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   BnArgs a = {};
   a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.dy = dy; a.dy_cs = dy_cstride; a.dy_co = dy_coff;
   a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dx_cs = dx_cstride; a.dx_co = dx_coff;
-  a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope;
+  a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope; a.eval_mode = eval_mode;
   a.rows_per_block = bn_rows_per_block(M);
   dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
   YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s, a));
@@ -977,6 +978,14 @@ extern "C" int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x
                                   double* work, int64_t M, int C, int act, float slope, void* stream) {
   return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
                      dx_coff, dgamma, dbeta, work, M, C, act, slope, stream);
+}
+
+extern "C" int yv4_bn_eval_act_bwd(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,
+                                   int dy_coff, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, void* dx, int dx_cstride, int dx_coff, float* dgamma, float* dbeta,
+                                   double* work, int64_t M, int C, int act, float slope, void* stream) {
+  return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
+                     dx_coff, dgamma, dbeta, work, M, C, act, slope, stream, 1);
 }
 
 extern "C" int yv4_spp_pool_bwd(const void* xcat, int x_cstride, int x_coff, const void* dcat, int d_cstride, int d_coff,

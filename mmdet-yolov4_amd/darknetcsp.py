@@ -98,10 +98,7 @@ class Conv(HipModule):
             x = F.pad(x, (0, 0, 0, 0, 0, padc))
             w = F.pad(w, (0, 0, 0, 0, 0, padc))
         y = T.conv2d(x, w, self.stride, self.padding, dtype=dt)
-        if self.with_norm:
-            if not self.norm.training:
-                raise NotImplementedError('eval-mode BatchNorm inside a training graph (norm_eval / frozen '
-                                          'stages) is not built')
+        if self.with_norm:      # batch statistics in training mode, running statistics under norm_eval / frozen stages
             return T.bn_act(y, self.norm, act_id(self.activate), residual)
         if self.conv.bias is not None:
             y = y + self.conv.bias.view(1, -1, 1, 1)

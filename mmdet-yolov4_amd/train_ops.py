@@ -173,7 +173,7 @@ class BNActFunction(torch.autograd.Function):
     """Train-mode BatchNorm2d + activation (+ residual add) as one forward and one backward."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual, training=True):
         _need_cuda(x, 'x')
         if x.dtype not in _DCODE:
             x = x.float()
@@ -187,11 +187,15 @@ class BNActFunction(torch.autograd.Function):
         work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
         mean = torch.empty(Cc, dtype=torch.float32, device=dev)
         invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
-        check(L.yv4_bn_train_stats_h16(x.data_ptr(), code, M, Cc, Cc, 0, float(eps), float(momentum), work.data_ptr(),
-                                       mean.data_ptr(), invstd.data_ptr(),
-                                       running_mean.data_ptr() if running_mean is not None else None,
-                                       running_var.data_ptr() if running_var is not None else None, stream_ptr()),
-              'yv4_bn_train_stats')
+        if training:
+            check(L.yv4_bn_train_stats_h16(x.data_ptr(), code, M, Cc, Cc, 0, float(eps), float(momentum),
+                                           work.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                           running_mean.data_ptr() if running_mean is not None else None,
+                                           running_var.data_ptr() if running_var is not None else None, stream_ptr()),
+                  'yv4_bn_train_stats')
+        else:       # eval-mode BN inside a training graph: the running statistics are constants
+            mean.copy_(running_mean.detach().float())
+            torch.rsqrt(running_var.detach().float() + eps, out=invstd)
         res = to_nhwc(residual.to(x.dtype)) if residual is not None else None
         y = torch.empty_like(x, memory_format=torch.channels_last)
         g = gamma.detach().float().contiguous()
@@ -201,6 +205,7 @@ class BNActFunction(torch.autograd.Function):
                                    0, M, Cc, int(act), float(slope), stream_ptr()), 'yv4_bn_act_fwd')
         ctx.save_for_backward(x, mean, invstd, g, b)
         ctx.act = (int(act), float(slope))
+        ctx.training = bool(training)
         ctx.has_res = residual is not None
         return y
 
@@ -217,21 +222,25 @@ class BNActFunction(torch.autograd.Function):
         dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
         dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
         work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
-        check(_lib.lib().yv4_bn_act_bwd_h16(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
-                                            invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
-                                            dgamma.data_ptr(), dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope,
-                                            stream_ptr()), 'yv4_bn_act_bwd')
+        fn = _lib.lib().yv4_bn_act_bwd_h16 if ctx.training else _lib.lib().yv4_bn_eval_act_bwd
+        check(fn(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+                 invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
+                 dgamma.data_ptr(), dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope,
+                 stream_ptr()), 'yv4_bn_act_bwd')
         dres = dy if ctx.has_res else None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, dres
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None
 
 
 def bn_act(x, bn, act=(0, 0.0), residual=None):
-    """``bn`` is a torch BatchNorm2d in training mode; act = (YV4_ACT_*, slope)."""
+    """``bn``: a torch BatchNorm2d; in training mode it normalises with batch statistics and updates
+    the running ones, in eval mode (``norm_eval`` / frozen stages inside a training graph) with the
+    running statistics as constants.  act = (YV4_ACT_*, slope)."""
     mom = bn.momentum if bn.momentum is not None else 0.1
+    use_batch = bn.training or not bn.track_running_stats
     out = BNActFunction.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                               bn.running_var if bn.track_running_stats else None, bn.eps, mom, act[0], act[1],
-                              residual)
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
+                              residual, use_batch)
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return out
 

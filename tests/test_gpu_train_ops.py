@@ -126,3 +126,64 @@ def test_spp_cat_forward_and_backward_match_max_pool_autograd(gpu_device, dtype,
     else:
         torch.testing.assert_close(a.sum((2, 3)), b.sum((2, 3)), rtol=tol, atol=tol * 10)
         assert float((a - b).abs().max()) <= 0.05 * float(b.abs().max()) or (a != b).float().mean() < 0.02
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_eval_mode_bn_inside_a_training_graph(gpu_device, dtype):
+    """norm_eval / frozen stages (darknetcsp.py:466-480): BN uses its running statistics as constants,
+    they are not updated, and the backward has no mean / variance terms."""
+    torch.manual_seed(4)
+    N, C_, H, W = 2, 16, 7, 9
+    bn = torch.nn.BatchNorm2d(C_, eps=1e-3, momentum=0.03).to(gpu_device)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.5); bn.running_var.uniform_(0.5, 2.0)
+    bn.eval()
+    rm, rv, nbt = bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)
+    x = torch.randn(N, C_, H, W, device=gpu_device).to(dtype)
+    xr = x.clone().requires_grad_(True)
+    y = T.bn_act(xr, bn, (1, 0.0))
+    g = torch.randn(N, C_, H, W, device=gpu_device).to(dtype)
+    y.backward(g)
+    assert torch.equal(bn.running_mean, rm) and torch.equal(bn.running_var, rv) and int(bn.num_batches_tracked) == nbt
+    x64 = x.double().requires_grad_(True)
+    w64 = bn.weight.detach().double().requires_grad_(True)
+    b64 = bn.bias.detach().double().requires_grad_(True)
+    z = F.batch_norm(x64, rm.double(), rv.double(), w64, b64, False, 0.0, 1e-3)
+    ref = z * torch.tanh(F.softplus(z))
+    ref.backward(g.double())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+
+    def rel(a, b):
+        return float((a.detach().double() - b).abs().max() / (b.abs().max() + 1e-12))
+    assert rel(y, ref.detach()) <= tol and rel(xr.grad, x64.grad) <= tol
+    assert rel(bn.weight.grad, w64.grad) <= max(tol / 10, 1e-5) and rel(bn.bias.grad, b64.grad) <= max(tol / 10, 1e-5)
+
+
+def test_detector_with_frozen_stage_and_norm_eval_trains(gpu_device):
+    torch.manual_seed(5)
+    det = pkg.build_detector(dict(
+        type='SingleStageDetector',
+        backbone=dict(type='DarknetCSP', scale=[['conv', 'bottleneck', 'csp', 'csp', 'csp', 'sppv4'],
+                                                [None, 1, 1, 1, 1, 1], [8, 16, 32, 64, 64, 64]], out_indices=[3, 4, 5],
+                      frozen_stages=1, norm_eval=True),
+        neck=dict(type='YOLOV4Neck', in_channels=[64, 64, 64], out_channels=[32, 64, 128], csp_repetition=1),
+        bbox_head=dict(type='YOLOCSPHead', num_classes=80, in_channels=[32, 64, 128]), train_cfg=None,
+        test_cfg=dict(nms_pre=-1, score_thr=0.001, nms=dict(type='nms', iou_threshold=0.65), max_per_img=300)))
+    det.init_weights()
+    det.to(gpu_device).train()
+    bns = [m for m in det.backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert bns and not any(m.training for m in bns)                  # norm_eval
+    rm = [m.running_mean.clone() for m in bns]
+    data = dict(img=torch.randn(2, 3, 64, 96, device=gpu_device), img_metas=[dict(), dict()],
+                gt_bboxes=[torch.tensor([[8., 10., 40., 44.]], device=gpu_device),
+                           torch.tensor([[20., 5., 90., 60.]], device=gpu_device)],
+                gt_labels=[torch.tensor([3], device=gpu_device), torch.tensor([7], device=gpu_device)])
+    out = det.train_step(data, None)
+    out['loss'].backward()
+    assert np.isfinite(out['log_vars']['loss'])
+    assert all(torch.equal(a, m.running_mean) for a, m in zip(rm, bns))   # statistics untouched
+    frozen = [p for n, p in det.backbone.named_parameters() if not p.requires_grad]
+    assert frozen and all(p.grad is None for p in frozen)
+    live = [p for p in det.parameters() if p.requires_grad]
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in live)
