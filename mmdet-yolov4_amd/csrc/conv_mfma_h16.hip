@@ -415,7 +415,9 @@ static int dispatch_h16_n(const ConvArgsH& a, int shape, bool general, hipStream
 
 // Deeper rings (NBUF 3: two slices in flight) were measured slower on every YOLOv4-L shape: a
 // slice costs ~1.3 us of memory latency against 0.2 us of MFMA, so throughput is set by the bytes in
-// flight per CU, and a third slot costs exactly the occupancy it buys (tools/conv_bench.py, round 1).
+// flight per CU, and a third slot costs exactly the occupancy it buys; a 4-slot ring that issues a
+// whole K <= 256 reduction up front was slower still on the 1x1 layers (64x64: 4112 vs 2975 us over the
+// network's 1x1 layers): resident workgroups per CU, not prefetch depth, hide the prologue / epilogue.
 template <bool BF16>
 static int dispatch_h16(const ConvArgsH& a, int tile, bool general, hipStream_t s) {
   return dispatch_h16_n<BF16, 2>(a, tile, general, s);
