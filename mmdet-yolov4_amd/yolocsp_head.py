@@ -176,6 +176,17 @@ class YOLOCSPHead(HipModule):
         plan.run(*[p.float() for p in pred_maps])
         return collect_results(plan.post, with_nms=with_nms, head=self)
 
+    def aug_test(self, feats, img_metas, rescale=False):
+        """yolocsp_head.py:577-593 delegates to ``BBoxTestMixin.aug_test_bboxes``
+        (dense_test_mixins.py:38-100), which for this head cannot run in the reference either:
+        ``get_bboxes(with_nms=False)`` returns ``((n,5) dets, (n,) class ids)`` (yolocsp_head.py:377-382)
+        and the mixin hands the class-id vector to ``multiclass_nms`` as its ``(n, #class+1)`` score
+        matrix (``multi_scores.size(1)`` on a 1-D tensor raises).  The ``with_nms=False`` branch itself
+        is built (including its double objectness factor); the merge is not, because there
+        is no reference behaviour to reproduce."""
+        raise NotImplementedError('YOLOCSPHead.aug_test: the reference\'s TTA merge for this head is not '
+                                  'executable (see docstring); use simple_test')
+
     # ---- training (yolocsp_head.py:384-575) -------------------------------------------------------
     def loss(self, pred_maps, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
         num_gts = pred_maps[0].new_tensor([g.size(0) for g in gt_bboxes]).mean()
