@@ -43,6 +43,7 @@ struct ConvArgsH {
   int M, K, Kw;
   int tiles_n;
   int out_f32;    // store fp32 instead of the operand type (pred maps feeding the fp32 decode kernel)
+  int ablate;     // measurement only (YV4_H16_ABLATE): 1 = issue no DMA after the first slice, 2 = no MFMA, 4 = no barrier
 };
 
 __device__ __forceinline__ void lds_dma16_h(u32x4_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
@@ -342,17 +343,17 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
   int rbuf = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (issued < nk) {     // slot wbuf was last read before the previous barrier
-      YV4_H_DMA(wbuf);
+      if (!(p.ablate & 1)) YV4_H_DMA(wbuf);
       ++issued;
       wbuf = wbuf + 1 == NBUF ? 0 : wbuf + 1;
     }
     __builtin_amdgcn_s_setprio(1);
-    YV4_H_COMPUTE(rbuf);
+    if (!(p.ablate & 2)) YV4_H_COMPUTE(rbuf);
     __builtin_amdgcn_s_setprio(0);
     rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
     if (kt + 1 < nk) {
       YV4_H_WAIT(issued - (kt + 2));
-      __builtin_amdgcn_s_barrier();
+      if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
     }
   }
 #undef YV4_H_WAIT
@@ -480,6 +481,8 @@ extern "C" int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int ou
   a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
   a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0;
   a.out_f32 = out_dtype == YV4_F32 ? 1 : 0;
+  static const int ablate = [] { const char* e = getenv("YV4_H16_ABLATE"); return e ? atoi(e) : 0; }();
+  a.ablate = ablate;
   const bool general = (d->Cin % kHBK) != 0;
   const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
