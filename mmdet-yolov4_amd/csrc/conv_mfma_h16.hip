@@ -424,11 +424,17 @@ static int dispatch_h16(const ConvArgsH& a, int tile, bool general, hipStream_t 
   return dispatch_h16_n<BF16, 2>(a, tile, general, s);
 }
 
-static int pick_tile_h16(long long M, int Cout) {
-  // 256 CUs x 2 resident workgroups: the biggest tile that still fills the chip twice
+static int pick_tile_h16(long long M, int Cout, long long K) {
+  // From the per-layer table of tools/conv_bench.py --dtype bf16 (YOLOv4-L, batch 32; round 1):
+  // deep reductions (3x3) amortise a workgroup's fixed cost and want the biggest tile that still
+  // gives every CU a workgroup; shallow ones (1x1, K <= ~1024) want many resident workgroups.
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
-  if (Cout > 64 && tiles(128, 128) >= 1024) return YV4_HTILE_128x128;
-  if (tiles(128, 64) >= 1024) return YV4_HTILE_128x64;
+  if (K >= 1024) {
+    if (Cout > 64 && tiles(128, 128) >= 256) return YV4_HTILE_128x128;
+    if (tiles(128, 64) >= 256) return YV4_HTILE_128x64;
+    return YV4_HTILE_64x64;
+  }
+  if (tiles(128, 64) >= 512) return YV4_HTILE_128x64;
   return YV4_HTILE_64x64;
 }
 
@@ -438,7 +444,7 @@ using namespace yv4;
 
 extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
   if (!d) return YV4_TILE_AUTO;
-  return pick_tile_h16((long long)d->N * d->Ho * d->Wo, d->Cout);
+  return pick_tile_h16((long long)d->N * d->Ho * d->Wo, d->Cout, (long long)d->KH * d->KW * d->Cin);
 }
 
 extern "C" int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x, const void* w,
@@ -484,7 +490,7 @@ extern "C" int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int ou
   static const int ablate = [] { const char* e = getenv("YV4_H16_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = ablate;
   const bool general = (d->Cin % kHBK) != 0;
-  const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout) : d->tile;
+  const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);
 }

@@ -5,6 +5,8 @@ Tolerance: the only differences are fp32 accumulation order (~1e-6 relative to t
 |products|) and the final rounding of the output to the 16-bit type (half an ulp: 2^-9 relative for
 bf16, 2^-12 for fp16); fp32 outputs (`out_dtype = YV4_F32`) are held to 2e-5."""
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -369,3 +371,23 @@ def test_detector_train_step_in_16_bit(golden, gpu_device, dtype, tol):
         return np.array(hist)
     h32, h16 = run(torch.float32), run(dtype)
     np.testing.assert_allclose(h16, h32, rtol=max(3 * tol, 0.04))      # six chaotic steps: a few percent
+
+
+def test_wgrad_widening_fallback_matches(gpu_device):
+    """YV4_WGRAD_WIDEN=1 routes 16-bit weight gradients through the widening fp32-MFMA kernel (the
+    fallback of the ds_read_b64_tr_b16 form): both must agree with each other to fp32 accumulation noise."""
+    import subprocess
+    code = (
+        "import torch, sys; sys.path.insert(0, %r); import mmdet_yolov4_amd; from mmdet_yolov4_amd import train_ops as T;"
+        "torch.manual_seed(0); x = torch.randn(2, 64, 13, 11, device='cuda').bfloat16();"
+        "w = (torch.randn(72, 64, 3, 3, device='cuda') * 0.04).requires_grad_(True);"
+        "y = T.conv2d(x, w, 1, 1, dtype=torch.bfloat16); g = torch.randn_like(y.float()).bfloat16(); y.backward(g);"
+        "print('DW', float(w.grad.double().sum()), float(w.grad.double().abs().sum()))"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for widen in ('0', '1'):
+        env = dict(os.environ, YV4_WGRAD_WIDEN=widen)
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([float(v) for v in [l for l in r.stdout.splitlines() if l.startswith('DW')][0].split()[1:]])
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-3 * outs[0][1] and abs(outs[0][1] - outs[1][1]) <= 1e-4 * outs[0][1]
