@@ -327,6 +327,19 @@ int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x_coff, cons
                        int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C,
                        int act, float slope, void* stream);
 
+/* One parity class of the data gradient of a stride-2 convolution: a stride-1 convolution of dY whose
+ * output pixel (n, ho, wo) is stored at y[n, ho*sh + oh, wo*sw + ow, y_coff + c] of an
+ * (N, Hy, Wy, y_cstride) tensor.  d->Ho / d->Wo are taken as given (rows past the input's edge read
+ * zeros), d->stride must be 1, the epilogue is scale1/shift1 only.  For the 3x3 / stride 2 / pad 1 convs
+ * of darknetcsp.py:288-335 and yolo_neck_csp.py the four classes (1, 2, 2 and 4 taps) cost exactly the
+ * forward FLOPs; the zero-dilated form (yv4_dilate2_fwd + yv4_conv_bn_act_fwd) costs 4x. */
+int yv4_conv_scatter_fwd(const yv4_conv_desc* d, const float* x, const float* w, const float* scale1,
+                         const float* shift1, float* y, int Hy, int Wy, int sh, int sw, int oh,
+                         int ow, void* stream);
+int yv4_conv_scatter_fwd_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
+                             const float* scale1, const float* shift1, void* y, int Hy, int Wy,
+                             int sh, int sw, int oh, int ow, void* stream);
+
 /* Backward of an EVAL-mode BatchNorm (+ activation) inside a training graph (frozen stages /
  * norm_eval, darknetcsp.py:466-480): mean / invstd are the running statistics (constants), so
  * dx = gamma * invstd * dy * act'(z); dgamma / dbeta as in yv4_bn_act_bwd.  The forward is

@@ -43,7 +43,20 @@ struct ConvArgs {
   float slope1, slope2;
   int M, K, Kw;  // Kw: row pitch of w (== K)
   int tiles_n;
+  // scattered output (sub-pixel / parity convolutions of the stride-2 data gradient): output pixel
+  // (n, ho, wo) is stored at row ((n*ys_H + ho*ys_sh + ys_oh)*ys_W + wo*ys_sw + ys_ow) of y
+  int ys_on, ys_H, ys_W, ys_sh, ys_sw, ys_oh, ys_ow;
 };
+
+__device__ __forceinline__ int64_t out_row(const ConvArgs& p, int m) {
+  if (!p.ys_on) return m;
+  const int hw = p.Ho * p.Wo;
+  const int n = m / hw;
+  const int r = m - n * hw;
+  const int ho = r / p.Wo;
+  const int wo = r - ho * p.Wo;
+  return ((int64_t)n * p.ys_H + ho * p.ys_sh + p.ys_oh) * p.ys_W + wo * p.ys_sw + p.ys_ow;
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool UNIFORM_TAP>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_kernel(ConvArgs p) {
@@ -304,7 +317,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const f32x16& a
           v.z = apply_act(v.z * s2.z + t2.z, p.act2, p.slope2);
           v.w = apply_act(v.w * s2.w + t2.w, p.act2, p.slope2);
         }
-        *reinterpret_cast<float4*>(p.y + (int64_t)m * p.y_cs + p.y_co + co) = v;
+        *reinterpret_cast<float4*>(p.y + out_row(p, m) * p.y_cs + p.y_co + co) = v;
       }
     }
   } else {
@@ -321,7 +334,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const f32x16& a
           v = apply_act(v, p.act1, p.slope1);
           if (p.res) v += p.res[(int64_t)m * p.r_cs + p.r_co + c];
           if (has2) v = apply_act(v * p.s2[c] + p.t2[c], p.act2, p.slope2);
-          p.y[(int64_t)m * p.y_cs + p.y_co + c] = v;
+          p.y[out_row(p, m) * p.y_cs + p.y_co + c] = v;
         }
       }
     }
@@ -794,6 +807,7 @@ extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const
   a.r_cs = d->r_cstride; a.r_co = d->r_coff;
   a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.Kw = a.K; a.tiles_n = 0;
+  a.ys_on = 0;
 
   const bool uniform = (d->Cin % kBK) == 0;
   // the LDS-DMA kernels address x and w through 32-bit buffer descriptors
@@ -839,8 +853,50 @@ extern "C" int yv4_conv_stem_fwd(const yv4_conv_desc* d, const float* x, const f
   a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = 0; a.r_co = 0;
   a.act1 = d->act1; a.act2 = 0; a.slope1 = d->slope1; a.slope2 = 0.f;
   a.M = (int)M; a.K = 36; a.Kw = 36; a.tiles_n = 0;
+  a.ys_on = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (out_dtype == YV4_F16) return launch_conv_stem<1>(a, s);
   if (out_dtype == YV4_BF16) return launch_conv_stem<2>(a, s);
   return launch_conv_stem<0>(a, s);
+}
+
+// Convolution with a scattered store: output pixel (n, ho, wo) goes to y[n, ho*sh + oh, wo*sw + ow, :]
+// of an (N, Hy, Wy, y_cstride) tensor, and d->Ho / d->Wo are taken as given (input rows past the
+// bottom / right edge read zeros).  This is one parity class of the data gradient of a stride-2
+// convolution: dX[2i+a, 2j+b] is a stride-1 correlation of dY with the taps of matching parity, so the
+// four classes together cost exactly the forward FLOPs (a zero-dilated dY costs 4x).
+extern "C" int yv4_conv_scatter_fwd(const yv4_conv_desc* d, const float* x, const float* w, const float* scale1,
+                                    const float* shift1, float* y, int Hy, int Wy, int sh, int sw, int oh, int ow,
+                                    void* stream) {
+  YV4_REQUIRE(d && x && w && scale1 && shift1 && y, "conv scatter: null argument");
+  YV4_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv scatter: empty shape");
+  YV4_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 64 && d->stride == 1 && d->pad >= 0, "conv scatter: stride-1 kernels only");
+  YV4_REQUIRE(d->Cin % kBK == 0 && d->x_cstride % 4 == 0 && d->x_coff % 4 == 0, "conv scatter: Cin must be a multiple of 32");
+  YV4_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "conv scatter: x / w must be 16-byte aligned");
+  YV4_REQUIRE(d->x_coff + d->Cin <= d->x_cstride && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_cstride,
+              "conv scatter: view exceeds its pixel stride");
+  YV4_REQUIRE(sh > 0 && sw > 0 && oh >= 0 && ow >= 0 && (d->Ho - 1) * sh + oh < Hy && (d->Wo - 1) * sw + ow < Wy,
+              "conv scatter: the scattered grid does not fit the output tensor");
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const long long K = (long long)d->KH * d->KW * d->Cin;
+  YV4_REQUIRE(M < (1LL << 31) && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL &&
+              (long long)d->Cout * K * 4 < 0xFFFFFFF0LL, "conv scatter: tensors of 4 GiB or more are not supported");
+  ConvArgs a;
+  a.x = x; a.w = w; a.s1 = scale1; a.t1 = shift1; a.s2 = nullptr; a.t2 = nullptr; a.res = nullptr; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KH = d->KH; a.KW = d->KW; a.stride = 1; a.pad = d->pad;
+  a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = 0; a.r_co = 0;
+  a.act1 = 0; a.act2 = 0; a.slope1 = 0.f; a.slope2 = 0.f;
+  a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0;
+  a.ys_on = 1; a.ys_H = Hy; a.ys_W = Wy; a.ys_sh = sh; a.ys_sw = sw; a.ys_oh = oh; a.ys_ow = ow;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int tile = d->tile == YV4_TILE_AUTO ? YV4_TILE_DMA_64x64 : d->tile;
+  switch (tile) {
+    case YV4_TILE_DMA_64x64: return launch_conv_dma<64, 64, 2, 2, 2>(a, s);
+    case YV4_TILE_DMA_128x64: return launch_conv_dma<128, 64, 2, 2, 2>(a, s);
+    case YV4_TILE_DMA_128x128: return launch_conv_dma<128, 128, 2, 2, 2>(a, s);
+    default: break;
+  }
+  set_error("conv scatter: tile id %d is not an LDS-DMA tile", tile);
+  return YV4_E_INVALID;
 }

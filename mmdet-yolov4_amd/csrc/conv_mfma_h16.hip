@@ -43,8 +43,19 @@ struct ConvArgsH {
   int M, K, Kw;
   int tiles_n;
   int out_f32;    // store fp32 instead of the operand type (pred maps feeding the fp32 decode kernel)
+  int ys_on, ys_H, ys_W, ys_sh, ys_sw, ys_oh, ys_ow;   // scattered output, see conv_mfma_f32.hip
   int ablate;     // measurement only (YV4_H16_ABLATE): 1 = issue no DMA after the first slice, 2 = no MFMA, 4 = no barrier
 };
+
+__device__ __forceinline__ int64_t out_row_h(const ConvArgsH& p, int m) {
+  if (!p.ys_on) return m;
+  const int hw = p.Ho * p.Wo;
+  const int n = m / hw;
+  const int r = m - n * hw;
+  const int ho = r / p.Wo;
+  const int wo = r - ho * p.Wo;
+  return ((int64_t)n * p.ys_H + ho * p.ys_sh + p.ys_oh) * p.ys_W + wo * p.ys_sw + p.ys_ow;
+}
 
 __device__ __forceinline__ void lds_dma16_h(u32x4_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -124,14 +135,14 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
           for (int u = 0; u < 8; ++u) v[u] = apply_act(v[u] * s2[u] + t2[u], p.act2, p.slope2);
         }
         if (p.out_f32) {
-          float* dst = reinterpret_cast<float*>(p.y) + (int64_t)m * p.y_cs + p.y_co + co;
+          float* dst = reinterpret_cast<float*>(p.y) + out_row_h(p, m) * p.y_cs + p.y_co + co;
           *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
           V8 o;
 #pragma unroll
           for (int u = 0; u < 8; ++u) o[u] = (T)v[u];
-          *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.y) + (int64_t)m * p.y_cs + p.y_co + co) = o;
+          *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.y) + out_row_h(p, m) * p.y_cs + p.y_co + co) = o;
         }
       }
     }
@@ -150,9 +161,9 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
           if (p.res) v += (float)reinterpret_cast<const T*>(p.res)[(int64_t)m * p.r_cs + p.r_co + c];
           if (has2) v = apply_act(v * p.s2[c] + p.t2[c], p.act2, p.slope2);
           if (p.out_f32)
-            reinterpret_cast<float*>(p.y)[(int64_t)m * p.y_cs + p.y_co + c] = v;
+            reinterpret_cast<float*>(p.y)[out_row_h(p, m) * p.y_cs + p.y_co + c] = v;
           else
-            reinterpret_cast<T*>(p.y)[(int64_t)m * p.y_cs + p.y_co + c] = (T)v;
+            reinterpret_cast<T*>(p.y)[out_row_h(p, m) * p.y_cs + p.y_co + c] = (T)v;
         }
       }
     }
@@ -487,8 +498,44 @@ extern "C" int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int ou
   a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
   a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0;
   a.out_f32 = out_dtype == YV4_F32 ? 1 : 0;
+  a.ys_on = 0;
   static const int ablate = [] { const char* e = getenv("YV4_H16_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = ablate;
+  const bool general = (d->Cin % kHBK) != 0;
+  const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);
+}
+
+// 16-bit form of yv4_conv_scatter_fwd (conv_mfma_f32.hip): one parity class of a stride-2 data gradient.
+extern "C" int yv4_conv_scatter_fwd_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
+                                        const float* scale1, const float* shift1, void* y, int Hy, int Wy, int sh, int sw,
+                                        int oh, int ow, void* stream) {
+  YV4_REQUIRE(d && x && w && scale1 && shift1 && y, "conv scatter h16: null argument");
+  YV4_REQUIRE(dtype == YV4_F16 || dtype == YV4_BF16, "conv scatter h16: dtype must be YV4_F16 or YV4_BF16");
+  YV4_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0,
+              "conv scatter h16: empty shape");
+  YV4_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 64 && d->stride == 1 && d->pad >= 0,
+              "conv scatter h16: stride-1 kernels only");
+  YV4_REQUIRE(d->Cin % 8 == 0 && d->x_cstride % 8 == 0 && d->x_coff % 8 == 0 && d->y_cstride % 8 == 0 && d->y_coff % 8 == 0,
+              "conv scatter h16: channel counts / strides / offsets must be multiples of 8");
+  YV4_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "conv scatter h16: x / w must be 16-byte aligned");
+  YV4_REQUIRE(d->x_coff + d->Cin <= d->x_cstride && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_cstride,
+              "conv scatter h16: view exceeds its pixel stride");
+  YV4_REQUIRE(sh > 0 && sw > 0 && oh >= 0 && ow >= 0 && (d->Ho - 1) * sh + oh < Hy && (d->Wo - 1) * sw + ow < Wy,
+              "conv scatter h16: the scattered grid does not fit the output tensor");
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const long long K = (long long)d->KH * d->KW * d->Cin;
+  YV4_REQUIRE(M < (1LL << 31) && (long long)d->N * d->H * d->W * d->x_cstride * 2 < 0xFFFFFFF0LL &&
+              (long long)d->Cout * K * 2 < 0xFFFFFFF0LL, "conv scatter h16: tensors of 4 GiB or more are not supported");
+  ConvArgsH a;
+  a.x = x; a.w = w; a.s1 = scale1; a.t1 = shift1; a.s2 = nullptr; a.t2 = nullptr; a.res = nullptr; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KH = d->KH; a.KW = d->KW; a.stride = 1; a.pad = d->pad;
+  a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = 0; a.r_co = 0;
+  a.act1 = 0; a.act2 = 0; a.slope1 = 0.f; a.slope2 = 0.f;
+  a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0; a.out_f32 = 0; a.ablate = 0;
+  a.ys_on = 1; a.ys_H = Hy; a.ys_W = Wy; a.ys_sh = sh; a.ys_sw = sw; a.ys_oh = oh; a.ys_ow = ow;
   const bool general = (d->Cin % kHBK) != 0;
   const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -70,6 +70,77 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out):
     return d
 
 
+def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype):
+    """dX = correlate(dY zero-dilated by `stride`, W flipped in (kh,kw) and transposed in (co,ci)), pad k-1-p."""
+    N, Cin, H, W = xshape
+    Cout, _, KH, KW = weight.shape
+    Ho, Wo = dy.shape[2], dy.shape[3]
+    h16 = dtype != torch.float32
+    L = _lib.lib()
+    wt = weight.detach().flip(2, 3).transpose(0, 1)          # (Cin, Cout, KH, KW)
+    wtp, _ = pack_conv_weight(wt, align=8 if h16 else 4)
+    if stride == 1:
+        src = dy
+    elif stride == 2:
+        src = torch.empty((N, Cout, 2 * Ho, 2 * Wo), device=dy.device, dtype=dtype, memory_format=torch.channels_last)
+        k = 2 if h16 else 1     # a 16-bit map with C % 8 == 0 is an fp32 map with C/2 channels
+        check(L.yv4_dilate2_fwd(dy.data_ptr(), src.data_ptr(), N, Ho, Wo, Cout // k, Cout // k, 0, stream_ptr()),
+              'yv4_dilate2_fwd')
+    else:
+        raise NotImplementedError('conv backward: stride must be 1 or 2')
+    p2 = KH - 1 - pad
+    Hs, Ws = src.shape[2], src.shape[3]
+    Hx = Hs + 2 * p2 - KH + 1
+    Wx = Ws + 2 * p2 - KW + 1
+    dxf = torch.empty((N, Cin, Hx, Wx), device=dy.device, dtype=dtype, memory_format=torch.channels_last)
+    _conv_launch(src, wtp.to(dtype), Cout, Cin, KH, KW, 1, p2, dxf)
+    if (Hx, Wx) != (H, W):
+        # stride 2 with odd input size: the dilated grid is one row/column larger or smaller
+        dx = torch.empty((N, Cin, H, W), device=dy.device, dtype=dtype, memory_format=torch.channels_last).zero_()
+        hh, ww = min(H, Hx), min(W, Wx)
+        dx[:, :, :hh, :ww] = dxf[:, :, :hh, :ww]
+        return dx
+    return dxf
+
+
+def _dgrad_s2_parity(dy, weight, xshape, dtype):
+    """Data gradient of a 3x3 / stride 2 / pad 1 convolution as four parity classes: with
+    hi = 2*ho - 1 + kh, the input rows hi = 2i + a receive only the taps kh with (a + 1 - kh) even
+    (a = 0: kh = 1 from dY row i;  a = 1: kh = 2 from row i and kh = 0 from row i + 1), likewise in x.
+    Each class is a stride-1 correlation of dY with 1, 2, 2 or 4 taps whose result is scattered to
+    dX[:, :, a::2, b::2] (``yv4_conv_scatter_fwd``): the forward FLOPs exactly, no dilated copy."""
+    N, Cin, H, W = xshape
+    Cout = weight.shape[0]
+    Ho, Wo = dy.shape[2], dy.shape[3]
+    h16 = dtype != torch.float32
+    L = _lib.lib()
+    dx = torch.empty((N, Cin, H, W), device=dy.device, dtype=dtype, memory_format=torch.channels_last)
+    ones, zeros = _identity_affine(dy.device, Cin)
+    taps = {0: [1], 1: [2, 0]}
+    wd = weight.detach()
+    for a in (0, 1):
+        Ha = (H - a + 1) // 2
+        for b in (0, 1):
+            Wb = (W - b + 1) // 2
+            if Ha == 0 or Wb == 0:
+                continue
+            ws = wd[:, :, taps[a]][:, :, :, taps[b]].permute(1, 0, 2, 3)       # (Cin, Cout, KH', KW')
+            wp, _ = pack_conv_weight(ws, align=8 if h16 else 4)
+            wp = wp.to(dtype)
+            d = ConvDesc()
+            d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, Ho, Wo, Cout, Ha, Wb, Cin
+            d.KH, d.KW, d.stride, d.pad = len(taps[a]), len(taps[b]), 1, 0
+            d.x_cstride, d.y_cstride = Cout, Cin
+            if h16:
+                check(L.yv4_conv_scatter_fwd_h16(C.byref(d), _DCODE[dtype], dy.data_ptr(), wp.data_ptr(), ones.data_ptr(),
+                                                 zeros.data_ptr(), dx.data_ptr(), H, W, 2, 2, a, b, stream_ptr()),
+                      'yv4_conv_scatter_fwd_h16')
+            else:
+                check(L.yv4_conv_scatter_fwd(C.byref(d), dy.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(),
+                                             dx.data_ptr(), H, W, 2, 2, a, b, stream_ptr()), 'yv4_conv_scatter_fwd')
+    return dx
+
+
 class ConvFunction(torch.autograd.Function):
     """``dtype``: torch.float32, or torch.float16 / torch.bfloat16 -- then x, y and their gradients are
     that type (fp32 accumulation in every kernel) while ``weight`` and its gradient stay fp32 (the
@@ -122,33 +193,10 @@ class ConvFunction(torch.autograd.Function):
             if cp != Cin:
                 dw = dw.contiguous()
         if ctx.needs_input_grad[0]:
-            # dX = correlate(dY (zero-dilated by `stride`), W flipped in (kh,kw) and transposed in (co,ci))
-            wt = weight.detach().flip(2, 3).transpose(0, 1)          # (Cin, Cout, KH, KW)
-            wtp, _ = pack_conv_weight(wt, align=4 if not h16 else 8)
-            if stride == 1:
-                src = dy
-            elif stride == 2:
-                src = torch.empty((N, Cout, 2 * Ho, 2 * Wo), device=x.device, dtype=dtype,
-                                  memory_format=torch.channels_last)
-                k = 2 if h16 else 1     # a 16-bit map with C % 8 == 0 is an fp32 map with C/2 channels
-                check(L.yv4_dilate2_fwd(dy.data_ptr(), src.data_ptr(), N, Ho, Wo, Cout // k, Cout // k, 0, stream_ptr()),
-                      'yv4_dilate2_fwd')
+            if stride == 2 and (KH, KW, pad) == (3, 3, 1) and Cout % (8 if h16 else 32) == 0:
+                dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype)
             else:
-                raise NotImplementedError('conv backward: stride must be 1 or 2')
-            p2 = KH - 1 - pad
-            Hs, Ws = src.shape[2], src.shape[3]
-            Hx = Hs + 2 * p2 - KH + 1
-            Wx = Ws + 2 * p2 - KW + 1
-            dxf = torch.empty((N, Cin, Hx, Wx), device=x.device, dtype=dtype, memory_format=torch.channels_last)
-            _conv_launch(src, wtp.to(dtype), Cout, Cin, KH, KW, 1, p2, dxf)
-            if (Hx, Wx) != (H, W):
-                # stride 2 with odd input size: the dilated grid is one row/column larger or smaller
-                dx = torch.empty((N, Cin, H, W), device=x.device, dtype=dtype,
-                                 memory_format=torch.channels_last).zero_()
-                hh, ww = min(H, Hx), min(W, Wx)
-                dx[:, :, :hh, :ww] = dxf[:, :, :hh, :ww]
-            else:
-                dx = dxf
+                dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype)
             dx = dx.to(ctx.x_dtype)
         return dx, dw, None, None, None
 
