@@ -79,9 +79,9 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   for (int i = threadIdx.x; i < nval; i += 256) sm[i] = sigmoid_f32(src[i]);
   __syncthreads();
 
-  const int b = threadIdx.x >> 2;
   const int part = threadIdx.x & 3;
-  if (b >= nb) return;
+  const int b = min((int)(threadIdx.x >> 2), nb - 1);   // threads past the tail recompute the last box, emit nothing
+  const bool live = (int)(threadIdx.x >> 2) < nb;
   const float* s = sm + b * attr;
   const int jl = b0 + b;  // box index within the level: (y*W + x)*A + a
   const int a = jl % p.A;
@@ -112,35 +112,53 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   const float cf = s[4];
   const int j = p.level_base[lvl] + jl;
   const size_t gj = (size_t)n * p.total_anchors + j;
-  if (part == 0) {
+  if (part == 0 && live) {
     reinterpret_cast<float4*>(p.boxes)[gj] = make_float4(x1, y1, x2, y2);
     if (p.conf) p.conf[gj] = cf;
   }
   // nms_pre (yolocsp_head.py:349-355): only the top-k anchors by conf stay candidates; the
   // k-th (conf, anchor) key of the image was selected by yv4_conf_topk
-  if (p.topk && (((uint64_t)score_to_key(cf) << 32) | (uint32_t)j) > p.topk[n]) return;
-  bool any = false;
-  if (p.C == 0) {                 // class_agnostic (yolocsp_head.py:357-360): one column, score = conf
-    if (part == 0 && cf > p.score_thr) {
-      any = true;
-      const int slot = atomicAdd(&p.counts[n], 1);
-      if (slot < p.key_cap) p.keys[(size_t)n * p.key_cap + slot] = ((uint64_t)score_to_key(cf) << 32) | (uint32_t)j;
-    }
-  }
-  for (int c = part; c < p.C; c += 4) {
-    const float sc = s[5 + c];
-    if (p.cls) p.cls[gj * p.C + c] = sc;
-    const float score = sc * cf;  // yolocsp_head.py:358
-    if (score > p.score_thr) {    // bbox_nms.py:54
-      any = true;
-      const int slot = atomicAdd(&p.counts[n], 1);
-      if (slot < p.key_cap) {
-        const uint32_t flat = (uint32_t)j * (uint32_t)p.C + (uint32_t)c;
-        p.keys[(size_t)n * p.key_cap + slot] = ((uint64_t)score_to_key(score) << 32) | flat;
+  const bool admitted = live && !(p.topk && (((uint64_t)score_to_key(cf) << 32) | (uint32_t)j) > p.topk[n]);
+  // Candidates are appended in two passes so that the per-image counter sees ONE atomic per
+  // workgroup instead of one per candidate (thousands of same-address atomics per image serialise:
+  // the single-pass form spent ~0.5 ms of a 34 ms step there).  Pass 1 counts, the workgroup reserves
+  // a range, pass 2 writes.  The order of keys inside an image's buffer is irrelevant (NMS sorts them).
+  __shared__ int wg_count, wg_base;
+  if (threadIdx.x == 0) wg_count = 0;
+  __syncthreads();
+  int mine = 0;
+  if (admitted) {
+    if (p.C == 0) {                 // class_agnostic (yolocsp_head.py:357-360): one column, score = conf
+      mine = (part == 0 && cf > p.score_thr) ? 1 : 0;
+    } else {
+      for (int c = part; c < p.C; c += 4) {
+        const float sc = s[5 + c];
+        if (p.cls) p.cls[gj * p.C + c] = sc;
+        mine += (sc * cf > p.score_thr) ? 1 : 0;     // yolocsp_head.py:358, bbox_nms.py:54
       }
     }
   }
-  if (any) {  // boxes.max() over the surviving candidates (mmcv batched_nms)
+  int slot = mine ? atomicAdd(&wg_count, mine) : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) wg_base = wg_count ? atomicAdd(&p.counts[n], wg_count) : 0;
+  __syncthreads();
+  if (mine) {
+    slot += wg_base;
+    if (p.C == 0) {
+      if (slot < p.key_cap) p.keys[(size_t)n * p.key_cap + slot] = ((uint64_t)score_to_key(cf) << 32) | (uint32_t)j;
+    } else {
+      for (int c = part; c < p.C; c += 4) {
+        const float score = s[5 + c] * cf;
+        if (score > p.score_thr) {
+          if (slot < p.key_cap) {
+            const uint32_t flat = (uint32_t)j * (uint32_t)p.C + (uint32_t)c;
+            p.keys[(size_t)n * p.key_cap + slot] = ((uint64_t)score_to_key(score) << 32) | flat;
+          }
+          ++slot;
+        }
+      }
+    }
+    // boxes.max() over the surviving candidates (mmcv batched_nms)
     atomic_max_float(&p.max_coord[n], fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
   }
 }
