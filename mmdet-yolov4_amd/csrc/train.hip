@@ -806,8 +806,11 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     a.tiles_k = (a.K + kWhTile - 1) / kWhTile;
     const int tc = (a.Cout + kWhTile - 1) / kWhTile;
     const long long tl = (long long)a.tiles_k * tc;
-    long long ch = (256 * 2 * 2 + tl - 1) / tl;           // ~2 rounds of 2 workgroups per CU
-    const long long mx = (M + 4 * kWhRows - 1) / (4 * kWhRows);   // at least 4 slices per chunk
+    static const int wg_target = [] { const char* e = getenv("YV4_WGRAD_WGS"); return e ? atoi(e) : 1024; }();
+    static const int min_slices = [] { const char* e = getenv("YV4_WGRAD_MINSL"); return e ? atoi(e) : 16; }();
+    long long ch = (wg_target + tl - 1) / tl;             // default: ~2 rounds of 2 workgroups per CU
+    const long long mx = (M + min_slices * kWhRows - 1) / (min_slices * kWhRows);   // at least min_slices (16) per chunk: fewer, longer chunks
+    // amortise a workgroup's fixed cost and its 16 K atomics on the shallow (1x1) layers
     if (ch > mx) ch = mx;
     if (ch < 1) ch = 1;
     if (ch > 65535) ch = 65535;
