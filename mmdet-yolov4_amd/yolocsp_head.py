@@ -26,6 +26,65 @@ from .plan import Plan
 from .registry import HEADS, LOSSES, ConfigDict, build_anchor_generator, build_bbox_coder, build_loss
 
 
+class HeadTapFunction(torch.autograd.Function):
+    """What the loss reads from one level's raw head-conv output, without ever materialising the
+    reference's dense fp32 ``(N, H*W*A, 85)`` view of it (yolocsp_head.py:433-437: permute + reshape,
+    ``pred_map[..., 4]``, ``pred_map[img_ind, anchor_ind]``): the objectness logit of every anchor
+    box and the full attribute rows of the positive ones, bias added, in fp32.  The backward writes the
+    two gradients straight into ONE zero-initialised tensor of the conv output's own type and layout --
+    the reference's graph makes ~10 passes over 380 MB fp32 tensors per level for the same result."""
+
+    @staticmethod
+    def forward(ctx, raw, bias, img_ind, anchor_ind, A, attr):
+        N, Cp, H, W = raw.shape
+        nhwc = raw.permute(0, 2, 3, 1)                       # channels_last storage: a contiguous view
+        assert nhwc.is_contiguous(), 'HeadTap: the conv output must be channels_last'
+        conf = nhwc[..., 4:A * attr:attr].float() + bias[4::attr]
+        cell = torch.div(anchor_ind, A, rounding_mode='floor')
+        a = anchor_ind - cell * A
+        rows = img_ind * (H * W) + cell
+        cols = a[:, None] * attr + torch.arange(attr, device=raw.device)[None]
+        pos = nhwc.reshape(N * H * W, Cp)[rows[:, None], cols].float() + bias[cols]
+        ctx.save_for_backward(rows, cols)
+        ctx.meta = (raw.shape, raw.dtype, A, attr, bias.shape[0])
+        return conf.reshape(N, H * W * A), pos
+
+    @staticmethod
+    def backward(ctx, dconf, dpos):
+        rows, cols = ctx.saved_tensors
+        (N, Cp, H, W), dtype, A, attr, nb = ctx.meta
+        draw = torch.zeros((N, Cp, H, W), dtype=dtype, device=dconf.device).contiguous(memory_format=torch.channels_last)
+        d = draw.permute(0, 2, 3, 1)
+        dbias = torch.zeros(nb, dtype=torch.float32, device=dconf.device)
+        dc = dconf.reshape(N, H, W, A)
+        d[..., 4:A * attr:attr] = dc.to(dtype)
+        dbias[4::attr] = dc.sum((0, 1, 2))
+        if rows.numel():
+            d.view(N * H * W, Cp).index_put_((rows[:, None], cols), dpos.to(dtype), accumulate=True)
+            dbias.index_put_((cols.reshape(-1),), dpos.reshape(-1).float(), accumulate=True)
+        return draw, dbias, None, None, None, None
+
+
+class RawPredMap:
+    """One level's head-conv output in training mode: the raw (bias-free, channel-padded, possibly
+    16-bit) NHWC tensor plus what is needed to read it the way the loss does."""
+
+    def __init__(self, raw, bias, A, attr):
+        self.raw, self.bias, self.A, self.attr = raw, bias, A, attr
+        self.shape = (raw.shape[0], A * attr, raw.shape[2], raw.shape[3])
+        self.device = raw.device
+
+    def __len__(self):
+        return self.shape[0]
+
+    def tap(self, img_ind, anchor_ind):
+        return HeadTapFunction.apply(self.raw, self.bias, img_ind, anchor_ind, self.A, self.attr)
+
+    def dense(self):
+        """The reference's (N, A*attr, H, W) fp32 pred map (what ``forward`` returns)."""
+        return self.raw[:, :self.A * self.attr].float() + self.bias.view(1, -1, 1, 1)
+
+
 @HEADS.register_module()
 class YOLOCSPHead(HipModule):
 
@@ -134,21 +193,26 @@ class YOLOCSPHead(HipModule):
             rescale=rescale, want_cls=want_cls, nms_pre=nms_pre, class_agnostic=self.class_agnostic)
 
     # ---- reference API ----------------------------------------------------------------------
-    def fwd(self, feats):
-        """Training-mode head forward: biased 1x1 convs through the HIP conv (output channels padded
-        255 -> 256 so that the gradient w.r.t. the pred map is a 16-byte aligned NHWC tensor)."""
+    def fwd_raw(self, feats):
+        """Training-mode head: biased 1x1 convs through the HIP conv with the bias left out and the
+        output channels padded 255 -> 256 (16-byte aligned NHWC gradient); the loss reads the result
+        through ``RawPredMap.tap``."""
         assert len(feats) == self.num_levels
         outs = []
-        for conv, x in zip(self.convs_pred, feats):
+        for i, (conv, x) in enumerate(zip(self.convs_pred, feats)):
             co = conv.out_channels
             w = conv.weight
             dt = T.train_dtype(self, x)
             padc = (-co) % (4 if dt == torch.float32 else 8)
             if padc:
                 w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, padc))
-            y = T.conv2d(x, w, 1, 0, dtype=dt)[:, :co]
-            outs.append(y.float() + conv.bias.view(1, -1, 1, 1))     # losses are computed in fp32 (force_fp32)
+            outs.append(RawPredMap(T.conv2d(x, w, 1, 0, dtype=dt), conv.bias, self.num_anchors[i], self.num_attrib))
         return tuple(outs)
+
+    def fwd(self, feats):
+        """Training-mode ``forward``: dense fp32 pred maps like the reference's (losses are computed in
+        fp32, yolocsp_head.py:384 force_fp32)."""
+        return tuple(r.dense() for r in self.fwd_raw(feats))
 
     def forward(self, feats):
         return self._dispatch((tuple(feats),), 'tuple'),
@@ -189,9 +253,9 @@ class YOLOCSPHead(HipModule):
 
     # ---- training (yolocsp_head.py:384-575) -------------------------------------------------------
     def loss(self, pred_maps, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
-        num_gts = pred_maps[0].new_tensor([g.size(0) for g in gt_bboxes]).mean()
-        pred_maps = [p.float() for p in pred_maps]
         device = pred_maps[0].device
+        num_gts = torch.tensor([g.size(0) for g in gt_bboxes], dtype=torch.float32, device=device).mean()
+        pred_maps = [p if isinstance(p, RawPredMap) else p.float() for p in pred_maps]
         featmap_sizes = [pred_maps[i].shape[-2:] for i in range(self.num_levels)]
         if self.assigner is not None:
             raise NotImplementedError
@@ -212,14 +276,18 @@ class YOLOCSPHead(HipModule):
 
     def loss_single_no_assigner(self, pred_map, anchors, stride, pos_indices, target_bboxes, target_labels):
         num_imgs = len(pred_map)
-        pred_map = pred_map.permute(0, 2, 3, 1).reshape(num_imgs, -1, self.num_attrib)
         img_ind, anchor_ind = pos_indices
-        pred_conf = pred_map[..., 4]
+        if isinstance(pred_map, RawPredMap):      # training fast path: no dense fp32 view of the map
+            pred_conf, pos_all = pred_map.tap(img_ind, anchor_ind)
+        else:
+            pred_map = pred_map.permute(0, 2, 3, 1).reshape(num_imgs, -1, self.num_attrib)
+            pred_conf = pred_map[..., 4]
+            pos_all = pred_map[img_ind, anchor_ind] if anchor_ind.numel() else None
         target_conf = torch.zeros_like(pred_conf, requires_grad=False)
-        loss_bbox = pred_map.new_zeros((1,))
-        loss_cls = pred_map.new_zeros((1,))
+        loss_bbox = pred_conf.new_zeros((1,))
+        loss_cls = pred_conf.new_zeros((1,))
         if anchor_ind.numel():
-            pos = pred_map[img_ind, anchor_ind]
+            pos = pos_all
             pb = pos[..., :4].sigmoid()
             xy = pb[..., :2] * 2. - 1.
             wh = (pb[..., 2:] * 2.) ** 2.
@@ -251,7 +319,7 @@ class YOLOCSPHead(HipModule):
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
                       **kwargs):
         """base_dense_head.py:22-59."""
-        outs = self(x)
+        outs = (self.fwd_raw(x),) if (self.training and proposal_cfg is None) else self(x)
         if gt_labels is None:
             loss_inputs = outs + (gt_bboxes, img_metas)
         else:
