@@ -468,6 +468,7 @@ __device__ __forceinline__ void red_flush(double* part, int C, int c, const floa
 }
 
 constexpr int kBnUnroll = 4;    // independent row loads in flight per thread (the loops are latency-bound otherwise)
+constexpr int kBnRedUnroll = 4; // (8 measured 3 % slower on the whole step: registers)
 
 // rows per workgroup: enough workgroups to fill the chip (>= ~1024) but at most kBnRows rows each
 static inline int bn_rows_per_block(int64_t M) {
@@ -492,15 +493,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
       float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
       const T* col = x + co + cq * 4;
-      for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnUnroll) {
-        float4 v[kBnUnroll];
+      for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnRedUnroll) {
+        float4 v[kBnRedUnroll];
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) {
+        for (int u = 0; u < kBnRedUnroll; ++u) {
           const int64_t row = rr + (int64_t)u * mp.rstep;
           v[u] = row < r1 ? El<T>::ld4(col + row * cs) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) {
+        for (int u = 0; u < kBnRedUnroll; ++u) {
           fs[0] += v[u].x; fs[1] += v[u].y; fs[2] += v[u].z; fs[3] += v[u].w;
           fq[0] += v[u].x * v[u].x; fq[1] += v[u].y * v[u].y; fq[2] += v[u].z * v[u].z; fq[3] += v[u].w * v[u].w;
         }
@@ -537,6 +538,7 @@ struct BnArgs {
   const void* dy; int dy_cs, dy_co;
   void* dx; int dx_cs, dx_co;
   double* sums;      // bwd: [dbeta (C) | dgamma (C)]
+  float* dgamma; float* dbeta;   // written by workgroup 0 of the apply pass
   int64_t M; int C; int act; float slope;
   int rows_per_block;
   int eval_mode;     // backward of an eval-mode BN (running statistics are constants): no mean/variance terms
@@ -606,17 +608,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
       const float ga[4] = {p.gamma[c], p.gamma[c + 1], p.gamma[c + 2], p.gamma[c + 3]};
       const float be[4] = {p.beta[c], p.beta[c + 1], p.beta[c + 2], p.beta[c + 3]};
       float db[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0};
-      for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnUnroll) {
-        float4 xv[kBnUnroll], gv[kBnUnroll];
+      for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnRedUnroll) {
+        float4 xv[kBnRedUnroll], gv[kBnRedUnroll];
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) {
+        for (int u = 0; u < kBnRedUnroll; ++u) {
           const int64_t row = rr + (int64_t)u * mp.rstep;
           const bool ok = row < r1;
           xv[u] = ok ? El<T>::ld4(px + row * p.x_cs + p.x_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
           gv[u] = ok ? El<T>::ld4(pdy + row * p.dy_cs + p.dy_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) {
+        for (int u = 0; u < kBnRedUnroll; ++u) {
           const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
           const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};   // zero beyond r1 -> contributes nothing
 #pragma unroll
@@ -644,6 +646,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
   const RedMap mp = red_map(C4);
   const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
   const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
+  if (blockIdx.x == 0) {      // the reduction kernel has completed (stream order): publish dbeta / dgamma as fp32
+    for (int i = threadIdx.x; i < p.C; i += 256) {
+      p.dbeta[i] = (float)p.sums[i];
+      p.dgamma[i] = (float)p.sums[p.C + i];
+    }
+  }
   if (!mp.active) return;
   const double invM = 1.0 / (double)p.M;
   for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
@@ -911,12 +919,11 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.dy = dy; a.dy_cs = dy_cstride; a.dy_co = dy_coff;
   a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dx_cs = dx_cstride; a.dx_co = dx_coff;
   a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope; a.eval_mode = eval_mode;
+  a.dgamma = dgamma; a.dbeta = dbeta;
   a.rows_per_block = bn_rows_per_block(M);
   dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
   YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s, a));
   YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, grid, dim3(256), 0, s, a));
-  hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
-  hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
   YV4_CHECK_LAUNCH("bn_act_bwd");
   return YV4_OK;
 }
