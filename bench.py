@@ -33,6 +33,8 @@ MODELS = {
     'yolov4l': dict(scale='v4l5p', neck_in=[256, 512, 512], neck_out=[256, 512, 1024], csp_rep=2),
     'yolov4s': dict(scale='v4s5p', neck_in=[128, 256, 256], neck_out=[128, 256, 512], csp_rep=1),
     # configs/yolov5/yolov5l_coco_mosaic.py: _base_ yolov4l + backbone v5l5p (out 2,3,4) + YOLOV5Neck
+    # configs/yolo/yolov3_d53_mstrain-608_273e_coco.py (the only path with a published upstream fps)
+    'yolov3': dict(scale='darknet53', v3=True),
     'yolov5l': dict(scale='v5l5p', neck='YOLOV5Neck', neck_in=[256, 512, 1024], neck_out=[256, 512, 1024], csp_rep=2,
                     out_indices=[2, 3, 4]),
 }
@@ -40,6 +42,14 @@ MODELS = {
 
 def model_cfg(name):
     m = MODELS[name]
+    if m.get('v3'):
+        return dict(
+            type='YOLOV3', backbone=dict(type='Darknet', depth=53, out_indices=(3, 4, 5)),
+            neck=dict(type='YOLOV3Neck', num_scales=3, in_channels=[1024, 512, 256], out_channels=[512, 256, 128]),
+            bbox_head=dict(type='YOLOV3Head', num_classes=80, in_channels=[512, 256, 128], out_channels=[1024, 512, 256]),
+            train_cfg=None,
+            test_cfg=dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, conf_thr=0.005,
+                          nms=dict(type='nms', iou_threshold=0.45), max_per_img=100))
     return dict(
         type='SingleStageDetector',
         backbone=dict(type='DarknetCSP', scale=m['scale'], out_indices=m.get('out_indices', [3, 4, 5])),
@@ -127,6 +137,8 @@ def cpu_baseline(det, size, budget_s=25.0):
     Test infrastructure used as a yardstick only; never on the product path."""
     from oracle import yolov4_oracle as O
     sd = {k: v.detach().cpu().clone() for k, v in det.state_dict().items()}
+    if det_scale(det) == 'darknet53':
+        return cpu_baseline_v3(det, sd, size, budget_s)
     stages, reps = O.ARCH[det_scale(det)]
     img = synthetic_images(1, size, 99, 'cpu')
     sf = [[1.0, 1.0, 1.0, 1.0]]
@@ -147,6 +159,41 @@ def cpu_baseline(det, size, budget_s=25.0):
     return dict(value=round(n / t_total, 4), unit='images/sec', cores=threads, kind='port',
                 sample=f'{n} single-image {size}x{size} forward+decode+NMS runs of the CPU oracle '
                        f'({t_total:.1f} s, {threads} torch threads = cgroup CPU quota), same weights as the GPU run')
+
+
+def cpu_baseline_v3(det, sd, size, budget_s):
+    from oracle import yolov3_oracle as V3
+    img = synthetic_images(1, size, 99, 'cpu')
+    threads = host_cpu_budget()
+    torch.set_num_threads(threads)
+    cfg = det.bbox_head.test_cfg
+
+    def run():
+        with torch.no_grad():
+            feats = V3.darknet(img, sd, det.backbone.layers, det.backbone.out_indices)
+            preds = V3.yolov3_head(V3.yolov3_neck(feats, sd), sd)
+            return V3.get_bboxes_v3(preds, [[1.0, 1.0, 1.0, 1.0]], 80, nms_pre=cfg['nms_pre'], score_thr=cfg['score_thr'],
+                                    conf_thr=cfg['conf_thr'], iou_threshold=cfg['nms']['iou_threshold'],
+                                    max_per_img=cfg['max_per_img'])
+    run()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s and n < 64:
+        run()
+        n += 1
+    el = time.perf_counter() - t0
+    return dict(value=round(n / el, 4), unit='images/sec', cores=threads, kind='port',
+                sample=f'{n} single-image {size}x{size} forward+decode+NMS runs of the CPU oracle (YOLOv3) '
+                       f'({el:.1f} s, {threads} torch threads = cgroup CPU quota), same weights as the GPU run')
+
+
+def vs_published(args, value):
+    """BASELINE.md holds published numbers only for upstream YOLOv3-DarkNet53 at batch 1 (fwd + post-processing,
+    one V100, configs/yolo/README.md:22-24); every other configuration has none."""
+    pub = {320: 63.9, 416: 61.2, 608: 48.1}
+    if MODELS[args.model].get('v3') and args.batch == 1 and args.gpus == 1 and args.dtype == 'f32' and args.size in pub:
+        return round(value / pub[args.size], 3)
+    return None
 
 
 def det_scale(det):
@@ -270,7 +317,8 @@ def main():
     conv_time = sum(v[1] for v in per_tile.values())
     dom = max(per_tile, key=lambda k: per_tile[k][1])
     dflops, dtime, dn = per_tile[dom]
-    traffic, traffic_src = pmc_traffic(dom)
+    headline = (args.model, args.size, args.batch, args.dtype) == ('yolov4l', 608, 32, 'f32')
+    traffic, traffic_src = pmc_traffic(dom) if headline else (None, None)   # the committed PMC summary is of the headline run
     peak = PEAK_H16_MFMA_TFLOPS if h16 else PEAK_FP32_MFMA_TFLOPS
     roofline = dict(bound='mfma', kernel=f'conv_mfma_{"h16" if h16 else "f32"}_kernel<{dom}>',
                     achieved=round(dflops / dtime / 1e12, 2), peak=peak, unit='TFLOP/s',
@@ -298,12 +346,14 @@ def main():
     if rank == 0:
         total_images = args.batch * world * args.steps
         out = dict(
-            metric=f'images/sec (inference) YOLOv4 {args.size}x{args.size}', value=round(total_images / elapsed, 2),
+            metric=f'images/sec (inference) {"YOLOv3" if MODELS[args.model].get("v3") else "YOLOv4"} {args.size}x{args.size}', value=round(total_images / elapsed, 2),
             unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
-            vs_baseline=None, dtype=args.dtype, data='synthetic',
-            config=dict(workload=f'{args.model} (DarknetCSP {MODELS[args.model]["scale"]} + '
-                                 f'{MODELS[args.model].get("neck", "YOLOV4Neck")} + YOLOCSPHead, 80 classes) '
+            vs_baseline=vs_published(args, total_images / elapsed), dtype=args.dtype, data='synthetic',
+            config=dict(workload=(f'{args.model} (Darknet-53 + YOLOV3Neck + YOLOV3Head, 80 classes) '
+                                  if MODELS[args.model].get('v3') else
+                                  f'{args.model} (DarknetCSP {MODELS[args.model]["scale"]} + '
+                                  f'{MODELS[args.model].get("neck", "YOLOV4Neck")} + YOLOCSPHead, 80 classes) ') +
                                  f'{args.size}x{args.size} {dict(f32="fp32", f16="fp16", bf16="bf16")[args.dtype]} inference, batch {args.batch}/GPU: image -> '
                                  'fused conv path -> decode -> per-class NMS -> detections on host ' +
                                  ('(BASELINE.json configs[1])' if (args.model, args.size, args.batch, args.dtype) == ('yolov4l', 608, 32, 'f32')

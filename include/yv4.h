@@ -200,6 +200,25 @@ int yv4_conf_topk(const yv4_level_desc* levels, int num_levels, int N, int A,
                   int num_classes, int k, void* work, uint64_t* topk_keys,
                   void* stream);
 
+/* ---- YOLOv3 head (mmdet/models/dense_heads/yolo_head.py:210-391) ----------------------
+ * Same buffers and key format as yv4_decode_filter, YOLOV3Head semantics:
+ *   box: cx = (sigmoid(t0) - 0.5)*stride + anchor_cx, w = exp(t2)*anchor_w
+ *        (core/bbox/coder/yolo_bbox_coder.py:61-89);
+ *   candidates: boxes inside their LEVEL's top-k by objectness (topk_keys_per_level: N*num_levels
+ *   values from yv4_conf_topk_levels, or NULL), with objectness >= conf_thr (<= 0: off), classes with
+ *   sigmoid(cls) > score_thr; the key carries cls*objectness (multiclass_nms' score_factors,
+ *   core/post_processing/bbox_nms.py:52-62).  NMS itself is yv4_nms_images / yv4_nms_split. */
+int yv4_decode_filter_v3(const yv4_level_desc* levels, int num_levels, int N, int A,
+                         int num_classes, float score_thr, float conf_thr,
+                         const float* scale_factor, float* boxes, float* conf, float* cls,
+                         uint64_t* keys, int64_t key_cap, int32_t* counts, float* max_coord,
+                         const uint64_t* topk_keys_per_level, void* stream);
+/* Per-level top-k thresholds: topk_keys[n*num_levels + l] = k-th key of level l of image n, or the
+ * all-admitting key when the level has <= k boxes (core/export/onnx_helper.py:45-78). */
+size_t yv4_conf_topk_levels_work(int N, int64_t total_anchors, int num_levels);
+int yv4_conf_topk_levels(const yv4_level_desc* levels, int num_levels, int N, int A,
+                         int num_classes, int k, void* work, uint64_t* topk_keys, void* stream);
+
 /* ---- batched NMS -----------------------------------------------------------
  * Per image n (one workgroup each): sort its counts[n] candidate keys by
  * (score desc, flat index asc), then greedy NMS in that order on the

@@ -18,6 +18,7 @@ from .darknetcsp import (Bottleneck, BottleneckCSP, BottleneckCSP2, Conv, CSPSta
 from .yolo_neck_csp import YOLOV4Neck, YOLOV5Neck
 from .yolocsp_head import YOLOCSPHead
 from .single_stage import SingleStageDetector, bbox2result
+from .yolov3 import Darknet, DetectionBlock, ResBlock, YOLOBBoxCoder, YOLOV3, YOLOV3Head, YOLOV3Neck
 from .plan import Plan
 
 __all__ = [n for n in dir() if not n.startswith('_')]

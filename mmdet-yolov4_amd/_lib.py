@@ -62,6 +62,10 @@ SIGNATURES = {
     'yv4_decode_filter': (C.c_int, [C.POINTER(LevelDesc), _i, _i, _i, _i, _f,
                                     _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                     _vp, _vp]),
+    'yv4_decode_filter_v3': (C.c_int, [C.POINTER(LevelDesc), _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
+                                       _vp, _vp, _vp]),
+    'yv4_conf_topk_levels_work': (_sz, [_i, _i64, _i]),
+    'yv4_conf_topk_levels': (C.c_int, [C.POINTER(LevelDesc), _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'yv4_conf_topk_work': (_sz, [_i, _i64]),
     'yv4_conf_topk': (C.c_int, [C.POINTER(LevelDesc), _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'yv4_nms_images': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i,

@@ -62,7 +62,10 @@ struct DecodeArgs {
   int64_t key_cap;
   int32_t* counts;
   float* max_coord;
-  const uint64_t* topk;   // per image: largest admissible (conf key << 32 | anchor) or NULL
+  const uint64_t* topk;   // largest admissible (conf key << 32 | anchor) per image (or per image x level), or NULL
+  int v3;                 // YOLOV3Head semantics (yolo_head.py:254-391) instead of YOLOCSPHead's
+  int topk_per_level;     // topk has N * num_levels entries (YOLOv3 selects the top-k per level)
+  float conf_thr;         // v3: boxes with objectness < conf_thr are dropped (<= 0: off)
 };
 
 __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
@@ -76,7 +79,10 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   const int nb = min(kDecBoxes, boxes_lvl - b0);
   const float* src = p.pred[lvl] + ((size_t)n * boxes_lvl + b0) * attr;
   const int nval = nb * attr;
-  for (int i = threadIdx.x; i < nval; i += 256) sm[i] = sigmoid_f32(src[i]);
+  for (int i = threadIdx.x; i < nval; i += 256) {
+    const int at = i % attr;
+    sm[i] = (p.v3 && (at == 2 || at == 3)) ? src[i] : sigmoid_f32(src[i]);   // v3: exp(t_w), exp(t_h) need the raw logit
+  }
   __syncthreads();
 
   const int part = threadIdx.x & 3;
@@ -94,16 +100,25 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   const float sy = (float)(gy * p.stride[lvl]);
   const float ax1 = p.base[lvl][a][0] + sx, ay1 = p.base[lvl][a][1] + sy;
   const float ax2 = p.base[lvl][a][2] + sx, ay2 = p.base[lvl][a][3] + sy;
-  // yolocsp_head.py:273-275
-  const float px = s[0] * 2.f - 1.f;
-  const float py = s[1] * 2.f - 1.f;
-  const float tw = s[2] * 2.f, th = s[3] * 2.f;
-  const float pw = tw * tw, ph = th * th;
-  // yolov4_bbox_coder.py:51-66
   const float xc = (ax1 + ax2) * 0.5f, yc = (ay1 + ay2) * 0.5f;
   const float aw = ax2 - ax1, ah = ay2 - ay1;
-  const float xcp = px * stride + xc, ycp = py * stride + yc;
-  const float wp = pw * aw, hp = ph * ah;
+  float xcp, ycp, wp, hp;
+  if (p.v3) {
+    // core/bbox/coder/yolo_bbox_coder.py:76-83
+    xcp = (s[0] - 0.5f) * stride + xc;
+    ycp = (s[1] - 0.5f) * stride + yc;
+    wp = expf(s[2]) * aw;
+    hp = expf(s[3]) * ah;
+  } else {
+    // yolocsp_head.py:273-275, yolov4_bbox_coder.py:51-66
+    const float px = s[0] * 2.f - 1.f;
+    const float py = s[1] * 2.f - 1.f;
+    const float tw = s[2] * 2.f, th = s[3] * 2.f;
+    xcp = px * stride + xc;
+    ycp = py * stride + yc;
+    wp = tw * tw * aw;
+    hp = th * th * ah;
+  }
   float x1 = xcp - wp / 2.f, y1 = ycp - hp / 2.f, x2 = xcp + wp / 2.f, y2 = ycp + hp / 2.f;
   if (p.scale_factor) {  // yolocsp_head.py:365-366
     const float* sf = p.scale_factor + n * 4;
@@ -118,7 +133,10 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   }
   // nms_pre (yolocsp_head.py:349-355): only the top-k anchors by conf stay candidates; the
   // k-th (conf, anchor) key of the image was selected by yv4_conf_topk
-  const bool admitted = live && !(p.topk && (((uint64_t)score_to_key(cf) << 32) | (uint32_t)j) > p.topk[n]);
+  const uint64_t ckey = ((uint64_t)score_to_key(cf) << 32) | (uint32_t)j;
+  const bool in_topk = !p.topk || ckey <= p.topk[p.topk_per_level ? n * p.num_levels + lvl : n];
+  // v3: per-image objectness threshold applied after the top-k (yolo_head.py:366-377, `ge`)
+  const bool admitted = live && in_topk && !(p.v3 && p.conf_thr > 0.f && !(cf >= p.conf_thr));
   // Candidates are appended in two passes so that the per-image counter sees ONE atomic per
   // workgroup instead of one per candidate (thousands of same-address atomics per image serialise:
   // the single-pass form spent ~0.5 ms of a 34 ms step there).  Pass 1 counts, the workgroup reserves
@@ -134,7 +152,9 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
       for (int c = part; c < p.C; c += 4) {
         const float sc = s[5 + c];
         if (p.cls) p.cls[gj * p.C + c] = sc;
-        mine += (sc * cf > p.score_thr) ? 1 : 0;     // yolocsp_head.py:358, bbox_nms.py:54
+        // YOLOCSPHead: cls * conf > thr (yolocsp_head.py:358, bbox_nms.py:54); YOLOV3Head: cls > thr, the
+        // objectness multiplies afterwards as multiclass_nms' score_factors (bbox_nms.py:52-62)
+        mine += ((p.v3 ? sc : sc * cf) > p.score_thr) ? 1 : 0;
       }
     }
   }
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
     } else {
       for (int c = part; c < p.C; c += 4) {
         const float score = s[5 + c] * cf;
-        if (score > p.score_thr) {
+        if ((p.v3 ? s[5 + c] : score) > p.score_thr) {
           if (slot < p.key_cap) {
             const uint32_t flat = (uint32_t)j * (uint32_t)p.C + (uint32_t)c;
             p.keys[(size_t)n * p.key_cap + slot] = ((uint64_t)score_to_key(score) << 32) | flat;
@@ -418,10 +438,10 @@ extern "C" int yv4_decode_reset(int32_t* counts, float* max_coord, int N, void* 
   return YV4_OK;
 }
 
-extern "C" int yv4_decode_filter(const yv4_level_desc* levels, int num_levels, int N, int A, int num_classes,
-                                 float score_thr, const float* scale_factor, float* boxes, float* conf, float* cls,
-                                 uint64_t* keys, int64_t key_cap, int32_t* counts, float* max_coord,
-                                 const uint64_t* topk_keys, void* stream) {
+static int decode_impl(const yv4_level_desc* levels, int num_levels, int N, int A, int num_classes, float score_thr,
+                       const float* scale_factor, float* boxes, float* conf, float* cls, uint64_t* keys,
+                       int64_t key_cap, int32_t* counts, float* max_coord, const uint64_t* topk_keys, void* stream,
+                       int v3, float conf_thr, int topk_per_level) {
   YV4_REQUIRE(levels && boxes && keys && counts && max_coord, "decode_filter: null pointer");
   YV4_REQUIRE(num_levels > 0 && num_levels <= kMaxLevels, "decode_filter: 1..%d levels supported", kMaxLevels);
   YV4_REQUIRE(N > 0 && N <= 65535 && A > 0 && A <= 8 && num_classes >= 0, "decode_filter: bad N/A/num_classes");
@@ -453,11 +473,29 @@ extern "C" int yv4_decode_filter(const yv4_level_desc* levels, int num_levels, i
   a.score_thr = score_thr; a.scale_factor = scale_factor; a.boxes = boxes; a.conf = conf; a.cls = cls;
   a.keys = keys; a.key_cap = key_cap; a.counts = counts; a.max_coord = max_coord;
   a.topk = topk_keys;
+  a.v3 = v3; a.conf_thr = conf_thr; a.topk_per_level = topk_per_level;
   const size_t lds = (size_t)kDecBoxes * (5 + num_classes) * sizeof(float);
   YV4_REQUIRE(lds <= 64 * 1024, "decode_filter: num_classes %d too large for the LDS tile", num_classes);
   hipLaunchKernelGGL(decode_filter_kernel, dim3(blocks, N), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
   YV4_CHECK_LAUNCH("decode_filter");
   return YV4_OK;
+}
+
+extern "C" int yv4_decode_filter(const yv4_level_desc* levels, int num_levels, int N, int A, int num_classes,
+                                 float score_thr, const float* scale_factor, float* boxes, float* conf, float* cls,
+                                 uint64_t* keys, int64_t key_cap, int32_t* counts, float* max_coord,
+                                 const uint64_t* topk_keys, void* stream) {
+  return decode_impl(levels, num_levels, N, A, num_classes, score_thr, scale_factor, boxes, conf, cls, keys, key_cap,
+                     counts, max_coord, topk_keys, stream, 0, 0.f, 0);
+}
+
+extern "C" int yv4_decode_filter_v3(const yv4_level_desc* levels, int num_levels, int N, int A, int num_classes,
+                                    float score_thr, float conf_thr, const float* scale_factor, float* boxes,
+                                    float* conf, float* cls, uint64_t* keys, int64_t key_cap, int32_t* counts,
+                                    float* max_coord, const uint64_t* topk_keys_per_level, void* stream) {
+  YV4_REQUIRE(num_classes > 0, "decode_filter_v3: num_classes must be positive");
+  return decode_impl(levels, num_levels, N, A, num_classes, score_thr, scale_factor, boxes, conf, cls, keys, key_cap,
+                     counts, max_coord, topk_keys_per_level, stream, 1, conf_thr, 1);
 }
 
 extern "C" int yv4_nms_images(uint64_t* keys, int64_t key_cap, const int32_t* counts, const float* max_coord,

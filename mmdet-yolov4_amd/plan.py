@@ -304,12 +304,15 @@ class Plan:
         return len(self.outputs) - 1
 
     def postprocess(self, pred_views, strides, base_anchors, num_classes, score_thr, iou_thr, max_per_img,
-                    split_thr=10000, rescale=True, want_cls=False, nms_pre=-1, class_agnostic=False):
+                    split_thr=10000, rescale=True, want_cls=False, nms_pre=-1, class_agnostic=False, v3=False,
+                    conf_thr=-1.0):
         """decode+filter and per-image NMS over the head's NHWC pred maps.
         base_anchors: list (per level) of (A,4) float tensors.  Returns a dict of result
         tensors (allocated at finalize).  ``class_agnostic``: 5 attributes per box, the score is the
         objectness (one pseudo-class); ``nms_pre`` > 0: only the top-k boxes by objectness are
-        candidates (yolocsp_head.py:349-360)."""
+        candidates (yolocsp_head.py:349-360).  ``v3``: YOLOV3Head semantics (yolo_head.py:210-391): the
+        v3 box decode, top-k PER LEVEL, objectness >= ``conf_thr``, class score > ``score_thr`` with the
+        objectness multiplied in afterwards."""
         N = pred_views[0].N
         A = base_anchors[0].shape[0]
         kclasses = 0 if class_agnostic else num_classes          # what the kernels see
@@ -325,8 +328,13 @@ class Plan:
         res = dict(N=N, total_anchors=total, num_classes=num_classes, max_per_img=max_per_img,
                    key_cap=total * num_classes, want_cls=want_cls, rescale=rescale,
                    iou_thr=iou_thr, split_thr=split_thr, score_thr=score_thr, class_agnostic=class_agnostic)
-        use_topk = 0 < nms_pre < total
+        if v3:
+            assert not class_agnostic, 'YOLOV3Head has no class-agnostic form'
+            use_topk = nms_pre > 0 and any(v.H * v.W * A > nms_pre for v in pred_views)
+        else:
+            use_topk = 0 < nms_pre < total
         res['nms_pre'] = nms_pre if use_topk else -1
+        res['v3'] = bool(v3)
         self.post = res
         self.params.append(levels)
 
@@ -337,11 +345,12 @@ class Plan:
             res['cls'] = (torch.empty((N, total, num_classes), dtype=torch.float32, device=dev)
                           if want_cls and not class_agnostic else None)
             if use_topk:
-                nbytes = _lib.lib().yv4_conf_topk_work(N, total)
+                nbytes = (_lib.lib().yv4_conf_topk_levels_work(N, total, len(pred_views)) if v3
+                          else _lib.lib().yv4_conf_topk_work(N, total))
                 if nbytes == 0:
                     raise RuntimeError('yv4_conf_topk_work: batch * anchors too large for the top-k pre-selection')
                 res['topk_work'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                res['topk_keys'] = torch.zeros(N, dtype=torch.int64, device=dev)
+                res['topk_keys'] = torch.zeros(N * (len(pred_views) if v3 else 1), dtype=torch.int64, device=dev)
             res['keys'] = torch.empty((N, res['key_cap']), dtype=torch.int64, device=dev)
             res['counts'] = torch.zeros(N, dtype=torch.int32, device=dev)
             res['max_coord'] = torch.zeros(N, dtype=torch.float32, device=dev)
@@ -364,9 +373,18 @@ class Plan:
                   'yv4_decode_reset')
 
         def topk(stream):
-            check(_lib.lib().yv4_conf_topk(levels, len(pred_views), N, A, kclasses, int(nms_pre),
-                                           res['topk_work'].data_ptr(), res['topk_keys'].data_ptr(), stream),
-                  'yv4_conf_topk')
+            fn = _lib.lib().yv4_conf_topk_levels if v3 else _lib.lib().yv4_conf_topk
+            check(fn(levels, len(pred_views), N, A, kclasses, int(nms_pre), res['topk_work'].data_ptr(),
+                     res['topk_keys'].data_ptr(), stream), 'yv4_conf_topk')
+
+        def decode_v3(stream):
+            check(_lib.lib().yv4_decode_filter_v3(
+                levels, len(pred_views), N, A, kclasses, float(score_thr), float(conf_thr),
+                res['scale_factor'].data_ptr() if rescale else None, res['boxes'].data_ptr(),
+                res['conf'].data_ptr(), res['cls'].data_ptr() if res['cls'] is not None else None,
+                res['keys'].data_ptr(), res['key_cap'], res['counts'].data_ptr(),
+                res['max_coord'].data_ptr(), res['topk_keys'].data_ptr() if use_topk else None, stream),
+                'yv4_decode_filter_v3')
 
         def decode(stream):
             check(_lib.lib().yv4_decode_filter(
@@ -386,7 +404,7 @@ class Plan:
         self.ops.append(Op('reset', 'decode_reset', reset))
         if use_topk:
             self.ops.append(Op('topk', 'conf_topk', topk))
-        self.ops.append(Op('decode', 'decode_filter', decode, nbytes=4.0 * N * total * attr))
+        self.ops.append(Op('decode', 'decode_filter', decode_v3 if v3 else decode, nbytes=4.0 * N * total * attr))
         self.ops.append(Op('nms', 'nms_images', nms))
         return res
 

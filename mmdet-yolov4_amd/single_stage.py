@@ -79,8 +79,7 @@ class SingleStageDetector(HipModule):
             plan = Plan(device, dtype)
             # 16-bit plans keep the image fp32 when the backbone starts with the 3x3 stem (its own
             # fp32 kernel, 16-bit output); otherwise the image is converted like any other tensor
-            first = getattr(self.backbone, getattr(self.backbone, 'layers', [''])[0], None)
-            conv0 = getattr(first, 'conv', None)
+            conv0 = next((m for m in self.backbone.modules() if isinstance(m, torch.nn.Conv2d)), None)
             stem32 = (plan.h16 and isinstance(conv0, torch.nn.Conv2d) and conv0.kernel_size == (3, 3)
                       and conv0.stride == (1, 1) and conv0.padding == (1, 1) and conv0.in_channels == 3
                       and conv0.out_channels <= 64 and conv0.out_channels % 8 == 0)

@@ -149,3 +149,40 @@ def test_head_loss_on_cpu_tensors_matches_oracle(golden):
         got = torch.stack([x.reshape(()) for x in L[k]]).numpy()
         np.testing.assert_allclose(got, g['loss/' + k], rtol=1e-6, atol=1e-7)
     assert float(L['num_gts']) == 2.5
+
+
+def test_yolov3_registry_names_and_checkpoint_layout(golden):
+    """YOLOv3 row (8f-3): the reference's registry names build, and the state-dict keys / order / shapes of
+    Darknet + YOLOV3Neck + YOLOV3Head equal the reference's (fixture from its own modules)."""
+    import mmdet_yolov4_amd as pkg
+    from conftest import state_dict_from
+    for reg, name in ((pkg.registry.BACKBONES, 'Darknet'), (pkg.registry.NECKS, 'YOLOV3Neck'),
+                      (pkg.registry.HEADS, 'YOLOV3Head'), (pkg.registry.DETECTORS, 'YOLOV3'),
+                      (pkg.registry.BBOX_CODERS, 'YOLOBBoxCoder')):
+        assert reg.get(name) is not None, name
+    g = golden('tiny_v3')
+
+    class TinyDarknet(pkg.Darknet):
+        arch_settings = {53: (tuple(int(v) for v in g['meta_layers']), tuple(tuple(int(c) for c in r) for r in g['meta_channels']))}
+    backbone = TinyDarknet(depth=53, out_indices=(3, 4, 5))
+    neck = pkg.YOLOV3Neck(num_scales=3, in_channels=[64, 64, 32], out_channels=[64, 32, 16])
+    head = pkg.YOLOV3Head(num_classes=6, in_channels=[64, 32, 16], out_channels=[96, 64, 32])
+    sd = state_dict_from(g)
+    mine = {}
+    for pre, m in (('backbone', backbone), ('neck', neck), ('bbox_head', head)):
+        mine.update({f'{pre}.{k}': v for k, v in m.state_dict().items()})
+    assert list(mine.keys()) == list(sd.keys())
+    assert all(tuple(mine[k].shape) == tuple(sd[k].shape) for k in sd)
+    # the full-size model has upstream's parameter count
+    full = pkg.build_detector(dict(
+        type='YOLOV3', backbone=dict(type='Darknet', depth=53, out_indices=(3, 4, 5)),
+        neck=dict(type='YOLOV3Neck', num_scales=3, in_channels=[1024, 512, 256], out_channels=[512, 256, 128]),
+        bbox_head=dict(type='YOLOV3Head', num_classes=80, in_channels=[512, 256, 128], out_channels=[1024, 512, 256])))
+    assert sum(p.numel() for p in full.parameters()) == 61949149
+    with pytest.raises(KeyError):
+        pkg.Darknet(depth=19)
+    # the coder's known answers (the reference's tests/test_utils/test_coder.py:8-24)
+    coder = pkg.YOLOBBoxCoder()
+    b, p_ = torch.from_numpy(g['coder/bboxes']), torch.from_numpy(g['coder/pred'])
+    np.testing.assert_array_equal(coder.decode(b, p_, 32).numpy(), g['coder/decode_s32'])
+    np.testing.assert_array_equal(coder.encode(b, torch.from_numpy(g['coder/encode_gt']), 32).numpy(), g['coder/encode_s32'])
