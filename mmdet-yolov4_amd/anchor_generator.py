@@ -65,6 +65,25 @@ class YOLOAnchorGenerator:
                                                self.strides[i], device=device)
                 for i in range(self.num_levels)]
 
+    # ---- training targets of YOLOV3Head (anchor_generator.py:667-727) ---------------------------
+    def responsible_flags(self, featmap_sizes, gt_bboxes, device='cuda'):
+        """Per level, a uint8 flag per anchor box: 1 for the A boxes of every cell that holds a gt centre."""
+        assert self.num_levels == len(featmap_sizes)
+        return [self.single_level_responsible_flags(featmap_sizes[i], gt_bboxes, self.strides[i],
+                                                    self.num_base_anchors[i], device=device)
+                for i in range(self.num_levels)]
+
+    def single_level_responsible_flags(self, featmap_size, gt_bboxes, stride, num_base_anchors, device='cuda'):
+        feat_h, feat_w = featmap_size
+        cx = ((gt_bboxes[:, 0] + gt_bboxes[:, 2]) * 0.5).to(device)
+        cy = ((gt_bboxes[:, 1] + gt_bboxes[:, 3]) * 0.5).to(device)
+        gx = torch.floor(cx / stride[0]).long()
+        gy = torch.floor(cy / stride[1]).long()
+        idx = gy * feat_w + gx                                  # row-major cell index
+        grid = torch.zeros(feat_h * feat_w, dtype=torch.uint8, device=device)
+        grid[idx] = 1
+        return grid[:, None].expand(grid.size(0), num_base_anchors).contiguous().view(-1)
+
 
 @ANCHOR_GENERATORS.register_module()
 class YOLOV4AnchorGenerator(YOLOAnchorGenerator):

@@ -33,6 +33,33 @@ def bbox_overlaps_giou_aligned(b1, b2, eps=1e-6):
     return ious - (earea - union) / earea
 
 
+def bbox_overlaps(b1, b2, eps=1e-6):
+    """Pairwise IoU, core/bbox/iou_calculators/iou2d_calculator.py:74-260 (mode='iou', is_aligned=False):
+    (m,4) x (n,4) -> (m,n)."""
+    area1 = (b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])
+    area2 = (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])
+    lt = torch.max(b1[..., :, None, :2], b2[..., None, :, :2])
+    rb = torch.min(b1[..., :, None, 2:], b2[..., None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    overlap = wh[..., 0] * wh[..., 1]
+    union = area1[..., None] + area2[..., None, :] - overlap
+    union = torch.max(union, union.new_tensor([eps]))
+    return overlap / union
+
+
+def weight_reduce_loss(loss, weight=None, reduction='mean', avg_factor=None):
+    """losses/utils.py:27-54."""
+    if weight is not None:
+        loss = loss * weight
+    if avg_factor is None:
+        return reduce_loss(loss, reduction)
+    if reduction == 'mean':
+        return loss.sum() / avg_factor
+    if reduction != 'none':
+        raise ValueError('avg_factor can not be used with reduction="sum"')
+    return loss
+
+
 def reduce_loss(loss, reduction):
     if reduction == 'none':
         return loss
@@ -68,11 +95,26 @@ class CrossEntropyLoss(torch.nn.Module):
         self.use_sigmoid, self.reduction, self.loss_weight, self.class_weight = True, reduction, loss_weight, class_weight
 
     def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, **kwargs):
-        assert weight is None and avg_factor is None
+        """cross_entropy_loss.py:58-91 (element-wise ``weight``, ``avg_factor``) + :187-214."""
         reduction = reduction_override if reduction_override else self.reduction
         pw = cls_score.new_tensor(self.class_weight) if self.class_weight is not None else None
         loss = F.binary_cross_entropy_with_logits(cls_score, label.float(), pos_weight=pw, reduction='none')
-        return self.loss_weight * reduce_loss(loss, reduction)
+        if weight is not None:
+            weight = weight.float()
+        return self.loss_weight * weight_reduce_loss(loss, weight, reduction=reduction, avg_factor=avg_factor)
+
+
+@LOSSES.register_module()
+class MSELoss(torch.nn.Module):
+    """losses/mse_loss.py:8-50 (``@weighted_loss`` element-wise MSE)."""
+
+    def __init__(self, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        loss = F.mse_loss(pred, target, reduction='none')
+        return self.loss_weight * weight_reduce_loss(loss, weight, reduction=self.reduction, avg_factor=avg_factor)
 
 
 @LOSSES.register_module()

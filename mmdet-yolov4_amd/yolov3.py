@@ -14,18 +14,24 @@ Everything reuses the YOLOv4 machinery: ``Conv`` (mmcv ConvModule layout) with t
 of the fused conv kernel, the residual add in the conv epilogue, nearest-upsample + concat as channel-
 offset stores, and decode + per-class NMS in two launches (``yv4_decode_filter_v3``: v3 box decode,
 per-LEVEL top-k by objectness, ``conf_thr``, ``score_factors``).  Training of the v3 head (GridAssigner +
-MSE / BCE losses, ``yolo_head.py:393-604``) is not built.
+MSE / BCE losses, ``yolo_head.py:393-560``) runs on the HIP training kernels for the convs / BN and
+torch tensor ops for the target assignment and the loss, like the YOLOv4 head's.
 """
+import warnings
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.modules.batchnorm import _BatchNorm
 
+from . import assigners as _assigners  # noqa: F401  (registers GridAssigner / PseudoSampler)
 from . import ops
+from . import train_ops as T
 from .bricks import HipModule
 from .darknetcsp import Conv
 from .plan import Plan
 from .registry import (BACKBONES, BBOX_CODERS, DETECTORS, HEADS, NECKS, ConfigDict, build_anchor_generator,
-                       build_bbox_coder)
+                       build_assigner, build_bbox_coder, build_loss, build_sampler)
 from .single_stage import SingleStageDetector
 from .yolocsp_head import collect_results, set_scale_factors
 
@@ -273,8 +279,11 @@ class YOLOV3Head(HipModule):
                                                    [(30, 61), (62, 45), (59, 119)],
                                                    [(10, 13), (16, 30), (33, 23)]], strides=[32, 16, 8]),
                  bbox_coder=dict(type='YOLOBBoxCoder'), featmap_strides=[32, 16, 8], one_hot_smoother=0., conv_cfg=None,
-                 norm_cfg=_NORM, act_cfg=_ACT, loss_cls=None, loss_conf=None, loss_xy=None, loss_wh=None,
-                 train_cfg=None, test_cfg=None,
+                 norm_cfg=_NORM, act_cfg=_ACT,
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 loss_conf=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 loss_xy=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 loss_wh=dict(type='MSELoss', loss_weight=1.0), train_cfg=None, test_cfg=None,
                  init_cfg=dict(type='Normal', std=0.01, override=dict(name='convs_pred'))):
         super().__init__(None)
         assert len(in_channels) == len(out_channels) == len(featmap_strides)
@@ -284,11 +293,18 @@ class YOLOV3Head(HipModule):
         self.featmap_strides = featmap_strides
         self.train_cfg = ConfigDict(train_cfg) if isinstance(train_cfg, dict) else train_cfg
         self.test_cfg = ConfigDict(test_cfg) if isinstance(test_cfg, dict) else test_cfg
+        if self.train_cfg:                                        # yolo_head.py:91-97
+            self.assigner = build_assigner(self.train_cfg.assigner)
+            sampler_cfg = self.train_cfg.sampler if hasattr(self.train_cfg, 'sampler') else dict(type='PseudoSampler')
+            self.sampler = build_sampler(sampler_cfg, context=self)
         self.one_hot_smoother = one_hot_smoother
         self.conv_cfg, self.norm_cfg, self.act_cfg = conv_cfg, norm_cfg, act_cfg
         self.bbox_coder = build_bbox_coder(bbox_coder)
         self.anchor_generator = build_anchor_generator(anchor_generator)
-        self.loss_cfgs = dict(loss_cls=loss_cls, loss_conf=loss_conf, loss_xy=loss_xy, loss_wh=loss_wh)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_conf = build_loss(loss_conf)
+        self.loss_xy = build_loss(loss_xy)
+        self.loss_wh = build_loss(loss_wh)
         self.num_anchors = self.anchor_generator.num_base_anchors[0]
         assert len(self.anchor_generator.num_base_anchors) == len(featmap_strides)
         self._init_layers()
@@ -344,8 +360,21 @@ class YOLOV3Head(HipModule):
 
     # ---- reference API ------------------------------------------------------------------------
     def fwd(self, feats):
-        raise NotImplementedError('YOLOV3Head: the training graph (GridAssigner, MSE/BCE losses, '
-                                  'yolo_head.py:393-604) is not built; call .eval()')
+        """Training-mode forward: bridge ConvModule on the HIP training ops, biased 1x1 prediction conv with
+        its output channels padded to a 16-byte multiple; dense fp32 pred maps (force_fp32, yolo_head.py:395)."""
+        assert len(feats) == self.num_levels
+        outs = []
+        for i, x in enumerate(feats):
+            x = self.convs_bridge[i].fwd(x)
+            conv = self.convs_pred[i]
+            co = conv.out_channels
+            w = conv.weight
+            dt = T.train_dtype(self, x)
+            padc = (-co) % (4 if dt == torch.float32 else 8)
+            if padc:
+                w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, padc))
+            outs.append(T.conv2d(x, w, 1, 0, dtype=dt)[:, :co].float() + conv.bias.view(1, -1, 1, 1))
+        return tuple(outs)
 
     def forward(self, feats):
         return self._dispatch((tuple(feats),), 'tuple'),
@@ -370,14 +399,89 @@ class YOLOV3Head(HipModule):
         plan.run(*[p.float() for p in pred_maps])
         return collect_results(plan.post, with_nms=True, head=self)
 
-    def loss(self, *args, **kwargs):
-        raise NotImplementedError('YOLOV3Head.loss (yolo_head.py:393-604) is not built')
+    # ---- training (yolo_head.py:393-560) ---------------------------------------------------------------
+    def loss(self, pred_maps, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
+        num_imgs = len(img_metas)
+        pred_maps = [p.float() for p in pred_maps]
+        device = pred_maps[0].device
+        featmap_sizes = [pred_maps[i].shape[-2:] for i in range(self.num_levels)]
+        multi_level_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device)
+        anchor_list = [multi_level_anchors for _ in range(num_imgs)]
+        responsible_flag_list = [self.anchor_generator.responsible_flags(featmap_sizes, gt_bboxes[i], device)
+                                 for i in range(num_imgs)]
+        target_maps_list, neg_maps_list = self.get_targets(anchor_list, responsible_flag_list, gt_bboxes, gt_labels)
+        res = [self.loss_single(p, t, n) for p, t, n in zip(pred_maps, target_maps_list, neg_maps_list)]
+        losses_cls, losses_conf, losses_xy, losses_wh = (list(x) for x in zip(*res))
+        return dict(loss_cls=losses_cls, loss_conf=losses_conf, loss_xy=losses_xy, loss_wh=losses_wh)
 
-    def forward_train(self, *args, **kwargs):
-        raise NotImplementedError('YOLOV3Head training is not built')
+    def loss_single(self, pred_map, target_map, neg_map):
+        num_imgs = len(pred_map)
+        pred_map = pred_map.permute(0, 2, 3, 1).reshape(num_imgs, -1, self.num_attrib)
+        neg_mask = neg_map.float()
+        pos_mask = target_map[..., 4]
+        pos_and_neg_mask = neg_mask + pos_mask
+        pos_mask = pos_mask.unsqueeze(dim=-1)
+        if torch.max(pos_and_neg_mask) > 1.:
+            warnings.warn('There is overlap between pos and neg sample.')
+            pos_and_neg_mask = pos_and_neg_mask.clamp(min=0., max=1.)
+        loss_cls = self.loss_cls(pred_map[..., 5:], target_map[..., 5:], weight=pos_mask)
+        loss_conf = self.loss_conf(pred_map[..., 4], target_map[..., 4], weight=pos_and_neg_mask)
+        loss_xy = self.loss_xy(pred_map[..., :2], target_map[..., :2], weight=pos_mask)
+        loss_wh = self.loss_wh(pred_map[..., 2:4], target_map[..., 2:4], weight=pos_mask)
+        return loss_cls, loss_conf, loss_xy, loss_wh
+
+    def get_targets(self, anchor_list, responsible_flag_list, gt_bboxes_list, gt_labels_list):
+        num_imgs = len(anchor_list)
+        num_level_anchors = [anchors.size(0) for anchors in anchor_list[0]]
+        res = [self._get_targets_single(a, f, b, l)
+               for a, f, b, l in zip(anchor_list, responsible_flag_list, gt_bboxes_list, gt_labels_list)]
+        all_target_maps, all_neg_maps = (list(x) for x in zip(*res))
+        assert num_imgs == len(all_target_maps) == len(all_neg_maps)
+        return _images_to_levels(all_target_maps, num_level_anchors), _images_to_levels(all_neg_maps, num_level_anchors)
+
+    def _get_targets_single(self, anchors, responsible_flags, gt_bboxes, gt_labels):
+        anchor_strides = torch.cat([torch.tensor(self.featmap_strides[i], device=gt_bboxes.device).repeat(len(anchors[i]))
+                                    for i in range(len(anchors))])
+        concat_anchors = torch.cat(anchors)
+        concat_responsible_flags = torch.cat(responsible_flags)
+        assert len(anchor_strides) == len(concat_anchors) == len(concat_responsible_flags)
+        assign_result = self.assigner.assign(concat_anchors, concat_responsible_flags, gt_bboxes)
+        sampling_result = self.sampler.sample(assign_result, concat_anchors, gt_bboxes)
+        target_map = concat_anchors.new_zeros(concat_anchors.size(0), self.num_attrib)
+        pos = sampling_result.pos_inds
+        target_map[pos, :4] = self.bbox_coder.encode(sampling_result.pos_bboxes, sampling_result.pos_gt_bboxes,
+                                                     anchor_strides[pos])
+        target_map[pos, 4] = 1
+        one_hot = F.one_hot(gt_labels, num_classes=self.num_classes).float()
+        if self.one_hot_smoother != 0:
+            one_hot = one_hot * (1 - self.one_hot_smoother) + self.one_hot_smoother / self.num_classes
+        target_map[pos, 5:] = one_hot[sampling_result.pos_assigned_gt_inds]
+        neg_map = concat_anchors.new_zeros(concat_anchors.size(0), dtype=torch.uint8)
+        neg_map[sampling_result.neg_inds] = 1
+        return target_map, neg_map
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
+                      **kwargs):
+        """base_dense_head.py:22-59."""
+        outs = self(x)
+        loss_inputs = outs + ((gt_bboxes, img_metas) if gt_labels is None else (gt_bboxes, gt_labels, img_metas))
+        losses = self.loss(*loss_inputs, gt_bboxes_ignore=gt_bboxes_ignore)
+        if proposal_cfg is None:
+            return losses
+        return losses, self.get_bboxes(*outs, img_metas, cfg=proposal_cfg)
 
     def aug_test(self, feats, img_metas, rescale=False):
         raise NotImplementedError('YOLOV3Head.aug_test (TTA) is not built')
+
+
+def _images_to_levels(target, num_levels):
+    """core/anchor/utils.py ``images_to_levels``: [per image: (A_total, ...)] -> [per level: (N, A_l, ...)]."""
+    target = torch.stack(target, 0)
+    out, start = [], 0
+    for n in num_levels:
+        out.append(target[:, start:start + n])
+        start += n
+    return out
 
 
 @DETECTORS.register_module()

@@ -148,3 +148,113 @@ def get_bboxes_v3(pred_maps, scale_factors, num_classes, nms_pre=1000, score_thr
         out.append(O.multiclass_nms(b, s, score_thr, dict(type='nms', iou_threshold=iou_threshold), max_per_img,
                                     score_factors=c))
     return out
+
+
+# =====================================================================================
+# Training side of YOLOV3Head -- yolo_head.py:393-560 (fp32, torch CPU)
+# =====================================================================================
+def responsible_flags(featmap_sizes, gt_bboxes, strides=V3_STRIDES, A=3):
+    """core/anchor/anchor_generator.py:667-727: 1 for the A boxes of every cell that holds a gt centre."""
+    out = []
+    for (h, w), s in zip(featmap_sizes, strides):
+        cx = (gt_bboxes[:, 0] + gt_bboxes[:, 2]) * 0.5
+        cy = (gt_bboxes[:, 1] + gt_bboxes[:, 3]) * 0.5
+        idx = torch.floor(cy / s).long() * w + torch.floor(cx / s).long()
+        grid = torch.zeros(h * w, dtype=torch.uint8)
+        grid[idx] = 1
+        out.append(grid[:, None].expand(h * w, A).contiguous().view(-1))
+    return out
+
+
+def _iou(b1, b2, eps=1e-6):
+    """core/bbox/iou_calculators/iou2d_calculator.py (mode 'iou'): (m,4),(n,4) -> (m,n)."""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = torch.max(b1[:, None, :2], b2[None, :, :2])
+    rb = torch.min(b1[:, None, 2:], b2[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    ov = wh[..., 0] * wh[..., 1]
+    union = torch.max(a1[:, None] + a2[None, :] - ov, ov.new_tensor([eps]))
+    return ov / union
+
+
+def grid_assign(bboxes, flags, gt_bboxes, pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.0):
+    """core/bbox/assigners/grid_assigner.py:73-156 (gt_max_assign_all=True): -1 / 0 / gt index + 1."""
+    G, B = gt_bboxes.size(0), bboxes.size(0)
+    ov = _iou(gt_bboxes, bboxes)
+    assigned = ov.new_full((B,), -1, dtype=torch.long)
+    if G == 0:
+        assigned[:] = 0
+        return assigned
+    mx, _ = ov.max(dim=0)
+    assigned[(mx >= 0) & (mx <= neg_iou_thr)] = 0
+    resp = flags.bool()
+    ov[:, ~resp] = -1.
+    mx, amx = ov.max(dim=0)
+    gmx, _ = ov.max(dim=1)
+    pos = (mx > pos_iou_thr) & resp
+    assigned[pos] = amx[pos] + 1
+    for i in range(G):
+        if gmx[i] > min_pos_iou:
+            assigned[(ov[i, :] == gmx[i]) & resp] = i + 1
+    return assigned
+
+
+def targets_v3(featmap_sizes, gt_bboxes_list, gt_labels_list, num_classes, base_sizes=V3_BASE_SIZES,
+               strides=V3_STRIDES):
+    """yolo_head.py:484-560: per level (N, A_l, 5+C) target maps and (N, A_l) uint8 negative maps."""
+    anchors = O.grid_anchors(featmap_sizes, base_sizes, strides)
+    cat = torch.cat(anchors)
+    astride = torch.cat([torch.tensor(s).repeat(len(a)) for a, s in zip(anchors, strides)])
+    tmaps, nmaps = [], []
+    for gtb, gtl in zip(gt_bboxes_list, gt_labels_list):
+        flags = torch.cat(responsible_flags(featmap_sizes, gtb, strides, anchors[0].shape[0] // (featmap_sizes[0][0] * featmap_sizes[0][1])))
+        assigned = grid_assign(cat, flags, gtb)
+        pos = torch.nonzero(assigned > 0, as_tuple=False).squeeze(-1).unique()
+        neg = torch.nonzero(assigned == 0, as_tuple=False).squeeze(-1).unique()
+        gi = assigned[pos] - 1
+        t = cat.new_zeros(cat.size(0), 5 + num_classes)
+        t[pos, :4] = yolo_bbox_encode(cat[pos], gtb[gi], astride[pos])
+        t[pos, 4] = 1
+        t[pos, 5:] = F.one_hot(gtl, num_classes=num_classes).float()[gi]
+        n = cat.new_zeros(cat.size(0), dtype=torch.uint8)
+        n[neg] = 1
+        tmaps.append(t)
+        nmaps.append(n)
+    T_, N_ = torch.stack(tmaps, 0), torch.stack(nmaps, 0)
+    out_t, out_n, start = [], [], 0
+    for a in anchors:
+        out_t.append(T_[:, start:start + a.size(0)])
+        out_n.append(N_[:, start:start + a.size(0)])
+        start += a.size(0)
+    return out_t, out_n
+
+
+def head_loss_v3(pred_maps, gt_bboxes, gt_labels, num_classes, w_cls=1.0, w_conf=1.0, w_xy=2.0, w_wh=2.0,
+                 base_sizes=V3_BASE_SIZES, strides=V3_STRIDES):
+    """yolo_head.py:395-482 with the loss configuration of configs/yolo/yolov3_d53_*: sigmoid BCE for cls /
+    conf / xy and MSE for wh, all reduction='sum', element-wise weights pos_mask / pos_and_neg_mask."""
+    pred_maps = [p.float() for p in pred_maps]
+    sizes = [p.shape[-2:] for p in pred_maps]
+    tmaps, nmaps = targets_v3(sizes, gt_bboxes, gt_labels, num_classes, base_sizes, strides)
+    bce = lambda p, t, w: (F.binary_cross_entropy_with_logits(p, t, reduction='none') * w).sum()
+    l_cls, l_conf, l_xy, l_wh = [], [], [], []
+    for pm, t, n in zip(pred_maps, tmaps, nmaps):
+        N = pm.shape[0]
+        pm = pm.permute(0, 2, 3, 1).reshape(N, -1, 5 + num_classes)
+        pos = t[..., 4]
+        pn = (n.float() + pos).clamp(0., 1.)
+        pos = pos.unsqueeze(-1)
+        l_cls.append(w_cls * bce(pm[..., 5:], t[..., 5:], pos))
+        l_conf.append(w_conf * bce(pm[..., 4], t[..., 4], pn))
+        l_xy.append(w_xy * bce(pm[..., :2], t[..., :2], pos))
+        l_wh.append(w_wh * (F.mse_loss(pm[..., 2:4], t[..., 2:4], reduction='none') * pos).sum())
+    return dict(loss_cls=l_cls, loss_conf=l_conf, loss_xy=l_xy, loss_wh=l_wh)
+
+
+def forward_train_v3(img, sd, layers, gt_bboxes, gt_labels, num_classes):
+    """detectors/single_stage.py:51-79 in training mode: batch-statistics BN (momentum 0.1, the mmcv
+    default every v3 module gets), loss dict out."""
+    with O._TrainBN(momentum_cfg=0.1, momentum_default=0.1):
+        preds = yolov3_head(yolov3_neck(darknet(img, sd, layers, (3, 4, 5)), sd), sd)
+    return head_loss_v3(preds, gt_bboxes, gt_labels, num_classes)

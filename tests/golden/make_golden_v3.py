@@ -50,6 +50,14 @@ def import_v3(ref):
     exp.add_dummy_nms_for_onnx = oh.add_dummy_nms_for_onnx
     sys.modules['mmdet.core.export'] = exp
     imp('mmdet.core.bbox.coder.yolo_bbox_coder')
+    # training side: GridAssigner + PseudoSampler (package __init__s pull unrelated assigners: bypass them)
+    for sub in ('core/bbox/assigners', 'core/bbox/samplers', 'utils'):
+        name = 'mmdet.' + sub.replace('/', '.')
+        if name not in sys.modules:
+            _ref_import._pkg(name, os.path.join(REF, 'mmdet', sub))
+    imp('mmdet.utils.util_mixins')
+    imp('mmdet.core.bbox.assigners.grid_assigner')
+    imp('mmdet.core.bbox.samplers.pseudo_sampler')
     # MSELoss is named by YOLOV3Head's defaults
     imp('mmdet.models.losses.mse_loss')
     return types.SimpleNamespace(darknet=imp('mmdet.models.backbones.darknet'),
@@ -128,12 +136,60 @@ def main():
     gt = torch.tensor([[-40., -30., 70., 60.], [-8., -20., 100., 58.], [20., -25., 130., 70.], [50., -33., 175., 55.]])
     data['coder/encode_gt'] = gt.numpy()
     data['coder/encode_s32'] = coder.encode(bboxes, gt, 32).numpy()
+    # ---- one training-mode forward + backward of the head's loss (yolo_head.py:393-560) ----------------
+    train_head = v3.head.YOLOV3Head(
+        num_classes=6, in_channels=[64, 32, 16], out_channels=[96, 64, 32],
+        loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0, reduction='sum'),
+        loss_conf=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0, reduction='sum'),
+        loss_xy=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=2.0, reduction='sum'),
+        loss_wh=dict(type='MSELoss', loss_weight=2.0, reduction='sum'),
+        train_cfg=ref.ConfigDict(assigner=dict(type='GridAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0)),
+        test_cfg=test_cfg)
+    train_head.load_state_dict(head.state_dict())
+    for m in (backbone, neck, train_head):
+        torch.nn.Module.train(m, True)       # batch-statistics BN everywhere (norm_eval is a Darknet.train() policy)
+    gt_bboxes = [torch.tensor([[8.0, 10.0, 40.0, 44.0], [50.5, 5.0, 95.0, 30.0], [20.0, 30.0, 28.0, 62.0]]),
+                 torch.tensor([[0.0, 0.0, 30.0, 20.0], [60.0, 20.0, 90.0, 63.5]])]
+    gt_labels = [torch.tensor([3, 1, 5]), torch.tensor([0, 4])]
+    for pm in (backbone, neck, train_head):
+        pm.zero_grad()
+    preds_t = train_head(neck(backbone(img)))[0]
+    losses = train_head.loss(preds_t, gt_bboxes, gt_labels, [dict(), dict()])
+    total = sum(sum(x.mean() for x in v) for k, v in losses.items() if 'loss' in k)
+    total.backward()
+    for k, v in losses.items():
+        data['train/' + k] = torch.stack([x.reshape(()) for x in v]).detach().numpy()
+    data['train/loss_total'] = total.detach().numpy()
+    names, sums = [], []
+    for pre, m in (('backbone', backbone), ('neck', neck), ('bbox_head', train_head)):
+        for n_, prm in m.named_parameters():
+            g_ = prm.grad
+            assert g_ is not None, n_
+            names.append(f'{pre}.{n_}')
+            sums.append([float(g_.double().sum()), float(g_.double().abs().sum()), float(g_.double().pow(2).sum().sqrt())])
+    data['train/grad_names'] = np.array(names)
+    data['train/grad_sums'] = np.array(sums)
+    data['train/grad/bbox_head.convs_pred.0.bias'] = train_head.convs_pred[0].bias.grad.numpy()
+    data['train/grad/bbox_head.convs_pred.2.weight'] = train_head.convs_pred[2].weight.grad.numpy()
+    data['train/grad/backbone.conv1.conv.weight'] = backbone.conv1.conv.weight.grad.numpy()
+    for i, (b_, l_) in enumerate(zip(gt_bboxes, gt_labels)):
+        data[f'train/gt_bboxes{i}'] = b_.numpy()
+        data[f'train/gt_labels{i}'] = l_.numpy()
+    # targets of the assigner for the same ground truth (per level: target map + negative map)
+    sizes_ = [p_.shape[-2:] for p_ in preds_t]
+    anchors_ = train_head.anchor_generator.grid_anchors(sizes_, 'cpu')
+    flags_ = [train_head.anchor_generator.responsible_flags(sizes_, gb, 'cpu') for gb in gt_bboxes]
+    tmaps, nmaps = train_head.get_targets([anchors_, anchors_], flags_, gt_bboxes, gt_labels)
+    for i, (t_, n_) in enumerate(zip(tmaps, nmaps)):
+        data[f'train/target_map{i}'] = t_.numpy()
+        data[f'train/neg_map{i}'] = n_.numpy()
     data['meta_layers'] = np.array(ARCH[0])
     data['meta_channels'] = np.array(ARCH[1])
     out = os.path.join(HERE, 'tiny_v3.npz')
     np.savez_compressed(out, **data)
     print('v3', out, f'{os.path.getsize(out) / 1e6:.2f} MB', 'dets', [data[f'dets{n}'].shape for n in range(N)],
-          'cfg2', [data[f'cfg2/dets{n}'].shape for n in range(N)])
+          'cfg2', [data[f'cfg2/dets{n}'].shape for n in range(N)], 'train loss', float(total),
+          {k: v.tolist() for k, v in data.items() if k.startswith('train/loss_')})
 
 
 if __name__ == '__main__':

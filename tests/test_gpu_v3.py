@@ -137,3 +137,56 @@ def test_v3_runs_in_16_bit(golden, gpu_device, dtype):
     tol = 2e-2 if dtype == torch.float16 else 1.5e-1
     for i, p in enumerate(preds):
         close(p, g[f'pred{i}'], tol, f'{dtype} pred{i}')
+
+
+def test_v3_train_step_matches_reference(golden, gpu_device):
+    """One training-mode forward + backward of YOLOV3 on the HIP training ops vs the reference: GridAssigner
+    targets exact, the four losses 1e-4, every parameter gradient (norms 1 %)."""
+    g = golden('tiny_v3')
+    train_cfg = dict(assigner=dict(type='GridAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0))
+    det = build(g, gpu_device)
+    sd = det.state_dict()
+    det.bbox_head = pkg.YOLOV3Head(
+        num_classes=6, in_channels=[64, 32, 16], out_channels=[96, 64, 32],
+        loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0, reduction='sum'),
+        loss_conf=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0, reduction='sum'),
+        loss_xy=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=2.0, reduction='sum'),
+        loss_wh=dict(type='MSELoss', loss_weight=2.0, reduction='sum'), train_cfg=train_cfg, test_cfg=TEST_CFG)
+    det.load_state_dict(sd)
+    det.to(gpu_device)
+    det.training = True
+    for m in (det.backbone, det.neck, det.bbox_head):
+        torch.nn.Module.train(m, True)     # batch-statistics BN everywhere, like the fixture (Darknet.train()'s norm_eval bypassed)
+    img = torch.from_numpy(g['img']).to(gpu_device)
+    gtb = [torch.from_numpy(g[f'train/gt_bboxes{i}']).to(gpu_device) for i in range(2)]
+    gtl = [torch.from_numpy(g[f'train/gt_labels{i}']).to(gpu_device) for i in range(2)]
+    # targets
+    sizes = [g[f'pred{i}'].shape[-2:] for i in range(3)]
+    anchors = det.bbox_head.anchor_generator.grid_anchors(sizes, gpu_device)
+    flags = [det.bbox_head.anchor_generator.responsible_flags(sizes, b, gpu_device) for b in gtb]
+    tm, nm = det.bbox_head.get_targets([anchors, anchors], flags, gtb, gtl)
+    for i in range(3):
+        np.testing.assert_allclose(tm[i].cpu().numpy(), g[f'train/target_map{i}'], rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(nm[i].cpu().numpy(), g[f'train/neg_map{i}'])
+    out = det.train_step(dict(img=img, img_metas=[dict(), dict()], gt_bboxes=gtb, gt_labels=gtl), None)
+    np.testing.assert_allclose(out['log_vars']['loss'], float(g['train/loss_total']), rtol=1e-4)
+    for k in ('loss_cls', 'loss_conf', 'loss_xy', 'loss_wh'):
+        np.testing.assert_allclose(out['log_vars'][k], float(g['train/' + k].sum()), rtol=1e-4, err_msg=k)
+    out['loss'].backward()
+    params = dict(det.named_parameters())
+    names = [str(n) for n in g['train/grad_names']]
+    assert names == list(params)
+    for i, n in enumerate(names):
+        gr = params[n].grad.double()
+        np.testing.assert_allclose([float(gr.abs().sum()), float(gr.pow(2).sum().sqrt())], g['train/grad_sums'][i][1:],
+                                   rtol=1e-2, atol=1e-5, err_msg=n)
+    for k in ('bbox_head.convs_pred.0.bias', 'bbox_head.convs_pred.2.weight', 'backbone.conv1.conv.weight'):
+        ref = g['train/grad/' + k]
+        np.testing.assert_allclose(params[k].grad.cpu().numpy(), ref, rtol=1e-2, atol=2e-3 * float(np.abs(ref).max()) + 2e-5)
+    # norm_eval (the Darknet default): BN statistics stay untouched by a training step
+    det.train()
+    bns = [m for m in det.backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert not any(m.training for m in bns)
+    rm = [m.running_mean.clone() for m in bns]
+    det.train_step(dict(img=img, img_metas=[dict(), dict()], gt_bboxes=gtb, gt_labels=gtl), None)['loss'].backward()
+    assert all(torch.equal(a, m.running_mean) for a, m in zip(rm, bns))

@@ -55,3 +55,33 @@ def test_yolo_bbox_coder_known_answers(golden):
     expect = torch.Tensor([[-53.6102, -10.3096, 83.7478, 49.6824], [-15.8700, -8.3901, 114.4236, 50.9693],
                            [11.1822, -8.0924, 146.6034, 50.4476], [41.2068, -8.9232, 181.4236, 48.5840]])
     assert V3.yolo_bbox_decode(bboxes, pred, 32).allclose(expect, atol=1e-3)
+
+
+def test_v3_training_targets_and_losses_match_reference(golden):
+    """GridAssigner targets and the four v3 losses / gradients of one training step vs the reference."""
+    g = golden('tiny_v3')
+    gtb = [torch.from_numpy(g['train/gt_bboxes0']), torch.from_numpy(g['train/gt_bboxes1'])]
+    gtl = [torch.from_numpy(g['train/gt_labels0']), torch.from_numpy(g['train/gt_labels1'])]
+    sizes = [g[f'pred{i}'].shape[-2:] for i in range(3)]
+    tm, nm = V3.targets_v3(sizes, gtb, gtl, 6)
+    for i in range(3):
+        np.testing.assert_array_equal(tm[i].numpy(), g[f'train/target_map{i}'])
+        np.testing.assert_array_equal(nm[i].numpy(), g[f'train/neg_map{i}'])
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and 'running' not in k else v.clone())
+          for k, v in state_dict_from(g).items()}
+    layers = [int(v) for v in g['meta_layers']]
+    losses = V3.forward_train_v3(torch.from_numpy(g['img']), sd, layers, gtb, gtl, 6)
+    for k in ('loss_cls', 'loss_conf', 'loss_xy', 'loss_wh'):
+        got = torch.stack([x.reshape(()) for x in losses[k]]).detach().numpy()
+        np.testing.assert_allclose(got, g['train/' + k], rtol=2e-5, atol=1e-5, err_msg=k)
+    total = sum(sum(x.mean() for x in v) for v in losses.values())
+    np.testing.assert_allclose(float(total), float(g['train/loss_total']), rtol=2e-5)
+    total.backward()
+    names = [str(n) for n in g['train/grad_names']]
+    sums = g['train/grad_sums']
+    for i, n in enumerate(names):
+        gr = sd[n].grad.double()
+        np.testing.assert_allclose([float(gr.abs().sum()), float(gr.pow(2).sum().sqrt())], sums[i][1:], rtol=2e-3,
+                                   atol=1e-6, err_msg=n)
+    np.testing.assert_allclose(sd['bbox_head.convs_pred.0.bias'].grad.numpy(), g['train/grad/bbox_head.convs_pred.0.bias'],
+                               rtol=1e-4, atol=1e-5)
