@@ -109,7 +109,7 @@ def main():
     el = D.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         per_img = {'yolov4l': 108.516e9 / 608.0 ** 2, 'yolov5l': 108.574e9 / 640.0 ** 2, 'yolov4s': 8.942e9 / 416.0 ** 2,
-                   'yolov3': 139.5e9 / 608.0 ** 2}     # Darknet-53 + neck + head conv FLOPs at 608 (plan.total_flops)
+                   'yolov3': 140.692e9 / 608.0 ** 2}    # 75 convs, Plan.total_flops() (= darknet's 140.69 BFLOPs)
         fl = 3 * per_img[a.model] * a.size ** 2      # fwd + dgrad + wgrad conv FLOPs
         print(json.dumps(dict(metric='images/sec (train step) ' + a.model, value=round(a.batch * world * a.steps / el, 2),
                               n_gpus=world, ms_per_step=round(el / a.steps * 1e3, 1), batch_per_gpu=a.batch,
