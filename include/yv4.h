@@ -405,6 +405,25 @@ int yv4_loss_scale_update(float* scale_state, const float* ctrl, float growth_fa
                           float backoff_factor, int growth_interval, void* stream);
 int yv4_ema_update(float* ema, const float* online, int64_t n, float momentum, void* stream);
 
+/* ---- evaluation: the reference's two Cython ops, batched over (image, class) problems ----------
+ * mmdet/ops/eval_utils/iou/iou_coco.pyx:8-56 and match/match_coco.pyx:8-57, called per image and class
+ * from core/evaluation/mean_ap_flexible.py:19-37.  Problem p owns detections [det_off[p], det_off[p+1])
+ * (rows of `det`, x1 y1 x2 y2), ground truths [gt_off[p], gt_off[p+1]) and the row-major
+ * (num_det x num_gt) IoU block at iou_off[p]; the offset tables have P+1 int64 entries (device).
+ * yv4_iou_coco_batched: IoU with the crowd convention (union = detection area for crowd gts), 0 for
+ *   non-overlapping pairs, union <= 0 -> 1e-7; bit-exact fp32.
+ * yv4_match_coco_batched: per IoU threshold t, detections in order take the best still-available gt
+ *   (crowd gts stay available; a match to a regular gt is not given up for an ignore gt);
+ *   matched[det_off[p]*num_thrs + t*num_det + d] = gt index inside the problem or -1.
+ *   work: num_thrs * total_gt bytes. */
+int yv4_iou_coco_batched(const float* det, const float* gt, const uint8_t* is_crowd,
+                         const int64_t* det_off, const int64_t* gt_off, const int64_t* iou_off,
+                         int P, int64_t total_pairs, float* iou, void* stream);
+int yv4_match_coco_batched(const float* iou, const int64_t* det_off, const int64_t* gt_off,
+                           const int64_t* iou_off, const float* iou_thrs, int num_thrs,
+                           const uint8_t* is_ignore, const uint8_t* is_crowd, int P, uint8_t* work,
+                           int32_t* matched, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

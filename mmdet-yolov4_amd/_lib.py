@@ -97,6 +97,8 @@ SIGNATURES = {
     'yv4_bn_eval_act_bwd': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i64,
                                       _i, _i, _f, _vp]),
     'yv4_spp_pool_bwd': (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    'yv4_iou_coco_batched': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    'yv4_match_coco_batched': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'yv4_grad_prepare': (C.c_int, [_vp, _i64, _vp, _f, _vp, _vp, _vp]),
     'yv4_sgd_step': (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _vp]),
     'yv4_loss_scale_update': (C.c_int, [_vp, _vp, _f, _f, _i, _vp]),
