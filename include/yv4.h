@@ -346,6 +346,31 @@ int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x_coff, cons
                        int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C,
                        int act, float slope, void* stream);
 
+/* SyncBN (the configs under configs/yolov5_ddp: norm_cfg type 'SyncBN' = torch.nn.SyncBatchNorm): the train-mode BN
+ * kernels above with the cross-rank exchange between their two halves.  Forward: yv4_bn_partial_sums
+ * leaves [sum x (C) | sum x^2 (C)] of the local rows in `work` (double); the caller all-reduces `work`
+ * (SUM) and the row count, then yv4_bn_finalize turns the totals into mean / invstd and updates the
+ * running statistics (unbiased variance over M_total).  Backward: yv4_bn_act_bwd_sums leaves
+ * [sum dz (C) | sum dz*xhat (C)] in `work` and writes the LOCAL dgamma / dbeta (what
+ * torch.nn.SyncBatchNorm returns: DDP averages them afterwards); the caller all-reduces `work`;
+ * yv4_bn_act_bwd_apply computes dx with the totals over M_total rows.  rows_dev (optional): the total
+ * row count as one double in device memory -- it is all-reduced together with the sums, so no host
+ * round trip is needed to learn it; when given it overrides M_total. */
+int yv4_bn_partial_sums(const void* x, int dtype, int64_t M, int C, int x_cstride, int x_coff,
+                        double* work, void* stream);
+int yv4_bn_finalize(const double* work, int64_t M_total, const double* rows_dev, int C, float eps,
+                    float momentum, float* mean, float* invstd, float* running_mean,
+                    float* running_var, void* stream);
+int yv4_bn_act_bwd_sums(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
+                        int dy_cstride, int dy_coff, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                        double* work, int64_t M, int C, int act, float slope, void* stream);
+int yv4_bn_act_bwd_apply(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
+                         int dy_cstride, int dy_coff, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, void* dx, int dx_cstride,
+                         int dx_coff, const double* work, int64_t M, int64_t M_total,
+                         const double* rows_dev, int C, int act, float slope, void* stream);
+
 /* One parity class of the data gradient of a stride-2 convolution: a stride-1 convolution of dY whose
  * output pixel (n, ho, wo) is stored at y[n, ho*sh + oh, wo*sw + ow, y_coff + c] of an
  * (N, Hy, Wy, y_cstride) tensor.  d->Ho / d->Wo are taken as given (rows past the input's edge read

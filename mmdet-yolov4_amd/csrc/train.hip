@@ -514,17 +514,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 }
 
 // mean / biased var / invstd from the sums; running stats update (unbiased var, momentum)
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M, int C, float eps, float momentum,
-                                   float* mean, float* invstd, float* running_mean, float* running_var) {
+// `rows`: optional device-resident row count (SyncBN: the all-reduced count travels with the sums)
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M_host, int C, float eps, float momentum,
+                                   float* mean, float* invstd, float* running_mean, float* running_var,
+                                   const double* __restrict__ rows) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double m = sums[c] / (double)M;
-  double var = sums[C + c] / (double)M - m * m;
+  const double M = rows ? *rows : (double)M_host;
+  const double m = sums[c] / M;
+  double var = sums[C + c] / M - m * m;
   if (var < 0) var = 0;
   mean[c] = (float)m;
   invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
   if (running_mean) {
-    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    const double unbiased = M > 1 ? var * M / (M - 1) : var;
     running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
     running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
   }
@@ -542,6 +545,9 @@ struct BnArgs {
   int64_t M; int C; int act; float slope;
   int rows_per_block;
   int eval_mode;     // backward of an eval-mode BN (running statistics are constants): no mean/variance terms
+  int64_t M_total;   // rows behind the statistics (= M, or the sum over ranks for SyncBN)
+  const double* rows; // optional device-resident M_total
+  int publish;       // the apply pass writes dgamma / dbeta from `sums` (not when `sums` were all-reduced)
 };
 
 // Elementwise passes use the reductions' thread map too: a thread keeps ONE channel quad (its
@@ -646,14 +652,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
   const RedMap mp = red_map(C4);
   const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
   const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
-  if (blockIdx.x == 0) {      // the reduction kernel has completed (stream order): publish dbeta / dgamma as fp32
+  if (blockIdx.x == 0 && p.publish) {   // the reduction kernel has completed (stream order): publish dbeta / dgamma as fp32
     for (int i = threadIdx.x; i < p.C; i += 256) {
       p.dbeta[i] = (float)p.sums[i];
       p.dgamma[i] = (float)p.sums[p.C + i];
     }
   }
   if (!mp.active) return;
-  const double invM = 1.0 / (double)p.M;
+  const double invM = 1.0 / (p.rows ? *p.rows : (double)p.M_total);
   for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
     const int c = cq * 4;
     float mu[4], is[4], ga[4], be[4], dbm[4], dgm[4];
@@ -864,10 +870,11 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
   return YV4_OK;
 }
 
+// phase: 0 = sums + finalize (one rank), 1 = sums only (SyncBN: the caller all-reduces `work`)
 static int bn_stats_impl(int dtype, const void* x, int64_t M, int C, int x_cstride, int x_coff, float eps, float momentum,
                          double* work, float* mean, float* invstd, float* running_mean, float* running_var,
-                         void* stream) {
-  YV4_REQUIRE(x && work && mean && invstd && M > 0 && C > 0, "bn_train_stats: bad argument");
+                         void* stream, int phase = 0) {
+  YV4_REQUIRE(x && work && (phase == 1 || (mean && invstd)) && M > 0 && C > 0, "bn_train_stats: bad argument");
   YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "bn_train_stats: dtype must be f32, f16 or bf16");
   YV4_REQUIRE(C % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0, "bn_train_stats: channels must be multiples of 4");
   YV4_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_stats: running stats come together");
@@ -878,8 +885,9 @@ static int bn_stats_impl(int dtype, const void* x, int64_t M, int C, int x_cstri
   dim3 grid((unsigned)((M + rpb - 1) / rpb));
   YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s,
                                            reinterpret_cast<const T*>(x), M, C, x_cstride, x_coff, work, rpb));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, M, C, eps, momentum, mean, invstd,
-                     running_mean, running_var);
+  if (phase == 0)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, M, C, eps, momentum, mean, invstd,
+                       running_mean, running_var, (const double*)nullptr);
   YV4_CHECK_LAUNCH("bn_train_stats");
   return YV4_OK;
 }
@@ -906,24 +914,41 @@ static int bn_fwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
 static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, const void* dy, int dy_cstride, int dy_coff,
                        const float* mean, const float* invstd, const float* gamma, const float* beta, void* dx,
                        int dx_cstride, int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C, int act,
-                       float slope, void* stream, int eval_mode = 0) {
-  YV4_REQUIRE(x && dy && mean && invstd && gamma && beta && dx && dgamma && dbeta && work && M > 0 && C > 0,
-              "bn_act_bwd: bad argument");
+                       float slope, void* stream, int eval_mode = 0, int phase = 0, int64_t M_total = 0,
+                       const double* rows_dev = nullptr) {
+  // phase 0: reduce + apply; 1: reduce only, dgamma / dbeta published from the LOCAL sums (SyncBN: the caller
+  // then all-reduces `work`); 2: apply only, `work` holding the sums over M_total rows
+  YV4_REQUIRE(x && dy && mean && invstd && gamma && beta && work && M > 0 && C > 0, "bn_act_bwd: bad argument");
+  YV4_REQUIRE(phase == 2 || (dgamma && dbeta), "bn_act_bwd: dgamma / dbeta missing");
+  YV4_REQUIRE(phase == 1 || dx, "bn_act_bwd: dx missing");
+  YV4_REQUIRE(phase != 2 || rows_dev || M_total >= M, "bn_act_bwd: total row count below the local one");
   YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "bn_act_bwd: dtype must be f32, f16 or bf16");
   YV4_REQUIRE(((C | x_cstride | x_coff | dy_cstride | dy_coff | dx_cstride | dx_coff) & 3) == 0,
               "bn_act_bwd: channels must be multiples of 4");
   YV4_REQUIRE(C <= 4096, "bn_act_bwd: more than 4096 channels");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) { set_error("bn_act_bwd: memset failed"); return YV4_E_LAUNCH; }
+  if (phase != 2 && hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) {
+    set_error("bn_act_bwd: memset failed");
+    return YV4_E_LAUNCH;
+  }
   BnArgs a = {};
   a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.dy = dy; a.dy_cs = dy_cstride; a.dy_co = dy_coff;
   a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dx_cs = dx_cstride; a.dx_co = dx_coff;
   a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope; a.eval_mode = eval_mode;
   a.dgamma = dgamma; a.dbeta = dbeta;
+  a.M_total = phase == 2 ? M_total : M;
+  a.publish = phase == 0;
+  a.rows = phase == 2 ? rows_dev : nullptr;
   a.rows_per_block = bn_rows_per_block(M);
   dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
-  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s, a));
-  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, grid, dim3(256), 0, s, a));
+  if (phase != 2)
+    YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s, a));
+  if (phase == 1) {
+    hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
+    hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
+  } else {
+    YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, grid, dim3(256), 0, s, a));
+  }
   YV4_CHECK_LAUNCH("bn_act_bwd");
   return YV4_OK;
 }
@@ -988,6 +1013,38 @@ extern "C" int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x
                                   double* work, int64_t M, int C, int act, float slope, void* stream) {
   return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
                      dx_coff, dgamma, dbeta, work, M, C, act, slope, stream);
+}
+
+// ---- SyncBN: the same kernels with the cross-rank exchange between their two halves -----------------
+extern "C" int yv4_bn_partial_sums(const void* x, int dtype, int64_t M, int C, int x_cstride, int x_coff, double* work,
+                                   void* stream) {
+  return bn_stats_impl(dtype, x, M, C, x_cstride, x_coff, 0.f, 0.f, work, nullptr, nullptr, nullptr, nullptr, stream, 1);
+}
+extern "C" int yv4_bn_finalize(const double* work, int64_t M_total, const double* rows_dev, int C, float eps,
+                               float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                               void* stream) {
+  YV4_REQUIRE(work && mean && invstd && (rows_dev || M_total > 0) && C > 0, "bn_finalize: bad argument");
+  YV4_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), work,
+                     M_total, C, eps, momentum, mean, invstd, running_mean, running_var, rows_dev);
+  YV4_CHECK_LAUNCH("bn_finalize");
+  return YV4_OK;
+}
+extern "C" int yv4_bn_act_bwd_sums(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,
+                                   int dy_coff, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float* dgamma, float* dbeta, double* work, int64_t M, int C,
+                                   int act, float slope, void* stream) {
+  return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, nullptr, 4, 0,
+                     dgamma, dbeta, work, M, C, act, slope, stream, 0, 1);
+}
+extern "C" int yv4_bn_act_bwd_apply(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,
+                                    int dy_coff, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, void* dx, int dx_cstride, int dx_coff, const double* work,
+                                    int64_t M, int64_t M_total, const double* rows_dev, int C, int act, float slope,
+                                    void* stream) {
+  return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
+                     dx_coff, nullptr, nullptr, const_cast<double*>(work), M, C, act, slope, stream, 0, 2, M_total,
+                     rows_dev);
 }
 
 extern "C" int yv4_bn_eval_act_bwd(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,

@@ -221,7 +221,10 @@ class BNActFunction(torch.autograd.Function):
     """Train-mode BatchNorm2d + activation (+ residual add) as one forward and one backward."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual, training=True):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual, training=True,
+                sync_group=None):
+        """``sync_group``: None, or a (process group or 'world') to synchronise the batch statistics over
+        (torch.nn.SyncBatchNorm semantics: statistics over all ranks' rows, local dgamma / dbeta)."""
         _need_cuda(x, 'x')
         if x.dtype not in _DCODE:
             x = x.float()
@@ -235,7 +238,23 @@ class BNActFunction(torch.autograd.Function):
         work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
         mean = torch.empty(Cc, dtype=torch.float32, device=dev)
         invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
-        if training:
+        rows = None
+        if training and sync_group is not None:
+            import torch.distributed as dist
+            group = None if sync_group == 'world' else sync_group
+            sums = torch.empty(2 * Cc + 1, dtype=torch.float64, device=dev)       # [sum | sum of squares | rows]
+            check(L.yv4_bn_partial_sums(x.data_ptr(), code, M, Cc, Cc, 0, sums.data_ptr(), stream_ptr()),
+                  'yv4_bn_partial_sums')
+            sums[2 * Cc:].fill_(float(M))
+            dist.all_reduce(sums, group=group)
+            rows = sums[2 * Cc:]
+            check(L.yv4_bn_finalize(sums.data_ptr(), 0, rows.data_ptr(), Cc, float(eps), float(momentum),
+                                    mean.data_ptr(), invstd.data_ptr(),
+                                    running_mean.data_ptr() if running_mean is not None else None,
+                                    running_var.data_ptr() if running_var is not None else None, stream_ptr()),
+                  'yv4_bn_finalize')
+            ctx.sync_group = group
+        elif training:
             check(L.yv4_bn_train_stats_h16(x.data_ptr(), code, M, Cc, Cc, 0, float(eps), float(momentum),
                                            work.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                            running_mean.data_ptr() if running_mean is not None else None,
@@ -252,6 +271,7 @@ class BNActFunction(torch.autograd.Function):
                                    b.data_ptr(), res.data_ptr() if res is not None else None, Cc, 0, y.data_ptr(), Cc,
                                    0, M, Cc, int(act), float(slope), stream_ptr()), 'yv4_bn_act_fwd')
         ctx.save_for_backward(x, mean, invstd, g, b)
+        ctx.rows = rows
         ctx.act = (int(act), float(slope))
         ctx.training = bool(training)
         ctx.has_res = residual is not None
@@ -270,13 +290,41 @@ class BNActFunction(torch.autograd.Function):
         dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
         dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
         work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
-        fn = _lib.lib().yv4_bn_act_bwd_h16 if ctx.training else _lib.lib().yv4_bn_eval_act_bwd
-        check(fn(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
-                 invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
-                 dgamma.data_ptr(), dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope,
-                 stream_ptr()), 'yv4_bn_act_bwd')
+        L = _lib.lib()
+        if ctx.rows is not None:            # SyncBN: local sums -> all-reduce -> apply with the totals
+            import torch.distributed as dist
+            check(L.yv4_bn_act_bwd_sums(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+                                        invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dgamma.data_ptr(),
+                                        dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope, stream_ptr()),
+                  'yv4_bn_act_bwd_sums')
+            dist.all_reduce(work, group=ctx.sync_group)
+            check(L.yv4_bn_act_bwd_apply(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+                                         invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
+                                         work.data_ptr(), M, 0, ctx.rows.data_ptr(), Cc, act, slope, stream_ptr()),
+                  'yv4_bn_act_bwd_apply')
+        else:
+            fn = L.yv4_bn_act_bwd_h16 if ctx.training else L.yv4_bn_eval_act_bwd
+            check(fn(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+                     invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
+                     dgamma.data_ptr(), dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope,
+                     stream_ptr()), 'yv4_bn_act_bwd')
         dres = dy if ctx.has_res else None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None
+
+
+def _sync_group(bn):
+    """The group a ``torch.nn.SyncBatchNorm`` (norm_cfg type 'SyncBN', configs/yolov5_ddp) synchronises over:
+    its ``process_group`` or the world; None for a plain BatchNorm2d or a single-process run (torch's
+    SyncBatchNorm also falls back to local statistics when world_size == 1, batchnorm.py ``need_sync``)."""
+    import torch.distributed as dist
+    if not isinstance(bn, torch.nn.SyncBatchNorm) or not bn.training:
+        return None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn.process_group
+    if dist.get_world_size(group) <= 1:
+        return None
+    return group if group is not None else 'world'
 
 
 def bn_act(x, bn, act=(0, 0.0), residual=None):
@@ -287,7 +335,7 @@ def bn_act(x, bn, act=(0, 0.0), residual=None):
     use_batch = bn.training or not bn.track_running_stats
     out = BNActFunction.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                               bn.running_var if bn.track_running_stats else None, bn.eps, mom, act[0], act[1],
-                              residual, use_batch)
+                              residual, use_batch, _sync_group(bn) if use_batch else None)
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return out

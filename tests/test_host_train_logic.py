@@ -255,3 +255,18 @@ def test_grad_reducer_buckets_cover_the_arena_and_fire_in_backward():
     with pytest.raises(RuntimeError):
         red.finish()
     red.remove()
+
+
+def test_syncbn_norm_cfg_builds_and_selects_group():
+    """configs/yolov5_ddp: norm_cfg type 'SyncBN' -> torch.nn.SyncBatchNorm; the HIP BN path synchronises only
+    for a training-mode SyncBatchNorm inside an initialised group of more than one rank."""
+    import torch
+    import mmdet_yolov4_amd as pkg
+    from mmdet_yolov4_amd import train_ops as T
+    bk = pkg.build_backbone(dict(type='DarknetCSP', scale=[['conv', 'bottleneck', 'csp'], [None, 1, 1], [4, 8, 16]],
+                                 out_indices=[1, 2], norm_cfg=dict(type='SyncBN', requires_grad=True, eps=0.001,
+                                                                   momentum=0.03)))
+    bns = [m for m in bk.modules() if isinstance(m, torch.nn.SyncBatchNorm)]
+    assert bns and all(b.eps == 0.001 and b.momentum == 0.03 for b in bns)
+    assert T._sync_group(bns[0].train()) is None                  # no process group in this process
+    assert T._sync_group(torch.nn.BatchNorm2d(4).train()) is None
