@@ -430,6 +430,50 @@ int yv4_loss_scale_update(float* scale_state, const float* ctrl, float growth_fa
                           float backoff_factor, int growth_interval, void* stream);
 int yv4_ema_update(float* ema, const float* online, int64_t n, float momentum, void* stream);
 
+/* ---- YOLOCSPHead training loss, forward and backward ------------------------------------------
+ * Replaces responsible_indices (core/anchor/yolov4_anchor_generator.py:12-134, neighbor = 2),
+ * get_targets_no_assigner + loss_single_no_assigner (models/dense_heads/yolocsp_head.py:437-575), the
+ * decode (yolov4_bbox_coder.py:39-67), aligned GIoU and the three sigmoid-BCE / GIoU reductions for ALL
+ * levels: forward = assign + positives + dense objectness pass, backward = positives + one pass that
+ * writes the whole gradient of each level's head-conv output (its dtype, its NHWC layout) and the bias
+ * gradient.  Nothing returns to the host in between.
+ *   raw:   (N, H, W, Cp) head conv output WITHOUT bias, channel c = a*(5+C) + j, Cp >= A*(5+C)
+ *   gt (G,4) fp32 x1 y1 x2 y2, gt_label (G) int64, gt_img (G) int64: the batch's ground truths concatenated
+ *   candidate slot s = (k*A + a)*G + g  (k: 0 own cell, 1 left, 2 up, 3 right, 4 down) -- the position the
+ *   positive has in the reference's index lists; duplicates of one anchor box resolve to the largest s
+ *   (what the reference's index_put gives when run in order), deterministically.
+ * work buffers (device): slot_anchor, conf_t: L*5*A*G; winner: N*anchors-per-image int32; npos: L int32;
+ *   sums: L*3 double = [sum of class BCE | sum of objectness BCE | sum of (1 - GIoU)] per level;
+ *   gpos (backward): L*5*A*G*(5+C) float.
+ * Losses (host, from sums/npos): cls = w_cls*sum/(npos*C), conf = w_conf*sum/(N*H*W*A), bbox = w_bbox*sum/npos.
+ * yv4_yolo_loss_bwd: grad_out (L,3) float (device) = upstream gradients of [cls, conf, bbox] per level. */
+#define YV4_LOSS_MAX_LEVELS 5
+typedef struct yv4_loss_level {
+  const void* raw;
+  void* draw;          /* backward: gradient of raw, same shape / dtype */
+  const float* bias;   /* A*(5+C) */
+  double* dbias;       /* backward: A*(5+C) */
+  int32_t H, W, Cp, stride;
+  float base_anchors[8][4];
+} yv4_loss_level;
+typedef struct yv4_loss_desc {
+  yv4_loss_level levels[YV4_LOSS_MAX_LEVELS];
+  int32_t num_levels, N, A, num_classes /* 0: class-agnostic */, G, dtype;
+  const float* gt;
+  const int64_t* gt_label;
+  const int64_t* gt_img;
+  float shape_thr, smooth /* one_hot_smoother */, ratio /* conf_iou_loss_ratio */, eps /* GIoU */;
+  float w_cls, w_conf, w_bbox;
+  int32_t* slot_anchor;
+  int32_t* winner;
+  int32_t* npos;
+  float* conf_t;
+  float* gpos;
+  double* sums;
+} yv4_loss_desc;
+int yv4_yolo_loss_fwd(const yv4_loss_desc* d, void* stream);
+int yv4_yolo_loss_bwd(const yv4_loss_desc* d, const float* grad_out, void* stream);
+
 /* ---- evaluation: the reference's two Cython ops, batched over (image, class) problems ----------
  * mmdet/ops/eval_utils/iou/iou_coco.pyx:8-56 and match/match_coco.pyx:8-57, called per image and class
  * from core/evaluation/mean_ap_flexible.py:19-37.  Problem p owns detections [det_off[p], det_off[p+1])

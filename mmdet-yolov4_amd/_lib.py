@@ -39,6 +39,25 @@ class LevelDesc(C.Structure):
                 ('stride', C.c_int32), ('base_anchors', (C.c_float * 4) * 8)]
 
 
+class LossLevel(C.Structure):
+    """``yv4_loss_level``."""
+    _fields_ = [('raw', C.c_void_p), ('draw', C.c_void_p), ('bias', C.c_void_p), ('dbias', C.c_void_p),
+                ('H', C.c_int32), ('W', C.c_int32), ('Cp', C.c_int32), ('stride', C.c_int32),
+                ('base_anchors', (C.c_float * 4) * 8)]
+
+
+class LossDesc(C.Structure):
+    """``yv4_loss_desc``."""
+    _fields_ = [('levels', LossLevel * 5),
+                ('num_levels', C.c_int32), ('N', C.c_int32), ('A', C.c_int32), ('num_classes', C.c_int32),
+                ('G', C.c_int32), ('dtype', C.c_int32),
+                ('gt', C.c_void_p), ('gt_label', C.c_void_p), ('gt_img', C.c_void_p),
+                ('shape_thr', C.c_float), ('smooth', C.c_float), ('ratio', C.c_float), ('eps', C.c_float),
+                ('w_cls', C.c_float), ('w_conf', C.c_float), ('w_bbox', C.c_float),
+                ('slot_anchor', C.c_void_p), ('winner', C.c_void_p), ('npos', C.c_void_p), ('conf_t', C.c_void_p),
+                ('gpos', C.c_void_p), ('sums', C.c_void_p)]
+
+
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 #: every exported symbol: name -> (restype, argtypes).  tests/test_abi.py checks
@@ -101,6 +120,8 @@ SIGNATURES = {
     'yv4_bn_finalize': (C.c_int, [_vp, _i64, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'yv4_bn_act_bwd_sums': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp]),
     'yv4_bn_act_bwd_apply': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i64, _vp, _i, _i, _f, _vp]),
+    'yv4_yolo_loss_fwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
+    'yv4_yolo_loss_bwd': (C.c_int, [C.POINTER(LossDesc), _vp, _vp]),
     'yv4_iou_coco_batched': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     'yv4_match_coco_batched': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'yv4_grad_prepare': (C.c_int, [_vp, _i64, _vp, _f, _vp, _vp, _vp]),

@@ -6,11 +6,10 @@ Mirror of ``mmdet/models/dense_heads/yolocsp_head.py:384-575`` (``loss``,
 ``mmdet/core/bbox/iou_calculators/iou2d_calculator.py:74-260`` and sigmoid
 ``CrossEntropyLoss`` (``mmdet/models/losses/cross_entropy_loss.py:58-91,142-214``).
 
-These are elementwise / gather ops over a few thousand positives plus one BCE over the
-objectness logits; like the reference they are expressed with torch tensor ops (on the GPU the
-tensors live on) and differentiated by autograd.  The dense part of the training step --
-convolutions, BatchNorm, activations -- runs on the HIP kernels (``train_ops.py``); fusing the
-loss into <= 3 kernels is listed in DESIGN.md as follow-up work.
+The training step's default configuration (sigmoid BCE + GIoU, no assigner) runs on the fused HIP loss
+(``csrc/loss.hip`` via ``YoloLossFunction`` in ``yolocsp_head.py``).  The classes here are the registry
+entries the configs name, the tensor-op statement of the same arithmetic (used for dense pred maps,
+non-default loss settings and as the GPU-side cross-check in the tests) and YOLOV3Head's losses.
 """
 import torch
 import torch.nn.functional as F

@@ -12,14 +12,18 @@ yolocsp_head.py:263-285,357-366 + bbox_nms.py:36-67) and ``yv4_nms_images``
 per-image python loop (:298-309), its (anchors x 81) score matrix and its 29 MB expanded
 box tensor never exist.
 """
+import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from . import losses as _losses  # noqa: F401  (registers GIoULoss / CrossEntropyLoss / SoftFocalLoss)
 from . import ops
+from ._lib import check
 from . import train_ops as T
 from .bricks import HipModule, normal_init
 from .plan import Plan
@@ -58,11 +62,96 @@ class HeadTapFunction(torch.autograd.Function):
         dbias = torch.zeros(nb, dtype=torch.float32, device=dconf.device)
         dc = dconf.reshape(N, H, W, A)
         d[..., 4:A * attr:attr] = dc.to(dtype)
-        dbias[4::attr] = dc.sum((0, 1, 2))
+        # (rows, A) -> A long contiguous rows: ATen's reduction over the OUTER dims of a 3-column matrix runs on
+        # a handful of workgroups (5.8 ms for the stride-8 level at batch 64); the transposed copy is 13 MB
+        dbias[4::attr] = dc.reshape(-1, A).t().contiguous().sum(1)
         if rows.numel():
             d.view(N * H * W, Cp).index_put_((rows[:, None], cols), dpos.to(dtype), accumulate=True)
             dbias.index_put_((cols.reshape(-1),), dpos.reshape(-1).float(), accumulate=True)
         return draw, dbias, None, None, None, None
+
+
+class YoloLossFunction(torch.autograd.Function):
+    """All levels' ``loss_single_no_assigner`` (+ ``responsible_indices`` and the target gathering) on
+    ``yv4_yolo_loss_fwd`` / ``yv4_yolo_loss_bwd``: returns the (num_levels, 3) fp32 matrix
+    [loss_cls, loss_conf (before the level balance weight), loss_bbox * loss_bbox_weight]; the backward
+    writes each level's whole conv-output gradient and bias gradient in one pass.  Nothing is read back
+    by the host in either direction (the reference path has two ``nonzero()`` syncs per level)."""
+
+    @staticmethod
+    def forward(ctx, head, gt, gt_label, gt_img, *maps):
+        L = head.num_levels
+        raws, biases = maps[:L], maps[L:]
+        dev = raws[0].device
+        A = head.num_anchors[0]
+        C_ = 0 if head.class_agnostic else head.num_classes
+        attr = 5 + C_
+        N = raws[0].shape[0]
+        G = int(gt.shape[0])
+        d = _lib.LossDesc()
+        d.num_levels, d.N, d.A, d.num_classes, d.G = L, N, A, C_, G
+        d.dtype = T._DCODE[raws[0].dtype]
+        keep = []
+        TA = 0
+        for l in range(L):
+            raw = raws[l]
+            _, Cp, H, W = raw.shape
+            assert raw.permute(0, 2, 3, 1).is_contiguous(), 'fused loss: the conv output must be channels_last'
+            assert head.num_anchors[l] == A and raw.dtype == raws[0].dtype
+            b = biases[l].detach().float().contiguous()
+            keep.append(b)
+            lv = d.levels[l]
+            lv.raw, lv.bias = raw.data_ptr(), b.data_ptr()
+            lv.H, lv.W, lv.Cp, lv.stride = H, W, Cp, int(head.featmap_strides[l])
+            ba = head.anchor_generator.base_anchors[l].float().cpu()
+            for k in range(A):
+                for c in range(4):
+                    lv.base_anchors[k][c] = float(ba[k, c])
+            TA += H * W * A
+        S = 5 * A * G
+        i32 = dict(dtype=torch.int32, device=dev)
+        slot_anchor = torch.empty(max(L * S, 1), **i32)
+        winner = torch.empty(N * TA, **i32)
+        npos = torch.empty(L, **i32)
+        conf_t = torch.empty(max(L * S, 1), dtype=torch.float32, device=dev)
+        sums = torch.empty(L, 3, dtype=torch.float64, device=dev)
+        gt = gt.detach().float().contiguous()
+        gt_label = gt_label.long().contiguous()
+        d.gt, d.gt_label, d.gt_img = gt.data_ptr(), gt_label.data_ptr(), gt_img.data_ptr()
+        d.shape_thr, d.smooth, d.ratio = float(head.shape_match_thres), float(head.one_hot_smoother), \
+            float(head.conf_iou_loss_ratio)
+        d.eps = float(head.loss_bbox.eps)
+        d.w_cls = float(head.loss_cls.loss_weight) if C_ else 0.
+        d.w_conf, d.w_bbox = float(head.loss_conf.loss_weight), float(head.loss_bbox_weight)
+        d.slot_anchor, d.winner, d.npos, d.conf_t, d.sums = (t.data_ptr() for t in (slot_anchor, winner, npos, conf_t,
+                                                                                   sums))
+        check(_lib.lib().yv4_yolo_loss_fwd(C.byref(d), ops.stream_ptr()), 'yv4_yolo_loss_fwd')
+        ctx.desc = d
+        ctx.keep = (raws, keep, gt, gt_label, gt_img, slot_anchor, winner, npos, conf_t, sums)
+        ctx.meta = (L, S, A, attr)
+        n = npos.double()
+        has = n > 0
+        per_pos = torch.where(has, 1. / n.clamp(min=1), torch.zeros_like(n))
+        boxes = sums.new_tensor([float(N * r.shape[2] * r.shape[3] * A) for r in raws])
+        out = torch.stack([sums[:, 0] * per_pos / max(C_, 1) * d.w_cls, sums[:, 1] / boxes * d.w_conf,
+                           sums[:, 2] * per_pos * d.w_bbox], dim=1)
+        return out.float()
+
+    @staticmethod
+    def backward(ctx, gout):
+        d = ctx.desc
+        raws = ctx.keep[0]
+        L, S, A, attr = ctx.meta
+        dev = raws[0].device
+        gout = gout.float().contiguous()
+        draws = [torch.empty_like(r) for r in raws]
+        dbias = [torch.empty(A * attr, dtype=torch.float64, device=dev) for _ in range(L)]
+        gpos = torch.empty(max(L * S * attr, 1), dtype=torch.float32, device=dev)
+        for l in range(L):
+            d.levels[l].draw, d.levels[l].dbias = draws[l].data_ptr(), dbias[l].data_ptr()
+        d.gpos = gpos.data_ptr()
+        check(_lib.lib().yv4_yolo_loss_bwd(C.byref(d), gout.data_ptr(), ops.stream_ptr()), 'yv4_yolo_loss_bwd')
+        return (None, None, None, None) + tuple(draws) + tuple(b.float() for b in dbias)
 
 
 class RawPredMap:
@@ -259,6 +348,8 @@ class YOLOCSPHead(HipModule):
         featmap_sizes = [pred_maps[i].shape[-2:] for i in range(self.num_levels)]
         if self.assigner is not None:
             raise NotImplementedError
+        if self._fused_loss_ok(pred_maps):
+            return self._loss_fused(pred_maps, gt_bboxes, gt_labels, num_gts)
         resp = self.anchor_generator.responsible_indices(
             featmap_sizes, gt_bboxes, neighbor=2, shape_match_thres=self.shape_match_thres, device=device)
         pos, tb, tl = self.get_targets_no_assigner(resp, gt_bboxes, gt_labels)
@@ -270,6 +361,36 @@ class YOLOCSPHead(HipModule):
             l_cls.append(c)
             l_conf.append(f * self.conf_level_balance_weight[lvl])
             l_box.append(b)
+        if not self.class_agnostic:
+            return dict(loss_cls=l_cls, loss_conf=l_conf, loss_bbox=l_box, num_gts=num_gts)
+        return dict(loss_conf=l_conf, loss_bbox=l_box, num_gts=num_gts)
+
+    def _fused_loss_ok(self, pred_maps):
+        """The fused kernels cover the configuration the recipes use: raw (training-mode) maps, sigmoid
+        CrossEntropyLoss without class weights and GIoULoss, both with mean reduction.  Anything else takes the
+        tensor-op path below (on the GPU as well).  YV4_FUSED_LOSS=0 forces that path (A/B, tests)."""
+        if os.environ.get('YV4_FUSED_LOSS', '1') == '0':
+            return False
+        if not all(isinstance(p, RawPredMap) for p in pred_maps) or len(pred_maps) > 5:
+            return False
+        ok = type(self.loss_conf) is _losses.CrossEntropyLoss and type(self.loss_bbox) is _losses.GIoULoss
+        ok = ok and self.loss_conf.class_weight is None and self.loss_conf.reduction == 'mean'
+        ok = ok and self.loss_bbox.reduction == 'mean'
+        if not self.class_agnostic:
+            ok = ok and type(self.loss_cls) is _losses.CrossEntropyLoss and self.loss_cls.class_weight is None \
+                and self.loss_cls.reduction == 'mean'
+        return ok and len(set(self.num_anchors)) == 1 and self.num_anchors[0] <= 8
+
+    def _loss_fused(self, pred_maps, gt_bboxes, gt_labels, num_gts):
+        device = pred_maps[0].device
+        sizes = [int(g.shape[0]) for g in gt_bboxes]
+        gt = torch.cat(list(gt_bboxes), dim=0).reshape(-1, 4)
+        labels = torch.cat(list(gt_labels), dim=0).reshape(-1)
+        img = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(device, non_blocking=True)
+        out = YoloLossFunction.apply(self, gt, labels, img, *[p.raw for p in pred_maps], *[p.bias for p in pred_maps])
+        l_cls = [out[l, 0].reshape(1) for l in range(self.num_levels)]
+        l_conf = [out[l, 1] * self.conf_level_balance_weight[l] for l in range(self.num_levels)]
+        l_box = [out[l, 2].reshape(1) for l in range(self.num_levels)]
         if not self.class_agnostic:
             return dict(loss_cls=l_cls, loss_conf=l_conf, loss_bbox=l_box, num_gts=num_gts)
         return dict(loss_conf=l_conf, loss_bbox=l_box, num_gts=num_gts)
