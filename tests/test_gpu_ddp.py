@@ -1,0 +1,138 @@
+"""Data-parallel training step end to end on the HIP kernels: two processes share cuda:0, gloo group
+(the only 2-rank transport a 1-GPU box offers; the same calls run over RCCL on a node).
+Rank r runs forward_train on ITS shard with SyncBN + the fused loss, the GradReducer all-reduces the flat
+gradient arena from backward hooks.  Every rank then checks the exchanged gradients against the same
+quantity computed by ONE process: BatchNorm over the concatenated batch, the loss of each shard averaged
+(what DDP's gradient averaging means).  Tolerance 1e-5 of each parameter's largest gradient entry (fp32
+kernels; the two computations order their reductions differently; measured 1e-6)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import torch
+    import torch.distributed as dist
+    import mmdet_yolov4_amd as pkg
+    from mmdet_yolov4_amd import dist as D
+    from mmdet_yolov4_amd.flat_state import FlatState
+    from mmdet_yolov4_amd.yolocsp_head import RawPredMap
+    rank = int(os.environ['RANK'])
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    dev = torch.device('cuda', 0)
+
+    def build(norm):
+        torch.manual_seed(0)
+        det = pkg.build_detector(dict(
+            type='SingleStageDetector',
+            backbone=dict(type='DarknetCSP', scale=[['conv', 'bottleneck', 'csp', 'csp', 'csp'], [None, 1, 1, 1, 1],
+                                                    [8, 16, 16, 32, 32]],
+                          out_indices=[2, 3, 4], norm_cfg=dict(type=norm, requires_grad=True, eps=0.001, momentum=0.03)),
+            neck=dict(type='YOLOV4Neck', in_channels=[16, 32, 32], out_channels=[16, 32, 32], csp_repetition=1,
+                      norm_cfg=dict(type=norm, requires_grad=True, eps=0.001, momentum=0.03)),
+            bbox_head=dict(type='YOLOCSPHead', num_classes=4, in_channels=[16, 32, 32], featmap_strides=[4, 8, 16],
+                           anchor_generator=dict(type='YOLOV4AnchorGenerator', strides=[4, 8, 16],
+                                                 base_sizes=[[(6, 8), (10, 6), (12, 12)], [(16, 20), (24, 16), (28, 30)],
+                                                             [(40, 36), (50, 60), (64, 64)]]))))
+        det.init_weights()
+        return det.train().to(dev)
+
+    def data(r, n):
+        g = torch.Generator().manual_seed(50 + r)
+        img = torch.randn(n, 3, 64, 64, generator=g).to(dev)
+        boxes, labels = [], []
+        for _ in range(n):
+            k = int(torch.randint(1, 4, (1,), generator=g))
+            c = torch.rand(k, 2, generator=g) * 64
+            wh = torch.rand(k, 2, generator=g) * 30 + 6
+            boxes.append(torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, 64).to(dev))
+            labels.append(torch.randint(0, 4, (k,), generator=g).to(dev))
+        return img, boxes, labels
+
+    def total(losses):
+        return sum(sum(x.mean() for x in v) if isinstance(v, (list, tuple)) else v.mean()
+                   for k, v in losses.items() if 'loss' in k)
+
+    sizes = [2, 3]                                          # ragged shards
+    # (no 'sppv4' stage: the reference's SPPV4Stage builds its SPPV4 without the norm_cfg, darknetcsp.py:313-314,
+    # so those BatchNorms stay per-rank under a SyncBN config -- mirrored by this package, and not what is tested here)
+    det = build('SyncBN')
+    start = {k: v.clone() for k, v in det.state_dict().items()}
+    fs = FlatState(det)
+    red = D.GradReducer(fs, bucket_mb=0.05)
+    img, boxes, labels = data(rank, sizes[rank])
+    fs.zero_grad()
+    red.arm()
+    loss = total(det(img=img, img_metas=[dict()] * sizes[rank], gt_bboxes=boxes, gt_labels=labels))
+    loss.backward()
+    launched = all(red._launched)
+    red.finish()
+    torch.cuda.synchronize()
+
+    # ---- the same step by one process --------------------------------------------------------------
+    ref = build('BN')
+    ref.load_state_dict(start)
+    shards = [data(r, sizes[r]) for r in range(2)]
+    feats = ref.extract_feat(torch.cat([s[0] for s in shards], 0))
+    maps = ref.bbox_head.fwd_raw(feats)
+    tot, lo, fwd_err = 0, 0, 0.0
+    for r in range(2):
+        part = [RawPredMap(m.raw[lo:lo + sizes[r]], m.bias, m.A, m.attr) for m in maps]
+        lr = total(ref.bbox_head.loss(part, shards[r][1], shards[r][2], None))
+        if r == rank:
+            fwd_err = abs(float(lr) - float(loss)) / abs(float(lr))
+        tot = tot + 0.5 * lr
+        lo += sizes[r]
+    tot.backward()
+    worst, name = 0.0, ''
+    errs = []
+    for (n, p), q in zip(det.named_parameters(), ref.parameters()):
+        e = float((p.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-12))
+        errs.append((e, n, float(q.grad.abs().max())))
+        if e > worst:
+            worst, name = e, n
+    if os.environ.get('YV4_TEST_VERBOSE'):
+        for e in sorted(errs, reverse=True)[:25]:
+            print('ERR', e, flush=True)
+    stats = max(float((a - b).abs().max()) for (_, a), (_, b) in zip(det.named_buffers(), ref.named_buffers())
+                if a.dtype.is_floating_point)
+    print('RESULT ' + json.dumps(dict(rank=rank, fwd_err=fwd_err, worst=worst, name=name, stats=stats, launched=launched,
+                                      nb=len(red.buckets), gsum=float(fs.grads.double().sum()))), flush=True)
+    dist.destroy_process_group()
+''')
+
+
+def test_two_rank_step_equals_one_process_big_batch(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % ROOT)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, out
+        if os.environ.get('YV4_TEST_VERBOSE'):
+            print(out)
+        outs.append(json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][0][7:]))
+    for o in outs:
+        assert o['nb'] > 1 and o['launched']                  # buckets went out from the backward hooks
+        assert o['worst'] < 1e-5, o                           # exchanged gradients == one-process gradients
+        assert o['stats'] < 1e-5, o                           # running statistics == big-batch BatchNorm's
+    assert outs[0]['gsum'] == outs[1]['gsum']                 # both ranks hold the same reduced arena
