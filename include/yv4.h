@@ -349,7 +349,8 @@ int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x_coff, cons
 /* SyncBN (the configs under configs/yolov5_ddp: norm_cfg type 'SyncBN' = torch.nn.SyncBatchNorm): the train-mode BN
  * kernels above with the cross-rank exchange between their two halves.  Forward: yv4_bn_partial_sums
  * leaves [sum x (C) | sum x^2 (C)] of the local rows in `work` (double); the caller all-reduces `work`
- * (SUM) and the row count, then yv4_bn_finalize turns the totals into mean / invstd and updates the
+ * (SUM) and the row count, then yv4_bn_finalize (replicas = 1; > 1: `work` is that many consecutive
+ * [2*C] blocks to be added up first, see yv4_conv_fwd_stats) turns the totals into mean / invstd and updates the
  * running statistics (unbiased variance over M_total).  Backward: yv4_bn_act_bwd_sums leaves
  * [sum dz (C) | sum dz*xhat (C)] in `work` and writes the LOCAL dgamma / dbeta (what
  * torch.nn.SyncBatchNorm returns: DDP averages them afterwards); the caller all-reduces `work`;
@@ -358,8 +359,17 @@ int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x_coff, cons
  * round trip is needed to learn it; when given it overrides M_total. */
 int yv4_bn_partial_sums(const void* x, int dtype, int64_t M, int C, int x_cstride, int x_coff,
                         double* work, void* stream);
-int yv4_bn_finalize(const double* work, int64_t M_total, const double* rows_dev, int C, float eps,
-                    float momentum, float* mean, float* invstd, float* running_mean,
+/* The statistics pass fused into the producing convolution: y = conv(x, w) with the identity epilogue
+ * (`ones` / `zeros`: Cout unit scales / zero shifts, dense output: y_cstride == Cout, y_coff == 0) and
+ * stats = YV4_STATS_REPLICAS x [sum y (Cout) | sum y^2 (Cout)] doubles whose column sums are the
+ * per-channel totals (the kernel spreads its atomics over the replicas; the buffer is cleared here).
+ * dtype YV4_F32 / YV4_F16 / YV4_BF16 = type of x, w and y.  Feed it to yv4_bn_finalize with
+ * replicas = YV4_STATS_REPLICAS. */
+#define YV4_STATS_REPLICAS 64
+int yv4_conv_fwd_stats(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
+                       const float* ones, const float* zeros, void* y, double* stats, void* stream);
+int yv4_bn_finalize(const double* work, int replicas, int64_t M_total, const double* rows_dev, int C,
+                    float eps, float momentum, float* mean, float* invstd, float* running_mean,
                     float* running_var, void* stream);
 int yv4_bn_act_bwd_sums(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
                         int dy_cstride, int dy_coff, const float* mean, const float* invstd,

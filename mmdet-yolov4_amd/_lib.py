@@ -16,6 +16,7 @@ CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 # ---- constants mirrored from include/yv4.h -------------------------------------
 ABI_VERSION = 2
+STATS_REPLICAS = 64        # YV4_STATS_REPLICAS
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_MISH, ACT_LEAKY, ACT_SWISH = 0, 1, 2, 3
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
@@ -117,7 +118,8 @@ SIGNATURES = {
                                       _i, _i, _f, _vp]),
     'yv4_spp_pool_bwd': (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'yv4_bn_partial_sums': (C.c_int, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
-    'yv4_bn_finalize': (C.c_int, [_vp, _i64, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'yv4_bn_finalize': (C.c_int, [_vp, _i, _i64, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'yv4_conv_fwd_stats': (C.c_int, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'yv4_bn_act_bwd_sums': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp]),
     'yv4_bn_act_bwd_apply': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i64, _vp, _i, _i, _f, _vp]),
     'yv4_yolo_loss_fwd': (C.c_int, [C.POINTER(LossDesc), _vp]),

@@ -46,6 +46,7 @@ struct ConvArgs {
   // scattered output (sub-pixel / parity convolutions of the stride-2 data gradient): output pixel
   // (n, ho, wo) is stored at row ((n*ys_H + ho*ys_sh + ys_oh)*ys_W + wo*ys_sw + ys_ow) of y
   int ys_on, ys_H, ys_W, ys_sh, ys_sw, ys_oh, ys_ow;
+  double* stats;   // training: [YV4_STATS_REPLICAS][sum (Cout) | sum of squares (Cout)] of the outputs, or null
 };
 
 __device__ __forceinline__ int64_t out_row(const ConvArgs& p, int m) {
@@ -552,6 +553,31 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
+  // BatchNorm statistics of the tile while it is in registers (identity-epilogue training convs; see the same
+  // block in conv_mfma_h16.hip)
+  if (p.stats) {
+    double* rep = p.stats + (size_t)(tile_m & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      float su = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * TM * 32 + i * 32 + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[i][jn][e];
+          if (mb + (e & 3) + 8 * (e >> 2) < p.M) { su += v; sq += v * v; }
+        }
+      }
+      su += __shfl_xor(su, 32);
+      sq += __shfl_xor(sq, 32);
+      const int col = n0 + wn * TN * 32 + jn * 32 + r;
+      if (h == 0 && col < p.Cout) {
+        atomicAdd(&rep[col], (double)su);
+        atomicAdd(&rep[p.Cout + col], (double)sq);
+      }
+    }
+  }
   const bool has2 = p.s2 != nullptr;
   const bool vec_ok = ((p.y_cs | p.y_co) & 3) == 0 && (p.res == nullptr || ((p.r_cs | p.r_co) & 3) == 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -771,10 +797,11 @@ extern "C" int yv4_conv_pick_tile(const yv4_conv_desc* d) {
   return pick_tile((long long)d->N * d->Ho * d->Wo, d->Cout, fast_ok);
 }
 
-extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const float* w,
-                                   const float* scale1, const float* shift1,
-                                   const float* scale2, const float* shift2,
-                                   const float* residual, float* y, void* stream) {
+// stats != null: identity-epilogue conv that also accumulates the BatchNorm sums of its output; *stats_done tells
+// the caller whether the selected kernel did (the LDS-DMA kernels do; the generic and stem kernels do not)
+static int conv_f32_impl(const yv4_conv_desc* d, const float* x, const float* w, const float* scale1, const float* shift1,
+                         const float* scale2, const float* shift2, const float* residual, float* y, double* stats,
+                         bool* stats_done, void* stream) {
   YV4_REQUIRE(d && x && w && scale1 && shift1 && y, "conv: null argument");
   YV4_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), "conv: scale2/shift2 must come together");
   YV4_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: empty shape");
@@ -808,6 +835,7 @@ extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const
   a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.Kw = a.K; a.tiles_n = 0;
   a.ys_on = 0;
+  a.stats = nullptr;
 
   const bool uniform = (d->Cin % kBK) == 0;
   // the LDS-DMA kernels address x and w through 32-bit buffer descriptors
@@ -816,6 +844,11 @@ extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const
   const bool can_stem = stem_ok(d, residual != nullptr, scale2 != nullptr);
   int tile = d->tile == YV4_TILE_AUTO ? (can_stem ? YV4_TILE_STEM : pick_tile(M, d->Cout, fast_ok)) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stats_done) *stats_done = false;
+  if (stats && fast_ok && (tile == YV4_TILE_DMA_64x64 || tile == YV4_TILE_DMA_128x64 || tile == YV4_TILE_DMA_128x128)) {
+    a.stats = stats;
+    *stats_done = true;
+  }
   switch (tile) {
     case YV4_TILE_128x128: return launch_conv<128, 128, 2, 2>(a, uniform, s);
     case YV4_TILE_128x64: return launch_conv<128, 64, 2, 2>(a, uniform, s);
@@ -830,6 +863,39 @@ extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const
   }
   set_error("conv: unknown or inapplicable tile id %d", tile);
   return YV4_E_INVALID;
+}
+
+extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const float* w,
+                                   const float* scale1, const float* shift1,
+                                   const float* scale2, const float* shift2,
+                                   const float* residual, float* y, void* stream) {
+  return conv_f32_impl(d, x, w, scale1, shift1, scale2, shift2, residual, y, nullptr, nullptr, stream);
+}
+
+int conv_stats_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w, const float* ones, const float* zeros,
+                   void* y, double* stats, void* stream);
+
+// Training-mode convolution feeding a BatchNorm: y = conv(x, w) (identity epilogue, `ones` / `zeros` = Cout unit
+// scales / zero shifts) and the per-channel sums of y for the batch statistics, accumulated by the conv kernel's
+// epilogue where the selected kernel supports it, else by the BN reduction kernel afterwards -- either way
+// `stats` holds YV4_STATS_REPLICAS x [sum (Cout) | sum of squares (Cout)] whose column sums are the totals.
+extern "C" int yv4_conv_fwd_stats(const yv4_conv_desc* d, int dtype, const void* x, const void* w, const float* ones,
+                                  const float* zeros, void* y, double* stats, void* stream) {
+  YV4_REQUIRE(d && stats, "conv_fwd_stats: null argument");
+  YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "conv_fwd_stats: dtype must be f32, f16 or bf16");
+  YV4_REQUIRE(d->y_coff == 0 && d->y_cstride == d->Cout && d->act1 == YV4_ACT_NONE,
+              "conv_fwd_stats: dense output and identity epilogue only");
+  if (hipMemsetAsync(stats, 0, sizeof(double) * YV4_STATS_REPLICAS * 2 * d->Cout, reinterpret_cast<hipStream_t>(stream)) !=
+      hipSuccess) {
+    set_error("conv_fwd_stats: memset failed");
+    return YV4_E_LAUNCH;
+  }
+  if (dtype != YV4_F32) return conv_stats_h16(d, dtype, x, w, ones, zeros, y, stats, stream);
+  bool done = false;
+  const int rc = conv_f32_impl(d, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(w), ones, zeros, nullptr,
+                               nullptr, nullptr, reinterpret_cast<float*>(y), stats, &done, stream);
+  if (rc != YV4_OK || done) return rc;
+  return yv4_bn_partial_sums(y, YV4_F32, (int64_t)d->N * d->Ho * d->Wo, d->Cout, d->Cout, 0, stats, stream);
 }
 
 // The stem of the 16-bit path: fp32 image (NHWC, C padded to 4) and fp32 weights in, fp32 MFMA,
@@ -847,6 +913,7 @@ extern "C" int yv4_conv_stem_fwd(const yv4_conv_desc* d, const float* x, const f
   YV4_REQUIRE(M < (1LL << 31), "conv stem: N*Ho*Wo does not fit 31 bits");
   ConvArgs a;
   a.x = x; a.w = w; a.s1 = scale1; a.t1 = shift1; a.s2 = nullptr; a.t2 = nullptr; a.res = nullptr;
+  a.stats = nullptr;
   a.y = reinterpret_cast<float*>(y);
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1;
@@ -883,6 +950,7 @@ extern "C" int yv4_conv_scatter_fwd(const yv4_conv_desc* d, const float* x, cons
               (long long)d->Cout * K * 4 < 0xFFFFFFF0LL, "conv scatter: tensors of 4 GiB or more are not supported");
   ConvArgs a;
   a.x = x; a.w = w; a.s1 = scale1; a.t1 = shift1; a.s2 = nullptr; a.t2 = nullptr; a.res = nullptr; a.y = y;
+  a.stats = nullptr;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = 1; a.pad = d->pad;
   a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = 0; a.r_co = 0;

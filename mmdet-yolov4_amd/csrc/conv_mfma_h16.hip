@@ -45,6 +45,7 @@ struct ConvArgsH {
   int out_f32;    // store fp32 instead of the operand type (pred maps feeding the fp32 decode kernel)
   int ys_on, ys_H, ys_W, ys_sh, ys_sw, ys_oh, ys_ow;   // scattered output, see conv_mfma_f32.hip
   int ablate;     // measurement only (YV4_H16_ABLATE): 1 = issue no DMA after the first slice, 2 = no MFMA, 4 = no barrier
+  double* stats;  // training: per-channel [sum | sum of squares] of the STORED outputs, YV4_STATS_REPLICAS x 2*Cout
 };
 
 __device__ __forceinline__ int64_t out_row_h(const ConvArgsH& p, int m) {
@@ -371,6 +372,35 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
 #undef YV4_H_DMA
 #undef YV4_H_COMPUTE
 
+  // BatchNorm statistics of the tile while it is still in registers (identity-epilogue convs only: the stored
+  // value is the accumulator rounded to the output type).  A lane owns column r of 16 rows of each 32x32 tile;
+  // the two half-waves hold the two row halves.  One double atomic per column per wave, spread over
+  // YV4_STATS_REPLICAS copies (indexed by the row tile) so that same-address atomics do not serialise.
+  if (p.stats) {
+    typedef typename Elem<BF16>::T TS;
+    double* rep = p.stats + (size_t)(tile_m & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      float su = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * TM * 32 + i * 32 + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mb + (e & 3) + 8 * (e >> 2);
+          const float v = p.out_f32 ? acc[i][jn][e] : (float)(TS)acc[i][jn][e];
+          if (m < p.M) { su += v; sq += v * v; }
+        }
+      }
+      su += __shfl_xor(su, 32);
+      sq += __shfl_xor(sq, 32);
+      const int col = n0 + wn * TN * 32 + jn * 32 + r;
+      if (h == 0 && col < p.Cout) {
+        atomicAdd(&rep[col], (double)su);
+        atomicAdd(&rep[p.Cout + col], (double)sq);
+      }
+    }
+  }
   const bool has2 = p.s2 != nullptr;
   const int ymask = p.out_f32 ? 3 : 7;
   const bool vec_ok = ((p.y_cs | p.y_co) & ymask) == 0 && (p.res == nullptr || ((p.r_cs | p.r_co) & 7) == 0);
@@ -458,9 +488,9 @@ extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
   return pick_tile_h16((long long)d->N * d->Ho * d->Wo, d->Cout, (long long)d->KH * d->KW * d->Cin);
 }
 
-extern "C" int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x, const void* w,
-                                       const float* scale1, const float* shift1, const float* scale2,
-                                       const float* shift2, const void* residual, void* y, void* stream) {
+static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x, const void* w,
+                         const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                         const void* residual, void* y, double* stats, void* stream) {
   YV4_REQUIRE(d && x && w && scale1 && shift1 && y, "conv h16: null argument");
   YV4_REQUIRE(dtype == YV4_F16 || dtype == YV4_BF16, "conv h16: dtype must be YV4_F16 or YV4_BF16");
   YV4_REQUIRE(out_dtype == dtype || out_dtype == YV4_F32, "conv h16: out_dtype must be the operand type or YV4_F32");
@@ -501,10 +531,23 @@ extern "C" int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int ou
   a.ys_on = 0;
   static const int ablate = [] { const char* e = getenv("YV4_H16_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = ablate;
+  a.stats = stats;
   const bool general = (d->Cin % kHBK) != 0;
   const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);
+}
+
+extern "C" int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x, const void* w,
+                                       const float* scale1, const float* shift1, const float* scale2,
+                                       const float* shift2, const void* residual, void* y, void* stream) {
+  return conv_h16_impl(d, dtype, out_dtype, x, w, scale1, shift1, scale2, shift2, residual, y, nullptr, stream);
+}
+
+// Pure convolution (identity epilogue) that also leaves the BatchNorm statistics of its output in `stats`.
+int conv_stats_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w, const float* ones, const float* zeros,
+                   void* y, double* stats, void* stream) {
+  return conv_h16_impl(d, dtype, dtype, x, w, ones, zeros, nullptr, nullptr, nullptr, y, stats, stream);
 }
 
 // 16-bit form of yv4_conv_scatter_fwd (conv_mfma_f32.hip): one parity class of a stride-2 data gradient.
@@ -533,7 +576,7 @@ extern "C" int yv4_conv_scatter_fwd_h16(const yv4_conv_desc* d, int dtype, const
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = 1; a.pad = d->pad;
   a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = 0; a.r_co = 0;
-  a.act1 = 0; a.act2 = 0; a.slope1 = 0.f; a.slope2 = 0.f;
+  a.act1 = 0; a.act2 = 0; a.slope1 = 0.f; a.slope2 = 0.f; a.stats = nullptr;
   a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0; a.out_f32 = 0; a.ablate = 0;
   a.ys_on = 1; a.ys_H = Hy; a.ys_W = Wy; a.ys_sh = sh; a.ys_sw = sw; a.ys_oh = oh; a.ys_ow = ow;
   const bool general = (d->Cin % kHBK) != 0;

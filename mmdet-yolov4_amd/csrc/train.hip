@@ -426,7 +426,14 @@ __device__ __forceinline__ float act_fwd_exact(float z, int act, float slope) {
   }
 }
 
-constexpr int kBnRows = 512;   // rows per workgroup in the reductions
+#ifndef YV4_BN_RED_WAVES
+#define YV4_BN_RED_WAVES 1
+#endif
+#ifndef YV4_BN_APPLY_WAVES
+#define YV4_BN_APPLY_WAVES 1
+#endif
+constexpr int kBnRows = 8192;  // rows per workgroup at most (512 measured 1.2-1.5x slower on the >= 1 M-row maps:
+                               // the per-workgroup LDS / global atomics then outweigh 32 KB of streaming)
 
 // Thread map of the per-channel reductions: a row of the NHWC view is C4 = C/4 float4s; the
 // workgroup's 256 threads cover rows_per_pass = 256 / C4 rows at a time (all threads busy and
@@ -456,25 +463,28 @@ __device__ __forceinline__ RedMap red_map(int C4) {
 
 // Block-level combine of per-thread partials (a: first C values, b: second C values) and one
 // double atomic per channel per workgroup.  part[] lives in LDS: [2][C] doubles.
-__device__ __forceinline__ void red_flush(double* part, int C, int c, const float (&a)[4], const float (&b)[4],
+__device__ __forceinline__ void red_flush(double* part, int C, int c, const double (&a)[4], const double (&b)[4],
                                           bool active) {
   if (active) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      atomicAdd(&part[c + k], (double)a[k]);
-      atomicAdd(&part[C + c + k], (double)b[k]);
+      atomicAdd(&part[c + k], a[k]);
+      atomicAdd(&part[C + c + k], b[k]);
     }
   }
 }
+constexpr int kBnFloatRun = 16;  // unrolled iterations (x4 rows) a thread sums in fp32 before folding into its doubles
 
 constexpr int kBnUnroll = 4;    // independent row loads in flight per thread (the loops are latency-bound otherwise)
 constexpr int kBnRedUnroll = 4; // (8 measured 3 % slower on the whole step: registers)
 
 // rows per workgroup: enough workgroups to fill the chip (>= ~1024) but at most kBnRows rows each
+static const int g_bn_rows_cap = [] { const char* e = getenv("YV4_BN_ROWS"); return e ? atoi(e) : kBnRows; }();
+static const int g_bn_min_wg = [] { const char* e = getenv("YV4_BN_MINWG"); return e ? atoi(e) : 1024; }();
 static inline int bn_rows_per_block(int64_t M) {
-  int64_t r = (M + 1023) / 1024;
+  int64_t r = (M + g_bn_min_wg - 1) / g_bn_min_wg;
   if (r < 32) r = 32;
-  if (r > kBnRows) r = kBnRows;
+  if (r > g_bn_rows_cap) r = g_bn_rows_cap;
   return (int)r;
 }
 
@@ -492,8 +502,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   if (mp.active) {
     for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
       float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
+      double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+      int it = 0;
       const T* col = x + co + cq * 4;
       for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnRedUnroll) {
+        if (++it == kBnFloatRun) {       // bound the length of an fp32 running sum (64 rows)
+          it = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { ds[k] += fs[k]; dq[k] += fq[k]; fs[k] = 0.f; fq[k] = 0.f; }
+        }
         float4 v[kBnRedUnroll];
 #pragma unroll
         for (int u = 0; u < kBnRedUnroll; ++u) {
@@ -506,7 +523,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
           fq[0] += v[u].x * v[u].x; fq[1] += v[u].y * v[u].y; fq[2] += v[u].z * v[u].z; fq[3] += v[u].w * v[u].w;
         }
       }
-      red_flush(part, C, cq * 4, fs, fq, true);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ds[k] += fs[k]; dq[k] += fq[k]; }
+      red_flush(part, C, cq * 4, ds, dq, true);
     }
   }
   __syncthreads();
@@ -517,12 +536,17 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 // `rows`: optional device-resident row count (SyncBN: the all-reduced count travels with the sums)
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M_host, int C, float eps, float momentum,
                                    float* mean, float* invstd, float* running_mean, float* running_var,
-                                   const double* __restrict__ rows) {
+                                   const double* __restrict__ rows, int replicas) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double M = rows ? *rows : (double)M_host;
-  const double m = sums[c] / M;
-  double var = sums[C + c] / M - m * m;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < replicas; ++r) {
+    s1 += sums[(size_t)r * 2 * C + c];
+    s2 += sums[(size_t)r * 2 * C + C + c];
+  }
+  const double m = s1 / M;
+  double var = s2 / M - m * m;
   if (var < 0) var = 0;
   mean[c] = (float)m;
   invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -554,7 +578,7 @@ struct BnArgs {
 // mean / invstd / gamma / beta live in registers) and walks rows -- no per-element index division,
 // kBnUnroll independent row loads in flight.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnArgs p) {
+__global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_fwd_kernel(BnArgs p) {
   const T* px = reinterpret_cast<const T*>(p.x);
   const T* pres = reinterpret_cast<const T*>(p.res);
   T* py = reinterpret_cast<T*>(p.y);
@@ -596,7 +620,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnArgs p) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
+__global__ __launch_bounds__(256, YV4_BN_RED_WAVES) void bn_act_bwd_reduce_kernel(BnArgs p) {
   extern __shared__ double part[];   // [2][C]: dbeta | dgamma
   const T* px = reinterpret_cast<const T*>(p.x);
   const T* pdy = reinterpret_cast<const T*>(p.dy);
@@ -613,6 +637,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
       const float is[4] = {p.invstd[c], p.invstd[c + 1], p.invstd[c + 2], p.invstd[c + 3]};
       const float ga[4] = {p.gamma[c], p.gamma[c + 1], p.gamma[c + 2], p.gamma[c + 3]};
       const float be[4] = {p.beta[c], p.beta[c + 1], p.beta[c + 2], p.beta[c + 3]};
+      // fp32 running sums over this thread's rows (at most rows_per_block / rows-per-pass, a few hundred terms):
+      // double registers here cost a wave of occupancy (135 -> 119 VGPRs) and 35 % of the kernel's speed
       float db[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0};
       for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnRedUnroll) {
         float4 xv[kBnRedUnroll], gv[kBnRedUnroll];
@@ -636,7 +662,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
           }
         }
       }
-      red_flush(part, p.C, c, db, dg, true);
+      const double ddb[4] = {db[0], db[1], db[2], db[3]}, ddg[4] = {dg[0], dg[1], dg[2], dg[3]};
+      red_flush(part, p.C, c, ddb, ddg, true);
     }
   }
   __syncthreads();
@@ -644,7 +671,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnArgs p) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnArgs p) {
+__global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_bwd_apply_kernel(BnArgs p) {
   const T* px = reinterpret_cast<const T*>(p.x);
   const T* pdy = reinterpret_cast<const T*>(p.dy);
   T* pdx = reinterpret_cast<T*>(p.dx);
@@ -887,7 +914,7 @@ static int bn_stats_impl(int dtype, const void* x, int64_t M, int C, int x_cstri
                                            reinterpret_cast<const T*>(x), M, C, x_cstride, x_coff, work, rpb));
   if (phase == 0)
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, M, C, eps, momentum, mean, invstd,
-                       running_mean, running_var, (const double*)nullptr);
+                       running_mean, running_var, (const double*)nullptr, 1);
   YV4_CHECK_LAUNCH("bn_train_stats");
   return YV4_OK;
 }
@@ -1020,13 +1047,13 @@ extern "C" int yv4_bn_partial_sums(const void* x, int dtype, int64_t M, int C, i
                                    void* stream) {
   return bn_stats_impl(dtype, x, M, C, x_cstride, x_coff, 0.f, 0.f, work, nullptr, nullptr, nullptr, nullptr, stream, 1);
 }
-extern "C" int yv4_bn_finalize(const double* work, int64_t M_total, const double* rows_dev, int C, float eps,
+extern "C" int yv4_bn_finalize(const double* work, int replicas, int64_t M_total, const double* rows_dev, int C, float eps,
                                float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                                void* stream) {
-  YV4_REQUIRE(work && mean && invstd && (rows_dev || M_total > 0) && C > 0, "bn_finalize: bad argument");
+  YV4_REQUIRE(work && mean && invstd && (rows_dev || M_total > 0) && C > 0 && replicas >= 1, "bn_finalize: bad argument");
   YV4_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come together");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), work,
-                     M_total, C, eps, momentum, mean, invstd, running_mean, running_var, rows_dev);
+                     M_total, C, eps, momentum, mean, invstd, running_mean, running_var, rows_dev, replicas);
   YV4_CHECK_LAUNCH("bn_finalize");
   return YV4_OK;
 }

@@ -14,6 +14,7 @@ Fusion map (reference line -> launch):
                   affine+act stage; bare conv2 writes half 1
   SPPV4 / SPPV5   max-pools complete the cat buffer in place (:176-181,220-229)
 """
+import os
 import warnings
 
 import torch
@@ -24,6 +25,8 @@ from torch.nn.modules.batchnorm import _BatchNorm
 from .bricks import (HipModule, build_activation_layer, build_norm_layer, _NO_INPLACE)
 from . import train_ops as T
 from .plan import act_id, bn_affine
+
+_CONV_STATS = os.environ.get('YV4_CONV_STATS', '1') != '0'    # BN statistics in the conv epilogue (A/B switch)
 from .registry import BACKBONES
 
 
@@ -97,9 +100,14 @@ class Conv(HipModule):
             padc = al - x.shape[1] % al
             x = F.pad(x, (0, 0, 0, 0, 0, padc))
             w = F.pad(w, (0, 0, 0, 0, 0, padc))
-        y = T.conv2d(x, w, self.stride, self.padding, dtype=dt)
         if self.with_norm:      # batch statistics in training mode, running statistics under norm_eval / frozen stages
-            return T.bn_act(y, self.norm, act_id(self.activate), residual)
+            bn = self.norm
+            stats = None
+            if (bn.training or not bn.track_running_stats) and _CONV_STATS:
+                stats = T.conv_stats_buffer(w.shape[0], x.device)     # the conv's epilogue leaves the BN sums here
+            y = T.conv2d(x, w, self.stride, self.padding, dtype=dt, stats=stats)
+            return T.bn_act(y, bn, act_id(self.activate), residual, sums=stats)
+        y = T.conv2d(x, w, self.stride, self.padding, dtype=dt)
         if self.conv.bias is not None:
             y = y + self.conv.bias.view(1, -1, 1, 1)
         if self.activate is not None:

@@ -20,9 +20,12 @@ def env_world():
 
 
 def init(backend='nccl', device=None):
-    """Join the process group when launched with WORLD_SIZE > 1; returns (rank, local_rank, world)."""
+    """Join the process group when launched with WORLD_SIZE > 1; returns (rank, local_rank, world).
+    YV4_DIST_FORCE_INIT=1 joins a one-rank group too (exercises the RCCL barrier / all-reduce of the timed
+    region on a 1-GPU box)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('YV4_DIST_FORCE_INIT') == '1' and 'MASTER_PORT' in os.environ
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         kwargs = {}
         if backend == 'nccl' and device is not None:

@@ -49,8 +49,10 @@ def _identity_affine(device, C_):
 _DCODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
-def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out):
-    """Identity-epilogue conv of a channels_last tensor; fp32, or fp16 / bf16 operands (fp32 accumulate)."""
+def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None):
+    """Identity-epilogue conv of a channels_last tensor; fp32, or fp16 / bf16 operands (fp32 accumulate).
+    ``stats``: a float64 buffer of ``STATS_REPLICAS * 2 * Cout`` entries that receives the BatchNorm sums of the
+    output (``yv4_conv_fwd_stats``: accumulated in the conv kernel's epilogue)."""
     N, _, H, W = x.shape
     Ho, Wo = out.shape[2], out.shape[3]
     d = ConvDesc()
@@ -58,6 +60,12 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out):
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.x_cstride, d.y_cstride = Cin_p, Cout
     ones, zeros = _identity_affine(x.device, Cout)
+    if stats is not None:
+        assert stats.dtype == torch.float64 and stats.numel() >= _lib.STATS_REPLICAS * 2 * Cout
+        check(_lib.lib().yv4_conv_fwd_stats(C.byref(d), _DCODE[x.dtype], x.data_ptr(), w_packed.data_ptr(),
+                                            ones.data_ptr(), zeros.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                                            stream_ptr()), 'yv4_conv_fwd_stats')
+        return d
     if x.dtype == torch.float32:
         check(_lib.lib().yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w_packed.data_ptr(), ones.data_ptr(),
                                              zeros.data_ptr(), None, None, None, out.data_ptr(), stream_ptr()),
@@ -147,7 +155,7 @@ class ConvFunction(torch.autograd.Function):
     master copy the optimizer steps; autocast semantics of the reference's Fp16 hook)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, dtype):
+    def forward(ctx, x, weight, stride, pad, dtype, stats=None):
         _need_cuda(x, 'x')
         Cout, Cin, KH, KW = weight.shape
         al = 4 if dtype == torch.float32 else 8
@@ -160,7 +168,7 @@ class ConvFunction(torch.autograd.Function):
         Wo = (W + 2 * pad - KW) // stride + 1
         wp, cp = pack_conv_weight(weight, align=al)
         y = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=dtype, memory_format=torch.channels_last)
-        _conv_launch(x, wp.to(dtype), cp, Cout, KH, KW, stride, pad, y)
+        _conv_launch(x, wp.to(dtype), cp, Cout, KH, KW, stride, pad, y, stats)
         ctx.save_for_backward(x, weight)
         ctx.geom = (stride, pad, dtype, cp)
         return y
@@ -198,7 +206,7 @@ class ConvFunction(torch.autograd.Function):
             else:
                 dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype)
             dx = dx.to(ctx.x_dtype)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def train_dtype(module, x):
@@ -210,11 +218,17 @@ def train_dtype(module, x):
     return x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
 
 
-def conv2d(x, weight, stride=1, pad=0, dtype=None):
-    """``dtype`` None: follow ``x`` (a 16-bit activation keeps the path 16-bit, anything else is fp32)."""
+def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None):
+    """``dtype`` None: follow ``x`` (a 16-bit activation keeps the path 16-bit, anything else is fp32).
+    ``stats``: see ``_conv_launch`` / ``conv_stats_buffer``; pass the same buffer to ``bn_act(..., sums=)``."""
     if dtype is None:
         dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
-    return ConvFunction.apply(x, weight, stride, pad, dtype)
+    return ConvFunction.apply(x, weight, stride, pad, dtype, stats)
+
+
+def conv_stats_buffer(cout, device):
+    """Scratch for the BatchNorm sums a training conv leaves for the BN that follows it (cleared by the kernel)."""
+    return torch.empty(_lib.STATS_REPLICAS * 2 * cout, dtype=torch.float64, device=device)
 
 
 class BNActFunction(torch.autograd.Function):
@@ -222,9 +236,11 @@ class BNActFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual, training=True,
-                sync_group=None):
+                sync_group=None, sums=None):
         """``sync_group``: None, or a (process group or 'world') to synchronise the batch statistics over
-        (torch.nn.SyncBatchNorm semantics: statistics over all ranks' rows, local dgamma / dbeta)."""
+        (torch.nn.SyncBatchNorm semantics: statistics over all ranks' rows, local dgamma / dbeta).
+        ``sums``: the replicated [sum | sum of squares] buffer the producing conv filled (``conv2d(stats=)``):
+        the statistics pass over ``x`` is skipped."""
         _need_cuda(x, 'x')
         if x.dtype not in _DCODE:
             x = x.float()
@@ -242,18 +258,28 @@ class BNActFunction(torch.autograd.Function):
         if training and sync_group is not None:
             import torch.distributed as dist
             group = None if sync_group == 'world' else sync_group
+            pre = sums
             sums = torch.empty(2 * Cc + 1, dtype=torch.float64, device=dev)       # [sum | sum of squares | rows]
-            check(L.yv4_bn_partial_sums(x.data_ptr(), code, M, Cc, Cc, 0, sums.data_ptr(), stream_ptr()),
-                  'yv4_bn_partial_sums')
+            if pre is not None:
+                torch.sum(pre.view(_lib.STATS_REPLICAS, 2 * Cc), dim=0, out=sums[:2 * Cc])
+            else:
+                check(L.yv4_bn_partial_sums(x.data_ptr(), code, M, Cc, Cc, 0, sums.data_ptr(), stream_ptr()),
+                      'yv4_bn_partial_sums')
             sums[2 * Cc:].fill_(float(M))
             dist.all_reduce(sums, group=group)
             rows = sums[2 * Cc:]
-            check(L.yv4_bn_finalize(sums.data_ptr(), 0, rows.data_ptr(), Cc, float(eps), float(momentum),
+            check(L.yv4_bn_finalize(sums.data_ptr(), 1, 0, rows.data_ptr(), Cc, float(eps), float(momentum),
                                     mean.data_ptr(), invstd.data_ptr(),
                                     running_mean.data_ptr() if running_mean is not None else None,
                                     running_var.data_ptr() if running_var is not None else None, stream_ptr()),
                   'yv4_bn_finalize')
             ctx.sync_group = group
+        elif training and sums is not None:
+            check(L.yv4_bn_finalize(sums.data_ptr(), _lib.STATS_REPLICAS, M, None, Cc, float(eps), float(momentum),
+                                    mean.data_ptr(), invstd.data_ptr(),
+                                    running_mean.data_ptr() if running_mean is not None else None,
+                                    running_var.data_ptr() if running_var is not None else None, stream_ptr()),
+                  'yv4_bn_finalize')
         elif training:
             check(L.yv4_bn_train_stats_h16(x.data_ptr(), code, M, Cc, Cc, 0, float(eps), float(momentum),
                                            work.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
@@ -309,7 +335,7 @@ class BNActFunction(torch.autograd.Function):
                      dgamma.data_ptr(), dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope,
                      stream_ptr()), 'yv4_bn_act_bwd')
         dres = dy if ctx.has_res else None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None
 
 
 def _sync_group(bn):
@@ -327,7 +353,7 @@ def _sync_group(bn):
     return group if group is not None else 'world'
 
 
-def bn_act(x, bn, act=(0, 0.0), residual=None):
+def bn_act(x, bn, act=(0, 0.0), residual=None, sums=None):
     """``bn``: a torch BatchNorm2d; in training mode it normalises with batch statistics and updates
     the running ones, in eval mode (``norm_eval`` / frozen stages inside a training graph) with the
     running statistics as constants.  act = (YV4_ACT_*, slope)."""
@@ -335,7 +361,8 @@ def bn_act(x, bn, act=(0, 0.0), residual=None):
     use_batch = bn.training or not bn.track_running_stats
     out = BNActFunction.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                               bn.running_var if bn.track_running_stats else None, bn.eps, mom, act[0], act[1],
-                              residual, use_batch, _sync_group(bn) if use_batch else None)
+                              residual, use_batch, _sync_group(bn) if use_batch else None,
+                              sums if use_batch else None)
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return out

@@ -187,3 +187,36 @@ def test_detector_with_frozen_stage_and_norm_eval_trains(gpu_device):
     assert frozen and all(p.grad is None for p in frozen)
     live = [p for p in det.parameters() if p.requires_grad]
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in live)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(3, 32, 64, 19, 3, 1), (2, 64, 40, 23, 1, 1), (2, 16, 32, 30, 3, 2), (1, 128, 256, 38, 3, 1)])
+def test_conv_epilogue_leaves_the_bn_sums(dtype, shape):
+    """yv4_conv_fwd_stats: the conv kernel's epilogue accumulates [sum | sum of squares] of the STORED outputs
+    (rounded to the output type) over YV4_STATS_REPLICAS copies; kernels without that epilogue (Cin % 32 != 0 in
+    fp32) fall back to the reduction kernel behind the same entry point.  Checked against float64 sums of the
+    output tensor (1e-6 relative) and through bn_act with / without the precomputed sums (identical up to 2e-6)."""
+    from mmdet_yolov4_amd import train_ops as T
+    from mmdet_yolov4_amd import _lib
+    N, Cin, Cout, hw, k, stride = shape
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(N, Cin, hw, hw, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5).to(dev)
+    stats = T.conv_stats_buffer(Cout, dev)
+    stats.fill_(float('nan'))                                  # the entry point clears it
+    y = T.conv2d(x, w, stride, k // 2, dtype=dtype, stats=stats)
+    y_plain = T.conv2d(x, w, stride, k // 2, dtype=dtype)
+    assert torch.equal(y, y_plain)
+    tot = stats.view(_lib.STATS_REPLICAS, 2, Cout).sum(0)
+    yd = y.double()
+    want = torch.stack([yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))])
+    assert float((tot - want).abs().max() / want.abs().max()) < 1e-6
+    bn_a, bn_b = torch.nn.BatchNorm2d(Cout).to(dev).train(), torch.nn.BatchNorm2d(Cout).to(dev).train()
+    out_a = T.bn_act(y, bn_a, (1, 0.0), sums=stats)
+    out_b = T.bn_act(y, bn_b, (1, 0.0))
+    tol = 2e-6 if dtype == torch.float32 else 1e-2
+    out_a, out_b = out_a.detach().float(), out_b.detach().float()
+    assert float((out_a - out_b).abs().max()) <= tol * float(out_b.abs().max())
+    assert float((bn_a.running_var - bn_b.running_var).abs().max()) < 1e-6
+    assert float((bn_a.running_mean - bn_b.running_mean).abs().max()) < 1e-6
