@@ -47,6 +47,7 @@ struct ConvArgs {
   // (n, ho, wo) is stored at row ((n*ys_H + ho*ys_sh + ys_oh)*ys_W + wo*ys_sw + ys_ow) of y
   int ys_on, ys_H, ys_W, ys_sh, ys_sw, ys_oh, ys_ow;
   double* stats;   // training: [YV4_STATS_REPLICAS][sum (Cout) | sum of squares (Cout)] of the outputs, or null
+  FastDiv fd_hw, fd_wo;   // m / (Ho*Wo), r / Wo (LDS-DMA kernels; set by launch_conv_dma)
 };
 
 __device__ __forceinline__ int64_t out_row(const ConvArgs& p, int m) {
@@ -406,17 +407,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
     unsigned off = 0u;
     if (m < p.M) {
       const int hw = p.Ho * p.Wo;
-      const int n = m / hw;
+      const int n = fd_div(m, p.fd_hw);
       const int rm = m - n * hw;
-      const int ho = rm / p.Wo;
+      const int ho = fd_div(rm, p.fd_wo);
       const int wo = rm - ho * p.Wo;
       const int hi0 = ho * p.stride - p.pad;
       const int wi0 = wo * p.stride - p.pad;
       off = (unsigned)((((int64_t)(n * p.H + hi0) * p.W + wi0) * p.x_cs + p.x_co + lc * 4) * 4);
-      for (int kh = 0; kh < p.KH; ++kh)
-        for (int kw = 0; kw < p.KW; ++kw)
-          if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
-            mk |= 1ull << (kh * p.KW + kw);
+      mk = tap_mask(hi0, wi0, p.KH, p.KW, p.H, p.W);
     }
     a_off[q] = off;
     a_mask[q] = mk;
@@ -596,6 +594,8 @@ static int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
   ConvArgs p = a;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Cout + BN - 1) / BN;
+  p.fd_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
+  p.fd_wo = make_fastdiv((unsigned)p.Wo);
   const long long tiles = (long long)tiles_m * p.tiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffLL) {
     set_error("conv: grid of %lld tiles out of range", tiles);
@@ -735,6 +735,8 @@ static int launch_conv(const ConvArgs& a, bool uniform_tap, hipStream_t stream) 
   ConvArgs p = a;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Cout + BN - 1) / BN;
+  p.fd_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
+  p.fd_wo = make_fastdiv((unsigned)p.Wo);
   const long long tiles = (long long)tiles_m * p.tiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffLL) {
     set_error("conv: grid of %lld tiles out of range", tiles);

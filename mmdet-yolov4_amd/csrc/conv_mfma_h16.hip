@@ -46,6 +46,7 @@ struct ConvArgsH {
   int ys_on, ys_H, ys_W, ys_sh, ys_sw, ys_oh, ys_ow;   // scattered output, see conv_mfma_f32.hip
   int ablate;     // measurement only (YV4_H16_ABLATE): 1 = issue no DMA after the first slice, 2 = no MFMA, 4 = no barrier
   double* stats;  // training: per-channel [sum | sum of squares] of the STORED outputs, YV4_STATS_REPLICAS x 2*Cout
+  FastDiv fd_hw, fd_wo;   // m / (Ho*Wo), r / Wo (set by launch_h16)
 };
 
 __device__ __forceinline__ int64_t out_row_h(const ConvArgsH& p, int m) {
@@ -229,17 +230,14 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
     unsigned off = 0u;
     if (m < p.M) {
       const int hw = p.Ho * p.Wo;
-      const int n = m / hw;
+      const int n = fd_div(m, p.fd_hw);
       const int rm = m - n * hw;
-      const int ho = rm / p.Wo;
+      const int ho = fd_div(rm, p.fd_wo);
       const int wo = rm - ho * p.Wo;
       const int hi0 = ho * p.stride - p.pad;
       const int wi0 = wo * p.stride - p.pad;
       off = (unsigned)((((int64_t)(n * p.H + hi0) * p.W + wi0) * p.x_cs + p.x_co + (GENERAL_K ? 0 : lc * 8)) * 2);
-      for (int kh = 0; kh < p.KH; ++kh)
-        for (int kw = 0; kw < p.KW; ++kw)
-          if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
-            mk |= 1ull << (kh * p.KW + kw);
+      mk = tap_mask(hi0, wi0, p.KH, p.KW, p.H, p.W);
     }
     a_off[q] = off;
     a_mask[q] = mk;
@@ -422,6 +420,8 @@ static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
   ConvArgsH p = a;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Cout + BN - 1) / BN;
+  p.fd_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
+  p.fd_wo = make_fastdiv((unsigned)p.Wo);
   const long long tiles = (long long)tiles_m * p.tiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffLL) {
     set_error("conv h16: grid of %lld tiles out of range", tiles);

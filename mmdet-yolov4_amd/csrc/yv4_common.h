@@ -29,6 +29,34 @@ void set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+// ---- division by a launch-invariant divisor: one mulhi + shift instead of the ~35-instruction runtime divide
+// (the per-row (n, ho, wo) decomposition in the conv prologues: 8 divides per lane were longer than the whole
+// MFMA phase of the K <= 256 layers).  Exact for 0 <= x < 2^31.
+struct FastDiv { unsigned mul, shr; };
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f = {0u, 0u};
+  if (d > 1) {
+    unsigned lg = 0;
+    while ((1ull << lg) < d) ++lg;                       // ceil(log2 d)
+    const unsigned pw = 31 + lg;
+    f.mul = (unsigned)(((1ull << pw) + d - 1) / d);
+    f.shr = pw - 32;
+  }
+  return f;
+}
+__device__ __forceinline__ int fd_div(int x, FastDiv f) {
+  return f.mul ? (int)(__umulhi((unsigned)x, f.mul) >> f.shr) : x;
+}
+// bit (kh*KW + kw) set when input pixel (hi0 + kh, wi0 + kw) is inside the image
+__device__ __forceinline__ unsigned long long tap_mask(int hi0, int wi0, int KH, int KW, int H, int W) {
+  unsigned colm = 0u;
+  for (int kw = 0; kw < KW; ++kw) colm |= ((unsigned)(wi0 + kw) < (unsigned)W ? 1u : 0u) << kw;
+  unsigned long long mk = 0ull;
+  for (int kh = 0; kh < KH; ++kh)
+    if ((unsigned)(hi0 + kh) < (unsigned)H) mk |= (unsigned long long)colm << (kh * KW);
+  return mk;
+}
+
 // ---- device math -------------------------------------------------------------
 // Mish, mmdet/ops/mish_cuda/src/mish.h:16-18:  x * tanh(x < 20 ? log1p(exp(x)) : x).
 // tanh(log1p(e)) == (e*e + 2e) / (e*e + 2e + 2) exactly, which needs one exp and
