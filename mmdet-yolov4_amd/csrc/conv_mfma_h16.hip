@@ -97,9 +97,39 @@ struct Elem<false> {
 // Epilogue of one 32x32 accumulator tile through a wave-private LDS patch (fp32, pitch 36):
 // afterwards lane l owns 8 consecutive channels of rows (l>>2) and (l>>2)+16, i.e. one 16-byte
 // store of 16-bit outputs per row (two dwordx4 when the output is fp32).
+// per-channel affine of a lane's 8 output columns (co .. co+7): two 16-byte loads per array when aligned
+struct AffH { float s1[8], t1[8], s2[8], t2[8]; };
+__device__ __forceinline__ void load_affine_h(const ConvArgsH& p, int co, bool has2, AffH& a) {
+  const bool al = (((uintptr_t)p.s1 | (uintptr_t)p.t1 | (uintptr_t)p.s2 | (uintptr_t)p.t2) & 15) == 0 && (co & 3) == 0;
+  if (al) {
+    const float4 a0 = *reinterpret_cast<const float4*>(p.s1 + co), a1 = *reinterpret_cast<const float4*>(p.s1 + co + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(p.t1 + co), b1 = *reinterpret_cast<const float4*>(p.t1 + co + 4);
+    a.s1[0] = a0.x; a.s1[1] = a0.y; a.s1[2] = a0.z; a.s1[3] = a0.w; a.s1[4] = a1.x; a.s1[5] = a1.y; a.s1[6] = a1.z; a.s1[7] = a1.w;
+    a.t1[0] = b0.x; a.t1[1] = b0.y; a.t1[2] = b0.z; a.t1[3] = b0.w; a.t1[4] = b1.x; a.t1[5] = b1.y; a.t1[6] = b1.z; a.t1[7] = b1.w;
+    if (has2) {
+      const float4 c0 = *reinterpret_cast<const float4*>(p.s2 + co), c1 = *reinterpret_cast<const float4*>(p.s2 + co + 4);
+      const float4 d0 = *reinterpret_cast<const float4*>(p.t2 + co), d1 = *reinterpret_cast<const float4*>(p.t2 + co + 4);
+      a.s2[0] = c0.x; a.s2[1] = c0.y; a.s2[2] = c0.z; a.s2[3] = c0.w; a.s2[4] = c1.x; a.s2[5] = c1.y; a.s2[6] = c1.z; a.s2[7] = c1.w;
+      a.t2[0] = d0.x; a.t2[1] = d0.y; a.t2[2] = d0.z; a.t2[3] = d0.w; a.t2[4] = d1.x; a.t2[5] = d1.y; a.t2[6] = d1.z; a.t2[7] = d1.w;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.s2[u] = 1.f; a.t2[u] = 0.f; }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a.s1[u] = p.s1[co + u];
+      a.t1[u] = p.t1[co + u];
+      a.s2[u] = has2 ? p.s2[co + u] : 1.f;
+      a.t2[u] = has2 ? p.t2[co + u] : 0.f;
+    }
+  }
+}
+
+// `full` (lane-uniform per tile column group): the vector path applies, `af` holds the lane's affine
 template <bool BF16>
 __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16& acc, float* ep, int lane, int m_base,
-                                                int co_base, bool vec_ok, bool has2) {
+                                                int co_base, bool full, bool has2, const AffH& af) {
   typedef typename Elem<BF16>::T T;
   typedef typename Elem<BF16>::V8 V8;
   const int r = lane & 31, h = lane >> 5;
@@ -108,15 +138,8 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
   for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + 4 * h) * kPitch + r] = acc[e];
   const int c8 = (lane & 3) * 8;
   const int co = co_base + c8;
-  if (vec_ok && co + 7 < p.Cout) {
-    float s1[8], t1[8], s2[8], t2[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      s1[u] = p.s1[co + u];
-      t1[u] = p.t1[co + u];
-      s2[u] = has2 ? p.s2[co + u] : 1.f;
-      t2[u] = has2 ? p.t2[co + u] : 0.f;
-    }
+  if (full) {
+    const float (&s1)[8] = af.s1; const float (&t1)[8] = af.t1; const float (&s2)[8] = af.s2; const float (&t2)[8] = af.t2;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int row = (lane >> 2) + 16 * k;
@@ -406,11 +429,16 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
   __builtin_amdgcn_s_barrier();
   float* ep = reinterpret_cast<float*>(smem_h) + wave * (32 * 36);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int jn = 0; jn < TN; ++jn) {
+    const int cb = n0 + wn * TN * 32 + jn * 32;
+    const int co = cb + (lane & 3) * 8;
+    const bool full = vec_ok && co + 7 < p.Cout;
+    AffH af;
+    if (full) load_affine_h(p, co, has2, af);        // once per column group, shared by the TM row tiles
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn)
-      epilogue_tile_h<BF16>(p, acc[i][jn], ep, lane, m0 + wm * TM * 32 + i * 32, n0 + wn * TN * 32 + jn * 32, vec_ok,
-                            has2);
+    for (int i = 0; i < TM; ++i)
+      epilogue_tile_h<BF16>(p, acc[i][jn], ep, lane, m0 + wm * TM * 32 + i * 32, cb, full, has2, af);
+  }
 }
 
 template <bool BF16, int BM, int BN, bool GENERAL_K, int NBUF>
