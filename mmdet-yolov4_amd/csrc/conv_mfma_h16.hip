@@ -490,20 +490,19 @@ static int dispatch_h16_n(const ConvArgsH& a, int shape, bool general, hipStream
 // network's 1x1 layers): resident workgroups per CU, not prefetch depth, hide the prologue / epilogue.
 template <bool BF16>
 static int dispatch_h16(const ConvArgsH& a, int tile, bool general, hipStream_t s) {
+  // (a 256x128 workgroup tile -- 128x64 per wave, 0.75 fragment reads per MFMA, one workgroup per CU, 2- or
+  // 3-slot ring -- measured 3-4x SLOWER on every YOLOv4-L shape: 128 accumulator registers plus the 12 DMA
+  // address sets do not fit the 256-VGPR budget of this 4-wave kernel without spilling)
   return dispatch_h16_n<BF16, 2>(a, tile, general, s);
 }
 
 static int pick_tile_h16(long long M, int Cout, long long K) {
-  // From the per-layer table of tools/conv_bench.py --dtype bf16 (YOLOv4-L, batch 32; round 1):
-  // deep reductions (3x3) amortise a workgroup's fixed cost and want the biggest tile that still
-  // gives every CU a workgroup; shallow ones (1x1, K <= ~1024) want many resident workgroups.
+  // From the per-layer table of tools/conv_bench.py --dtype bf16 (YOLOv4-L, batch 32; after the prologue /
+  // epilogue work of round 1 the 128x64 tile -- three workgroups per CU -- is the best or within 2 % of the best
+  // on every shape but the widest deep reductions with several rounds of tiles).
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
-  if (K >= 1024) {
-    if (Cout > 64 && tiles(128, 128) >= 256) return YV4_HTILE_128x128;
-    if (tiles(128, 64) >= 256) return YV4_HTILE_128x64;
-    return YV4_HTILE_64x64;
-  }
-  if (tiles(128, 64) >= 512) return YV4_HTILE_128x64;
+  if (K >= 2304 && Cout >= 512 && tiles(128, 128) >= 1024) return YV4_HTILE_128x128;
+  if (tiles(128, 64) >= 256) return YV4_HTILE_128x64;
   return YV4_HTILE_64x64;
 }
 
