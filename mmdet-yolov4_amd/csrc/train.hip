@@ -77,6 +77,7 @@ struct WgradArgs {
   int x_cs, x_co, dy_cs, dy_co;
   int M, K;
   int tiles_k, rows_per_chunk;
+  FastDiv fd_hw, fd_wo;     // m / (Ho*Wo), r / Wo: the per-slice row decode sits inside the pipelined loop
 };
 
 constexpr int kWgRows = 32;   // reduction rows per slice
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p, unsigne
         if (dco_ok) doff = (unsigned)((((int64_t)m * p.dy_cs) + p.dy_co + dco) * ES);
         if (k_ok) {
           const int hw = p.Ho * p.Wo;
-          const int n = m / hw;
+          const int n = fd_div(m, p.fd_hw);
           const int rm = m - n * hw;
-          const int ho = rm / p.Wo;
+          const int ho = fd_div(rm, p.fd_wo);
           const int wo = rm - ho * p.Wo;
           const int hi = ho * p.stride - p.pad + kh;
           const int wi = wo * p.stride - p.pad + kw;
@@ -263,9 +264,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(WgradArgs p, uns
     // first row of this lane in the slice, decoded once; rows of q = 1..3 follow by +4 pixels
     int m = m_base + 16 * wave + srow;
     const int hw = p.Ho * p.Wo;
-    int n = m / hw;
+    int n = fd_div(m, p.fd_hw);
     int rm = m - n * hw;
-    int ho = rm / p.Wo;
+    int ho = fd_div(rm, p.fd_wo);
     int wo = rm - ho * p.Wo;
     const unsigned lrow0 = (unsigned)(buf * 2 * kOpBytes + (16 * wave) * kRowB);
 #pragma unroll
@@ -844,6 +845,8 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.dy_cs = d->y_cstride; a.dy_co = d->y_coff;
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin;
+  a.fd_hw = make_fastdiv((unsigned)(d->Ho * d->Wo));
+  a.fd_wo = make_fastdiv((unsigned)d->Wo);
   if (dtype != YV4_F32 && !g_wgrad_widen) {
     // 16-bit MFMA form: 128 x 128 tiles of dW, 64-row slices
     a.tiles_k = (a.K + kWhTile - 1) / kWhTile;
