@@ -97,6 +97,27 @@ struct Elem<false> {
 // Epilogue of one 32x32 accumulator tile through a wave-private LDS patch (fp32, pitch 36):
 // afterwards lane l owns 8 consecutive channels of rows (l>>2) and (l>>2)+16, i.e. one 16-byte
 // store of 16-bit outputs per row (two dwordx4 when the output is fp32).
+// the activation of 8 values with ONE (uniform) branch on the activation id: apply_act() inside the element
+// loop left a scalar compare-and-branch chain per element in the epilogue (the compiler does not unswitch it)
+__device__ __forceinline__ void act_row8(float (&v)[8], int act, float slope) {
+  switch (act) {
+    case YV4_ACT_MISH:
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = apply_act(v[u], YV4_ACT_MISH, 0.f);
+      break;
+    case YV4_ACT_LEAKY:
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = v[u] >= 0.f ? v[u] : v[u] * slope;
+      break;
+    case YV4_ACT_SWISH:
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = apply_act(v[u], YV4_ACT_SWISH, 0.f);
+      break;
+    default:
+      break;
+  }
+}
+
 // per-channel affine of a lane's 8 output columns (co .. co+7): two 16-byte loads per array when aligned
 struct AffH { float s1[8], t1[8], s2[8], t2[8]; };
 __device__ __forceinline__ void load_affine_h(const ConvArgsH& p, int co, bool has2, AffH& a) {
@@ -149,7 +170,8 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
       if (m < p.M) {
         float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = apply_act(v[u] * s1[u] + t1[u], p.act1, p.slope1);
+        for (int u = 0; u < 8; ++u) v[u] = v[u] * s1[u] + t1[u];
+        act_row8(v, p.act1, p.slope1);
         if (p.res) {
           const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.r_cs + p.r_co + co);
 #pragma unroll
@@ -157,7 +179,8 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
         }
         if (has2) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = apply_act(v[u] * s2[u] + t2[u], p.act2, p.slope2);
+          for (int u = 0; u < 8; ++u) v[u] = v[u] * s2[u] + t2[u];
+          act_row8(v, p.act2, p.slope2);
         }
         if (p.out_f32) {
           float* dst = reinterpret_cast<float*>(p.y) + out_row_h(p, m) * p.y_cs + p.y_co + co;
