@@ -22,8 +22,9 @@ def env_world():
 def init(backend='nccl', device=None):
     """Join the process group when launched with WORLD_SIZE > 1; returns (rank, local_rank, world).
     YV4_DIST_FORCE_INIT=1 joins a one-rank group too (exercises the RCCL barrier / all-reduce of the timed
-    region on a 1-GPU box)."""
+    region on a 1-GPU box); YV4_DIST_BACKEND overrides the backend (tests: gloo with both ranks on cuda:0)."""
     rank, local_rank, world = env_world()
+    backend = os.environ.get('YV4_DIST_BACKEND', backend)     # e.g. gloo: two ranks sharing the one GPU of a test box
     force = os.environ.get('YV4_DIST_FORCE_INIT') == '1' and 'MASTER_PORT' in os.environ
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

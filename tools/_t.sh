@@ -1,7 +1,5 @@
-timeout 600 python -m pytest tests/test_gpu_h16.py -x -q 2>&1 < /dev/null | tail -2
-for i in 1 2 3; do
-for v in lib_alt lib; do
-echo "== $v"
-YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/$v/libyv4_hip.so timeout 300 python bench.py --dtype bf16 --no-cpu-baseline --steps 10 --warmup 3 2>&1 < /dev/null | tail -1 | cut -c1-150
-done
-done
+export YV4_DIST_BACKEND=gloo MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 WORLD_SIZE=2 LOCAL_RANK=0
+RANK=1 timeout 600 python bench.py --gpus 2 --steps 6 --warmup 2 --batch 16 > /tmp/r1.log 2>&1 < /dev/null &
+P=$!
+RANK=0 timeout 600 python bench.py --gpus 2 --steps 6 --warmup 2 --batch 16 2>&1 < /dev/null | tail -2 | cut -c1-700
+wait $P; echo "rank1 rc=$?"; tail -2 /tmp/r1.log | cut -c1-200
