@@ -282,6 +282,27 @@ __device__ __forceinline__ u32x4_t make_rsrc(const void* base, unsigned bytes) {
 // channels of one pixel, so the tile leaves (and the residual arrives) in 4 dwordx4
 // instructions per lane and the per-channel scale/shift become vector loads.
 // `vec_ok` (uniform): all views are 16-byte aligned per pixel (false for the 255-channel heads).
+// the activation of a lane's 4 values behind ONE uniform branch on the activation id (apply_act() per element left
+// a scalar compare-and-branch chain per element: the compiler does not unswitch the unrolled loop)
+__device__ __forceinline__ void act_row4(float4& v, int act, float slope) {
+  switch (act) {
+    case YV4_ACT_MISH:
+      v.x = apply_act(v.x, YV4_ACT_MISH, 0.f); v.y = apply_act(v.y, YV4_ACT_MISH, 0.f);
+      v.z = apply_act(v.z, YV4_ACT_MISH, 0.f); v.w = apply_act(v.w, YV4_ACT_MISH, 0.f);
+      break;
+    case YV4_ACT_LEAKY:
+      v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
+      v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
+      break;
+    case YV4_ACT_SWISH:
+      v.x = apply_act(v.x, YV4_ACT_SWISH, 0.f); v.y = apply_act(v.y, YV4_ACT_SWISH, 0.f);
+      v.z = apply_act(v.z, YV4_ACT_SWISH, 0.f); v.w = apply_act(v.w, YV4_ACT_SWISH, 0.f);
+      break;
+    default:
+      break;
+  }
+}
+
 __device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const f32x16& acc, float* ep, int lane, int m_base,
                                               int co_base, bool vec_ok, bool has2) {
   const int r = lane & 31, h = lane >> 5;
@@ -304,20 +325,15 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const f32x16& a
       const int m = m_base + row;
       const float4 a = *reinterpret_cast<const float4*>(ep + row * kPitch + c4);
       if (m < p.M) {
-        float4 v;
-        v.x = apply_act(a.x * s1.x + t1.x, p.act1, p.slope1);
-        v.y = apply_act(a.y * s1.y + t1.y, p.act1, p.slope1);
-        v.z = apply_act(a.z * s1.z + t1.z, p.act1, p.slope1);
-        v.w = apply_act(a.w * s1.w + t1.w, p.act1, p.slope1);
+        float4 v = make_float4(a.x * s1.x + t1.x, a.y * s1.y + t1.y, a.z * s1.z + t1.z, a.w * s1.w + t1.w);
+        act_row4(v, p.act1, p.slope1);
         if (p.res) {
           const float4 rr = *reinterpret_cast<const float4*>(p.res + (int64_t)m * p.r_cs + p.r_co + co);
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         if (has2) {
-          v.x = apply_act(v.x * s2.x + t2.x, p.act2, p.slope2);
-          v.y = apply_act(v.y * s2.y + t2.y, p.act2, p.slope2);
-          v.z = apply_act(v.z * s2.z + t2.z, p.act2, p.slope2);
-          v.w = apply_act(v.w * s2.w + t2.w, p.act2, p.slope2);
+          v = make_float4(v.x * s2.x + t2.x, v.y * s2.y + t2.y, v.z * s2.z + t2.z, v.w * s2.w + t2.w);
+          act_row4(v, p.act2, p.slope2);
         }
         *reinterpret_cast<float4*>(p.y + out_row(p, m) * p.y_cs + p.y_co + co) = v;
       }
