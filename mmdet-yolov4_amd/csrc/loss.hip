@@ -34,6 +34,7 @@ struct LossLv {
   float base[8][4];
   long long anchor_off;   // first anchor box of the level inside an image
   long long block0;       // first workgroup of the level in the dense backward launch
+  FastDiv fd_hw, fd_cpr;  // row / (H*W), chunk index / (Cp / chunk): the dense backward runs one divide per 16 bytes
 };
 
 struct LossArgs {
@@ -41,6 +42,7 @@ struct LossArgs {
   int L, N, A, attr, C, G;
   long long TA;           // anchor boxes per image, all levels
   long long S;            // candidate slots per level = 5 * A * G
+  FastDiv fd_TA, fd_A;
   const float* gt; const int64_t* gt_label; const int64_t* gt_img;
   float shape_thr, smooth, ratio, eps, w_cls, w_conf, w_bbox;
   int32_t* slot_anchor; int32_t* winner; int32_t* npos; float* conf_t; float* gpos; double* sums;
@@ -62,12 +64,14 @@ __device__ __forceinline__ float bce_logits(float x, float t) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void yolo_assign_kernel(LossArgs p) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.S * p.L) return;
-  const int l = (int)(i / p.S);
-  const long long s = i % p.S;
-  const int g = (int)(s % p.G);
-  const int a = (int)((s / p.G) % p.A);
-  const int k = (int)(s / ((long long)p.G * p.A));
+  if (i >= p.S * p.L) return;            // (tail lanes leave; __ballot() below only sees the lanes still here)
+  const int ii = (int)i, S = (int)p.S;   // S * L < 2^31 (host)
+  const int l = ii / S;
+  const int s = ii - l * S;
+  const int ag = s / p.G;
+  const int g = s - ag * p.G;
+  const int k = ag / p.A;
+  const int a = ag - k * p.A;
   const LossLv& lv = p.lv[l];
   const float* b = p.gt + 4 * (size_t)g;
   const float cx = 0.5f * (b[2] + b[0]), cy = 0.5f * (b[3] + b[1]);
@@ -95,9 +99,17 @@ __global__ __launch_bounds__(256) void yolo_assign_kernel(LossArgs p) {
   if (ok) {
     anchor = (int)((py * lv.W + px) * p.A + a);
     atomicMax(&p.winner[img * p.TA + lv.anchor_off + anchor], (int)s);
-    atomicAdd(&p.npos[l], 1);
   }
   p.slot_anchor[i] = anchor;
+  // positives per level: one atomic per wavefront (all of a level's positives hit the same counter)
+  const int l0 = __builtin_amdgcn_readfirstlane(l);
+  const unsigned long long same = __ballot(l == l0), live = __ballot(true);
+  if (same == live) {
+    const unsigned long long votes = __ballot(ok);
+    if (votes && (int)(threadIdx.x & 63) == __ffsll((long long)live) - 1) atomicAdd(&p.npos[l0], __popcll(votes));
+  } else if (ok) {
+    atomicAdd(&p.npos[l], 1);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -162,16 +174,21 @@ __device__ __forceinline__ BoxTerms box_terms(const float t[4], const LossLv& lv
   return r;
 }
 
+constexpr int kSlotsPerWave = 8;
+
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void yolo_pos_kernel(LossArgs p) {
   const int lane = threadIdx.x & 63;
-  const long long ws = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ws >= p.S * p.L) return;
+  const int S = (int)p.S, total = S * p.L;
+  const int ws0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSlotsPerWave;
+  float part_cls = 0.f, part_box = 0.f;     // forward: this wave's sums for level part_l (lane 0)
+  int part_l = -1;
+  for (int ws = ws0; ws < ws0 + kSlotsPerWave && ws < total; ++ws) {
   const int anchor = p.slot_anchor[ws];
-  if (anchor < 0) return;                                   // wave-uniform
-  const int l = (int)(ws / p.S);
-  const long long s = ws % p.S;
-  const int g = (int)(s % p.G);
+  if (anchor < 0) continue;                                 // wave-uniform
+  const int l = ws / S;
+  const int s = ws - l * S;
+  const int g = s % p.G;
   const LossLv& lv = p.lv[l];
   const int a = anchor % p.A;
   const int cell = anchor / p.A;
@@ -192,9 +209,16 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(LossArgs p) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if (lane == 0) {
-      if (p.C > 0) atomicAdd(&p.sums[l * 3 + 0], (double)acc);
+      if (l != part_l) {          // a wave's slots rarely straddle two levels: flush, then start the new level
+        if (part_l >= 0) {
+          if (p.C > 0) atomicAdd(&p.sums[part_l * 3 + 0], (double)part_cls);
+          atomicAdd(&p.sums[part_l * 3 + 2], (double)part_box);
+        }
+        part_l = l; part_cls = 0.f; part_box = 0.f;
+      }
+      part_cls += acc;
       const float gl = 1.f - bt.giou;                        // the GIoU loss of the positive
-      atomicAdd(&p.sums[l * 3 + 2], (double)gl);
+      part_box += gl;
       const float q = fminf(fmaxf(1.f - gl, 0.f), 1.f);      // (1 - giou_loss).clamp(0, 1)
       p.conf_t[ws] = (1.f - p.ratio) + p.ratio * q;
     }
@@ -202,7 +226,7 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(LossArgs p) {
     const int np = p.npos[l];
     const float k_box = p.gout[l * 3 + 2] * p.w_bbox / (float)np;
     const int wslot = p.winner[img * p.TA + lv.anchor_off + anchor];
-    float* grow = p.gpos + ((size_t)l * p.S + wslot) * p.attr;
+    float* grow = p.gpos + ((size_t)l * S + wslot) * p.attr;
     if (lane < 4) atomicAdd(&grow[lane], bt.dt[lane] * k_box);
     if (p.C > 0) {
       const float k_cls = p.gout[l * 3 + 0] * p.w_cls / ((float)np * (float)p.C);
@@ -211,6 +235,11 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(LossArgs p) {
         atomicAdd(&grow[5 + c], (sigmoid_f32(x) - (c == label ? t_on : t_off)) * k_cls);
       }
     }
+  }
+  }   // slots of this wave
+  if (!BWD && lane == 0 && part_l >= 0) {
+    if (p.C > 0) atomicAdd(&p.sums[part_l * 3 + 0], (double)part_cls);
+    atomicAdd(&p.sums[part_l * 3 + 2], (double)part_box);
   }
 }
 
@@ -222,13 +251,14 @@ __global__ __launch_bounds__(256) void yolo_dense_fwd_kernel(LossArgs p) {
   __syncthreads();
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < p.TA * p.N) {
-    const long long n = i / p.TA, j = i % p.TA;
+    const int n = fd_div((int)i, p.fd_TA);                 // N * TA < 2^31 (host)
+    const int j = (int)i - n * (int)p.TA;
     int l = 0;
-    while (l + 1 < p.L && j >= p.lv[l + 1].anchor_off) ++l;
+    while (l + 1 < p.L && j >= (int)p.lv[l + 1].anchor_off) ++l;
     const LossLv& lv = p.lv[l];
-    const long long jl = j - lv.anchor_off;
-    const int a = (int)(jl % p.A);
-    const long long cell = jl / p.A;
+    const int jl = j - (int)lv.anchor_off;
+    const int cell = fd_div(jl, p.fd_A);
+    const int a = jl - cell * p.A;
     const int c = a * p.attr + 4;
     const float x = ldf(reinterpret_cast<const T*>(lv.raw) + ((size_t)n * lv.H * lv.W + cell) * lv.Cp + c) + lv.bias[c];
     const int w = p.winner[i];
@@ -254,16 +284,20 @@ __global__ __launch_bounds__(256) void yolo_dense_bwd_kernel(LossArgs p) {
   for (int c = threadIdx.x; c < lv.Cp; c += 256) db[c] = 0.f;
   __syncthreads();
   const int cpr = lv.Cp / CH;
-  const long long rows = (long long)p.N * lv.H * lv.W;
-  const long long idx = ((long long)blockIdx.x - lv.block0) * 256 + threadIdx.x;
-  const long long row = idx / cpr;
-  if (row < rows) {
-    const int c0 = (int)(idx % cpr) * CH;
-    const long long HW = (long long)lv.H * lv.W;
-    const long long n = row / HW, cell = row % HW;
-    const float k_conf = p.gout[l * 3 + 1] * p.w_conf / (float)(p.N * HW * p.A);
+  const int rows = p.N * lv.H * lv.W;                      // rows * cpr < 2^31 (host)
+  // a level's workgroups stride over its 16-byte chunks: few, long-lived workgroups keep the number of
+  // same-address bias-gradient atomics at the end small (one per workgroup per channel: with one workgroup per
+  // 256 chunks the three objectness channels saw 46 k serialised atomics each, 650 us of a 60 us pass)
+  const int nblk = (int)((l + 1 < p.L ? p.lv[l + 1].block0 : (long long)gridDim.x) - lv.block0);
+  for (int idx = (int)(((long long)blockIdx.x - lv.block0) * 256 + threadIdx.x); idx < rows * cpr; idx += nblk * 256) {
+  const int row = fd_div(idx, lv.fd_cpr);
+  {
+    const int c0 = (idx - row * cpr) * CH;
+    const int HW = lv.H * lv.W;
+    const int n = fd_div(row, lv.fd_hw), cell = row - n * HW;
+    const float k_conf = p.gout[l * 3 + 1] * p.w_conf / (float)((long long)p.N * HW * p.A);
     const T* src = reinterpret_cast<const T*>(lv.raw) + (size_t)row * lv.Cp;
-    const int32_t* win = p.winner + n * p.TA + lv.anchor_off + cell * p.A;
+    const int32_t* win = p.winner + (long long)n * p.TA + lv.anchor_off + (long long)cell * p.A;
     float v[CH];
     int a_cached = -1, w_cached = -1;
 #pragma unroll
@@ -288,6 +322,7 @@ __global__ __launch_bounds__(256) void yolo_dense_bwd_kernel(LossArgs p) {
     for (int u = 0; u < CH; ++u) o[u] = (T)v[u];
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
   }
+  }   // chunks of this workgroup
   __syncthreads();
   for (int c = threadIdx.x; c < p.A * p.attr; c += 256)
     if (db[c] != 0.f) atomicAdd(&lv.dbias[c], (double)db[c]);
@@ -319,8 +354,13 @@ static int fill_args(const yv4_loss_desc* d, LossArgs& a, const char* who) {
       for (int c = 0; c < 4; ++c) t.base[k][c] = s.base_anchors[k][c];
     t.anchor_off = off;
     off += (long long)s.H * s.W * a.A;
+    t.fd_hw = make_fastdiv((unsigned)(s.H * s.W));
+    t.fd_cpr = make_fastdiv((unsigned)(s.Cp / ch));
+    YV4_REQUIRE((long long)d->N * s.H * s.W * (s.Cp / ch) < (1LL << 31), "%s: level %d: map too large", who, l);
   }
   a.TA = off;
+  a.fd_TA = make_fastdiv((unsigned)off);
+  a.fd_A = make_fastdiv((unsigned)a.A);
   YV4_REQUIRE(a.TA * a.N < (1LL << 31) && a.S * a.L < (1LL << 31), "%s: index space exceeds 31 bits", who);
   a.gt = d->gt; a.gt_label = d->gt_label; a.gt_img = d->gt_img;
   a.shape_thr = d->shape_thr; a.smooth = d->smooth; a.ratio = d->ratio; a.eps = d->eps;
@@ -352,8 +392,8 @@ extern "C" int yv4_yolo_loss_fwd(const yv4_loss_desc* d, void* stream) {
   const long long slots = a.S * a.L;
   if (slots > 0) {
     hipLaunchKernelGGL(yolo_assign_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, a);
-    YV4_LOSS_DISPATCH(d->dtype, hipLaunchKernelGGL((yolo_pos_kernel<T, false>), dim3((unsigned)((slots + 3) / 4)), dim3(256),
-                                                   0, s, a));
+    YV4_LOSS_DISPATCH(d->dtype, hipLaunchKernelGGL((yolo_pos_kernel<T, false>), dim3((unsigned)((slots + 4 * kSlotsPerWave - 1) / (4 * kSlotsPerWave))),
+                                                  dim3(256), 0, s, a));
   }
   const long long boxes = a.TA * a.N;
   YV4_LOSS_DISPATCH(d->dtype, hipLaunchKernelGGL(yolo_dense_fwd_kernel<T>, dim3((unsigned)((boxes + 255) / 256)), dim3(256), 0,
@@ -378,7 +418,9 @@ extern "C" int yv4_yolo_loss_bwd(const yv4_loss_desc* d, const float* grad_out, 
     YV4_REQUIRE(((uintptr_t)a.lv[l].draw & 15) == 0, "yolo_loss_bwd: level %d: draw must be 16-byte aligned", l);
     a.lv[l].block0 = blocks;
     const long long chunks = (long long)a.N * a.lv[l].H * a.lv[l].W * (a.lv[l].Cp / ch);
-    blocks += (chunks + 255) / 256;
+    long long nb = (chunks + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    blocks += nb;
     if (a.lv[l].Cp > max_cp) max_cp = a.lv[l].Cp;
     ok = ok && hipMemsetAsync(a.lv[l].dbias, 0, sizeof(double) * a.A * a.attr, s) == hipSuccess;
   }
@@ -387,8 +429,8 @@ extern "C" int yv4_yolo_loss_bwd(const yv4_loss_desc* d, const float* grad_out, 
   if (!ok) { set_error("yolo_loss_bwd: memset failed"); return YV4_E_LAUNCH; }
   YV4_REQUIRE(blocks < (1LL << 31), "yolo_loss_bwd: too many workgroups");
   if (slots > 0)
-    YV4_LOSS_DISPATCH(d->dtype, hipLaunchKernelGGL((yolo_pos_kernel<T, true>), dim3((unsigned)((slots + 3) / 4)), dim3(256), 0,
-                                                   s, a));
+    YV4_LOSS_DISPATCH(d->dtype, hipLaunchKernelGGL((yolo_pos_kernel<T, true>), dim3((unsigned)((slots + 4 * kSlotsPerWave - 1) / (4 * kSlotsPerWave))),
+                                                  dim3(256), 0, s, a));
   YV4_LOSS_DISPATCH(d->dtype, hipLaunchKernelGGL(yolo_dense_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256),
                                                  sizeof(float) * max_cp, s, a));
   YV4_CHECK_LAUNCH("yolo_loss_bwd");
