@@ -47,6 +47,7 @@ struct ConvArgsH {
   int ablate;     // measurement only (YV4_H16_ABLATE): 1 = issue no DMA after the first slice, 2 = no MFMA, 4 = no barrier
   double* stats;  // training: per-channel [sum | sum of squares] of the STORED outputs, YV4_STATS_REPLICAS x 2*Cout
   FastDiv fd_hw, fd_wo;   // m / (Ho*Wo), r / Wo (set by launch_h16)
+  FastDiv fd_cin, fd_kw;  // GENERAL_K: k / Cin, tap / KW, once per lane per slice
 };
 
 __device__ __forceinline__ int64_t out_row_h(const ConvArgsH& p, int m) {
@@ -305,9 +306,9 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
     const unsigned lb_ = lds_base + (unsigned)((NBUF * BM + (BUF) * BN + 8 * wave) * kRowB);      \
     if (GENERAL_K) {                                                                             \
       const bool kin = g_k < p.K;                                                                \
-      const int tap = kin ? g_k / p.Cin : 0;                                                     \
+      const int tap = kin ? fd_div(g_k, p.fd_cin) : 0;                                           \
       const int c = g_k - tap * p.Cin;                                                           \
-      const int kh = tap / p.KW;                                                                 \
+      const int kh = fd_div(tap, p.fd_kw);                                                       \
       const int kw = tap - kh * p.KW;                                                            \
       const unsigned step = (unsigned)((((int64_t)kh * p.W + kw) * p.x_cs + c) * 2);             \
       _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                           \
@@ -473,6 +474,8 @@ static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
   p.tiles_n = (p.Cout + BN - 1) / BN;
   p.fd_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
   p.fd_wo = make_fastdiv((unsigned)p.Wo);
+  p.fd_cin = make_fastdiv((unsigned)p.Cin);
+  p.fd_kw = make_fastdiv((unsigned)p.KW);
   const long long tiles = (long long)tiles_m * p.tiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffLL) {
     set_error("conv h16: grid of %lld tiles out of range", tiles);
