@@ -795,6 +795,79 @@ __global__ __launch_bounds__(256) void spp_pool_bwd_kernel(const T* __restrict__
   }
 }
 
+// The same scatter with the accumulator of one (image, 32-channel group) in LDS: the maps an SPP block sees are
+// small (19x19 at 608 px), so the whole H*W x 32 fp32 slice fits a workgroup's LDS, the 16 adds per element become
+// LDS atomics and dx is written once with plain stores -- the global-atomic form above spends most of its 2 ms
+// (batch 64, 512 channels) on 47 M float atomics into a 47 MB tensor.
+constexpr int kSppCG = 32;     // channels per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void spp_pool_bwd_lds_kernel(const T* __restrict__ xcat, int x_cs, int x_co,
+                                                               const T* __restrict__ dcat, int d_cs, int d_co,
+                                                               float* __restrict__ dx, int H, int W, int C) {
+  extern __shared__ float sacc[];          // [H*W][kSppCG]
+  const int HW = H * W;
+  const int n = blockIdx.y;
+  const int cg0 = blockIdx.x * kSppCG;
+  const int nq = min(kSppCG, C - cg0) >> 2;                 // channel quads of this group
+  for (int i = threadIdx.x; i < HW * kSppCG; i += 256) sacc[i] = 0.f;
+  __syncthreads();
+  const float ninf = -__builtin_huge_valf();
+  const T* xb = xcat + (size_t)n * HW * x_cs + x_co + cg0;
+  const T* gb = dcat + (size_t)n * HW * d_cs + d_co + cg0;
+  for (int item = threadIdx.x; item < HW * 8; item += 256) {
+    const int q = item & 7;
+    if (q >= nq) continue;
+    const int pos0 = item >> 3;
+    const int y = pos0 / W, x = pos0 - y * W;
+    const T* base = xb + q * 4;
+    float m[3][4];
+    int am[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { m[k][u] = ninf; am[k][u] = pos0; }
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int yy = y + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      const int ady = dy < 0 ? -dy : dy;
+      for (int dxx = -6; dxx <= 6; ++dxx) {
+        const int xx = x + dxx;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        const int adx = dxx < 0 ? -dxx : dxx;
+        const int rad = ady > adx ? ady : adx;
+        const int pos = yy * W + xx;
+        const float4 v4 = El<T>::ld4(base + (size_t)pos * x_cs);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (v[u] > m[2][u]) { m[2][u] = v[u]; am[2][u] = pos; }
+          if (rad <= 4 && v[u] > m[1][u]) { m[1][u] = v[u]; am[1][u] = pos; }
+          if (rad <= 2 && v[u] > m[0][u]) { m[0][u] = v[u]; am[0][u] = pos; }
+        }
+      }
+    }
+    const T* g = gb + (size_t)pos0 * d_cs + q * 4;
+    const float4 g0 = El<T>::ld4(g);
+    const float gi[4] = {g0.x, g0.y, g0.z, g0.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) atomicAdd(&sacc[pos0 * kSppCG + q * 4 + u], gi[u]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 gk = El<T>::ld4(g + (k + 1) * C);
+      const float gv[4] = {gk.x, gk.y, gk.z, gk.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) atomicAdd(&sacc[am[k][u] * kSppCG + q * 4 + u], gv[u]);
+    }
+  }
+  __syncthreads();
+  float* out = dx + (size_t)n * HW * C + cg0;
+  for (int i = threadIdx.x; i < HW * 8; i += 256) {
+    const int q = i & 7, pos = i >> 3;
+    if (q < nq)
+      *reinterpret_cast<float4*>(out + (size_t)pos * C + q * 4) = *reinterpret_cast<const float4*>(&sacc[pos * kSppCG + q * 4]);
+  }
+}
+
 __global__ void sums_to_float_kernel(const double* __restrict__ sums, int n, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (float)sums[i];
@@ -1094,6 +1167,16 @@ extern "C" int yv4_spp_pool_bwd(const void* xcat, int x_cstride, int x_coff, con
   YV4_REQUIRE(((C | x_cstride | x_coff | d_cstride | d_coff) & 3) == 0, "spp_pool_bwd: channels must be multiples of 4");
   YV4_REQUIRE(x_coff + C <= x_cstride && d_coff + 4 * C <= d_cstride, "spp_pool_bwd: view exceeds its pixel stride");
   YV4_REQUIRE((long long)H * W < (1LL << 31), "spp_pool_bwd: H*W does not fit 31 bits");
+  const size_t lds = (size_t)H * W * kSppCG * sizeof(float);
+  if (lds <= 64 * 1024 && N <= 65535) {        // small maps: LDS-resident accumulator, dx written once
+    dim3 grid((unsigned)((C + kSppCG - 1) / kSppCG), (unsigned)N);
+    YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(spp_pool_bwd_lds_kernel<T>, grid, dim3(256), lds,
+                                             reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(xcat),
+                                             x_cstride, x_coff, reinterpret_cast<const T*>(dcat), d_cstride, d_coff, dx, H,
+                                             W, C));
+    YV4_CHECK_LAUNCH("spp_pool_bwd");
+    return YV4_OK;
+  }
   const size_t total = (size_t)N * H * W * (C / 4);
   YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(spp_pool_bwd_kernel<T>, dim3(ew_grid_t(total)), dim3(256), 0,
                                            reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(xcat),

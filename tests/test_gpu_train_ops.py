@@ -220,3 +220,23 @@ def test_conv_epilogue_leaves_the_bn_sums(dtype, shape):
     assert float((out_a - out_b).abs().max()) <= tol * float(out_b.abs().max())
     assert float((bn_a.running_var - bn_b.running_var).abs().max()) < 1e-6
     assert float((bn_a.running_mean - bn_b.running_mean).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize('shape', [(3, 80, 19, 19), (1, 40, 40, 36), (2, 36, 9, 30)])
+def test_spp_backward_lds_and_atomic_forms(gpu_device, shape):
+    """The SPP backward keeps one (image, 32-channel group) accumulator in LDS when H*W*128 B fits 64 KB (every map an
+    SPP block sees in the recipes) and falls back to global float atomics otherwise: both against ATen's autograd,
+    fp32, channel counts that are not multiples of the group."""
+    from mmdet_yolov4_amd import train_ops as T
+    N, C_, H, W = shape
+    torch.manual_seed(1)
+    x = torch.randn(N, C_, H, W, device=gpu_device)
+    xr = x.clone().requires_grad_(True)
+    out = T.spp_cat(xr)
+    g = torch.randn(N, 4 * C_, H, W, device=gpu_device)
+    out.backward(g)
+    x2 = x.clone().requires_grad_(True)
+    ref = torch.cat([x2] + [F.max_pool2d(x2, k, 1, k // 2) for k in (5, 9, 13)], 1)
+    ref.backward(g)
+    assert torch.equal(out, ref.detach())
+    torch.testing.assert_close(xr.grad, x2.grad, rtol=1e-5, atol=1e-5)
