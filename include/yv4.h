@@ -381,6 +381,14 @@ int yv4_bn_act_bwd_apply(const void* x, int dtype, int x_cstride, int x_coff, co
                          int dx_coff, const double* work, int64_t M, int64_t M_total,
                          const double* rows_dev, int C, int act, float slope, void* stream);
 
+/* A conv weight (Cout, Cin, KH, KW), addressed through its element strides (contiguous or channels_last), to
+ * the packed operand of the conv kernels in one pass: rows x (KH*KW*ICp), K ordered (kh, kw, channel), the channel
+ * count zero-padded to a multiple of pad_to, cast to `dtype`.  transpose_flip = 0: rows = Cout, channels = Cin (the
+ * forward operand); 1: rows = Cin, channels = Cout, taps mirrored (the operand of the data gradient). */
+int yv4_pack_weight(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw, int Cout,
+                    int Cin, int KH, int KW, int transpose_flip, int pad_to, void* dst, int dtype,
+                    void* stream);
+
 /* One parity class of the data gradient of a stride-2 convolution: a stride-1 convolution of dY whose
  * output pixel (n, ho, wo) is stored at y[n, ho*sh + oh, wo*sw + ow, y_coff + c] of an
  * (N, Hy, Wy, y_cstride) tensor.  d->Ho / d->Wo are taken as given (rows past the input's edge read

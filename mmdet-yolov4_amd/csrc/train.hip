@@ -868,6 +868,30 @@ __global__ __launch_bounds__(256) void spp_pool_bwd_lds_kernel(const T* __restri
   }
 }
 
+// Conv weight -> the kernels' packed operand in ONE pass (cast included): rows x (KH*KW*ICp) with K ordered
+// (kh, kw, channel), zero-padded channels.  transpose_flip = 0: rows = Cout, channel = Cin (forward operand);
+// 1: rows = Cin, channel = Cout, taps mirrored -- the operand of the data gradient (ATen needs flip + transpose +
+// contiguous + cast = 3 launches per conv per step for it).  The source is addressed through its element strides,
+// so contiguous and channels_last parameters both go without a copy.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, long long s_co, long long s_ci,
+                                                          long long s_kh, long long s_kw, int Cout, int Cin, int KH, int KW,
+                                                          int tf, int ICp, T* __restrict__ dst, int nrows) {
+  // one output row (r, kh, kw) of ICp channels per workgroup iteration: two small divides per row, none per element
+  const int IC = tf ? Cout : Cin;
+  const int taps = KH * KW;
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int r = row / taps;
+    const int tap = row - r * taps;
+    const int kh = tap / KW, kw = tap - kh * KW;
+    const int kh2 = tf ? KH - 1 - kh : kh, kw2 = tf ? KW - 1 - kw : kw;
+    const float* src = w + kh2 * s_kh + kw2 * s_kw + (tf ? r * s_ci : r * s_co);
+    const long long s_ic = tf ? s_co : s_ci;
+    T* d = dst + (size_t)row * ICp;
+    for (int ic = threadIdx.x; ic < ICp; ic += 256) d[ic] = (T)(ic < IC ? src[ic * s_ic] : 0.f);
+  }
+}
+
 __global__ void sums_to_float_kernel(const double* __restrict__ sums, int n, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (float)sums[i];
@@ -1158,6 +1182,23 @@ extern "C" int yv4_bn_eval_act_bwd(const void* x, int dtype, int x_cstride, int 
                                    double* work, int64_t M, int C, int act, float slope, void* stream) {
   return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
                      dx_coff, dgamma, dbeta, work, M, C, act, slope, stream, 1);
+}
+
+extern "C" int yv4_pack_weight(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw, int Cout, int Cin,
+                               int KH, int KW, int transpose_flip, int pad_to, void* dst, int dtype, void* stream) {
+  YV4_REQUIRE(w && dst && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && pad_to > 0, "pack_weight: bad argument");
+  YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "pack_weight: dtype must be f32, f16 or bf16");
+  const int IC = transpose_flip ? Cout : Cin, R = transpose_flip ? Cin : Cout;
+  const int ICp = (IC + pad_to - 1) / pad_to * pad_to;
+  const long long nrows = (long long)R * KH * KW;
+  YV4_REQUIRE(nrows < (1LL << 31), "pack_weight: too many rows");
+  const unsigned grid = (unsigned)(nrows < 8192 ? nrows : 8192);
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(grid), dim3(256), 0,
+                                           reinterpret_cast<hipStream_t>(stream), w, (long long)s_co, (long long)s_ci,
+                                           (long long)s_kh, (long long)s_kw, Cout, Cin, KH, KW, transpose_flip ? 1 : 0, ICp,
+                                           reinterpret_cast<T*>(dst), (int)nrows));
+  YV4_CHECK_LAUNCH("pack_weight");
+  return YV4_OK;
 }
 
 extern "C" int yv4_spp_pool_bwd(const void* xcat, int x_cstride, int x_coff, const void* dcat, int d_cstride, int d_coff,

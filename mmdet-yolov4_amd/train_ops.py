@@ -78,6 +78,24 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None)
     return d
 
 
+def packed_weight(weight, dtype, transpose_flip=False):
+    """The conv kernels' weight operand from an fp32 (Cout, Cin, KH, KW) parameter in one launch (``yv4_pack_weight``):
+    rows x (KH*KW*Cp), K ordered (kh, kw, channel), channels zero-padded to a 16-byte chunk, cast to ``dtype``.
+    ``transpose_flip``: the data gradient's operand (rows = Cin, channels = Cout, taps mirrored).  Returns (w, Cp)."""
+    Cout, Cin, KH, KW = weight.shape
+    al = 4 if dtype == torch.float32 else 8
+    rows, ic = (Cin, Cout) if transpose_flip else (Cout, Cin)
+    cp = (ic + al - 1) // al * al
+    w = weight.detach()
+    if w.dtype != torch.float32:
+        w = w.float()
+    out = torch.empty((rows, KH * KW * cp), device=w.device, dtype=dtype)
+    st = w.stride()
+    check(_lib.lib().yv4_pack_weight(w.data_ptr(), st[0], st[1], st[2], st[3], Cout, Cin, KH, KW, int(transpose_flip), al,
+                                     out.data_ptr(), _DCODE[dtype], stream_ptr()), 'yv4_pack_weight')
+    return out, cp
+
+
 def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype):
     """dX = correlate(dY zero-dilated by `stride`, W flipped in (kh,kw) and transposed in (co,ci)), pad k-1-p."""
     N, Cin, H, W = xshape
@@ -85,8 +103,7 @@ def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype):
     Ho, Wo = dy.shape[2], dy.shape[3]
     h16 = dtype != torch.float32
     L = _lib.lib()
-    wt = weight.detach().flip(2, 3).transpose(0, 1)          # (Cin, Cout, KH, KW)
-    wtp, _ = pack_conv_weight(wt, align=8 if h16 else 4)
+    wtp, _ = packed_weight(weight, dtype, transpose_flip=True)     # rows = Cin, taps mirrored, cast: one launch
     if stride == 1:
         src = dy
     elif stride == 2:
@@ -101,7 +118,7 @@ def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype):
     Hx = Hs + 2 * p2 - KH + 1
     Wx = Ws + 2 * p2 - KW + 1
     dxf = torch.empty((N, Cin, Hx, Wx), device=dy.device, dtype=dtype, memory_format=torch.channels_last)
-    _conv_launch(src, wtp.to(dtype), Cout, Cin, KH, KW, 1, p2, dxf)
+    _conv_launch(src, wtp, Cout, Cin, KH, KW, 1, p2, dxf)
     if (Hx, Wx) != (H, W):
         # stride 2 with odd input size: the dilated grid is one row/column larger or smaller
         dx = torch.empty((N, Cin, H, W), device=dy.device, dtype=dtype, memory_format=torch.channels_last).zero_()
@@ -166,9 +183,9 @@ class ConvFunction(torch.autograd.Function):
         N, _, H, W = x.shape
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        wp, cp = pack_conv_weight(weight, align=al)
+        wp, cp = packed_weight(weight, dtype)
         y = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=dtype, memory_format=torch.channels_last)
-        _conv_launch(x, wp.to(dtype), cp, Cout, KH, KW, stride, pad, y, stats)
+        _conv_launch(x, wp, cp, Cout, KH, KW, stride, pad, y, stats)
         ctx.save_for_backward(x, weight)
         ctx.geom = (stride, pad, dtype, cp)
         return y
