@@ -59,6 +59,38 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_h16_kernel(const T* __restri
   }
 }
 
+// MaxPool2d(5, 1, 2) of one channel slice into another; chained three times it gives the 5 / 9 / 13 pools exactly
+// (see pool5_kernel in elementwise.hip).
+template <typename T, typename V8>
+__global__ __launch_bounds__(256) void pool5_h16_kernel(T* __restrict__ buf, int H, int W, int C8, int cs, int src_co,
+                                                        int dst_co) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= W * C8) return;
+  const int x = idx / C8, c8 = idx - x * C8;
+  const int row = blockIdx.y;
+  const int y = row % H;
+  const float ninf = -__builtin_huge_valf();
+  float m[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) m[u] = ninf;
+  const T* base = buf + (size_t)(row - y) * W * cs + src_co + c8 * 8;
+  for (int dy = -2; dy <= 2; ++dy) {
+    const int yy = y + dy;
+    if ((unsigned)yy >= (unsigned)H) continue;
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int xx = x + dx;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const V8 v = *reinterpret_cast<const V8*>(base + ((size_t)yy * W + xx) * cs);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m[u] = fmaxf(m[u], (float)v[u]);
+    }
+  }
+  V8 o;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) o[u] = (T)m[u];
+  *reinterpret_cast<V8*>(buf + ((size_t)row * W + x) * cs + dst_co + c8 * 8) = o;
+}
+
 // One thread owns (n, y, x, 8 channels): a 16-byte load per tap, maxima kept in fp32 (exact for
 // values that are already fp16 / bf16), three 16-byte stores.
 template <typename T, typename V8>
@@ -169,8 +201,21 @@ extern "C" int yv4_spp_pool_fwd_h16(void* buf, int N, int H, int W, int C, int c
   YV4_REQUIRE(C % 8 == 0 && cstride % 8 == 0 && coff % 8 == 0, "spp_h16: C, cstride and coff must be multiples of 8");
   YV4_REQUIRE(coff >= 0 && coff + 4 * C <= cstride, "spp_h16: the 4C-channel concat view exceeds the pixel stride");
   YV4_REQUIRE(((uintptr_t)buf & 15) == 0, "spp_h16: buffer must be 16-byte aligned");
-  const size_t total = (size_t)N * H * W * (C / 8);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if ((long long)N * H <= 65535) {      // three chained 5x5 pools
+    const dim3 grid((unsigned)((W * (C / 8) + 255) / 256), (unsigned)(N * H));
+    for (int k = 0; k < 3; ++k) {
+      if (dtype == YV4_BF16)
+        hipLaunchKernelGGL((pool5_h16_kernel<__bf16, bf16x8_e>), grid, dim3(256), 0, s, (__bf16*)buf, H, W, C / 8, cstride,
+                           coff + k * C, coff + (k + 1) * C);
+      else
+        hipLaunchKernelGGL((pool5_h16_kernel<_Float16, f16x8_e>), grid, dim3(256), 0, s, (_Float16*)buf, H, W, C / 8, cstride,
+                           coff + k * C, coff + (k + 1) * C);
+    }
+    YV4_CHECK_LAUNCH("spp_pool_h16");
+    return YV4_OK;
+  }
+  const size_t total = (size_t)N * H * W * (C / 8);
   if (dtype == YV4_BF16)
     hipLaunchKernelGGL((spp_pool_h16_kernel<__bf16, bf16x8_e>), dim3(ew_grid_h(total)), dim3(256), 0, s, (__bf16*)buf, N, H, W,
                        C / 8, cstride, coff, C);
