@@ -35,6 +35,22 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_h16_kernel(const float* __re
   }
 }
 
+// Small-C form (the 3-channel image padded to one 16-byte chunk, C + pad == 8): one thread per pixel reads its C
+// planar fp32 values (coalesced per plane) and writes 8 sixteen-bit values in one store; grid (pixel blocks, image).
+template <typename T, typename V8>
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_h16_kernel(const float* __restrict__ src, T* __restrict__ dst, int C,
+                                                                int HW, int dst_cs, int dst_co) {
+  const int n = blockIdx.y;
+  const float* s0 = src + (size_t)n * C * HW;
+  T* d0 = dst + (size_t)n * HW * dst_cs + dst_co;
+  for (int px = blockIdx.x * 256 + threadIdx.x; px < HW; px += gridDim.x * 256) {
+    V8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (T)(c < C ? s0[(size_t)c * HW + px] : 0.f);
+    *reinterpret_cast<V8*>(d0 + (size_t)px * dst_cs) = o;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_h16_kernel(const T* __restrict__ src, float* __restrict__ dst, int C,
                                                                int HW, int src_cs, int src_co) {
@@ -162,8 +178,20 @@ extern "C" int yv4_nchw_to_nhwc_h16(const float* src, void* dst, int N, int C, i
   YV4_REQUIRE(dst_coff >= 0 && dst_coff + C + zero_pad <= dst_cstride, "nchw_to_nhwc_h16: view exceeds pixel stride");
   YV4_REQUIRE(N <= 65535, "nchw_to_nhwc_h16: N > 65535");
   const int HW = H * W;
-  dim3 grid((HW + 63) / 64, (C + zero_pad + 63) / 64, N);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (C + zero_pad == 8 && dst_cstride % 8 == 0 && dst_coff % 8 == 0 && ((uintptr_t)dst & 15) == 0) {
+    unsigned gx = (unsigned)((HW + 255) / 256);
+    if (gx > 4096) gx = 4096;
+    if (dtype == YV4_BF16)
+      hipLaunchKernelGGL((nchw_to_nhwc8_h16_kernel<__bf16, bf16x8_e>), dim3(gx, (unsigned)N), dim3(256), 0, s, src, (__bf16*)dst,
+                         C, HW, dst_cstride, dst_coff);
+    else
+      hipLaunchKernelGGL((nchw_to_nhwc8_h16_kernel<_Float16, f16x8_e>), dim3(gx, (unsigned)N), dim3(256), 0, s, src,
+                         (_Float16*)dst, C, HW, dst_cstride, dst_coff);
+    YV4_CHECK_LAUNCH("nchw_to_nhwc_h16");
+    return YV4_OK;
+  }
+  dim3 grid((HW + 63) / 64, (C + zero_pad + 63) / 64, N);
   if (dtype == YV4_BF16)
     hipLaunchKernelGGL(nchw_to_nhwc_h16_kernel<__bf16>, grid, dim3(256), 0, s, src, (__bf16*)dst, C, HW, dst_cstride,
                        dst_coff, zero_pad);
