@@ -54,3 +54,43 @@ def test_cpu_tensors_are_refused():
         pkg.batched_nms(torch.zeros(1, 4), torch.zeros(1), torch.zeros(1, dtype=torch.long), dict(iou_threshold=0.5))
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         pkg.Conv(4, 8, 3).eval()(torch.zeros(1, 4, 8, 8))
+
+
+def test_binding_argument_types_match_the_header():
+    """Every prototype in include/yv4.h against the ctypes signature bound to it: argument count, and per argument
+    the C scalar type (int / int64_t / float / double / size_t) or pointer-ness.  A wrong argtype (an int64_t bound
+    as c_int, a missing argument) would corrupt the call silently."""
+    import ctypes
+    text = open(os.path.join(ROOT, 'include', 'yv4.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    text = re.sub(r'//[^\n]*', '', text)
+    protos = re.findall(r'\b([A-Za-z_][\w\s\*]*?)\b(yv4_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S)
+    assert len(protos) >= 50
+    scalar = {'int': ctypes.c_int, 'int32_t': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float,
+              'double': ctypes.c_double, 'size_t': ctypes.c_size_t}
+
+    def is_pointer_type(t):
+        return t in (ctypes.c_void_p, ctypes.c_char_p) or isinstance(t, type(ctypes.POINTER(ctypes.c_int)))
+
+    seen = set()
+    for ret, name, args in protos:
+        if name not in pkg._lib.SIGNATURES:
+            continue
+        seen.add(name)
+        restype, argtypes = pkg._lib.SIGNATURES[name]
+        args = ' '.join(args.split())
+        params = [] if args in ('', 'void') else [a.strip() for a in args.split(',')]
+        assert len(params) == len(argtypes), f'{name}: header has {len(params)} arguments, binding {len(argtypes)}'
+        for i, (prm, bound) in enumerate(zip(params, argtypes)):
+            if '*' in prm or '[' in prm:
+                assert is_pointer_type(bound), f'{name} arg {i} ({prm}): bound as {bound}, header says pointer'
+            else:
+                ctype = prm.replace('const ', '').split()[0]
+                assert ctype in scalar, f'{name} arg {i}: unhandled C type {prm!r}'
+                assert bound is scalar[ctype], f'{name} arg {i} ({prm}): bound as {bound}'
+        ret = ret.replace('const', '').strip()
+        if '*' in ret:
+            assert is_pointer_type(restype), name
+        elif ret in scalar:
+            assert restype is scalar[ret], f'{name}: returns {ret}, bound as {restype}'
+    assert seen == set(pkg._lib.SIGNATURES), set(pkg._lib.SIGNATURES) - seen
