@@ -178,9 +178,13 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
         }
       }
     }
-    // boxes.max() over the surviving candidates (mmcv batched_nms)
-    atomic_max_float(&p.max_coord[n], fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
   }
+  // boxes.max() over the surviving candidates (mmcv batched_nms): reduced over the wavefront first -- one atomic per
+  // candidate meant ~2000 serialised same-address atomics per image
+  float mx = mine ? fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)) : -__builtin_huge_valf();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0 && mx > -__builtin_huge_valf()) atomic_max_float(&p.max_coord[n], mx);
 }
 
 // ---------------------------------------------------------------------------------
