@@ -99,9 +99,23 @@ class GradReducer:
         self._launched = []
         self._handles = []
         self._hooks = []
+        self._index_of = {}
         for si, p in enumerate(flat._params):
             if p.requires_grad:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(si)))
+                self._index_of[id(p)] = si
+        # conv weights whose dW is accumulated straight into the arena bypass autograd's accumulation (and its
+        # hooks): train_ops tells us when such a gradient is final
+        from . import train_ops as _T
+        self._direct_cb = _T.add_direct_grad_listener(self._on_direct_grad)
+
+    def _on_direct_grad(self, p):
+        si = self._index_of.get(id(p))
+        if si is not None and self._armed:
+            bi = self._bucket_of[si]
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
 
     def _make_hook(self, si):
         def hook(_p):
@@ -144,6 +158,8 @@ class GradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        from . import train_ops as _T
+        _T.remove_direct_grad_listener(self._direct_cb)
 
 
 def finalize():

@@ -130,6 +130,7 @@ class FlatState:
                 want = _view_as_param(self.grads, seg)
                 if g is None or g.data_ptr() != want.data_ptr():
                     p.grad = want
+                p._yv4_grad_in_arena = True      # conv weights: dW may be accumulated here directly (train_ops)
 
     def zero_grad(self):
         self.grads.zero_()

@@ -166,14 +166,60 @@ def _dgrad_s2_parity(dy, weight, xshape, dtype):
     return dx
 
 
+# ---- weight gradients straight into the gradient arena -----------------------------------------------------
+# When a conv weight's ``.grad`` is a channels_last fp32 tensor that already exists at backward time (the flat
+# gradient arena of ``flat_state.FlatState``, zeroed once per step), ``yv4_conv_wgrad*`` accumulates INTO it -- its
+# (Cout, KH, KW, Cin) memory is exactly the kernel's dW layout and the kernels only ever atomicAdd -- and the
+# Function returns no gradient for the weight.  That removes, per conv and step, the zero fill of a scratch dW and
+# autograd's ``grad += dW`` (230 launches of the YOLOv4-L step).  autograd's post-accumulate hooks do not fire for
+# such a weight (the Function is given the detached weight, so autograd never sees it), so whoever needs to know
+# that a weight gradient is final registers a listener here
+# (``dist.GradReducer`` does).  YV4_DIRECT_WGRAD=0 restores the autograd path.
+import os as _os
+
+_DIRECT_WGRAD = _os.environ.get('YV4_DIRECT_WGRAD', '1') != '0'
+_direct_grad_listeners = []
+
+
+def add_direct_grad_listener(cb):
+    """``cb(weight)`` is called after a conv's backward accumulated dW into ``weight.grad`` directly."""
+    _direct_grad_listeners.append(cb)
+    return cb
+
+
+def remove_direct_grad_listener(cb):
+    if cb in _direct_grad_listeners:
+        _direct_grad_listeners.remove(cb)
+
+
+class _ParamRef:
+    """Carries a parameter through ``Function.apply`` without autograd seeing a tensor argument."""
+    __slots__ = ('p',)
+
+    def __init__(self, p):
+        self.p = p
+
+
+def _direct_grad_target(weight, cp):
+    g = weight.grad
+    if not _DIRECT_WGRAD or g is None or g.dtype != torch.float32 or g.shape != weight.shape or cp != weight.shape[1]:
+        return None
+    if not getattr(weight, '_yv4_grad_in_arena', False) or not g.permute(0, 2, 3, 1).is_contiguous():
+        return None
+    return g
+
+
 class ConvFunction(torch.autograd.Function):
     """``dtype``: torch.float32, or torch.float16 / torch.bfloat16 -- then x, y and their gradients are
     that type (fp32 accumulation in every kernel) while ``weight`` and its gradient stay fp32 (the
     master copy the optimizer steps; autocast semantics of the reference's Fp16 hook)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, dtype, stats=None):
+    def forward(ctx, x, weight, stride, pad, dtype, stats=None, direct=None):
+        """``direct``: a ``_ParamRef`` to the parameter whose ``.grad`` receives dW in place (then ``weight`` is the
+        detached parameter: autograd does not track it through this Function, see ``conv2d``)."""
         _need_cuda(x, 'x')
+        ctx.direct = direct
         Cout, Cin, KH, KW = weight.shape
         al = 4 if dtype == torch.float32 else 8
         assert x.shape[1] == Cin and Cout % al == 0 and Cin % al == 0, \
@@ -202,8 +248,10 @@ class ConvFunction(torch.autograd.Function):
         h16 = dtype != torch.float32
         code = _DCODE[dtype]
         dx = dw = None
-        if ctx.needs_input_grad[1]:
-            dwp = torch.zeros((Cout, KH * KW * cp), device=x.device, dtype=torch.float32)
+        if ctx.needs_input_grad[1] or ctx.direct is not None:
+            target = _direct_grad_target(ctx.direct.p, cp) if ctx.direct is not None else None
+            dwp = target if target is not None else torch.zeros((Cout, KH * KW * cp), device=x.device,
+                                                                dtype=torch.float32)
             d = ConvDesc()
             d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, cp, Ho, Wo, Cout
             d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
@@ -214,16 +262,24 @@ class ConvFunction(torch.autograd.Function):
             else:
                 check(L.yv4_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), stream_ptr()),
                       'yv4_conv_wgrad')
-            dw = dwp.view(Cout, KH, KW, cp)[..., :Cin].permute(0, 3, 1, 2)
-            if cp != Cin:
-                dw = dw.contiguous()
+            if target is None:
+                dw = dwp.view(Cout, KH, KW, cp)[..., :Cin].permute(0, 3, 1, 2)
+                if cp != Cin:
+                    dw = dw.contiguous()
+            if ctx.direct is not None:       # autograd does not track the weight here: hand the gradient over
+                prm = ctx.direct.p
+                if target is None:           # (.grad went away between forward and backward)
+                    prm.grad = dw.clone() if prm.grad is None else prm.grad.add_(dw)
+                dw = None
+                for cb in _direct_grad_listeners:
+                    cb(prm)
         if ctx.needs_input_grad[0]:
             if stride == 2 and (KH, KW, pad) == (3, 3, 1) and Cout % (8 if h16 else 32) == 0:
                 dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype)
             else:
                 dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype)
             dx = dx.to(ctx.x_dtype)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 def train_dtype(module, x):
@@ -240,7 +296,12 @@ def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None):
     ``stats``: see ``_conv_launch`` / ``conv_stats_buffer``; pass the same buffer to ``bn_act(..., sums=)``."""
     if dtype is None:
         dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
-    return ConvFunction.apply(x, weight, stride, pad, dtype, stats)
+    if (_DIRECT_WGRAD and weight.requires_grad and weight.is_leaf and x.requires_grad and torch.is_grad_enabled()
+            and _direct_grad_target(weight, weight.shape[1]) is not None
+            and weight.shape[1] % (4 if dtype == torch.float32 else 8) == 0):
+        # dW goes straight into weight.grad (see the note above ConvFunction): the Function sees the detached weight
+        return ConvFunction.apply(x, weight.detach(), stride, pad, dtype, stats, _ParamRef(weight))
+    return ConvFunction.apply(x, weight, stride, pad, dtype, stats, None)
 
 
 def conv_stats_buffer(cout, device):
