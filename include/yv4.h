@@ -346,6 +346,14 @@ int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x_coff, cons
                        int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C,
                        int act, float slope, void* stream);
 
+/* yv4_bn_act_bwd_h16 (eval_mode = 0) / yv4_bn_eval_act_bwd (eval_mode = 1) with dgamma / dbeta ADDED to the given
+ * arrays -- the parameters' own gradients -- instead of overwriting them. */
+int yv4_bn_act_bwd_accum(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
+                         int dy_cstride, int dy_coff, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, void* dx, int dx_cstride,
+                         int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C,
+                         int act, float slope, int eval_mode, void* stream);
+
 /* SyncBN (the configs under configs/yolov5_ddp: norm_cfg type 'SyncBN' = torch.nn.SyncBatchNorm): the train-mode BN
  * kernels above with the cross-rank exchange between their two halves.  Forward: yv4_bn_partial_sums
  * leaves [sum x (C) | sum x^2 (C)] of the local rows in `work` (double); the caller all-reduces `work`

@@ -117,6 +117,7 @@ SIGNATURES = {
     'yv4_bn_eval_act_bwd': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i64,
                                       _i, _i, _f, _vp]),
     'yv4_spp_pool_bwd': (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    'yv4_bn_act_bwd_accum': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp]),
     'yv4_bn_partial_sums': (C.c_int, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     'yv4_bn_finalize': (C.c_int, [_vp, _i, _i64, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'yv4_conv_fwd_stats': (C.c_int, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

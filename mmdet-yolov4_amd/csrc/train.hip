@@ -695,8 +695,13 @@ __global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_bwd_apply_kern
   const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
   if (blockIdx.x == 0 && p.publish) {   // the reduction kernel has completed (stream order): publish dbeta / dgamma as fp32
     for (int i = threadIdx.x; i < p.C; i += 256) {
-      p.dbeta[i] = (float)p.sums[i];
-      p.dgamma[i] = (float)p.sums[p.C + i];
+      if (p.publish == 2) {             // accumulate into existing gradients (the parameter's .grad itself)
+        p.dbeta[i] += (float)p.sums[i];
+        p.dgamma[i] += (float)p.sums[p.C + i];
+      } else {
+        p.dbeta[i] = (float)p.sums[i];
+        p.dgamma[i] = (float)p.sums[p.C + i];
+      }
     }
   }
   if (!mp.active) return;
@@ -1055,7 +1060,7 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
                        const float* mean, const float* invstd, const float* gamma, const float* beta, void* dx,
                        int dx_cstride, int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C, int act,
                        float slope, void* stream, int eval_mode = 0, int phase = 0, int64_t M_total = 0,
-                       const double* rows_dev = nullptr) {
+                       const double* rows_dev = nullptr, int accumulate = 0) {
   // phase 0: reduce + apply; 1: reduce only, dgamma / dbeta published from the LOCAL sums (SyncBN: the caller
   // then all-reduces `work`); 2: apply only, `work` holding the sums over M_total rows
   YV4_REQUIRE(x && dy && mean && invstd && gamma && beta && work && M > 0 && C > 0, "bn_act_bwd: bad argument");
@@ -1077,7 +1082,7 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope; a.eval_mode = eval_mode;
   a.dgamma = dgamma; a.dbeta = dbeta;
   a.M_total = phase == 2 ? M_total : M;
-  a.publish = phase == 0;
+  a.publish = phase == 0 ? (accumulate ? 2 : 1) : 0;
   a.rows = phase == 2 ? rows_dev : nullptr;
   a.rows_per_block = bn_rows_per_block(M);
   dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
@@ -1185,6 +1190,16 @@ extern "C" int yv4_bn_act_bwd_apply(const void* x, int dtype, int x_cstride, int
   return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
                      dx_coff, nullptr, nullptr, const_cast<double*>(work), M, C, act, slope, stream, 0, 2, M_total,
                      rows_dev);
+}
+
+// As yv4_bn_act_bwd_h16 / yv4_bn_eval_act_bwd, but dgamma / dbeta are ADDED to (the parameters' own .grad: no temporary,
+// no accumulation kernel afterwards)
+extern "C" int yv4_bn_act_bwd_accum(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,
+                                    int dy_coff, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, void* dx, int dx_cstride, int dx_coff, float* dgamma, float* dbeta,
+                                    double* work, int64_t M, int C, int act, float slope, int eval_mode, void* stream) {
+  return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
+                     dx_coff, dgamma, dbeta, work, M, C, act, slope, stream, eval_mode ? 1 : 0, 0, 0, nullptr, 1);
 }
 
 extern "C" int yv4_bn_eval_act_bwd(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,

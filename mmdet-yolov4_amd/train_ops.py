@@ -192,6 +192,10 @@ def remove_direct_grad_listener(cb):
         _direct_grad_listeners.remove(cb)
 
 
+def _flat_f32(g, n):
+    return g is not None and g.dtype == torch.float32 and g.numel() == n and g.is_contiguous()
+
+
 class _ParamRef:
     """Carries a parameter through ``Function.apply`` without autograd seeing a tensor argument."""
     __slots__ = ('p',)
@@ -314,7 +318,7 @@ class BNActFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual, training=True,
-                sync_group=None, sums=None):
+                sync_group=None, sums=None, direct=None):
         """``sync_group``: None, or a (process group or 'world') to synchronise the batch statistics over
         (torch.nn.SyncBatchNorm semantics: statistics over all ranks' rows, local dgamma / dbeta).
         ``sums``: the replicated [sum | sum of squares] buffer the producing conv filled (``conv2d(stats=)``):
@@ -375,6 +379,7 @@ class BNActFunction(torch.autograd.Function):
                                    b.data_ptr(), res.data_ptr() if res is not None else None, Cc, 0, y.data_ptr(), Cc,
                                    0, M, Cc, int(act), float(slope), stream_ptr()), 'yv4_bn_act_fwd')
         ctx.save_for_backward(x, mean, invstd, g, b)
+        ctx.direct = direct      # (_ParamRef(weight), _ParamRef(bias)): dgamma / dbeta are added to their .grad in place
         ctx.rows = rows
         ctx.act = (int(act), float(slope))
         ctx.training = bool(training)
@@ -395,6 +400,7 @@ class BNActFunction(torch.autograd.Function):
         dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
         work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
         L = _lib.lib()
+        gw = gb = None
         if ctx.rows is not None:            # SyncBN: local sums -> all-reduce -> apply with the totals
             import torch.distributed as dist
             check(L.yv4_bn_act_bwd_sums(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
@@ -407,13 +413,31 @@ class BNActFunction(torch.autograd.Function):
                                          work.data_ptr(), M, 0, ctx.rows.data_ptr(), Cc, act, slope, stream_ptr()),
                   'yv4_bn_act_bwd_apply')
         else:
-            fn = L.yv4_bn_act_bwd_h16 if ctx.training else L.yv4_bn_eval_act_bwd
-            check(fn(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
-                     invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
-                     dgamma.data_ptr(), dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope,
-                     stream_ptr()), 'yv4_bn_act_bwd')
+            if ctx.direct is not None:
+                gw, gb = ctx.direct[0].p.grad, ctx.direct[1].p.grad
+                if not (_flat_f32(gw, Cc) and _flat_f32(gb, Cc)):
+                    gw = gb = None
+            if gw is not None:       # dgamma / dbeta added to the parameters' gradients by the kernel itself
+                check(L.yv4_bn_act_bwd_accum(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+                                             invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
+                                             gw.data_ptr(), gb.data_ptr(), work.data_ptr(), M, Cc, act, slope,
+                                             0 if ctx.training else 1, stream_ptr()), 'yv4_bn_act_bwd_accum')
+            else:
+                fn = L.yv4_bn_act_bwd_h16 if ctx.training else L.yv4_bn_eval_act_bwd
+                check(fn(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+                         invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
+                         dgamma.data_ptr(), dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope,
+                         stream_ptr()), 'yv4_bn_act_bwd')
         dres = dy if ctx.has_res else None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None
+        if ctx.direct is not None:   # autograd does not track gamma / beta through this Function
+            if ctx.rows is not None or gw is None:
+                for ref, gr in zip(ctx.direct, (dgamma, dbeta)):
+                    ref.p.grad = gr.clone() if ref.p.grad is None else ref.p.grad.add_(gr)
+            for ref in ctx.direct:
+                for cb in _direct_grad_listeners:
+                    cb(ref.p)
+            dgamma = dbeta = None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None, None
 
 
 def _sync_group(bn):
@@ -437,10 +461,17 @@ def bn_act(x, bn, act=(0, 0.0), residual=None, sums=None):
     running statistics as constants.  act = (YV4_ACT_*, slope)."""
     mom = bn.momentum if bn.momentum is not None else 0.1
     use_batch = bn.training or not bn.track_running_stats
-    out = BNActFunction.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+    gamma, beta, direct = bn.weight, bn.bias, None
+    if (_DIRECT_WGRAD and x.requires_grad and torch.is_grad_enabled() and gamma.requires_grad and beta.requires_grad
+            and getattr(gamma, '_yv4_grad_in_arena', False) and getattr(beta, '_yv4_grad_in_arena', False)
+            and _flat_f32(gamma.grad, gamma.numel()) and _flat_f32(beta.grad, beta.numel())):
+        # dgamma / dbeta go straight into the parameters' gradients (see the note above ConvFunction)
+        direct = (_ParamRef(gamma), _ParamRef(beta))
+        gamma, beta = gamma.detach(), beta.detach()
+    out = BNActFunction.apply(x, gamma, beta, bn.running_mean if bn.track_running_stats else None,
                               bn.running_var if bn.track_running_stats else None, bn.eps, mom, act[0], act[1],
                               residual, use_batch, _sync_group(bn) if use_batch else None,
-                              sums if use_batch else None)
+                              sums if use_batch else None, direct)
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return out
