@@ -184,7 +184,14 @@ class HipModule(nn.Module):
         """forward() of every registered module: training mode -> autograd graph over the HIP
         training ops (batch-statistics BN); eval mode -> fused launch plan."""
         if self.training:
-            return self.fwd(*args)
+            from . import train_ops as _T
+            _T._fwd_depth[0] += 1
+            try:
+                return self.fwd(*args)
+            finally:
+                _T._fwd_depth[0] -= 1
+                if _T._fwd_depth[0] == 0:
+                    _T.flush_batch_counters()
         return self._run_plan(args, structure)
 
     def _param_version(self):
