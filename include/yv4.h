@@ -347,12 +347,13 @@ int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x_coff, cons
                        int act, float slope, void* stream);
 
 /* yv4_bn_act_bwd_h16 (eval_mode = 0) / yv4_bn_eval_act_bwd (eval_mode = 1) with dgamma / dbeta ADDED to the given
- * arrays -- the parameters' own gradients -- instead of overwriting them. */
+ * arrays -- the parameters' own gradients -- instead of overwriting them (flags bit 0 = eval_mode). */
 int yv4_bn_act_bwd_accum(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
                          int dy_cstride, int dy_coff, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, void* dx, int dx_cstride,
                          int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C,
-                         int act, float slope, int eval_mode, void* stream);
+                         int act, float slope, int flags /* 1: eval-mode BN, 2: work already zero */,
+                         void* stream);
 
 /* SyncBN (the configs under configs/yolov5_ddp: norm_cfg type 'SyncBN' = torch.nn.SyncBatchNorm): the train-mode BN
  * kernels above with the cross-rank exchange between their two halves.  Forward: yv4_bn_partial_sums
@@ -375,10 +376,14 @@ int yv4_bn_partial_sums(const void* x, int dtype, int64_t M, int C, int x_cstrid
  * replicas = YV4_STATS_REPLICAS. */
 #define YV4_STATS_REPLICAS 64
 int yv4_conv_fwd_stats(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
-                       const float* ones, const float* zeros, void* y, double* stats, void* stream);
-int yv4_bn_finalize(const double* work, int replicas, int64_t M_total, const double* rows_dev, int C,
+                       const float* ones, const float* zeros, void* y, double* stats,
+                       int stats_is_zero /* the caller keeps the buffer clean (yv4_bn_finalize clear_work) */,
+                       void* stream);
+int yv4_bn_finalize(double* work, int replicas, int64_t M_total, const double* rows_dev, int C,
                     float eps, float momentum, float* mean, float* invstd, float* running_mean,
-                    float* running_var, void* stream);
+                    float* running_var, int clear_work /* zero `work` once read */,
+                    double* zero_after /* NULL, or 2*C doubles to clear for the layer's backward reduction */,
+                    void* stream);
 int yv4_bn_act_bwd_sums(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
                         int dy_cstride, int dy_coff, const float* mean, const float* invstd,
                         const float* gamma, const float* beta, float* dgamma, float* dbeta,
@@ -390,12 +395,14 @@ int yv4_bn_act_bwd_apply(const void* x, int dtype, int x_cstride, int x_coff, co
                          const double* rows_dev, int C, int act, float slope, void* stream);
 
 /* A conv weight (Cout, Cin, KH, KW), addressed through its element strides (contiguous or channels_last), to
- * the packed operand of the conv kernels in one pass: rows x (KH*KW*ICp), K ordered (kh, kw, channel), the channel
- * count zero-padded to a multiple of pad_to, cast to `dtype`.  transpose_flip = 0: rows = Cout, channels = Cin (the
- * forward operand); 1: rows = Cin, channels = Cout, taps mirrored (the operand of the data gradient). */
+ * the packed operand of the conv kernels in one pass: rows x (KHo*KWo*ICp), K ordered (kh, kw, channel), the
+ * channel count zero-padded to a multiple of pad_to, cast to `dtype`.  Output tap (kh, kw) reads source tap
+ * (kh0 + kh*kh_step, kw0 + kw*kw_step).  transpose = 0: rows = Cout, channels = Cin (the forward operand:
+ * KHo = KH, kh0 = 0, step 1); 1: rows = Cin, channels = Cout -- mirrored taps (kh0 = KH-1, step -1) give the
+ * operand of the data gradient, a tap subset the operand of one parity class of a stride-2 data gradient. */
 int yv4_pack_weight(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw, int Cout,
-                    int Cin, int KH, int KW, int transpose_flip, int pad_to, void* dst, int dtype,
-                    void* stream);
+                    int Cin, int KH, int KW, int KHo, int KWo, int kh0, int kh_step, int kw0,
+                    int kw_step, int transpose, int pad_to, void* dst, int dtype, void* stream);
 
 /* One parity class of the data gradient of a stride-2 convolution: a stride-1 convolution of dY whose
  * output pixel (n, ho, wo) is stored at y[n, ho*sh + oh, wo*sw + ow, y_coff + c] of an

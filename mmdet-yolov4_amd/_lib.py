@@ -119,11 +119,11 @@ SIGNATURES = {
     'yv4_spp_pool_bwd': (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'yv4_bn_act_bwd_accum': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp]),
     'yv4_bn_partial_sums': (C.c_int, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
-    'yv4_bn_finalize': (C.c_int, [_vp, _i, _i64, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
-    'yv4_conv_fwd_stats': (C.c_int, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'yv4_bn_finalize': (C.c_int, [_vp, _i, _i64, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'yv4_conv_fwd_stats': (C.c_int, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'yv4_bn_act_bwd_sums': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp]),
     'yv4_bn_act_bwd_apply': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i64, _vp, _i, _i, _f, _vp]),
-    'yv4_pack_weight': (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    'yv4_pack_weight': (C.c_int, [_vp, _i64, _i64, _i64, _i64] + [_i] * 12 + [_vp, _i, _vp]),
     'yv4_yolo_loss_fwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
     'yv4_yolo_loss_bwd': (C.c_int, [C.POINTER(LossDesc), _vp, _vp]),
     'yv4_iou_coco_batched': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),

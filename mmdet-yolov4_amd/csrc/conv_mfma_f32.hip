@@ -898,13 +898,14 @@ int conv_stats_h16(const yv4_conv_desc* d, int dtype, const void* x, const void*
 // epilogue where the selected kernel supports it, else by the BN reduction kernel afterwards -- either way
 // `stats` holds YV4_STATS_REPLICAS x [sum (Cout) | sum of squares (Cout)] whose column sums are the totals.
 extern "C" int yv4_conv_fwd_stats(const yv4_conv_desc* d, int dtype, const void* x, const void* w, const float* ones,
-                                  const float* zeros, void* y, double* stats, void* stream) {
+                                  const float* zeros, void* y, double* stats, int stats_is_zero, void* stream) {
   YV4_REQUIRE(d && stats, "conv_fwd_stats: null argument");
   YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "conv_fwd_stats: dtype must be f32, f16 or bf16");
   YV4_REQUIRE(d->y_coff == 0 && d->y_cstride == d->Cout && d->act1 == YV4_ACT_NONE,
               "conv_fwd_stats: dense output and identity epilogue only");
-  if (hipMemsetAsync(stats, 0, sizeof(double) * YV4_STATS_REPLICAS * 2 * d->Cout, reinterpret_cast<hipStream_t>(stream)) !=
-      hipSuccess) {
+  if (!stats_is_zero &&
+      hipMemsetAsync(stats, 0, sizeof(double) * YV4_STATS_REPLICAS * 2 * d->Cout, reinterpret_cast<hipStream_t>(stream)) !=
+          hipSuccess) {
     set_error("conv_fwd_stats: memset failed");
     return YV4_E_LAUNCH;
   }

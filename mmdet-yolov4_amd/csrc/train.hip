@@ -537,9 +537,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 
 // mean / biased var / invstd from the sums; running stats update (unbiased var, momentum)
 // `rows`: optional device-resident row count (SyncBN: the all-reduced count travels with the sums)
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M_host, int C, float eps, float momentum,
+// clear_work: the replicas are zeroed as they are read (a persistent statistics buffer is clean again for the next
+// forward); zero_after: 2*C doubles cleared for the backward reduction of the same layer -- both replace memsets.
+__global__ void bn_finalize_kernel(double* __restrict__ sums, int64_t M_host, int C, float eps, float momentum,
                                    float* mean, float* invstd, float* running_mean, float* running_var,
-                                   const double* __restrict__ rows, int replicas) {
+                                   const double* __restrict__ rows, int replicas, int clear_work,
+                                   double* __restrict__ zero_after) {
   // 256 threads = 32 channels x 8 replica lanes: a lane adds every 8th replica (independent loads in flight), the 8
   // lanes of a channel combine by shuffle.  (One thread per channel walking 64 replicas was a chain of 128 dependent
   // loads: 18 us per call, 2 ms of the bf16 train step over its 108 BatchNorms.)
@@ -550,6 +553,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M_ho
     for (int r = rl; r < replicas; r += 8) {
       s1 += sums[(size_t)r * 2 * C + c];
       s2 += sums[(size_t)r * 2 * C + C + c];
+      if (clear_work) {
+        sums[(size_t)r * 2 * C + c] = 0.0;
+        sums[(size_t)r * 2 * C + C + c] = 0.0;
+      }
+    }
+    if (zero_after && rl == 0) {
+      zero_after[c] = 0.0;
+      zero_after[C + c] = 0.0;
     }
   }
 #pragma unroll
@@ -884,24 +895,26 @@ __global__ __launch_bounds__(256) void spp_pool_bwd_lds_kernel(const T* __restri
   }
 }
 
-// Conv weight -> the kernels' packed operand in ONE pass (cast included): rows x (KH*KW*ICp) with K ordered
-// (kh, kw, channel), zero-padded channels.  transpose_flip = 0: rows = Cout, channel = Cin (forward operand);
-// 1: rows = Cin, channel = Cout, taps mirrored -- the operand of the data gradient (ATen needs flip + transpose +
-// contiguous + cast = 3 launches per conv per step for it).  The source is addressed through its element strides,
+// Conv weight -> the kernels' packed operand in ONE pass (cast included): rows x (KHo*KWo*ICp) with K ordered
+// (kh, kw, channel), zero-padded channels; output tap (kh, kw) reads source tap (kh0 + kh*kh_step, kw0 + kw*kw_step).
+// transpose = 0: rows = Cout, channel = Cin (forward operand); 1: rows = Cin, channel = Cout -- with the taps
+// mirrored (kh0 = KH-1, step -1) the operand of the data gradient (ATen needs flip + transpose + contiguous + cast = 3
+// launches per conv per step for it), with a tap subset the operand of one parity class of a stride-2 data gradient
+// (list-indexing the taps cost two host-to-device index uploads and two gather kernels per class).  The source is addressed through its element strides,
 // so contiguous and channels_last parameters both go without a copy.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, long long s_co, long long s_ci,
-                                                          long long s_kh, long long s_kw, int Cout, int Cin, int KH, int KW,
-                                                          int tf, int ICp, T* __restrict__ dst, int nrows) {
+                                                          long long s_kh, long long s_kw, int Cout, int Cin, int KHo, int KWo,
+                                                          int kh0, int kh_step, int kw0, int kw_step, int tf, int ICp,
+                                                          T* __restrict__ dst, int nrows) {
   // one output row (r, kh, kw) of ICp channels per workgroup iteration: two small divides per row, none per element
   const int IC = tf ? Cout : Cin;
-  const int taps = KH * KW;
+  const int taps = KHo * KWo;
   for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
     const int r = row / taps;
     const int tap = row - r * taps;
-    const int kh = tap / KW, kw = tap - kh * KW;
-    const int kh2 = tf ? KH - 1 - kh : kh, kw2 = tf ? KW - 1 - kw : kw;
-    const float* src = w + kh2 * s_kh + kw2 * s_kw + (tf ? r * s_ci : r * s_co);
+    const int kh = tap / KWo, kw = tap - kh * KWo;
+    const float* src = w + (kh0 + kh * kh_step) * s_kh + (kw0 + kw * kw_step) * s_kw + (tf ? r * s_ci : r * s_co);
     const long long s_ic = tf ? s_co : s_ci;
     T* d = dst + (size_t)row * ICp;
     for (int ic = threadIdx.x; ic < ICp; ic += 256) d[ic] = (T)(ic < IC ? src[ic * s_ic] : 0.f);
@@ -1032,7 +1045,7 @@ static int bn_stats_impl(int dtype, const void* x, int64_t M, int C, int x_cstri
                                            reinterpret_cast<const T*>(x), M, C, x_cstride, x_coff, work, rpb));
   if (phase == 0)
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, work, M, C, eps, momentum, mean, invstd,
-                       running_mean, running_var, (const double*)nullptr, 1);
+                       running_mean, running_var, (const double*)nullptr, 1, 0, (double*)nullptr);
   YV4_CHECK_LAUNCH("bn_train_stats");
   return YV4_OK;
 }
@@ -1060,7 +1073,7 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
                        const float* mean, const float* invstd, const float* gamma, const float* beta, void* dx,
                        int dx_cstride, int dx_coff, float* dgamma, float* dbeta, double* work, int64_t M, int C, int act,
                        float slope, void* stream, int eval_mode = 0, int phase = 0, int64_t M_total = 0,
-                       const double* rows_dev = nullptr, int accumulate = 0) {
+                       const double* rows_dev = nullptr, int accumulate = 0, int work_is_zero = 0) {
   // phase 0: reduce + apply; 1: reduce only, dgamma / dbeta published from the LOCAL sums (SyncBN: the caller
   // then all-reduces `work`); 2: apply only, `work` holding the sums over M_total rows
   YV4_REQUIRE(x && dy && mean && invstd && gamma && beta && work && M > 0 && C > 0, "bn_act_bwd: bad argument");
@@ -1072,7 +1085,7 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
               "bn_act_bwd: channels must be multiples of 4");
   YV4_REQUIRE(C <= 4096, "bn_act_bwd: more than 4096 channels");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (phase != 2 && hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) {
+  if (phase != 2 && !work_is_zero && hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) {
     set_error("bn_act_bwd: memset failed");
     return YV4_E_LAUNCH;
   }
@@ -1165,13 +1178,14 @@ extern "C" int yv4_bn_partial_sums(const void* x, int dtype, int64_t M, int C, i
                                    void* stream) {
   return bn_stats_impl(dtype, x, M, C, x_cstride, x_coff, 0.f, 0.f, work, nullptr, nullptr, nullptr, nullptr, stream, 1);
 }
-extern "C" int yv4_bn_finalize(const double* work, int replicas, int64_t M_total, const double* rows_dev, int C, float eps,
+extern "C" int yv4_bn_finalize(double* work, int replicas, int64_t M_total, const double* rows_dev, int C, float eps,
                                float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
-                               void* stream) {
+                               int clear_work, double* zero_after, void* stream) {
   YV4_REQUIRE(work && mean && invstd && (rows_dev || M_total > 0) && C > 0 && replicas >= 1, "bn_finalize: bad argument");
   YV4_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come together");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), work,
-                     M_total, C, eps, momentum, mean, invstd, running_mean, running_var, rows_dev, replicas);
+                     M_total, C, eps, momentum, mean, invstd, running_mean, running_var, rows_dev, replicas, clear_work ? 1 : 0,
+                     zero_after);
   YV4_CHECK_LAUNCH("bn_finalize");
   return YV4_OK;
 }
@@ -1197,9 +1211,10 @@ extern "C" int yv4_bn_act_bwd_apply(const void* x, int dtype, int x_cstride, int
 extern "C" int yv4_bn_act_bwd_accum(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,
                                     int dy_coff, const float* mean, const float* invstd, const float* gamma,
                                     const float* beta, void* dx, int dx_cstride, int dx_coff, float* dgamma, float* dbeta,
-                                    double* work, int64_t M, int C, int act, float slope, int eval_mode, void* stream) {
+                                    double* work, int64_t M, int C, int act, float slope, int flags, void* stream) {
+  // flags: bit 0 = eval-mode BN, bit 1 = `work` is already zero (yv4_bn_finalize's zero_after cleared it)
   return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
-                     dx_coff, dgamma, dbeta, work, M, C, act, slope, stream, eval_mode ? 1 : 0, 0, 0, nullptr, 1);
+                     dx_coff, dgamma, dbeta, work, M, C, act, slope, stream, flags & 1, 0, 0, nullptr, 1, (flags >> 1) & 1);
 }
 
 extern "C" int yv4_bn_eval_act_bwd(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,
@@ -1211,18 +1226,23 @@ extern "C" int yv4_bn_eval_act_bwd(const void* x, int dtype, int x_cstride, int 
 }
 
 extern "C" int yv4_pack_weight(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw, int Cout, int Cin,
-                               int KH, int KW, int transpose_flip, int pad_to, void* dst, int dtype, void* stream) {
-  YV4_REQUIRE(w && dst && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && pad_to > 0, "pack_weight: bad argument");
+                               int KH, int KW, int KHo, int KWo, int kh0, int kh_step, int kw0, int kw_step, int transpose,
+                               int pad_to, void* dst, int dtype, void* stream) {
+  YV4_REQUIRE(w && dst && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KHo > 0 && KWo > 0 && pad_to > 0,
+              "pack_weight: bad argument");
   YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "pack_weight: dtype must be f32, f16 or bf16");
-  const int IC = transpose_flip ? Cout : Cin, R = transpose_flip ? Cin : Cout;
+  const int khl = kh0 + (KHo - 1) * kh_step, kwl = kw0 + (KWo - 1) * kw_step;
+  YV4_REQUIRE(kh0 >= 0 && kh0 < KH && khl >= 0 && khl < KH && kw0 >= 0 && kw0 < KW && kwl >= 0 && kwl < KW,
+              "pack_weight: tap selection leaves the %dx%d kernel", KH, KW);
+  const int IC = transpose ? Cout : Cin, R = transpose ? Cin : Cout;
   const int ICp = (IC + pad_to - 1) / pad_to * pad_to;
-  const long long nrows = (long long)R * KH * KW;
+  const long long nrows = (long long)R * KHo * KWo;
   YV4_REQUIRE(nrows < (1LL << 31), "pack_weight: too many rows");
   const unsigned grid = (unsigned)(nrows < 8192 ? nrows : 8192);
   YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(grid), dim3(256), 0,
                                            reinterpret_cast<hipStream_t>(stream), w, (long long)s_co, (long long)s_ci,
-                                           (long long)s_kh, (long long)s_kw, Cout, Cin, KH, KW, transpose_flip ? 1 : 0, ICp,
-                                           reinterpret_cast<T*>(dst), (int)nrows));
+                                           (long long)s_kh, (long long)s_kw, Cout, Cin, KHo, KWo, kh0, kh_step, kw0, kw_step,
+                                           transpose ? 1 : 0, ICp, reinterpret_cast<T*>(dst), (int)nrows));
   YV4_CHECK_LAUNCH("pack_weight");
   return YV4_OK;
 }

@@ -104,9 +104,17 @@ class Conv(HipModule):
             bn = self.norm
             stats = None
             if (bn.training or not bn.track_running_stats) and _CONV_STATS:
-                stats = T.conv_stats_buffer(w.shape[0], x.device)     # the conv's epilogue leaves the BN sums here
-            y = T.conv2d(x, w, self.stride, self.padding, dtype=dt, stats=stats)
-            return T.bn_act(y, bn, act_id(self.activate), residual, sums=stats)
+                # the conv's epilogue leaves the BN sums here; the buffer is this module's, kept zero by the
+                # finalize kernel that reads it (no memset per step)
+                stats = getattr(self, '_yv4_stats', None)
+                if stats is None or stats.device != x.device or stats.numel() != T.stats_numel(w.shape[0]):
+                    stats = self._yv4_stats = T.conv_stats_buffer(w.shape[0], x.device, persistent=True)
+            try:
+                y = T.conv2d(x, w, self.stride, self.padding, dtype=dt, stats=stats)
+                return T.bn_act(y, bn, act_id(self.activate), residual, sums=stats)
+            except Exception:
+                self._yv4_stats = None       # a half-used statistics buffer is not clean: drop it
+                raise
         y = T.conv2d(x, w, self.stride, self.padding, dtype=dt)
         if self.conv.bias is not None:
             y = y + self.conv.bias.view(1, -1, 1, 1)

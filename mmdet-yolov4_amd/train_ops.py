@@ -62,9 +62,10 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None)
     ones, zeros = _identity_affine(x.device, Cout)
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.numel() >= _lib.STATS_REPLICAS * 2 * Cout
+        clean = 1 if getattr(stats, '_yv4_kept_clean', False) else 0
         check(_lib.lib().yv4_conv_fwd_stats(C.byref(d), _DCODE[x.dtype], x.data_ptr(), w_packed.data_ptr(),
                                             ones.data_ptr(), zeros.data_ptr(), out.data_ptr(), stats.data_ptr(),
-                                            stream_ptr()), 'yv4_conv_fwd_stats')
+                                            clean, stream_ptr()), 'yv4_conv_fwd_stats')
         return d
     if x.dtype == torch.float32:
         check(_lib.lib().yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w_packed.data_ptr(), ones.data_ptr(),
@@ -78,21 +79,31 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None)
     return d
 
 
-def packed_weight(weight, dtype, transpose_flip=False):
+def packed_weight(weight, dtype, transpose_flip=False, taps=None):
     """The conv kernels' weight operand from an fp32 (Cout, Cin, KH, KW) parameter in one launch (``yv4_pack_weight``):
-    rows x (KH*KW*Cp), K ordered (kh, kw, channel), channels zero-padded to a 16-byte chunk, cast to ``dtype``.
-    ``transpose_flip``: the data gradient's operand (rows = Cin, channels = Cout, taps mirrored).  Returns (w, Cp)."""
+    rows x (KH'*KW'*Cp), K ordered (kh, kw, channel), channels zero-padded to a 16-byte chunk, cast to ``dtype``.
+    ``transpose_flip``: the data gradient's operand (rows = Cin, channels = Cout, taps mirrored).  ``taps``:
+    ((kh0, kh_step, KH'), (kw0, kw_step, KW')) selects source taps explicitly (rows = Cin, channels = Cout): the
+    operand of one parity class of a stride-2 data gradient.  Returns (w, Cp)."""
     Cout, Cin, KH, KW = weight.shape
     al = 4 if dtype == torch.float32 else 8
-    rows, ic = (Cin, Cout) if transpose_flip else (Cout, Cin)
+    transpose = bool(transpose_flip or taps is not None)
+    rows, ic = (Cin, Cout) if transpose else (Cout, Cin)
     cp = (ic + al - 1) // al * al
+    if taps is not None:
+        (kh0, khs, KHo), (kw0, kws, KWo) = taps
+    elif transpose_flip:
+        kh0, khs, KHo, kw0, kws, KWo = KH - 1, -1, KH, KW - 1, -1, KW
+    else:
+        kh0, khs, KHo, kw0, kws, KWo = 0, 1, KH, 0, 1, KW
     w = weight.detach()
     if w.dtype != torch.float32:
         w = w.float()
-    out = torch.empty((rows, KH * KW * cp), device=w.device, dtype=dtype)
+    out = torch.empty((rows, KHo * KWo * cp), device=w.device, dtype=dtype)
     st = w.stride()
-    check(_lib.lib().yv4_pack_weight(w.data_ptr(), st[0], st[1], st[2], st[3], Cout, Cin, KH, KW, int(transpose_flip), al,
-                                     out.data_ptr(), _DCODE[dtype], stream_ptr()), 'yv4_pack_weight')
+    check(_lib.lib().yv4_pack_weight(w.data_ptr(), st[0], st[1], st[2], st[3], Cout, Cin, KH, KW, KHo, KWo, kh0, khs, kw0,
+                                     kws, int(transpose), al, out.data_ptr(), _DCODE[dtype], stream_ptr()),
+          'yv4_pack_weight')
     return out, cp
 
 
@@ -141,7 +152,7 @@ def _dgrad_s2_parity(dy, weight, xshape, dtype):
     L = _lib.lib()
     dx = torch.empty((N, Cin, H, W), device=dy.device, dtype=dtype, memory_format=torch.channels_last)
     ones, zeros = _identity_affine(dy.device, Cin)
-    taps = {0: [1], 1: [2, 0]}
+    taps = {0: (1, 1, 1), 1: (2, -2, 2)}          # (first source tap, step, count): [1] and [2, 0]
     wd = weight.detach()
     for a in (0, 1):
         Ha = (H - a + 1) // 2
@@ -149,12 +160,10 @@ def _dgrad_s2_parity(dy, weight, xshape, dtype):
             Wb = (W - b + 1) // 2
             if Ha == 0 or Wb == 0:
                 continue
-            ws = wd[:, :, taps[a]][:, :, :, taps[b]].permute(1, 0, 2, 3)       # (Cin, Cout, KH', KW')
-            wp, _ = pack_conv_weight(ws, align=8 if h16 else 4)
-            wp = wp.to(dtype)
+            wp, _ = packed_weight(wd, dtype, taps=(taps[a], taps[b]))          # (Cin, KH'*KW'*Cout), one launch
             d = ConvDesc()
             d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, Ho, Wo, Cout, Ha, Wb, Cin
-            d.KH, d.KW, d.stride, d.pad = len(taps[a]), len(taps[b]), 1, 0
+            d.KH, d.KW, d.stride, d.pad = taps[a][2], taps[b][2], 1, 0
             d.x_cstride, d.y_cstride = Cout, Cin
             if h16:
                 check(L.yv4_conv_scatter_fwd_h16(C.byref(d), _DCODE[dtype], dy.data_ptr(), wp.data_ptr(), ones.data_ptr(),
@@ -308,9 +317,20 @@ def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None):
     return ConvFunction.apply(x, weight, stride, pad, dtype, stats, None)
 
 
-def conv_stats_buffer(cout, device):
-    """Scratch for the BatchNorm sums a training conv leaves for the BN that follows it (cleared by the kernel)."""
-    return torch.empty(_lib.STATS_REPLICAS * 2 * cout, dtype=torch.float64, device=device)
+def stats_numel(cout):
+    return _lib.STATS_REPLICAS * 2 * cout
+
+
+def conv_stats_buffer(cout, device, persistent=False):
+    """Scratch for the BatchNorm sums a training conv leaves for the BN that follows it.  ``persistent``: a zeroed
+    buffer its owner keeps across steps; it is marked so that the conv skips the memset and ``bn_act`` has the
+    finalize kernel clear it again as it reads it (the owner must pair every ``conv2d(stats=)`` with
+    ``bn_act(sums=)``)."""
+    if not persistent:
+        return torch.empty(_lib.STATS_REPLICAS * 2 * cout, dtype=torch.float64, device=device)
+    buf = torch.zeros(_lib.STATS_REPLICAS * 2 * cout, dtype=torch.float64, device=device)
+    buf._yv4_kept_clean = True
+    return buf
 
 
 class BNActFunction(torch.autograd.Function):
@@ -337,6 +357,7 @@ class BNActFunction(torch.autograd.Function):
         mean = torch.empty(Cc, dtype=torch.float32, device=dev)
         invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
         rows = None
+        bwd_work = None
         if training and sync_group is not None:
             import torch.distributed as dist
             group = None if sync_group == 'world' else sync_group
@@ -344,6 +365,8 @@ class BNActFunction(torch.autograd.Function):
             sums = torch.empty(2 * Cc + 1, dtype=torch.float64, device=dev)       # [sum | sum of squares | rows]
             if pre is not None:
                 torch.sum(pre.view(_lib.STATS_REPLICAS, 2 * Cc), dim=0, out=sums[:2 * Cc])
+                if getattr(pre, '_yv4_kept_clean', False):
+                    pre.zero_()
             else:
                 check(L.yv4_bn_partial_sums(x.data_ptr(), code, M, Cc, Cc, 0, sums.data_ptr(), stream_ptr()),
                       'yv4_bn_partial_sums')
@@ -353,15 +376,18 @@ class BNActFunction(torch.autograd.Function):
             check(L.yv4_bn_finalize(sums.data_ptr(), 1, 0, rows.data_ptr(), Cc, float(eps), float(momentum),
                                     mean.data_ptr(), invstd.data_ptr(),
                                     running_mean.data_ptr() if running_mean is not None else None,
-                                    running_var.data_ptr() if running_var is not None else None, stream_ptr()),
+                                    running_var.data_ptr() if running_var is not None else None, 0, None, stream_ptr()),
                   'yv4_bn_finalize')
             ctx.sync_group = group
         elif training and sums is not None:
+            # the finalize kernel also clears the backward's reduction buffer (and a persistent statistics buffer)
+            bwd_work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
             check(L.yv4_bn_finalize(sums.data_ptr(), _lib.STATS_REPLICAS, M, None, Cc, float(eps), float(momentum),
                                     mean.data_ptr(), invstd.data_ptr(),
                                     running_mean.data_ptr() if running_mean is not None else None,
-                                    running_var.data_ptr() if running_var is not None else None, stream_ptr()),
-                  'yv4_bn_finalize')
+                                    running_var.data_ptr() if running_var is not None else None,
+                                    1 if getattr(sums, '_yv4_kept_clean', False) else 0, bwd_work.data_ptr(),
+                                    stream_ptr()), 'yv4_bn_finalize')
         elif training:
             check(L.yv4_bn_train_stats_h16(x.data_ptr(), code, M, Cc, Cc, 0, float(eps), float(momentum),
                                            work.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
@@ -380,6 +406,7 @@ class BNActFunction(torch.autograd.Function):
                                    0, M, Cc, int(act), float(slope), stream_ptr()), 'yv4_bn_act_fwd')
         ctx.save_for_backward(x, mean, invstd, g, b)
         ctx.direct = direct      # (_ParamRef(weight), _ParamRef(bias)): dgamma / dbeta are added to their .grad in place
+        ctx.bwd_work = bwd_work  # 2*C doubles already cleared by the finalize kernel, or None
         ctx.rows = rows
         ctx.act = (int(act), float(slope))
         ctx.training = bool(training)
@@ -418,10 +445,15 @@ class BNActFunction(torch.autograd.Function):
                 if not (_flat_f32(gw, Cc) and _flat_f32(gb, Cc)):
                     gw = gb = None
             if gw is not None:       # dgamma / dbeta added to the parameters' gradients by the kernel itself
+                flags = 0 if ctx.training else 1
+                wk = work
+                if ctx.bwd_work is not None:
+                    wk, flags = ctx.bwd_work, flags | 2
+                    ctx.bwd_work = None          # one use: a second backward through this node memsets again
                 check(L.yv4_bn_act_bwd_accum(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
                                              invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
-                                             gw.data_ptr(), gb.data_ptr(), work.data_ptr(), M, Cc, act, slope,
-                                             0 if ctx.training else 1, stream_ptr()), 'yv4_bn_act_bwd_accum')
+                                             gw.data_ptr(), gb.data_ptr(), wk.data_ptr(), M, Cc, act, slope,
+                                             flags, stream_ptr()), 'yv4_bn_act_bwd_accum')
             else:
                 fn = L.yv4_bn_act_bwd_h16 if ctx.training else L.yv4_bn_eval_act_bwd
                 check(fn(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
