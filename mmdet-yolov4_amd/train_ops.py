@@ -31,6 +31,26 @@ def to_nhwc(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
+import os as _os0
+
+_SLICE_GRADS = _os0.environ.get('YV4_SLICE_GRADS', '1') != '0'     # A/B switch
+
+
+def nhwc_or_slice(t, dtype):
+    """(tensor, pixel stride in elements): ``t`` itself when it already is ``dtype`` and either dense NHWC or a
+    channel slice of a dense NHWC tensor (what ``torch.cat``'s backward hands to each branch: every kernel takes
+    a pixel stride, so the slice needs no copy); else a dense NHWC copy."""
+    if _SLICE_GRADS and t.dtype == dtype and t.dim() == 4:
+        N, C_, H, W = t.shape
+        sn, sc, sh, sw = t.stride()
+        al = 4 if dtype == torch.float32 else 8
+        if (sc == 1 or C_ == 1) and sw >= C_ and sh == W * sw and sn == H * W * sw and sw % al == 0 \
+                and t.data_ptr() % 16 == 0:
+            return t, sw
+    t = to_nhwc(t.to(dtype))
+    return t, t.shape[1]
+
+
 def _is_nhwc(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
@@ -49,7 +69,7 @@ def _identity_affine(device, C_):
 _DCODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
-def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None):
+def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None, x_cs=None):
     """Identity-epilogue conv of a channels_last tensor; fp32, or fp16 / bf16 operands (fp32 accumulate).
     ``stats``: a float64 buffer of ``STATS_REPLICAS * 2 * Cout`` entries that receives the BatchNorm sums of the
     output (``yv4_conv_fwd_stats``: accumulated in the conv kernel's epilogue)."""
@@ -58,7 +78,7 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None)
     d = ConvDesc()
     d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin_p, Ho, Wo, Cout
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-    d.x_cstride, d.y_cstride = Cin_p, Cout
+    d.x_cstride, d.y_cstride = (x_cs if x_cs is not None else Cin_p), Cout
     ones, zeros = _identity_affine(x.device, Cout)
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.numel() >= _lib.STATS_REPLICAS * 2 * Cout
@@ -107,7 +127,7 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None):
     return out, cp
 
 
-def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype):
+def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None):
     """dX = correlate(dY zero-dilated by `stride`, W flipped in (kh,kw) and transposed in (co,ci)), pad k-1-p."""
     N, Cin, H, W = xshape
     Cout, _, KH, KW = weight.shape
@@ -115,9 +135,12 @@ def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype):
     h16 = dtype != torch.float32
     L = _lib.lib()
     wtp, _ = packed_weight(weight, dtype, transpose_flip=True)     # rows = Cin, taps mirrored, cast: one launch
+    src_cs = None
     if stride == 1:
-        src = dy
+        src, src_cs = dy, dy_cs
     elif stride == 2:
+        if dy_cs is not None and dy_cs != Cout:
+            dy = to_nhwc(dy)
         src = torch.empty((N, Cout, 2 * Ho, 2 * Wo), device=dy.device, dtype=dtype, memory_format=torch.channels_last)
         k = 2 if h16 else 1     # a 16-bit map with C % 8 == 0 is an fp32 map with C/2 channels
         check(L.yv4_dilate2_fwd(dy.data_ptr(), src.data_ptr(), N, Ho, Wo, Cout // k, Cout // k, 0, stream_ptr()),
@@ -129,7 +152,7 @@ def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype):
     Hx = Hs + 2 * p2 - KH + 1
     Wx = Ws + 2 * p2 - KW + 1
     dxf = torch.empty((N, Cin, Hx, Wx), device=dy.device, dtype=dtype, memory_format=torch.channels_last)
-    _conv_launch(src, wtp, Cout, Cin, KH, KW, 1, p2, dxf)
+    _conv_launch(src, wtp, Cout, Cin, KH, KW, 1, p2, dxf, x_cs=src_cs)
     if (Hx, Wx) != (H, W):
         # stride 2 with odd input size: the dilated grid is one row/column larger or smaller
         dx = torch.empty((N, Cin, H, W), device=dy.device, dtype=dtype, memory_format=torch.channels_last).zero_()
@@ -139,7 +162,7 @@ def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype):
     return dxf
 
 
-def _dgrad_s2_parity(dy, weight, xshape, dtype):
+def _dgrad_s2_parity(dy, weight, xshape, dtype, dy_cs=None):
     """Data gradient of a 3x3 / stride 2 / pad 1 convolution as four parity classes: with
     hi = 2*ho - 1 + kh, the input rows hi = 2i + a receive only the taps kh with (a + 1 - kh) even
     (a = 0: kh = 1 from dY row i;  a = 1: kh = 2 from row i and kh = 0 from row i + 1), likewise in x.
@@ -164,7 +187,7 @@ def _dgrad_s2_parity(dy, weight, xshape, dtype):
             d = ConvDesc()
             d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, Ho, Wo, Cout, Ha, Wb, Cin
             d.KH, d.KW, d.stride, d.pad = taps[a][2], taps[b][2], 1, 0
-            d.x_cstride, d.y_cstride = Cout, Cin
+            d.x_cstride, d.y_cstride = (dy_cs if dy_cs is not None else Cout), Cin
             if h16:
                 check(L.yv4_conv_scatter_fwd_h16(C.byref(d), _DCODE[dtype], dy.data_ptr(), wp.data_ptr(), ones.data_ptr(),
                                                  zeros.data_ptr(), dx.data_ptr(), H, W, 2, 2, a, b, stream_ptr()),
@@ -255,7 +278,7 @@ class ConvFunction(torch.autograd.Function):
         stride, pad, dtype, cp = ctx.geom
         Cout, Cin, KH, KW = weight.shape
         N, _, H, W = x.shape
-        dy = to_nhwc(dy.to(dtype))
+        dy, dy_cs = nhwc_or_slice(dy, dtype)
         Ho, Wo = dy.shape[2], dy.shape[3]
         L = _lib.lib()
         h16 = dtype != torch.float32
@@ -268,7 +291,7 @@ class ConvFunction(torch.autograd.Function):
             d = ConvDesc()
             d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, cp, Ho, Wo, Cout
             d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-            d.x_cstride, d.y_cstride = cp, Cout
+            d.x_cstride, d.y_cstride = cp, dy_cs
             if h16:
                 check(L.yv4_conv_wgrad_h16(C.byref(d), code, x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), stream_ptr()),
                       'yv4_conv_wgrad_h16')
@@ -288,9 +311,9 @@ class ConvFunction(torch.autograd.Function):
                     cb(prm)
         if ctx.needs_input_grad[0]:
             if stride == 2 and (KH, KW, pad) == (3, 3, 1) and Cout % (8 if h16 else 32) == 0:
-                dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype)
+                dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype, dy_cs)
             else:
-                dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype)
+                dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype, dy_cs)
             dx = dx.to(ctx.x_dtype)
         return dx, dw, None, None, None, None, None
 
@@ -417,7 +440,7 @@ class BNActFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x, mean, invstd, g, b = ctx.saved_tensors
         act, slope = ctx.act
-        dy = to_nhwc(dy.to(x.dtype))
+        dy, dcs = nhwc_or_slice(dy, x.dtype)
         code = _DCODE[x.dtype]
         N, Cc, H, W = x.shape
         M = N * H * W
@@ -430,12 +453,12 @@ class BNActFunction(torch.autograd.Function):
         gw = gb = None
         if ctx.rows is not None:            # SyncBN: local sums -> all-reduce -> apply with the totals
             import torch.distributed as dist
-            check(L.yv4_bn_act_bwd_sums(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+            check(L.yv4_bn_act_bwd_sums(x.data_ptr(), code, Cc, 0, dy.data_ptr(), dcs, 0, mean.data_ptr(),
                                         invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dgamma.data_ptr(),
                                         dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope, stream_ptr()),
                   'yv4_bn_act_bwd_sums')
             dist.all_reduce(work, group=ctx.sync_group)
-            check(L.yv4_bn_act_bwd_apply(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+            check(L.yv4_bn_act_bwd_apply(x.data_ptr(), code, Cc, 0, dy.data_ptr(), dcs, 0, mean.data_ptr(),
                                          invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
                                          work.data_ptr(), M, 0, ctx.rows.data_ptr(), Cc, act, slope, stream_ptr()),
                   'yv4_bn_act_bwd_apply')
@@ -450,13 +473,13 @@ class BNActFunction(torch.autograd.Function):
                 if ctx.bwd_work is not None:
                     wk, flags = ctx.bwd_work, flags | 2
                     ctx.bwd_work = None          # one use: a second backward through this node memsets again
-                check(L.yv4_bn_act_bwd_accum(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+                check(L.yv4_bn_act_bwd_accum(x.data_ptr(), code, Cc, 0, dy.data_ptr(), dcs, 0, mean.data_ptr(),
                                              invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
                                              gw.data_ptr(), gb.data_ptr(), wk.data_ptr(), M, Cc, act, slope,
                                              flags, stream_ptr()), 'yv4_bn_act_bwd_accum')
             else:
                 fn = L.yv4_bn_act_bwd_h16 if ctx.training else L.yv4_bn_eval_act_bwd
-                check(fn(x.data_ptr(), code, Cc, 0, dy.data_ptr(), Cc, 0, mean.data_ptr(),
+                check(fn(x.data_ptr(), code, Cc, 0, dy.data_ptr(), dcs, 0, mean.data_ptr(),
                          invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
                          dgamma.data_ptr(), dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope,
                          stream_ptr()), 'yv4_bn_act_bwd')
