@@ -317,6 +317,30 @@ def make_post(ref, out):
           {k: v.shape for k, v in data.items() if k.endswith('dets0')})
 
 
+def make_softfocal(ref, out):
+    """SoftFocalLoss (yolocsp_head.py:21-50) around the reference's sigmoid CrossEntropyLoss: soft targets, the three
+    reductions, two (gamma, alpha) settings; outputs and input gradients."""
+    gen = torch.Generator().manual_seed(11)
+    pred = torch.randn(48, 6, generator=gen) * 3
+    gt = torch.rand(48, 6, generator=gen)
+    gt[::5] = 0.
+    gt[1::7] = 1.
+    res = dict(pred=pred.numpy(), gt=gt.numpy())
+    for tag, (gamma, alpha, red, weight) in dict(a=(1.5, 0.25, 'mean', 1.0), b=(2.0, 0.5, 'sum', 64.0),
+                                                  c=(1.5, 0.25, 'none', 1.0)).items():
+        crit = ref.head.SoftFocalLoss(ref.ConfigDict(type='CrossEntropyLoss', use_sigmoid=True, reduction=red,
+                                                     loss_weight=weight), gamma=gamma, alpha=alpha)
+        x = pred.clone().requires_grad_(True)
+        y = crit(x, gt)
+        y.sum().backward()
+        res[f'{tag}/out'] = y.detach().numpy()
+        res[f'{tag}/grad'] = x.grad.numpy()
+        res[f'{tag}/cfg'] = np.array([gamma, alpha, weight])
+        res[f'{tag}/reduction'] = np.array(red)
+    np.savez_compressed(out, **res)
+    print('softfocal', out)
+
+
 def main():
     if not _ref_import.available():
         print('reference not present: nothing to do')
@@ -326,6 +350,9 @@ def main():
     torch.manual_seed(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'post':      # only the newest fixture
         make_post(ref, os.path.join(HERE, 'post_variants.npz'))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'softfocal':
+        make_softfocal(ref, os.path.join(HERE, 'softfocal.npz'))
         return
     make_mish(ref, os.path.join(HERE, 'mish.npz'))
     v4 = [['conv', 'bottleneck', 'csp', 'csp', 'csp', 'sppv4'], [None, 1, 1, 2, 2, 1], [4, 8, 16, 32, 64, 64]]
@@ -337,6 +364,7 @@ def main():
     make_nms(ref, os.path.join(HERE, 'nms.npz'))
     make_train(ref, os.path.join(HERE, 'train_v4.npz'))
     make_post(ref, os.path.join(HERE, 'post_variants.npz'))
+    make_softfocal(ref, os.path.join(HERE, 'softfocal.npz'))
 
 
 if __name__ == '__main__':

@@ -270,3 +270,25 @@ def test_syncbn_norm_cfg_builds_and_selects_group():
     assert bns and all(b.eps == 0.001 and b.momentum == 0.03 for b in bns)
     assert T._sync_group(bns[0].train()) is None                  # no process group in this process
     assert T._sync_group(torch.nn.BatchNorm2d(4).train()) is None
+
+
+def test_soft_focal_loss_matches_reference(golden):
+    """SoftFocalLoss (registered by the reference's head file, yolocsp_head.py:21-50) around the sigmoid
+    CrossEntropyLoss: outputs and input gradients of the reference module on soft targets (tests/golden/softfocal.npz,
+    made by make_golden.py from /root/reference).  Pure tensor ops: compared on the CPU at 1e-6."""
+    import numpy as np
+    import torch
+    import mmdet_yolov4_amd as pkg
+    z = golden('softfocal')
+    pred, gt = torch.from_numpy(z['pred']), torch.from_numpy(z['gt'])
+    for tag in 'abc':
+        gamma, alpha, weight = (float(v) for v in z[f'{tag}/cfg'])
+        from mmdet_yolov4_amd.registry import build_loss
+        crit = build_loss(dict(type='SoftFocalLoss', gamma=gamma, alpha=alpha,
+                                   raw_loss=dict(type='CrossEntropyLoss', use_sigmoid=True,
+                                                 reduction=str(z[f'{tag}/reduction']), loss_weight=weight)))
+        x = pred.clone().requires_grad_(True)
+        y = crit(x, gt)
+        y.sum().backward()
+        np.testing.assert_allclose(y.detach().numpy(), z[f'{tag}/out'], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(x.grad.numpy(), z[f'{tag}/grad'], rtol=2e-6, atol=1e-7)
