@@ -672,12 +672,14 @@ __global__ __launch_bounds__(kThreads) void conv_stem3x3_kernel(ConvArgs p, unsi
       for (int j = 0; j < 2; ++j) wv[jn][tap][j] = cok ? p.w[(size_t)co * p.Kw + tap * 4 + 2 * h + j] : 0.f;
   }
 
-  const long long wave_id = (long long)blockIdx.x * 4 + (tid >> 6);
-  const long long nwaves = (long long)gridDim.x * 4;
-  for (long long t = wave_id; t < ntiles; t += nwaves) {
-    const int tx = (int)(t % tiles_w);
-    const long long ty = t / tiles_w;       // n*H + y
-    const int y = (int)(ty % p.H);
+  // tile walk in wave-uniform 32-bit arithmetic with magic-number divisors (the 64-bit per-lane divides of the
+  // first version were a third of the instructions of a tile)
+  const int wave_id = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (tid >> 6));
+  const int nwaves = (int)gridDim.x * 4;
+  for (int t = wave_id; t < (int)ntiles; t += nwaves) {
+    const long long ty = fd_div(t, p.fd_wo);     // n*H + y   (fd_wo: tiles per row, fd_hw: H -- set by launch_conv_stem)
+    const int tx = t - (int)ty * tiles_w;
+    const int y = (int)ty - fd_div((int)ty, p.fd_hw) * p.H;
     const int x = tx * 32 + r;
     // byte offset of x[n, y, x, x_co + 2h]
     const unsigned base = (unsigned)(((ty * p.W + x) * p.x_cs + p.x_co + 2 * h) * 4);
@@ -732,13 +734,20 @@ static int launch_conv_stem(const ConvArgs& a, hipStream_t stream) {
   }
   const int tiles_w = (a.W + 31) / 32;
   const long long ntiles = (long long)a.N * a.H * tiles_w;
+  if (ntiles >= (1LL << 31)) {
+    set_error("conv stem: %lld tiles do not fit 31 bits", ntiles);
+    return YV4_E_UNSUPPORTED;
+  }
   long long blocks = (ntiles + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;   // 8 workgroups per CU, grid-stride over the tiles
+  ConvArgs p = a;
+  p.fd_wo = make_fastdiv((unsigned)tiles_w);   // the stem kernel's tile walk: t / tiles_w, (n*H + y) / H
+  p.fd_hw = make_fastdiv((unsigned)a.H);
   if (a.Cout <= 32)
-    hipLaunchKernelGGL((conv_stem3x3_kernel<1, OUT>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, (unsigned)xb,
+    hipLaunchKernelGGL((conv_stem3x3_kernel<1, OUT>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, (unsigned)xb,
                        tiles_w, ntiles);
   else
-    hipLaunchKernelGGL((conv_stem3x3_kernel<2, OUT>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, (unsigned)xb,
+    hipLaunchKernelGGL((conv_stem3x3_kernel<2, OUT>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, (unsigned)xb,
                        tiles_w, ntiles);
   YV4_CHECK_LAUNCH("conv_stem3x3");
   return YV4_OK;
