@@ -79,9 +79,13 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   const int nb = min(kDecBoxes, boxes_lvl - b0);
   const float* src = p.pred[lvl] + ((size_t)n * boxes_lvl + b0) * attr;
   const int nval = nb * attr;
-  for (int i = threadIdx.x; i < nval; i += 256) {
-    const int at = i % attr;
-    sm[i] = (p.v3 && (at == 2 || at == 3)) ? src[i] : sigmoid_f32(src[i]);   // v3: exp(t_w), exp(t_h) need the raw logit
+  if (p.v3) {
+    for (int i = threadIdx.x; i < nval; i += 256) {
+      const int at = i % attr;
+      sm[i] = (at == 2 || at == 3) ? src[i] : sigmoid_f32(src[i]);   // v3: exp(t_w), exp(t_h) need the raw logit
+    }
+  } else {        // (no per-element modulo on the YOLOCSPHead path: every attribute goes through the sigmoid)
+    for (int i = threadIdx.x; i < nval; i += 256) sm[i] = sigmoid_f32(src[i]);
   }
   __syncthreads();
 
