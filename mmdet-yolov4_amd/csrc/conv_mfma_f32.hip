@@ -790,10 +790,17 @@ static bool stem_ok(const yv4_conv_desc* d, bool has_res, bool has2) {
          !has2 && d->x_coff % 2 == 0 && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL;
 }
 
-static int pick_tile(long long M, int Cout, bool fast_ok) {
-  // Measured on MI355X (tools/conv_bench.py, batch 32 YOLOv4-L shapes): the 64x64 LDS-DMA
-  // kernel at 5 workgroups per CU is the best or within 2 % of the best on every layer.
-  if (fast_ok) return YV4_TILE_DMA_64x64;
+static int pick_tile(long long M, int Cout, bool fast_ok, long long K = 0) {
+  // Static choice for callers that do not autotune (training; Plan.autotune re-decides per layer on the box it runs
+  // on).  From profiles/r01_conv_shapes.txt (batch 32 YOLOv4-L shapes): deep reductions with several rounds of
+  // 128x128 tiles gain 5-9 % on the big tile, the remaining K >= 576 layers and the wide 1x1 layers 3-7 % on
+  // 128x64; everything else stays on 64x64 (5 workgroups per CU).
+  if (fast_ok) {
+    auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
+    if (K >= 576 && Cout >= 128 && ntiles(128, 128) >= 700) return YV4_TILE_DMA_128x128;
+    if (Cout >= 64 && (K >= 288 || Cout >= 256) && ntiles(128, 64) >= 512) return YV4_TILE_DMA_128x64;
+    return YV4_TILE_DMA_64x64;
+  }
   // 256 CUs x 2 resident workgroups.  Prefer the biggest tile that still gives the
   // chip >= 2 full rounds of workgroups; small maps (19x19) fall to smaller tiles.
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
@@ -821,7 +828,7 @@ extern "C" int yv4_conv_pick_tile(const yv4_conv_desc* d) {
   const bool fast_ok = d->Cin % kBK == 0 && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL &&
                        (long long)d->Cout * d->KH * d->KW * d->Cin * 4 < 0xFFFFFFF0LL;
   if (stem_ok(d, false, false)) return YV4_TILE_STEM;
-  return pick_tile((long long)d->N * d->Ho * d->Wo, d->Cout, fast_ok);
+  return pick_tile((long long)d->N * d->Ho * d->Wo, d->Cout, fast_ok, (long long)d->KH * d->KW * d->Cin);
 }
 
 // stats != null: identity-epilogue conv that also accumulates the BatchNorm sums of its output; *stats_done tells
@@ -869,7 +876,7 @@ static int conv_f32_impl(const yv4_conv_desc* d, const float* x, const float* w,
   const bool fast_ok = uniform && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL &&
                        (long long)d->Cout * a.K * 4 < 0xFFFFFFF0LL;
   const bool can_stem = stem_ok(d, residual != nullptr, scale2 != nullptr);
-  int tile = d->tile == YV4_TILE_AUTO ? (can_stem ? YV4_TILE_STEM : pick_tile(M, d->Cout, fast_ok)) : d->tile;
+  int tile = d->tile == YV4_TILE_AUTO ? (can_stem ? YV4_TILE_STEM : pick_tile(M, d->Cout, fast_ok, a.K)) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (stats_done) *stats_done = false;
   if (stats && fast_ok && (tile == YV4_TILE_DMA_64x64 || tile == YV4_TILE_DMA_128x64 || tile == YV4_TILE_DMA_128x128)) {
