@@ -22,12 +22,9 @@ class YOLOV4BBoxCoder:
     def decode(self, bboxes, pred_bboxes, stride):
         assert pred_bboxes.size(0) == bboxes.size(0)
         assert pred_bboxes.size(-1) == bboxes.size(-1) == 4
-        xc = (bboxes[..., 0] + bboxes[..., 2]) * 0.5
-        yc = (bboxes[..., 1] + bboxes[..., 3]) * 0.5
-        w = bboxes[..., 2] - bboxes[..., 0]
-        h = bboxes[..., 3] - bboxes[..., 1]
-        xcp = pred_bboxes[..., 0] * stride + xc
-        ycp = pred_bboxes[..., 1] * stride + yc
-        wp = pred_bboxes[..., 2] * w
-        hp = pred_bboxes[..., 3] * h
-        return torch.stack((xcp - wp / 2, ycp - hp / 2, xcp + wp / 2, ycp + hp / 2), dim=-1)
+        # the same fp32 operations per coordinate as the reference (centre = (lo + hi) * 0.5, size = hi - lo,
+        # centre' = t_xy * stride + centre, size' = t_wh * size, corners = centre' -/+ size' / 2), on (…, 2) halves
+        lo, hi = bboxes[..., :2], bboxes[..., 2:]
+        centre = pred_bboxes[..., :2] * stride + (lo + hi) * 0.5
+        half = pred_bboxes[..., 2:] * (hi - lo) / 2
+        return torch.cat((centre - half, centre + half), dim=-1)
