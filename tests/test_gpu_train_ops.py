@@ -240,3 +240,65 @@ def test_spp_backward_lds_and_atomic_forms(gpu_device, shape):
     ref.backward(g)
     assert torch.equal(out, ref.detach())
     torch.testing.assert_close(xr.grad, x2.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_direct_gradient_accumulation_matches_autograd(gpu_device):
+    """Conv dW and BatchNorm dgamma / dbeta written straight into the flat gradient arena (train_ops' direct path:
+    detached weights, kernels that accumulate) over two micro-batches == autograd's own accumulation on a copy of
+    the model that has no arena (fp32, 2e-5 of each gradient's largest entry)."""
+    import copy
+    from mmdet_yolov4_amd.flat_state import FlatState
+    from mmdet_yolov4_amd import train_ops as T
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(pkg.Conv(8, 16, 3, stride=2), pkg.Conv(16, 16, 1), pkg.Conv(16, 32, 3)).to(gpu_device).train()
+    ref = copy.deepcopy(net)
+    fs = FlatState(net)
+    fs.zero_grad()
+    assert all(getattr(p, '_yv4_grad_in_arena', False) for p in net.parameters())
+    fired = []
+    cb = T.add_direct_grad_listener(lambda p: fired.append(id(p)))
+    try:
+        for seed in (0, 1):
+            x = torch.randn(2, 8, 20, 24, device=gpu_device, generator=torch.Generator(gpu_device).manual_seed(seed))
+            for m in (net, ref):
+                xi = x.clone().requires_grad_(True)
+                m(xi).square().mean().backward()
+    finally:
+        T.remove_direct_grad_listener(cb)
+    # the second and third convs see an input that requires grad: their weights and all three BatchNorms go direct
+    assert len(fired) >= 2 * (2 + 4)
+    assert fs.grads_attached()
+    for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert p.grad.data_ptr() == fs.grads.data_ptr() + 4 * fs.param_segments[[id(t) for t in fs._params].index(id(p))].offset
+        err = float((p.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-12))
+        assert err < 2e-5, (n, err)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layout', ['contiguous', 'channels_last'])
+def test_pack_weight_forms(gpu_device, dtype, layout):
+    """yv4_pack_weight against tensor ops: forward form, data-gradient form (transposed, taps mirrored) and the tap
+    subsets of the stride-2 parity classes; contiguous and channels_last sources; channel padding."""
+    from mmdet_yolov4_amd import train_ops as T
+    torch.manual_seed(5)
+    for (Cout, Cin) in ((24, 16), (16, 40)):
+        w = torch.randn(Cout, Cin, 3, 3, device=gpu_device)
+        if layout == 'channels_last':
+            w = w.contiguous(memory_format=torch.channels_last)
+        al = 4 if dtype == torch.float32 else 8
+
+        def pack_ref(t):          # (R, IC, KH, KW) -> (R, KH*KW*ICp) with K = (kh, kw, ic), zero-padded ic
+            R, IC, KH, KW = t.shape
+            icp = (IC + al - 1) // al * al
+            out = torch.zeros(R, KH, KW, icp, device=t.device)
+            out[..., :IC] = t.permute(0, 2, 3, 1)
+            return out.reshape(R, -1).to(dtype)
+
+        got, cp = T.packed_weight(w, dtype)
+        assert cp == (Cin + al - 1) // al * al and torch.equal(got, pack_ref(w))
+        got, cp = T.packed_weight(w, dtype, transpose_flip=True)
+        assert cp == (Cout + al - 1) // al * al and torch.equal(got, pack_ref(w.flip(2, 3).transpose(0, 1)))
+        for ta, la in (((1, 1, 1), [1]), ((2, -2, 2), [2, 0])):
+            for tb, lb in (((1, 1, 1), [1]), ((2, -2, 2), [2, 0])):
+                got, _ = T.packed_weight(w, dtype, taps=(ta, tb))
+                assert torch.equal(got, pack_ref(w[:, :, la][:, :, :, lb].permute(1, 0, 2, 3)))
