@@ -478,8 +478,14 @@ __device__ __forceinline__ void red_flush(double* part, int C, int c, const doub
 }
 constexpr int kBnFloatRun = 16;  // unrolled iterations (x4 rows) a thread sums in fp32 before folding into its doubles
 
-constexpr int kBnUnroll = 4;    // independent row loads in flight per thread (the loops are latency-bound otherwise)
-constexpr int kBnRedUnroll = 4; // (8 measured 3 % slower on the whole step: registers)
+#ifndef YV4_BN_UNROLL
+#define YV4_BN_UNROLL 4
+#endif
+constexpr int kBnUnroll = YV4_BN_UNROLL;    // independent row loads in flight per thread (the loops are latency-bound otherwise)
+#ifndef YV4_BN_RED_UNROLL
+#define YV4_BN_RED_UNROLL 2
+#endif
+constexpr int kBnRedUnroll = YV4_BN_RED_UNROLL;   // (4 and 8 measured 0.8 % / 3 % slower on the whole step: registers -> occupancy)
 
 // rows per workgroup: enough workgroups to fill the chip (>= ~1024) but at most kBnRows rows each
 static const int g_bn_rows_cap = [] { const char* e = getenv("YV4_BN_ROWS"); return e ? atoi(e) : kBnRows; }();
