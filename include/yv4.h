@@ -507,6 +507,17 @@ typedef struct yv4_loss_desc {
 int yv4_yolo_loss_fwd(const yv4_loss_desc* d, void* stream);
 int yv4_yolo_loss_bwd(const yv4_loss_desc* d, const float* grad_out, void* stream);
 
+/* ---- test-time input pipeline (Resize keep_ratio -> Pad -> Normalize -> ImageToTensor of
+ * configs/yolov4/yolov4l_coco_mosaic.py:70-84) for one 8-bit HWC image: bilinear resize with OpenCV's 8-bit
+ * fixed-point INTER_LINEAR arithmetic to (new_h, new_w), padding to (Hp, Wp) with pad_val, (v - mean) * (1/std)
+ * in fp32 with the channel order swapped if to_rgb (mean / std in OUTPUT channel order, host pointers), written as
+ * 3 fp32 planes of Hp*Wp (plane_stride elements apart) -- the image's slot of an NCHW batch.
+ * pad_before_normalize: the Pad transform precedes Normalize (the pad value is normalised as well).
+ * PARITY UNPINNED: the arithmetic being mirrored is mmcv's / OpenCV's (absent from the build image). */
+int yv4_letterbox_u8(const uint8_t* src, int src_h, int src_w, int src_pitch, float* dst, int Hp, int Wp,
+                     int64_t plane_stride, int new_h, int new_w, const float* mean3, const float* std3,
+                     int to_rgb, int pad_val, int pad_before_normalize, void* stream);
+
 /* ---- evaluation: the reference's two Cython ops, batched over (image, class) problems ----------
  * mmdet/ops/eval_utils/iou/iou_coco.pyx:8-56 and match/match_coco.pyx:8-57, called per image and class
  * from core/evaluation/mean_ap_flexible.py:19-37.  Problem p owns detections [det_off[p], det_off[p+1])

@@ -126,6 +126,7 @@ SIGNATURES = {
     'yv4_pack_weight': (C.c_int, [_vp, _i64, _i64, _i64, _i64] + [_i] * 12 + [_vp, _i, _vp]),
     'yv4_yolo_loss_fwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
     'yv4_yolo_loss_bwd': (C.c_int, [C.POINTER(LossDesc), _vp, _vp]),
+    'yv4_letterbox_u8': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _i64, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     'yv4_iou_coco_batched': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     'yv4_match_coco_batched': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'yv4_grad_prepare': (C.c_int, [_vp, _i64, _vp, _f, _vp, _vp, _vp]),

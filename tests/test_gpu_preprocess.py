@@ -1,0 +1,80 @@
+"""Test-time input pipeline (PARITY UNPINNED: mmcv / OpenCV are absent from the build image):
+``yv4_letterbox_u8`` / ``FusedTestPipeline`` against oracle/preprocess_oracle.py, the restatement of OpenCV's 8-bit
+INTER_LINEAR and mmcv's imnormalize.  Bit-exact (integer interpolation, one fp32 subtract and multiply)."""
+import numpy as np
+import pytest
+import torch
+
+import mmdet_yolov4_amd as pkg
+from oracle import preprocess_oracle as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('shape', [(375, 500), (480, 640), (640, 427), (97, 1024), (1333, 800), (32, 32), (1, 7)])
+@pytest.mark.parametrize('cfg', [dict(), dict(mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True,
+                                              pad_before_normalize=False), dict(to_rgb=False, img_scale=(608, 608))])
+def test_pipeline_matches_the_restatement(shape, cfg):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    img = rng.integers(0, 256, (shape[0], shape[1], 3), dtype=np.uint8)
+    okw = dict(cfg)
+    scale = okw.pop('img_scale', (640, 640))
+    want, meta = P.pipeline(img, scale=scale, **okw)
+    batch, metas = pkg.FusedTestPipeline(img_scale=scale, **okw)([img])
+    got = batch[0].cpu().numpy()
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.array_equal(got, want)
+    for k in ('ori_shape', 'img_shape', 'pad_shape', 'flip'):
+        assert metas[0][k] == meta[k]
+    assert np.array_equal(metas[0]['scale_factor'], meta['scale_factor'])
+
+
+def test_ragged_batch_is_zero_padded_like_collate():
+    rng = np.random.default_rng(1)
+    imgs = [rng.integers(0, 256, s + (3,), dtype=np.uint8) for s in ((375, 500), (500, 375), (200, 640))]
+    batch, metas = pkg.FusedTestPipeline()(imgs)
+    assert batch.shape == (3, 3, 640, 640)
+    for i, img in enumerate(imgs):
+        want, meta = P.pipeline(img)
+        hp, wp = meta['pad_shape'][:2]
+        got = batch[i].cpu().numpy()
+        assert np.array_equal(got[:, :hp, :wp], want)
+        assert not got[:, hp:, :].any() and not got[:, :, wp:].any()      # collate's zero padding
+
+
+def test_feeds_the_detector():
+    rng = np.random.default_rng(2)
+    imgs = [rng.integers(0, 256, (120, 160, 3), dtype=np.uint8) for _ in range(2)]
+    batch, metas = pkg.FusedTestPipeline(img_scale=(128, 128))(imgs)
+    det = pkg.build_detector(dict(
+        type='SingleStageDetector',
+        backbone=dict(type='DarknetCSP', scale=[['conv', 'bottleneck', 'csp', 'csp'], [None, 1, 1, 1], [8, 16, 16, 32]],
+                      out_indices=[1, 2, 3]),
+        neck=dict(type='YOLOV4Neck', in_channels=[16, 16, 32], out_channels=[16, 16, 32], csp_repetition=1),
+        bbox_head=dict(type='YOLOCSPHead', num_classes=3, in_channels=[16, 16, 32], featmap_strides=[4, 8, 16],
+                       anchor_generator=dict(type='YOLOV4AnchorGenerator', strides=[4, 8, 16],
+                                             base_sizes=[[(8, 8)] * 3, [(16, 16)] * 3, [(32, 32)] * 3])),
+        test_cfg=dict(nms_pre=-1, score_thr=0.001, nms=dict(type='nms', iou_threshold=0.65), max_per_img=10)))
+    det.init_weights()
+    det.eval().to(batch.device)
+    res = det.simple_test(batch, metas, rescale=True)
+    assert len(res) == 2 and len(res[0]) == 3 and all(r.shape[1] == 5 for r in res[0])
+
+
+def test_built_from_the_reference_config_block():
+    """The test_pipeline list of configs/yolov4/yolov4l_coco_mosaic.py:70-84, verbatim."""
+    img_norm_cfg = dict(mean=[114, 114, 114], std=[255, 255, 255], to_rgb=True)
+    test_pipeline = [
+        dict(type='LoadImageFromFile'),
+        dict(type='MultiScaleFlipAug', img_scale=(640, 640), flip=False,
+             transforms=[dict(type='Resize', keep_ratio=True), dict(type='RandomFlip'), dict(type='Pad', size_divisor=32),
+                         dict(type='Normalize', **img_norm_cfg), dict(type='ImageToTensor', keys=['img']),
+                         dict(type='Collect', keys=['img'])])]
+    pipe = pkg.FusedTestPipeline.from_config(test_pipeline)
+    assert pipe.img_scale == (640, 640) and pipe.size_divisor == 32 and pipe.pad_first and pipe.to_rgb
+    img = np.random.default_rng(4).integers(0, 256, (300, 451, 3), dtype=np.uint8)
+    batch, metas = pipe([img])
+    want, meta = P.pipeline(img)
+    assert np.array_equal(batch[0].cpu().numpy(), want) and metas[0]['pad_shape'] == meta['pad_shape']
+    with pytest.raises(NotImplementedError):
+        pkg.FusedTestPipeline.from_config([dict(type='MultiScaleFlipAug', img_scale=(640, 640), flip=True, transforms=[])])
