@@ -59,6 +59,17 @@ def test_feeds_the_detector():
     det.eval().to(batch.device)
     res = det.simple_test(batch, metas, rescale=True)
     assert len(res) == 2 and len(res[0]) == 3 and all(r.shape[1] == 5 for r in res[0])
+    # inference_detector (mmdet/apis/inference.py:88-158) = the same two steps behind the reference's name
+    cfg_pipeline = [dict(type='LoadImageFromFile'),
+                    dict(type='MultiScaleFlipAug', img_scale=(128, 128), flip=False,
+                         transforms=[dict(type='Resize', keep_ratio=True), dict(type='RandomFlip'),
+                                     dict(type='Pad', size_divisor=32),
+                                     dict(type='Normalize', mean=[114, 114, 114], std=[255, 255, 255], to_rgb=True),
+                                     dict(type='ImageToTensor', keys=['img']), dict(type='Collect', keys=['img'])])]
+    res2 = pkg.inference_detector(det, imgs, test_pipeline=cfg_pipeline)
+    assert all(np.array_equal(a, b) for ra, rb in zip(res, res2) for a, b in zip(ra, rb))
+    one = pkg.inference_detector(det, imgs[0], test_pipeline=cfg_pipeline)
+    assert len(one) == 3 and all(np.array_equal(a, b) for a, b in zip(one, res[0]))
 
 
 def test_built_from_the_reference_config_block():
