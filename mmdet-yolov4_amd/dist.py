@@ -42,6 +42,45 @@ def shard(num_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def sampler_indices(num_items, rank, world):
+    """The dataset indices rank ``rank`` evaluates in a distributed test run: the order of
+    ``DistributedSampler(shuffle=False)`` (datasets/builder.py:112-113) -- the index list is padded with its own
+    head to a multiple of ``world`` and dealt round-robin -- which is what ``collect_results`` undoes."""
+    per_rank = -(-num_items // world)
+    padded = [i % max(num_items, 1) for i in range(per_rank * world)] if num_items else []
+    return padded[rank::world]
+
+
+def collect_results(result_part, size, device='cpu'):
+    """Merge every rank's list of per-image results on rank 0, in dataset order (other ranks get None).
+
+    The result-gather step of a distributed test run (mmdet/apis/test.py:160-191, ``collect_results_gpu``):
+    results are variable-length python objects, so each rank ships one byte string -- an all-gather of the
+    lengths, then one all-gather of the parts padded to the longest -- and rank 0 re-interleaves them (rank r
+    holds items r, r+world, ...) and drops the sampler's padding beyond ``size``.  Host-side; ``device`` is
+    where the byte buffers live ('cpu' for gloo, the rank's GPU for RCCL)."""
+    import pickle
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(result_part)[:size]
+    rank, world = dist.get_rank(), dist.get_world_size()
+    part = torch.frombuffer(bytearray(pickle.dumps(result_part)), dtype=torch.uint8).to(device)
+    length = torch.tensor([part.numel()], dtype=torch.int64, device=device)
+    lengths = [torch.zeros_like(length) for _ in range(world)]
+    dist.all_gather(lengths, length)
+    longest = int(max(int(l) for l in lengths))
+    send = torch.zeros(longest, dtype=torch.uint8, device=device)
+    send[:part.numel()] = part
+    recv = [torch.zeros_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    if rank != 0:
+        return None
+    parts = [pickle.loads(r[:int(l)].cpu().numpy().tobytes()) for r, l in zip(recv, lengths)]
+    ordered = []
+    for group in zip(*parts):
+        ordered.extend(group)
+    return ordered[:size]
+
+
 def barrier(sync_device=True):
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

@@ -141,3 +141,65 @@ def test_grad_reducer_two_ranks_gloo(tmp_path):
     assert outs[0]['nb'] >= 2 and all(o['launched'] for o in outs)
     assert all(o['err'] < 1e-6 for o in outs), outs      # averaged sum of both ranks' gradients
     assert outs[0]['gsum'] == outs[1]['gsum']            # bit-identical arenas after the exchange
+
+
+# ---- result gather of a distributed test run: ragged per-image results, 2 ranks -------------------
+GATHER_WORKER = textwrap.dedent('''
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch
+    from mmdet_yolov4_amd import dist as D
+    rank, local_rank, world = D.init(backend='gloo')
+    size = 7                                               # odd: the sampler pads rank 1 with image 0
+    def result_of(i):                                      # per-image result: one (k_c, 5) array per class, ragged
+        return [np.full((i + c, 5), 10 * i + c, dtype=np.float32) for c in range(3)]
+    mine = D.sampler_indices(size, rank, world)
+    merged = D.collect_results([result_of(i) for i in mine], size)
+    ok = None
+    if rank == 0:
+        ok = len(merged) == size and all(
+            len(m) == 3 and all(a.shape == b.shape and (a == b).all() for a, b in zip(m, result_of(i)))
+            for i, m in enumerate(merged))
+    empty = D.collect_results([], 0)
+    print('RESULT ' + json.dumps(dict(rank=rank, mine=mine, ok=ok, none=merged is None, empty=empty)), flush=True)
+    D.finalize()
+''')
+
+
+def test_collect_results_two_ranks_gloo(tmp_path):
+    script = tmp_path / 'gather_worker.py'
+    script.write_text(GATHER_WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out
+        outs.append(json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][0][7:]))
+    outs.sort(key=lambda o: o['rank'])
+    assert outs[0]['mine'] == [0, 2, 4, 6] and outs[1]['mine'] == [1, 3, 5, 0]
+    assert outs[0]['ok'] is True and outs[0]['none'] is False
+    assert outs[1]['none'] is True                         # only rank 0 holds the merged list
+    assert outs[0]['empty'] == [] and outs[1]['empty'] is None
+
+
+def test_sampler_indices_match_torch_sampler():
+    from torch.utils.data import DistributedSampler
+    from mmdet_yolov4_amd import dist as D
+    for n in (1, 2, 7, 16, 33):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                ref = list(DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=False))
+                assert D.sampler_indices(n, rank, world) == ref, (n, world, rank)
+    assert D.sampler_indices(0, 0, 2) == []
+
+
+def test_collect_results_single_process():
+    from mmdet_yolov4_amd import dist as D
+    assert D.collect_results([1, 2, 3], 2) == [1, 2]
