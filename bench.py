@@ -215,7 +215,10 @@ def main():
     ap.add_argument('--candidates', type=float, default=2000.0, help='target NMS candidates per image')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layers', default='', help='write a per-conv timing table (JSON) to this path')
-    ap.add_argument('--no-autotune', action='store_true', help='keep the static conv tile choice')
+    ap.add_argument('--autotune', action='store_true',
+                    help='re-decide the conv tile of every layer by timing the candidates on this box (default: the static '
+                         'choice of pick_tile, which measures the same images/s; see DESIGN.md 2.3)')
+    ap.add_argument('--no-autotune', action='store_true', help='accepted for old command lines: the default now')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'],
                     help='operand type of the convs (f32 = the headline / parity configuration)')
     ap.add_argument('--event-every', type=int, default=4,
@@ -255,7 +258,7 @@ def main():
         plan.run(img)
         torch.cuda.synchronize()
         ncand = float(plan.post['counts'].float().mean())
-    if not args.no_autotune:
+    if args.autotune and not args.no_autotune:
         plan.autotune()
 
     conv_ops = [o for o in plan.ops if o.kind == 'conv']

@@ -349,3 +349,37 @@ def eval_map_flexible(det_results, annotations, iou_thrs=[0.5], breakdown=[], io
     assert len(det_results) == len(annotations)
     fse = FlexibleStatisticsEval(classes, iou_thrs, breakdown, iou_calculator, matcher, nproc or 0)
     return fse.report(fse.statistics_eval(det_results, annotations), report_config)
+
+
+def coco_test_annotation(ann_info, cat_ids, cat2label):
+    """One image's COCO annotation records -> the dict ``eval_map_flexible`` consumes
+    (``CocoDataset.get_ann_info_test``, datasets/coco.py:357-409, without the mask / seg-map fields the bbox
+    evaluation never reads).  ``ann_info``: the image's ``annotations`` entries (``bbox`` = x, y, w, h);
+    crowd boxes and boxes of unlisted categories are kept and flagged ``ignore``."""
+    boxes, labels, ignore, crowd, area = [], [], [], [], []
+    for ann in ann_info:
+        is_crowd = ann.get('iscrowd', False)
+        ignore.append(bool(ann.get('ignore', False) or is_crowd or ann['category_id'] not in cat_ids))
+        crowd.append(bool(is_crowd))
+        area.append(ann['area'])
+        x, y, w, h = ann['bbox']
+        boxes.append([x, y, x + w, y + h])
+        labels.append(cat2label[ann['category_id']])
+    return dict(gt_bboxes=np.array(boxes, dtype=np.float32).reshape(-1, 4), gt_labels=np.array(labels, dtype=np.int64),
+                gt_attrs=dict(ignore=np.array(ignore, dtype=bool), iscrowd=np.array(crowd, dtype=bool),
+                              area=np.array(area, dtype=np.float32)))
+
+
+def evaluate_fast_bbox(results, annotations, classes, logger=None):
+    """``dataset.evaluate(results, metric='fast-bbox')`` (datasets/coco.py:464-496): the ten COCO IoU thresholds, the
+    three object-scale breakdowns, and the six-number report ``map, map50, map75, s_map, m_map, l_map``."""
+    return eval_map_flexible(
+        results, annotations, iou_thrs=[0.5 + 0.05 * x for x in range(10)],
+        breakdown=[dict(type='ScaleBreakdown', scale_ranges=dict(Scale_S=(0, 32), Scale_M=(32, 96), Scale_L=(96, 10000)))],
+        report_config=[('map', lambda x: x['breakdown'] == 'All'),
+                       ('map50', lambda x: x['iou_threshold'] == 0.5 and x['breakdown'] == 'All'),
+                       ('map75', lambda x: x['iou_threshold'] == 0.75 and x['breakdown'] == 'All'),
+                       ('s_map', lambda x: x['breakdown'] == 'Scale_S'),
+                       ('m_map', lambda x: x['breakdown'] == 'Scale_M'),
+                       ('l_map', lambda x: x['breakdown'] == 'Scale_L')],
+        classes=classes, iou_calculator=dict(type='IOU2DCoCo'), matcher=dict(type='MatcherCoCo'), nproc=-1, logger=logger)

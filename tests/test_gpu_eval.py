@@ -101,6 +101,9 @@ def test_eval_map_flexible_against_fixture(golden):
     assert list(report) == [n for n, _ in REPORT]
     for name, _ in REPORT:
         assert float(report[name]) == float(z[f'report/{name}'])
+    # dataset.evaluate(metric='fast-bbox') (datasets/coco.py:464-496) = the same call with the recipe's constants
+    fast = pkg.evaluate_fast_bbox(dets, annos, classes)
+    assert list(fast) == list(report) and all(float(fast[k]) == float(report[k]) for k in fast)
 
 
 def test_shared_tp_quirk_and_custom_matcher(golden):

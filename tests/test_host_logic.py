@@ -186,3 +186,23 @@ def test_yolov3_registry_names_and_checkpoint_layout(golden):
     b, p_ = torch.from_numpy(g['coder/bboxes']), torch.from_numpy(g['coder/pred'])
     np.testing.assert_array_equal(coder.decode(b, p_, 32).numpy(), g['coder/decode_s32'])
     np.testing.assert_array_equal(coder.encode(b, torch.from_numpy(g['coder/encode_gt']), 32).numpy(), g['coder/encode_s32'])
+
+
+def test_coco_test_annotation():
+    """datasets/coco.py:357-409: xywh -> xyxy, crowd and unlisted categories flagged ignore (and kept), dtypes."""
+    import numpy as np
+    from mmdet_yolov4_amd.eval_utils import coco_test_annotation
+    cat_ids, cat2label = [1, 3, 7], {1: 0, 3: 1, 7: 2}
+    anns = [dict(bbox=[10, 20, 30, 40], category_id=3, area=1200.0),
+            dict(bbox=[0.5, 1.5, 2, 3], category_id=7, area=6, iscrowd=1),
+            dict(bbox=[5, 5, 1, 1], category_id=1, area=1, ignore=True)]
+    a = coco_test_annotation(anns, cat_ids, cat2label)
+    assert a['gt_bboxes'].dtype == np.float32 and a['gt_bboxes'].tolist() == [[10, 20, 40, 60], [0.5, 1.5, 2.5, 4.5], [5, 5, 6, 6]]
+    assert a['gt_labels'].dtype == np.int64 and a['gt_labels'].tolist() == [1, 2, 0]
+    assert a['gt_attrs']['ignore'].tolist() == [False, True, True] and a['gt_attrs']['iscrowd'].tolist() == [False, True, False]
+    assert a['gt_attrs']['area'].dtype == np.float32 and a['gt_attrs']['ignore'].dtype == bool
+    e = coco_test_annotation([], cat_ids, cat2label)
+    assert e['gt_bboxes'].shape == (0, 4) and e['gt_labels'].shape == (0,) and e['gt_attrs']['iscrowd'].shape == (0,)
+    import pytest
+    with pytest.raises(KeyError):                          # the reference indexes cat2label before it could skip the box
+        coco_test_annotation([dict(bbox=[0, 0, 1, 1], category_id=2, area=1)], cat_ids, cat2label)
