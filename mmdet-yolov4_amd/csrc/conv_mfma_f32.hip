@@ -444,6 +444,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
     b_off[q] = co < p.Cout ? (unsigned)(((int64_t)co * p.Kw + lc * 4) * 4) : kOOB;
   }
 
+  // K is walked channel-chunk-major: the KH*KW taps of one 32-channel chunk in consecutive slices, then the next
+  // chunk.  A tap re-reads the 128-B lines its neighbours read one (kw) or KW (kh) slices ago, which are still in the
+  // XCD's L2; with the taps outermost each line came back Cin/32 slices later, after every concurrent tile had streamed
+  // its whole window through the 4 MB L2 (profiles/r01_layer_traffic.md).  The weights stay [Cout][kh][kw][cin].
+  const int ntaps = p.KH * p.KW;
   int s_tap = 0, s_c0 = 0, s_kh = 0, s_kw = 0;
   unsigned s_kb = 0;
 
@@ -458,15 +463,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
     }                                                                               \
     _Pragma("unroll") for (int q = 0; q < PB; ++q)                                  \
       lds_dma16(rsB, lb_ + 32 * q * kRow * 4, b_off[q], s_kb);                       \
-    s_kb += kBK * 4;                                                                \
-    s_c0 += kBK;                                                                    \
-    const int wrap_c = s_c0 >= p.Cin ? 1 : 0;                                       \
-    s_c0 = wrap_c ? 0 : s_c0;                                                       \
-    s_tap += wrap_c;                                                                \
-    s_kw += wrap_c;                                                                 \
+    s_tap += 1;                                                                     \
+    s_kw += 1;                                                                      \
     const int wrap_w = s_kw == p.KW ? 1 : 0;                                        \
     s_kw = wrap_w ? 0 : s_kw;                                                       \
     s_kh += wrap_w;                                                                 \
+    const int wrap_t = s_tap == ntaps ? 1 : 0;                                      \
+    s_tap = wrap_t ? 0 : s_tap;                                                     \
+    s_kh = wrap_t ? 0 : s_kh;                                                       \
+    s_c0 += wrap_t ? kBK : 0;                                                       \
+    s_kb = (unsigned)((s_tap * p.Cin + s_c0) * 4);                                  \
   }
 
   // fragment read addresses: row*128 B + ((chunk ^ swz) << 4); chunk = 2j + h

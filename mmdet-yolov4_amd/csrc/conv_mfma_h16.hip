@@ -296,6 +296,9 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
     b_off[q] = co < p.Cout ? (unsigned)(((int64_t)co * p.Kw + (GENERAL_K ? 0 : lc * 8)) * 2) : kOOB;
   }
 
+  // uniform-K path: channel-chunk-major walk of K (all taps of one 64-channel chunk, then the next chunk), so a tap
+  // finds the lines its neighbour taps fetched one or KW slices ago still in L2 (see conv_mfma_f32.hip)
+  const int ntaps = p.KH * p.KW;
   int s_tap = 0, s_c0 = 0, s_kh = 0, s_kw = 0;
   unsigned s_kb = 0;
   int g_k = lc * 8;     // GENERAL_K: first K index of this lane's chunk in the next slice
@@ -326,15 +329,16 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
       }                                                                                          \
       _Pragma("unroll") for (int q = 0; q < PB; ++q)                                             \
         lds_dma16_h(rsB, lb_ + 32 * q * kRowB, b_off[q], s_kb);                                   \
-      s_kb += kHBK * 2;                                                                          \
-      s_c0 += kHBK;                                                                              \
-      const int wrap_c = s_c0 >= p.Cin ? 1 : 0;                                                  \
-      s_c0 = wrap_c ? 0 : s_c0;                                                                  \
-      s_tap += wrap_c;                                                                           \
-      s_kw += wrap_c;                                                                            \
+      s_tap += 1;                                                                                \
+      s_kw += 1;                                                                                 \
       const int wrap_w = s_kw == p.KW ? 1 : 0;                                                   \
       s_kw = wrap_w ? 0 : s_kw;                                                                  \
       s_kh += wrap_w;                                                                            \
+      const int wrap_t = s_tap == ntaps ? 1 : 0;                                                 \
+      s_tap = wrap_t ? 0 : s_tap;                                                                \
+      s_kh = wrap_t ? 0 : s_kh;                                                                  \
+      s_c0 += wrap_t ? kHBK : 0;                                                                 \
+      s_kb = (unsigned)((s_tap * p.Cin + s_c0) * 2);                                             \
     }                                                                                            \
   }
 
