@@ -346,7 +346,8 @@ def main():
             i = op.info
             rows.append(dict(name=op.name, Cin=i['Cin'], Cout=i['Cout'], k=i['k'], stride=i['stride'], H=i['H'],
                              W=i['W'], tile=tile, us=round(tsum / n * 1e6, 1),
-                             tflops=round(op.flops / (tsum / n) / 1e12, 1), gflop=round(op.flops / 1e9, 2)))
+                             tflops=round(op.flops / (tsum / n) / 1e12, 1), gflop=round(op.flops / 1e9, 2),
+                             mbytes=round(op.bytes / 1e6, 2), residual=i['launch']['res'] is not None))
         with open(args.layers, 'w') as f:
             json.dump(rows, f, indent=1)
 

@@ -29,7 +29,7 @@ def per_dispatch(d, counter):
 fetch = per_dispatch(fetch_dir, 'FETCH_SIZE')
 write = per_dispatch(write_dir, 'WRITE_SIZE')
 N = int(os.environ.get('YV4_BATCH', '32'))
-lines = ['| # | layer | tile | µs | algorithmic MB (in + w + out) | fetched MB | written MB | traffic ÷ algorithmic |',
+lines = ['| # | layer | tile | µs | algorithmic MB (in + w + out + residual) | fetched MB | written MB | traffic ÷ algorithmic |',
          '|---|---|---|---|---|---|---|---|']
 tot_a = tot_t = 0.0
 by_tile = {}
@@ -40,19 +40,20 @@ for i, (L, f, w) in enumerate(zip(layers, fetch, write)):
     assert (want in f[1] or alt in f[1]) and (want in w[1] or alt in w[1]), (i, L, f[1])   # launch order, checked per row
     Ho, Wo = -(-L['H'] // L['stride']), -(-L['W'] // L['stride'])
     a_in, a_w, a_out = N * L['H'] * L['W'] * L['Cin'] * 4, L['Cout'] * L['Cin'] * L['k'] ** 2 * 4, N * Ho * Wo * L['Cout'] * 4
-    alg = a_in + a_w + a_out
+    a_res = a_out if L.get('residual') else 0
+    alg = a_in + a_w + a_out + a_res
     rd, wr = f[2] * 1024 * 2, w[2] * 1024
     tot_a += alg
     tot_t += rd + wr
     t = by_tile.setdefault(L['tile'], [0.0, 0.0, 0])
     t[0] += alg; t[1] += rd + wr; t[2] += 1
-    lines.append('| %d | %dx%d s%d %d->%d @%dx%d | %s | %.0f | %.1f (%.1f + %.1f + %.1f) | %.1f | %.1f | %.2f |'
+    lines.append('| %d | %dx%d s%d %d->%d @%dx%d | %s | %.0f | %.1f (%.1f + %.1f + %.1f + %.1f) | %.1f | %.1f | %.2f |'
                  % (i, L['k'], L['k'], L['stride'], L['Cin'], L['Cout'], L['H'], L['W'], L['tile'], L['us'], alg / 1e6,
-                    a_in / 1e6, a_w / 1e6, a_out / 1e6, rd / 1e6, wr / 1e6, (rd + wr) / alg))
+                    a_in / 1e6, a_w / 1e6, a_out / 1e6, a_res / 1e6, rd / 1e6, wr / 1e6, (rd + wr) / alg))
 head = ['# Per-layer HBM-side traffic of one step (YOLOv4-L 608x608 fp32, batch %d)' % N, '',
         'Counters: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes) over `bench.py`; per-dispatch values of the',
-        'last step joined to the layer table by launch order (kernel template checked per row).  Residual reads are not in the',
-        'algorithmic column.  Whole step: %.0f MB algorithmic, %.0f MB counted = %.2fx.' % (tot_a / 1e6, tot_t / 1e6, tot_t / tot_a), '']
+        'last step joined to the layer table by launch order (kernel template checked per row).',
+        'Whole step: %.0f MB algorithmic, %.0f MB counted = %.2fx.' % (tot_a / 1e6, tot_t / 1e6, tot_t / tot_a), '']
 for k, (a, t, n) in sorted(by_tile.items()):
     head.append('* %s: %d layers, %.0f MB algorithmic, %.0f MB counted = %.2fx' % (k, n, a / 1e6, t / 1e6, t / a))
 open(out_path, 'w').write('\n'.join(head + [''] + lines) + '\n')
