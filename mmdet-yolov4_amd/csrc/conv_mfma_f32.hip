@@ -680,9 +680,19 @@ __global__ __launch_bounds__(kThreads) void conv_stem3x3_kernel(ConvArgs p, unsi
 
   // tile walk in wave-uniform 32-bit arithmetic with magic-number divisors (the 64-bit per-lane divides of the
   // first version were a third of the instructions of a tile)
-  const int wave_id = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (tid >> 6));
-  const int nwaves = (int)gridDim.x * 4;
-  for (int t = wave_id; t < (int)ntiles; t += nwaves) {
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: XCD c walks the c-th eighth of the tile
+  // list with all its waves side by side, so the rows a tile shares with the tiles above and below it (3 input rows
+  // per output row) are fetched by one L2 once instead of by three (measured 3.4x the input before, FETCH_SIZE).
+  const int nblk_all = (int)gridDim.x;
+  const int nch = nblk_all < 8 ? nblk_all : 8;
+  const int chunk = (int)blockIdx.x % nch, local = (int)blockIdx.x / nch;
+  const int nblk = (nblk_all - chunk + nch - 1) / nch;               // workgroups walking this chunk
+  const int cq = (int)ntiles / nch, crem = (int)ntiles % nch;
+  const int t_lo = chunk * cq + (chunk < crem ? chunk : crem);
+  const int t_hi = t_lo + cq + (chunk < crem ? 1 : 0);
+  const int wave_id = __builtin_amdgcn_readfirstlane(local * 4 + (tid >> 6));
+  const int nwaves = nblk * 4;
+  for (int t = t_lo + wave_id; t < t_hi; t += nwaves) {
     const long long ty = fd_div(t, p.fd_wo);     // n*H + y   (fd_wo: tiles per row, fd_hw: H -- set by launch_conv_stem)
     const int tx = t - (int)ty * tiles_w;
     const int y = (int)ty - fd_div((int)ty, p.fd_hw) * p.H;
