@@ -29,17 +29,20 @@ def per_dispatch(d, counter):
 fetch = per_dispatch(fetch_dir, 'FETCH_SIZE')
 write = per_dispatch(write_dir, 'WRITE_SIZE')
 N = int(os.environ.get('YV4_BATCH', '32'))
+ES = int(os.environ.get('YV4_ESIZE', '4'))                 # bytes per activation / weight element (2 on the 16-bit path)
 lines = ['| # | layer | tile | µs | algorithmic MB (in + w + out + residual) | fetched MB | written MB | traffic ÷ algorithmic |',
          '|---|---|---|---|---|---|---|---|']
 tot_a = tot_t = 0.0
 by_tile = {}
 for i, (L, f, w) in enumerate(zip(layers, fetch, write)):
-    tile = L['tile'].replace('dma', '')
-    want = 'stem' if 'stem' in tile else '<%s,' % tile.replace('x', ', ')
-    alt = 'stem' if 'stem' in tile else 'ILi%sELi%sE' % tuple(tile.split('x'))     # mangled spelling of the same template
+    tile = L['tile'].replace('dma', '').replace('h16_', '')
+    want = 'stem' if 'stem' in tile else ' %s,' % tile.replace('x', ', ')           # '<128, 64,' or '<true, 128, 64,'
+    alt = 'stem' if 'stem' in tile else 'Li%sELi%sE' % tuple(tile.split('x'))      # mangled spelling of the same template
     assert (want in f[1] or alt in f[1]) and (want in w[1] or alt in w[1]), (i, L, f[1])   # launch order, checked per row
     Ho, Wo = -(-L['H'] // L['stride']), -(-L['W'] // L['stride'])
-    a_in, a_w, a_out = N * L['H'] * L['W'] * L['Cin'] * 4, L['Cout'] * L['Cin'] * L['k'] ** 2 * 4, N * Ho * Wo * L['Cout'] * 4
+    es = ES
+    ies = 4 if 'stem' in tile else es                                              # the image stays fp32 on every path
+    a_in, a_w, a_out = N * L['H'] * L['W'] * L['Cin'] * ies, L['Cout'] * L['Cin'] * L['k'] ** 2 * ies, N * Ho * Wo * L['Cout'] * es
     a_res = a_out if L.get('residual') else 0
     alg = a_in + a_w + a_out + a_res
     rd, wr = f[2] * 1024 * 2, w[2] * 1024
@@ -50,7 +53,7 @@ for i, (L, f, w) in enumerate(zip(layers, fetch, write)):
     lines.append('| %d | %dx%d s%d %d->%d @%dx%d | %s | %.0f | %.1f (%.1f + %.1f + %.1f + %.1f) | %.1f | %.1f | %.2f |'
                  % (i, L['k'], L['k'], L['stride'], L['Cin'], L['Cout'], L['H'], L['W'], L['tile'], L['us'], alg / 1e6,
                     a_in / 1e6, a_w / 1e6, a_out / 1e6, a_res / 1e6, rd / 1e6, wr / 1e6, (rd + wr) / alg))
-head = ['# Per-layer HBM-side traffic of one step (YOLOv4-L 608x608 fp32, batch %d)' % N, '',
+head = ['# Per-layer HBM-side traffic of one step (YOLOv4-L 608x608 %s, batch %d)' % ('fp32' if ES == 4 else '16-bit', N), '',
         'Counters: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes) over `bench.py`; per-dispatch values of the',
         'last step joined to the layer table by launch order (kernel template checked per row).',
         'Whole step: %.0f MB algorithmic, %.0f MB counted = %.2fx.' % (tot_a / 1e6, tot_t / 1e6, tot_t / tot_a), '']
