@@ -651,6 +651,33 @@ static int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
 // the buffer descriptor), holds the 18 weight values it needs for the whole kernel, issues
 // 18 MFMAs per tile and streams the epilogue to HBM in 128-byte rows.
 // ---------------------------------------------------------------------------------
+__device__ __forceinline__ void act_row16(float (&v)[16], int act, float slope) {
+  switch (act) {
+    case YV4_ACT_MISH:
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = apply_act(v[e], YV4_ACT_MISH, 0.f);
+      break;
+    case YV4_ACT_LEAKY:
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * slope;
+      break;
+    case YV4_ACT_SWISH:
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = apply_act(v[e], YV4_ACT_SWISH, 0.f);
+      break;
+    default:
+      break;
+  }
+}
+
+// one value to y[row_base + lane_off]: row_base (elements) is wave-uniform, lane_off a 32-bit per-lane constant
+template <int OUT>
+__device__ __forceinline__ void stem_store(float* y, long long row_base, unsigned lane_off, float v) {
+  if (OUT == 0) (y + row_base)[lane_off] = v;
+  else if (OUT == 1) (reinterpret_cast<_Float16*>(y) + row_base)[lane_off] = (_Float16)v;
+  else (reinterpret_cast<__bf16*>(y) + row_base)[lane_off] = (__bf16)v;
+}
+
 // OUT: 0 fp32 (p.y), 1 fp16, 2 bf16 (p.y reinterpreted; the 16-bit inference path keeps the image
 // and this layer's arithmetic in fp32 and only rounds the layer's output).
 template <int TN, int OUT>
@@ -722,20 +749,28 @@ __global__ __launch_bounds__(kThreads) void conv_stem3x3_kernel(ConvArgs p, unsi
         acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[tap].x), wv[jn][tap][0], acc[jn], 0, 0, 0);
         acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[tap].y), wv[jn][tap][1], acc[jn], 0, 0, 0);
       }
+    // epilogue: lane (r, h) holds channel jn*32 + r of the tile's pixels (e&3) + 8*(e>>2) + 4h.  The row address is
+    // wave-uniform (scalar base + one per-lane offset that never changes), the activation sits behind one uniform
+    // switch and the bounds test is per tile: the per-element form of all three cost 2.7x the 18 MFMAs in VALU time.
     const long long mrow = ty * p.W + tx * 32;
+    const bool full = tx * 32 + 32 <= p.W;
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
-      const int co = jn * 32 + r;
+      if (jn * 32 + r >= p.Cout) continue;
+      float v[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (co < p.Cout && tx * 32 + row < p.W) {
-          const float v = apply_act(acc[jn][e] * s1[jn] + t1[jn], p.act1, p.slope1);
-          const long long idx = (mrow + row) * p.y_cs + p.y_co + co;
-          if (OUT == 0) p.y[idx] = v;
-          else if (OUT == 1) reinterpret_cast<_Float16*>(p.y)[idx] = (_Float16)v;
-          else reinterpret_cast<__bf16*>(p.y)[idx] = (__bf16)v;
-        }
+      for (int e = 0; e < 16; ++e) v[e] = acc[jn][e] * s1[jn] + t1[jn];
+      act_row16(v, p.act1, p.slope1);
+      const unsigned lane_off = (unsigned)(4 * h * p.y_cs + jn * 32 + r);
+      if (full) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          stem_store<OUT>(p.y, (mrow + (e & 3) + 8 * (e >> 2)) * p.y_cs + p.y_co, lane_off, v[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (tx * 32 + (e & 3) + 8 * (e >> 2) + 4 * h < p.W)
+            stem_store<OUT>(p.y, (mrow + (e & 3) + 8 * (e >> 2)) * p.y_cs + p.y_co, lane_off, v[e]);
       }
     }
   }
