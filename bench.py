@@ -14,6 +14,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
                measured inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak
   cpu_baseline the CPU oracle (plain torch CPU restatement of the reference) timed on this
                box's host cores on a bounded sample (rank 0, N=1 only)
+  train_step   the bf16 batch-64/GPU training step (BASELINE.json configs[2]) measured by
+               tools/train_bench.py in a child process per rank, data-parallel over RCCL when N > 1
 """
 import argparse
 import json
@@ -200,6 +202,42 @@ def vs_published(args, value):
     return None
 
 
+def train_step_leg(args, rank, local_rank, world):
+    """The train-step half of BASELINE.json's metric (configs[2]: bf16, batch 64/GPU, data-parallel with the RCCL
+    all-reduce of ``dist.GradReducer`` when WORLD_SIZE > 1), measured by ``tools/train_bench.py`` in a CHILD process of
+    every rank after this process has left its own process group: a fault or a stuck collective in the training path
+    then costs the ``train_step`` object, not the inference line.  The children rendezvous on their own port."""
+    import subprocess
+    env = dict(os.environ)
+    port = int(env.get('MASTER_PORT', '29500'))
+    env['MASTER_PORT'] = str(port + 7 if port < 65000 else port - 7)
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    env['RANK'], env['LOCAL_RANK'], env['WORLD_SIZE'] = str(rank), str(local_rank), str(world)
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'train_bench.py'),
+           '--batch', str(args.train_batch), '--size', str(args.size), '--steps', str(args.steps),
+           '--warmup', str(args.warmup), '--dtype', args.train_dtype, '--model', args.model]
+    try:
+        r = subprocess.run(cmd, env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=args.train_timeout, text=True)
+    except subprocess.TimeoutExpired:
+        return dict(error=f'train_bench.py still running after {args.train_timeout} s; killed')
+    if rank != 0:
+        return None
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    if r.returncode != 0 or not lines:
+        return dict(error=f'train_bench.py exit {r.returncode}: ' + r.stderr.strip()[-400:])
+    t = json.loads(lines[-1])
+    t['unit'] = 'images/sec'
+    t['steps'], t['warmup'] = args.steps, args.warmup
+    t['config'] = dict(workload=f'{args.model} {args.size}x{args.size} {args.train_dtype} train step (forward, fused loss, '
+                                f'backward, gradient all-reduce, SGD-Nesterov + EMA through the recipe hooks), batch '
+                                f'{args.train_batch}/GPU (BASELINE.json configs[2])',
+                       global_batch=args.train_batch * world,
+                       parallelism=f'dp{world}: replicated weights, bucketed RCCL all-reduce of the flat gradient arena'
+                       if world > 1 else 'one rank, no collective')
+    return t
+
+
 def det_scale(det):
     return det._bench_scale
 
@@ -221,6 +259,10 @@ def main():
     ap.add_argument('--no-autotune', action='store_true', help='accepted for old command lines: the default now')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'],
                     help='operand type of the convs (f32 = the headline / parity configuration)')
+    ap.add_argument('--no-train', action='store_true', help='skip the train-step leg (the "train_step" object)')
+    ap.add_argument('--train-batch', type=int, default=64, help='images per GPU per training step (configs[2])')
+    ap.add_argument('--train-dtype', default='bf16', choices=['f32', 'f16', 'bf16'])
+    ap.add_argument('--train-timeout', type=float, default=420.0, help='seconds the train-step child may take')
     ap.add_argument('--event-every', type=int, default=4,
                     help='bracket the conv launches with HIP events in every n-th timed step (events cost ~2 %%)')
     args = ap.parse_args()
@@ -351,6 +393,15 @@ def main():
         with open(args.layers, 'w') as f:
             json.dump(rows, f, indent=1)
 
+    # the inference numbers are final here: leave the group, free the plan, then let a child measure the train step
+    D.finalize()
+    train = None
+    if not args.no_train:
+        del plan, conv_ops, events, per_layer, post
+        det._engines.clear()
+        torch.cuda.empty_cache()
+        train = train_step_leg(args, rank, local_rank, world)
+
     if rank == 0:
         total_images = args.batch * world * args.steps
         out = dict(
@@ -370,13 +421,12 @@ def main():
                         weights='random init (seed 0), BN statistics fitted on the batch, head bias set for '
                                 f'~{ncand:.0f} NMS candidates/image', parallelism=f'replicated weights, batch '
                                 f'sharded over {world} rank(s), no collective'),
-            roofline=roofline)
+            roofline=roofline, train_step=train)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(det, args.size)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    D.finalize()
 
 
 if __name__ == '__main__':

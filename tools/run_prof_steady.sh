@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_steady
 rm -rf $OUT; mkdir -p $OUT/summary
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-autotune > $OUT/trace.log 2>&1 < /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train --no-autotune > $OUT/trace.log 2>&1 < /dev/null
 python3 tools/summarize_prof.py $OUT $OUT/summary > /dev/null
 mv $OUT/summary/kernel_stats.csv $OUT/summary/steady_kernel_stats.csv
 grep '^{"metric"' $OUT/trace.log | tail -1 > $OUT/summary/steady_bench_profiled.json
