@@ -203,3 +203,49 @@ def test_sampler_indices_match_torch_sampler():
 def test_collect_results_single_process():
     from mmdet_yolov4_amd import dist as D
     assert D.collect_results([1, 2, 3], 2) == [1, 2]
+
+
+# ---- bench.py's train-step leg: host logic around the child process (no GPU, the child is a stand-in) ----
+def _leg_args(**kw):
+    import argparse
+    d = dict(train_batch=64, size=608, steps=3, warmup=1, train_dtype='bf16', model='yolov4l', train_timeout=5.0)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_train_leg_child_gets_its_own_port_and_rank0_reports(monkeypatch):
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env, **kw):
+        seen['cmd'], seen['env'] = cmd, env
+        line = json.dumps(dict(metric='images/sec (train step) yolov4l', value=123.4, n_gpus=2, ms_per_step=1.0))
+        return subprocess.CompletedProcess(cmd, 0, stdout='noise\n' + line + '\n', stderr='')
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setenv('MASTER_PORT', '29500')
+    out = bench.train_step_leg(_leg_args(), rank=0, local_rank=0, world=2)
+    assert seen['env']['MASTER_PORT'] == '29507' and seen['env']['WORLD_SIZE'] == '2' and seen['env']['RANK'] == '0'
+    assert seen['cmd'][1].endswith(os.path.join('tools', 'train_bench.py'))
+    assert seen['cmd'][seen['cmd'].index('--batch') + 1] == '64' and seen['cmd'][seen['cmd'].index('--dtype') + 1] == 'bf16'
+    assert out['value'] == 123.4 and out['steps'] == 3 and out['config']['global_batch'] == 128
+    assert 'dp2' in out['config']['parallelism']
+    # the other ranks run the child but report nothing
+    assert bench.train_step_leg(_leg_args(), rank=1, local_rank=1, world=2) is None
+    assert seen['env']['RANK'] == '1' and seen['env']['LOCAL_RANK'] == '1'
+
+
+def test_train_leg_failure_costs_only_the_train_object(monkeypatch):
+    import subprocess
+    import bench
+
+    def fails(cmd, env, **kw):
+        return subprocess.CompletedProcess(cmd, 3, stdout='', stderr='RuntimeError: boom')
+    monkeypatch.setattr(subprocess, 'run', fails)
+    out = bench.train_step_leg(_leg_args(), 0, 0, 1)
+    assert 'exit 3' in out['error'] and 'boom' in out['error']
+
+    def hangs(cmd, env, timeout, **kw):
+        raise subprocess.TimeoutExpired(cmd, timeout)
+    monkeypatch.setattr(subprocess, 'run', hangs)
+    assert 'killed' in bench.train_step_leg(_leg_args(), 0, 0, 1)['error']
