@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_H16_MFMA_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, same guide (not the 2:1-sparsity figure)
+PEAK_HBM_GBPS = 8000.0          # HBM3E, same guide
 
 MODELS = {
     'yolov4l': dict(scale='v4l5p', neck_in=[256, 512, 512], neck_out=[256, 512, 1024], csp_rep=2),
@@ -369,12 +370,12 @@ def main():
     headline = (args.model, args.size, args.batch, args.dtype) == ('yolov4l', 608, 32, 'f32')
     traffic, traffic_src = pmc_traffic(dom) if headline else (None, None)   # the committed PMC summary is of the headline run
     peak = PEAK_H16_MFMA_TFLOPS if h16 else PEAK_FP32_MFMA_TFLOPS
+    dbytes = sum(o.bytes for o, _, _ in events if tile_of(o) == dom)
     roofline = dict(bound='mfma', kernel=f'conv_mfma_{"h16" if h16 else "f32"}_kernel<{dom}>',
                     achieved=round(dflops / dtime / 1e12, 2), peak=peak, unit='TFLOP/s',
                     frac=round(dflops / dtime / 1e12 / peak, 4), traffic=traffic,
                     traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=round(sum(o.bytes for o, _, _ in events
-                                                           if tile_of(o) == dom) / dn),
+                    algorithmic_bytes_per_launch=round(dbytes / dn),
                     launches=dn, avg_launch_us=round(dtime / dn * 1e6, 2),
                     gflop_per_launch=round(dflops / dn / 1e9, 3),
                     all_convs_tflops=round(conv_flops / conv_time / 1e12, 2),
@@ -382,6 +383,13 @@ def main():
                     conv_share_of_step=round(conv_time / max(len(events) // len(conv_ops), 1) /
                                              (elapsed / args.steps), 4),
                     instrumented_steps=len(events) // len(conv_ops))
+    # which roof bounds the dominant kernel: the higher of its two floors (FLOPs / matrix peak, algorithmic bytes /
+    # HBM peak).  fp32: the matrix core by 14x; the 16-bit operands move the small-model / batch-256 configurations
+    # (BASELINE.json configs[3]) and most tile classes of YOLOv4-L under the HBM roof
+    if dbytes / (PEAK_HBM_GBPS * 1e9) > dflops / (peak * 1e12):
+        roofline.update(bound='hbm', achieved=round(dbytes / dtime / 1e9, 1), peak=PEAK_HBM_GBPS, unit='GB/s',
+                        frac=round(dbytes / dtime / 1e9 / PEAK_HBM_GBPS, 4),
+                        mfma_tflops=round(dflops / dtime / 1e12, 2), mfma_frac=round(dflops / dtime / 1e12 / peak, 4))
     if args.layers and rank == 0:
         rows = []
         for op, tsum, n, tile in per_layer.values():
