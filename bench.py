@@ -115,6 +115,13 @@ def pmc_traffic(tile_name):
     kern = {'dma64x64': 'yv4::conv_mfma_f32_dma_kernel<64, 64, 2, 2, 2>',
             'dma128x64': 'yv4::conv_mfma_f32_dma_kernel<128, 64, 2, 2, 2>',
             'dma128x128': 'yv4::conv_mfma_f32_dma_kernel<128, 128, 2, 2, 2>'}.get(tile_name)
+    if tile_name.startswith('h16_'):       # 16-bit path: per tile class, from the per-layer traffic table (bf16 run)
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_tiles_bf16.json')))
+        try:
+            d = json.load(open(files[-1]))['tiles'][tile_name]
+            return d['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)
+        except Exception:
+            return None, None
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel.json')))
     if not kern or not files:
         return None, None
@@ -368,7 +375,9 @@ def main():
     dom = max(per_tile, key=lambda k: per_tile[k][1])
     dflops, dtime, dn = per_tile[dom]
     headline = (args.model, args.size, args.batch, args.dtype) == ('yolov4l', 608, 32, 'f32')
-    traffic, traffic_src = pmc_traffic(dom) if headline else (None, None)   # the committed PMC summary is of the headline run
+    # the committed PMC summaries are of the headline run and of the same workload on bf16 operands
+    v4l = (args.model, args.size, args.batch) == ('yolov4l', 608, 32)
+    traffic, traffic_src = pmc_traffic(dom) if headline or (v4l and args.dtype == 'bf16') else (None, None)
     peak = PEAK_H16_MFMA_TFLOPS if h16 else PEAK_FP32_MFMA_TFLOPS
     dbytes = sum(o.bytes for o, _, _ in events if tile_of(o) == dom)
     roofline = dict(bound='mfma', kernel=f'conv_mfma_{"h16" if h16 else "f32"}_kernel<{dom}>',
