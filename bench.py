@@ -74,6 +74,22 @@ def synthetic_images(batch, size, seed, device):
     return ((img.float() - 114.0) / 255.0).to(device)     # img_norm_cfg of configs/yolov4/*
 
 
+def synthetic_gts(batch, size, seed, device):
+    """SURVEY 8d ground truth of the training configurations: per image Poisson(12) boxes (>= 1), centre
+    U[0, size), w and h log-uniform in [8, 400], clipped to the image; labels U{0..79}."""
+    g = torch.Generator().manual_seed(seed)
+    boxes, labels = [], []
+    lo, hi = torch.log(torch.tensor(8.0)), torch.log(torch.tensor(400.0))
+    for _ in range(batch):
+        n = max(1, int(torch.poisson(torch.tensor(12.0), generator=g)))
+        c = torch.rand(n, 2, generator=g) * size
+        wh = torch.exp(torch.rand(n, 2, generator=g) * (hi - lo) + lo)
+        b = torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, size)
+        boxes.append(b.to(device))
+        labels.append(torch.randint(0, 80, (n,), generator=g).to(device))
+    return boxes, labels
+
+
 def init_head(det, plan, img, target_per_img, logit_std=2.0):
     """Random head whose logits have std ~2 around a common bias, the bias bisected so that
     about `target_per_img` (box, class) scores pass score_thr -- the realistic post-process
@@ -241,7 +257,7 @@ def train_step_leg(args, rank, local_rank, world):
                                 f'backward, gradient all-reduce, SGD-Nesterov + EMA through the recipe hooks), batch '
                                 f'{args.train_batch}/GPU (BASELINE.json configs[2])',
                        global_batch=args.train_batch * world,
-                       parallelism=f'dp{world}: replicated weights, bucketed RCCL all-reduce of the flat gradient arena'
+                       parallelism=f'dp{world}: replicated weights, ' + str(t.get('grad_exchange'))
                        if world > 1 else 'one rank, no collective')
     return t
 
@@ -410,6 +426,28 @@ def main():
         with open(args.layers, 'w') as f:
             json.dump(rows, f, indent=1)
 
+    # the timed batch's output is the real thing: image 0 (and 1) of the batch-N step must equal, bit for bit, what a
+    # batch-2 plan computes for the same two images (per-image NMS, eval-mode BN, every conv tile walks K in the same
+    # order) -- a wrong fast path (cached outputs, skipped images) cannot pass this
+    torch.cuda.synchronize()
+    if args.batch >= 2:
+        small = det.compile(2, args.size, args.size, device=dev, rescale=True,
+                            dtype={'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.dtype])
+        small.run(img[:2])
+        torch.cuda.synchronize()
+        for n in range(2):
+            k = int(host_count[n])
+            assert int(small.post['count'][n]) == k, f'image {n}: batch-{args.batch} step kept {k} detections, batch-2 plan ' \
+                                                     f'{int(small.post["count"][n])}'
+            assert torch.equal(small.post['dets'][n, :k].cpu(), host_dets[n, :k]) and \
+                torch.equal(small.post['labels'][n, :k].cpu().to(torch.int32), host_labels[n, :k]), \
+                f'image {n} of the batch-{args.batch} step differs from the batch-2 plan'
+        del small
+        output_check = f'images 0-1 of the timed batch-{args.batch} step == a batch-2 plan on the same images (bit-exact; ' \
+                       f'{int(host_count[0])} + {int(host_count[1])} detections)'
+    else:
+        output_check = None
+
     # the inference numbers are final here: leave the group, free the plan, then let a child measure the train step
     D.finalize()
     train = None
@@ -438,7 +476,7 @@ def main():
                         weights='random init (seed 0), BN statistics fitted on the batch, head bias set for '
                                 f'~{ncand:.0f} NMS candidates/image', parallelism=f'replicated weights, batch '
                                 f'sharded over {world} rank(s), no collective'),
-            roofline=roofline, train_step=train)
+            roofline=roofline, output_check=output_check, train_step=train)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(det, args.size)
         else:

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YV4_ABI_VERSION 2
+#define YV4_ABI_VERSION 3
 
 /* error codes */
 #define YV4_OK 0
@@ -253,6 +253,20 @@ int yv4_nms_split(const uint64_t* keys, int64_t n, float max_coord,
                   float iou_thr, int max_out, void* work, float* out_dets,
                   int32_t* out_labels, int64_t* out_index, int32_t* out_count,
                   void* stream);
+
+/* The suppression predicate of every NMS entry point, process-wide (set it once, before launching):
+ *   YV4_NMS_IOU_DIV (default)  inter / (Sa + Sb - inter) > iou_thr    -- mmcv-full 1.3.x's CPU kernel (nms_cpu) and
+ *                                                                        the definition SURVEY 8c fixes; oracle/nms_ref.c
+ *   YV4_NMS_IOU_MUL            inter > iou_thr * (Sa + Sb - inter)    -- mmcv-full 1.3.x's CUDA kernel (devIoU), i.e.
+ *                                                                        what the reference executes on a GPU
+ * Both in fp32 without contraction; they select differently only on pairs whose IoU rounds across iou_thr
+ * (tests/golden/nms_boundary.npz).  mmcv is third party and absent from the reference tree (call site
+ * mmdet/core/post_processing/bbox_nms.py:84): parity unpinned against either kernel.
+ * Returns YV4_OK / YV4_E_ARG. */
+#define YV4_NMS_IOU_DIV 0
+#define YV4_NMS_IOU_MUL 1
+int yv4_nms_set_iou_form(int form);
+int yv4_nms_get_iou_form(void);
 
 /* Build candidate keys for the standalone batched_nms op from plain
  * boxes/scores (n candidates of one image): keys[i] = ~bits(score_i)<<32 | i,

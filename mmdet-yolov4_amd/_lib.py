@@ -15,10 +15,11 @@ LIB_PATH = os.environ.get('YV4_LIB_PATH') or os.path.join(LIB_DIR, 'libyv4_hip.s
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 # ---- constants mirrored from include/yv4.h -------------------------------------
-ABI_VERSION = 2
+ABI_VERSION = 3
 STATS_REPLICAS = 64        # YV4_STATS_REPLICAS
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_MISH, ACT_LEAKY, ACT_SWISH = 0, 1, 2, 3
+NMS_IOU_DIV, NMS_IOU_MUL = 0, 1
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
 TILE_DMA_64x64, TILE_DMA_128x64, TILE_DMA_128x128, TILE_STEM = 5, 6, 7, 8
 TILE_NAMES = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '64x128', 5: 'dma64x64', 6: 'dma128x64',
@@ -94,6 +95,8 @@ SIGNATURES = {
     'yv4_nms_split': (C.c_int, [_vp, _i64, _f, _vp, _vp, _i, _f, _i, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
     'yv4_nms_prepare': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'yv4_nms_set_iou_form': (C.c_int, [_i]),
+    'yv4_nms_get_iou_form': (C.c_int, []),
     'yv4_conv_wgrad': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     'yv4_dilate2_fwd': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_bn_train_stats': (C.c_int, [_vp, _i64, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -172,6 +175,9 @@ def lib():
         got = handle.yv4_abi_version()
         if got != ABI_VERSION:
             raise RuntimeError(f'libyv4_hip.so ABI {got} != binding ABI {ABI_VERSION}; rebuild')
+        form = os.environ.get('YV4_NMS_IOU_FORM', '').lower()
+        if form in ('mul', '1', 'product', 'cuda'):
+            handle.yv4_nms_set_iou_form(NMS_IOU_MUL)      # mmcv's CUDA-kernel predicate instead of its CPU kernel's
         _lib = handle
     return _lib
 

@@ -142,6 +142,30 @@ def apply_init_cfg(module, init_cfg):
 
 
 # ---- plan-backed module base -------------------------------------------------------------
+PLAN_CACHE_ENTRIES = 4
+
+
+def plan_cache_get(cache, key):
+    """LRU lookup: a hit becomes the most recently used entry."""
+    plan = cache.get(key)
+    if plan is not None:
+        cache[key] = cache.pop(key)
+    return plan
+
+
+def plan_cache_put(cache, key, plan, version_index, cap=None):
+    """Insert a freshly built plan.  Entries built for another parameter version can never be hit again (the version
+    only grows) and are dropped; beyond ``cap`` geometries the least recently used one goes.  Alternating input shapes
+    (keep-ratio resize, the short last batch of a dataset) therefore reuse their plans instead of rebuilding --
+    re-packing ~115 conv weights, reallocating activations and re-capturing a hipGraph -- on every call."""
+    cap = PLAN_CACHE_ENTRIES if cap is None else cap
+    for k in [k for k in cache if k[version_index] != key[version_index]]:
+        del cache[k]
+    cache[key] = plan
+    while len(cache) > cap:
+        del cache[next(iter(cache))]
+
+
 class HipModule(nn.Module):
     """Base of every registered module.  In eval mode ``forward`` compiles (once per input
     geometry and parameter version) the module's own launch plan via ``emit`` and replays it;
@@ -226,9 +250,8 @@ class HipModule(nn.Module):
                 'to differentiate through the HIP training ops')
         dtype = getattr(self, 'compute_dtype', torch.float32)
         key = (tuple(tuple(t.shape) for t in flat), str(flat[0].device), self._param_version(), dtype)
-        plan = self._plan_cache.get(key)
+        plan = plan_cache_get(self._plan_cache, key)
         if plan is None:
-            self._plan_cache.clear()
             plan = Plan(flat[0].device, dtype)
             views = [plan.add_input_nchw(*t.shape, name=f'in{i}') for i, t in enumerate(flat)]
             outs = self.emit(plan, *(views if structure == 'flat' else [views]))
@@ -237,7 +260,7 @@ class HipModule(nn.Module):
                 plan.add_output_nchw(v, name=f'out{i}')
             plan.single = not isinstance(outs, (tuple, list))
             plan.finalize()
-            self._plan_cache[key] = plan
+            plan_cache_put(self._plan_cache, key, plan, 2)
         res = plan.run(*flat)
         return res[0] if plan.single else tuple(res)
 

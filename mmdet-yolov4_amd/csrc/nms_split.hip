@@ -50,6 +50,7 @@ struct SplitArgs {
   int fused;
   float off_unit;            // max_coord + 1
   float iou_thr;
+  int iou_form;
   float4* kept_box;          // scratch, n entries (class segment c uses [seg[c], ...))
   float* kept_area;          // scratch, n entries
   uint64_t* out_keys;        // n entries: key if kept else ~0
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_class_nms_kernel(SplitArg
         for (int k = q; k < kept && !dead; k += 4) {
           float4 bk;
           bk.x = vb[k].x; bk.y = vb[k].y; bk.z = vb[k].z; bk.w = vb[k].w;
-          dead = iou_gt(bk, va[k], bj, aj, p.iou_thr);
+          dead = iou_gt(bk, va[k], bj, aj, p.iou_thr, p.iou_form);
         }
       }
       const unsigned long long live = __ballot(!dead);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_class_nms_kernel(SplitArg
         const float ai = carea[i];
         for (int jj = 0; jj < 64; ++jj) {
           const int j = w * 64 + jj;
-          if (j > i && j < cn && iou_gt(bi, ai, cbox[j], carea[j], p.iou_thr)) bits |= 1ull << jj;
+          if (j > i && j < cn && iou_gt(bi, ai, cbox[j], carea[j], p.iou_thr, p.iou_form)) bits |= 1ull << jj;
         }
       }
       cmask[i * 4 + w] = bits;
@@ -259,7 +260,7 @@ extern "C" int yv4_nms_split(const uint64_t* keys, int64_t n, float max_coord, c
   // 3. per-class NMS; survivors' keys into keys_a (others ~0)
   SplitArgs a;
   a.keys = keys_b; a.seg = seg; a.boxes = boxes; a.fused = fused_classes; a.off_unit = max_coord + 1.f;
-  a.iou_thr = iou_thr; a.kept_box = reinterpret_cast<float4*>(w + L.kbox); a.kept_area = reinterpret_cast<float*>(w + L.karea);
+  a.iou_thr = iou_thr; a.iou_form = nms_iou_form(); a.kept_box = reinterpret_cast<float4*>(w + L.kbox); a.kept_area = reinterpret_cast<float*>(w + L.karea);
   a.out_keys = keys_a;
   hipLaunchKernelGGL(split_class_nms_kernel, dim3(num_classes), dim3(kSplitThreads), 0, s, a);
   // 4. survivors by (score desc, index asc), first max_out

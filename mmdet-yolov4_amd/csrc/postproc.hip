@@ -216,6 +216,7 @@ struct NmsArgs {
   int64_t label_stride;
   int fused_classes;
   float iou_thr;
+  int iou_form;
   int max_out;
   int split_thr;
   float* out_dets;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
             bk = make_float4(vd[k * 5 + 0] + off, vd[k * 5 + 1] + off, vd[k * 5 + 2] + off, vd[k * 5 + 3] + off);
             ak = (bk.z - bk.x) * (bk.w - bk.y);
           }
-          dead = iou_gt(bk, ak, bj, aj, p.iou_thr);
+          dead = iou_gt(bk, ak, bj, aj, p.iou_thr, p.iou_form);
         }
       } else {
         dead = true;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
         const int j0 = w * 64;
         for (int jj = 0; jj < 64; ++jj) {
           const int j = j0 + jj;
-          if (j > i && j < cn && iou_gt(bi, ai, cbox[j], carea[j], p.iou_thr)) bits |= 1ull << jj;
+          if (j > i && j < cn && iou_gt(bi, ai, cbox[j], carea[j], p.iou_thr, p.iou_form)) bits |= 1ull << jj;
         }
       }
       cmask[i * 4 + w] = bits;
@@ -519,7 +520,7 @@ extern "C" int yv4_nms_images(uint64_t* keys, int64_t key_cap, const int32_t* co
   NmsArgs a;
   a.keys = keys; a.key_cap = key_cap; a.counts = counts; a.max_coord = max_coord; a.boxes = boxes;
   a.boxes_per_image = boxes_per_image; a.labels = labels; a.label_stride = label_stride;
-  a.fused_classes = fused_classes; a.iou_thr = iou_thr; a.max_out = max_out; a.split_thr = split_thr;
+  a.fused_classes = fused_classes; a.iou_thr = iou_thr; a.iou_form = nms_iou_form(); a.max_out = max_out; a.split_thr = split_thr;
   a.out_dets = out_dets; a.out_labels = out_labels; a.out_index = out_index; a.out_count = out_count;
   static bool attr_done = false;
   if (!attr_done) {

@@ -110,13 +110,16 @@ class Fp16GradAccumulateOptimizerHook(Hook):
     multiplier the step kernel applies (``ctrl[0]``), so ``p.grad`` is not rewritten in place."""
 
     def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, loss_scale=512., distributed=True,
-                 nominal_batch_size=None, accumulation=None, compute_dtype=None):
+                 nominal_batch_size=None, accumulation=None, compute_dtype=None, grad_exchange=None):
         # compute_dtype: None leaves the model as it is (fp32 unless wrap_fp16_model was applied);
         # 'fp16' / 'bf16' (or the torch dtypes) make before_run wrap the model like the reference's
         # Fp16OptimizerHook.before_run does (mmcv wrap_fp16_model): 16-bit activations, fp32 master weights
         self.compute_dtype = {None: None, 'fp16': torch.float16, 'bf16': torch.bfloat16, 'fp32': torch.float32,
                               torch.float16: torch.float16, torch.bfloat16: torch.bfloat16,
                               torch.float32: torch.float32}[compute_dtype]
+        # grad_exchange: None (YV4_GRAD_EXCHANGE or 'allreduce') | 'allreduce' | 'direct' | 'direct_bf16', see
+        # dist.GradReducer
+        self.grad_exchange = grad_exchange
         self.grad_clip = grad_clip
         self.coalesce = coalesce
         self.bucket_size_mb = bucket_size_mb
@@ -160,7 +163,7 @@ class Fp16GradAccumulateOptimizerHook(Hook):
             if self.distributed and _world_size() > 1:
                 from .dist import GradReducer
                 mb = self.bucket_size_mb if self.bucket_size_mb and self.bucket_size_mb > 0 else 64
-                self.reducer = GradReducer(flat, bucket_mb=mb)
+                self.reducer = GradReducer(flat, bucket_mb=mb, mode=self.grad_exchange)
 
     def before_run(self, runner):
         self._ensure_state(runner)
@@ -169,9 +172,7 @@ class Fp16GradAccumulateOptimizerHook(Hook):
             wrap_fp16_model(_unwrap(runner.model), self.compute_dtype)
         meta = getattr(runner, 'meta', None)
         if meta and 'fp16' in meta and 'loss_scaler' in meta['fp16']:
-            sd = meta['fp16']['loss_scaler']
-            self.scale_state[0] = float(sd['scale'])
-            self.scale_state[1] = float(sd.get('_growth_tracker', 0))
+            self.load_loss_scaler_state_dict(meta['fp16']['loss_scaler'])
 
     def before_train_epoch(self, runner):
         if self.accumulation is None:
@@ -214,33 +215,39 @@ class Fp16GradAccumulateOptimizerHook(Hook):
                                           float(self.scaler_cfg['backoff_factor']),
                                           int(self.scaler_cfg['growth_interval']), stream_ptr()),
                   'yv4_loss_scale_update')
+
+    # ---- checkpoint state (mmcv Fp16OptimizerHook keeps GradScaler.state_dict() in runner.meta['fp16']) -------
+    def loss_scaler_state_dict(self):
+        """``torch.cuda.amp.GradScaler.state_dict()`` layout: what the reference's base hook stores in
+        ``runner.meta['fp16']['loss_scaler']`` and ``GradScaler.load_state_dict`` requires (one device read)."""
+        if self.scale_state is None:
+            scale, tracker = float(self.scaler_cfg['init_scale']), 0
+        else:
+            scale, tracker = self.scale_state.tolist()
+        return dict(scale=float(scale), growth_factor=float(self.scaler_cfg['growth_factor']),
+                    backoff_factor=float(self.scaler_cfg['backoff_factor']),
+                    growth_interval=int(self.scaler_cfg['growth_interval']), _growth_tracker=int(tracker))
+
+    def load_loss_scaler_state_dict(self, sd):
+        for k in ('growth_factor', 'backoff_factor', 'growth_interval'):
+            if k in sd:
+                self.scaler_cfg[k] = sd[k]
+        self.scale_state[0] = float(sd['scale'])
+        self.scale_state[1] = float(sd.get('_growth_tracker', 0))
+
+    def sync_meta(self, runner):
+        """Write the plain loss-scaler dict into ``runner.meta``.  The reference does this after every iteration
+        (a device read per step); here it happens when the state is wanted: before a checkpoint is written
+        (``Runner.save_checkpoint``), at the end of every epoch and at the end of the run."""
         meta = getattr(runner, 'meta', None)
-        if isinstance(meta, dict):
-            meta.setdefault('fp16', {})['loss_scaler'] = _LazyScalerState(self.scale_state)
+        if isinstance(meta, dict) and self.scale_state is not None:
+            meta.setdefault('fp16', {})['loss_scaler'] = self.loss_scaler_state_dict()
 
+    def after_train_epoch(self, runner):
+        self.sync_meta(runner)
 
-class _LazyScalerState(dict):
-    """``runner.meta['fp16']['loss_scaler']`` (saved into checkpoints by the reference's base
-    hook) without a device->host copy per step: materialised only when read."""
-
-    def __init__(self, state):
-        super().__init__()
-        self._state = state
-
-    def _fill(self):
-        s = self._state.tolist()
-        super().update(scale=s[0], _growth_tracker=int(s[1]))
-
-    def __getitem__(self, k):
-        self._fill()
-        return super().__getitem__(k)
-
-    def get(self, k, default=None):
-        self._fill()
-        return super().get(k, default)
-
-    def __contains__(self, k):
-        return k in ('scale', '_growth_tracker')
+    def after_run(self, runner):
+        self.sync_meta(runner)
 
 
 # ---- a23 ---------------------------------------------------------------------------------------------
@@ -285,8 +292,17 @@ class StateEMAHook(Hook):
             bname = f"ema_{name.replace('.', '_')}"
             self.param_ema_mapping[name] = bname
             model.register_buffer(bname, views[name])
-        if self.checkpoint is not None and hasattr(runner, 'resume'):
-            runner.resume(self.checkpoint)
+        # ema_hooks.py:66-74: resume AFTER the ema_ buffers exist, from the hook's own argument or from the
+        # ``resume_from`` of the config text the training script stored in ``runner.meta['config']``
+        checkpoint = self.checkpoint
+        if checkpoint is None:
+            cfg_text = (getattr(runner, 'meta', None) or {}).get('config')
+            if cfg_text is not None:
+                cfg_dict = dict()
+                exec(cfg_text, cfg_dict)
+                checkpoint = cfg_dict.get('resume_from')
+        if checkpoint is not None:
+            runner.resume(checkpoint)
 
     def current_momentum(self, cur_iter):
         return ema_momentum(self.momentum, cur_iter, self.warm_up, self.interval)
@@ -476,6 +492,62 @@ class Runner:
     @property
     def max_iters(self):
         return self.max_epochs * len(self.data_loader)
+
+    # ---- checkpoints: mmcv ``BaseRunner.save_checkpoint`` / ``resume`` (``epoch_based_runner.py``,
+    # ``base_runner.py``): {'meta': {..., epoch, iter}, 'state_dict': weights on the CPU (the ``ema_*`` buffers
+    # included: they are registered buffers, ema_hooks.py:52-64), 'optimizer': torch-layout state dict} ------------
+    def save_checkpoint(self, out_dir, filename_tmpl='epoch_{}.pth', save_optimizer=True, meta=None,
+                        create_symlink=True):
+        import os
+        import time
+        from collections import OrderedDict
+        for h in self._hooks:
+            if hasattr(h, 'sync_meta'):
+                h.sync_meta(self)
+        meta = dict(meta or {})
+        meta.update(self.meta or {})
+        meta.update(epoch=self.epoch + 1, iter=self.iter, time=time.asctime())
+        model = _unwrap(self.model)
+        state = OrderedDict((k, v.detach().cpu()) for k, v in model.state_dict().items())
+        ckpt = dict(meta=meta, state_dict=state)
+        if save_optimizer and self.optimizer is not None:
+            ckpt['optimizer'] = self.optimizer.state_dict()
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, filename_tmpl.format(self.epoch + 1))
+        torch.save(ckpt, path)
+        if create_symlink:
+            link = os.path.join(out_dir, 'latest.pth')
+            if os.path.islink(link) or os.path.exists(link):
+                os.remove(link)
+            os.symlink(os.path.basename(path), link)
+        return path
+
+    def load_checkpoint(self, filename, map_location='cpu', strict=False):
+        ckpt = torch.load(filename, map_location=map_location, weights_only=False)
+        state = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
+        if all(k.startswith('module.') for k in state):
+            state = {k[7:]: v for k, v in state.items()}
+        model = _unwrap(self.model)
+        missing, unexpected = model.load_state_dict(state, strict=strict)
+        flat = getattr(model, '_flat_state', None)
+        if flat is not None:
+            flat.bump_versions()
+        elif hasattr(model, 'invalidate_plans'):
+            model.invalidate_plans()
+        ckpt['_missing_keys'], ckpt['_unexpected_keys'] = list(missing), list(unexpected)
+        return ckpt
+
+    def resume(self, checkpoint, resume_optimizer=True, map_location='cpu'):
+        ckpt = self.load_checkpoint(checkpoint, map_location=map_location)
+        self.epoch = ckpt['meta']['epoch']
+        self.iter = ckpt['meta']['iter']
+        hook_msgs = dict((self.meta or {}).get('hook_msgs', {}))
+        hook_msgs.update(ckpt['meta'].get('hook_msgs', {}))
+        self.meta = dict(ckpt['meta'])                       # mmcv: "resume meta information meta"
+        self.meta['hook_msgs'] = hook_msgs
+        if 'optimizer' in ckpt and resume_optimizer and self.optimizer is not None:
+            self.optimizer.load_state_dict(ckpt['optimizer'])
+        return ckpt
 
     def run(self, data_loader, max_epochs=None):
         if max_epochs is not None:

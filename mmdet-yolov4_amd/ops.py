@@ -168,6 +168,20 @@ def nms(boxes, scores, iou_threshold, offset=0, score_threshold=0, max_num=-1):
     return dets, keep
 
 
+def set_nms_iou_form(form):
+    """Choose which of mmcv-full 1.3.x's two suppression predicates every NMS launch of this process applies:
+    'div' (default) -- ``inter / (Sa + Sb - inter) > thr``, mmcv's CPU kernel and the documented definition of this
+    package; 'mul' -- ``inter > thr * (Sa + Sb - inter)``, mmcv's CUDA kernel, i.e. what the reference executes on a GPU.
+    They select differently only on pairs whose fp32 IoU rounds across the threshold (tests/golden/nms_boundary.npz).
+    Also settable through the environment: ``YV4_NMS_IOU_FORM=mul``."""
+    code = {'div': _lib.NMS_IOU_DIV, 'mul': _lib.NMS_IOU_MUL, 0: 0, 1: 1}[form]
+    check(_lib.lib().yv4_nms_set_iou_form(code), 'yv4_nms_set_iou_form')
+
+
+def get_nms_iou_form():
+    return {0: 'div', 1: 'mul'}[_lib.lib().yv4_nms_get_iou_form()]
+
+
 def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
     """``mmcv.ops.nms.batched_nms`` as called at
     mmdet/core/post_processing/bbox_nms.py:84.  ``idxs`` may live on the CPU (Q6)."""

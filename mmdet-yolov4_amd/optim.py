@@ -119,6 +119,7 @@ class FlatSGD:
         self._hyper_dev = torch.zeros((nseg, 4), dtype=torch.float32, device=dev)
         self._hyper_last = None
         self.state = {}     # torch.optim.Optimizer attribute some hooks poke at
+        self._stepped = False
 
     # ---- torch.optim.Optimizer surface -------------------------------------------------------
     def zero_grad(self, set_to_none=False):
@@ -159,15 +160,52 @@ class FlatSGD:
         # the kernel wrote the parameters behind autograd's back: bump the version counters the
         # eval-mode plan caches key on (HipModule._param_version)
         f.bump_versions()
+        self._stepped = True
+
+    # ---- torch.optim.Optimizer.state_dict() layout, so checkpoints interchange with the reference's
+    # torch.optim.SGD ({'state': {i: {'momentum_buffer': t}}, 'param_groups': [{..., 'params': [i, ...]}]},
+    # i = running index over the groups' parameters).  Momentum buffers are slices of one arena here. ---------
+    def _param_order(self):
+        index = self.flat.param_index()
+        return [index[id(p)] for g in self.param_groups for p in g['params']]
 
     def state_dict(self):
-        return {'momentum_buf': self.momentum_buf,
-                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+        from .flat_state import _view_as_param
+        order = self._param_order()
+        state = {}
+        for i, si in enumerate(order):
+            if self._stepped:
+                state[i] = {'momentum_buffer': _view_as_param(self.momentum_buf, self.flat.param_segments[si]).clone()}
+        groups, start = [], 0
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != 'params'}
+            d['params'] = list(range(start, start + len(g['params'])))
+            start += len(g['params'])
+            groups.append(d)
+        return {'state': state, 'param_groups': groups}
 
     def load_state_dict(self, sd):
-        self.momentum_buf.copy_(sd['momentum_buf'])
+        from .flat_state import _view_as_param
+        if 'momentum_buf' in sd:                       # round-1 layout of this package
+            self.momentum_buf.copy_(sd['momentum_buf'])
+            self._stepped = True
+        else:
+            order = self._param_order()
+            if len(sd['param_groups']) != len(self.param_groups) or \
+                    sum(len(g['params']) for g in sd['param_groups']) != len(order):
+                raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+            self.momentum_buf.zero_()
+            for i, st in sd.get('state', {}).items():
+                buf = st.get('momentum_buffer')
+                if buf is None:
+                    continue
+                seg = self.flat.param_segments[order[int(i)]]
+                with torch.no_grad():
+                    _view_as_param(self.momentum_buf, seg).copy_(buf.reshape(seg.shape))
+                self._stepped = True
         for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update(s)
+            g.update({k: v for k, v in s.items() if k != 'params'})
+        self._hyper_last = None
 
 
 def build_optimizer(model, cfg):

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .bricks import HipModule
+from .bricks import HipModule, plan_cache_get, plan_cache_put
 from .plan import Plan
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 from .yolocsp_head import collect_results, set_scale_factors
@@ -73,9 +73,8 @@ class SingleStageDetector(HipModule):
         the parity dtype), torch.float16 or torch.bfloat16 (``wrap_fp16_model`` sets the default)."""
         dtype = dtype or getattr(self, 'compute_dtype', torch.float32)
         key = (batch, height, width, str(device), bool(rescale), bool(graph), self._param_version(), dtype)
-        eng = self._engines.get(key)
+        eng = plan_cache_get(self._engines, key)
         if eng is None:
-            self._engines.clear()
             plan = Plan(device, dtype)
             # 16-bit plans keep the image fp32 when the backbone starts with the 3x3 stem (its own
             # fp32 kernel, 16-bit output); otherwise the image is converted like any other tensor
@@ -95,7 +94,7 @@ class SingleStageDetector(HipModule):
             if graph:
                 plan.capture()
             eng = plan
-            self._engines[key] = eng
+            plan_cache_put(self._engines, key, eng, 6)
         return eng
 
     # ---- reference API ------------------------------------------------------------------------
@@ -142,8 +141,10 @@ class SingleStageDetector(HipModule):
         return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore)
 
     def _parse_losses(self, losses):
-        """detectors/base.py:171-204: total = sum of the entries whose key contains 'loss'; every
-        log variable is averaged over ranks (one small all-reduce each, as the reference does)."""
+        """detectors/base.py:171-204: total = sum of the entries whose key contains 'loss'; every log variable is the
+        mean over ranks, returned as a python float.  The reference issues one all-reduce and one ``.item()`` (a host
+        sync) PER log variable (base.py:197-202); here the variables are stacked on the device, exchanged by ONE
+        all-reduce and read back by ONE device-to-host copy -- same values, one sync per step."""
         log_vars = OrderedDict()
         for name, value in losses.items():
             if isinstance(value, torch.Tensor):
@@ -154,11 +155,11 @@ class SingleStageDetector(HipModule):
                 raise TypeError(f'{name} is not a tensor or list of tensors')
         loss = sum(v for k, v in log_vars.items() if 'loss' in k)
         log_vars['loss'] = loss
-        for name, value in log_vars.items():
-            if dist.is_available() and dist.is_initialized():
-                value = value.data.clone()
-                dist.all_reduce(value.div_(dist.get_world_size()))
-            log_vars[name] = value.item()
+        stacked = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(stacked.div_(dist.get_world_size()))
+        for name, value in zip(list(log_vars), stacked.tolist()):
+            log_vars[name] = value
         return loss, log_vars
 
     def train_step(self, data, optimizer):

@@ -31,8 +31,18 @@ static int cmp_ord(const void* a, const void* b) {
   return (x->idx > y->idx) - (x->idx < y->idx);
 }
 
-/* boxes: n x 4 (x1,y1,x2,y2); keep: room for n indices.  Returns the number kept. */
+/* boxes: n x 4 (x1,y1,x2,y2); keep: room for n indices.  Returns the number kept.
+ * form 0: the definition above (mmcv's CPU kernel, IEEE division);
+ * form 1: `inter > iou_threshold * (areas[i] + areas[j] - inter)` -- the predicate of mmcv-full 1.3.x's CUDA kernel
+ *         (devIoU in nms_cuda_kernel.cuh), i.e. what the reference runs on a GPU.  Same sort, same greedy loop; the two
+ *         forms select differently only where the fp32 quotient / product rounds across the threshold. */
+int64_t oracle_nms_form(const float* boxes, const float* scores, int64_t n, float iou_threshold, int64_t* keep, int form);
+
 int64_t oracle_nms(const float* boxes, const float* scores, int64_t n, float iou_threshold, int64_t* keep) {
+  return oracle_nms_form(boxes, scores, n, iou_threshold, keep, 0);
+}
+
+int64_t oracle_nms_form(const float* boxes, const float* scores, int64_t n, float iou_threshold, int64_t* keep, int form) {
   if (n <= 0) return 0;
   ord_t* order = (ord_t*)malloc((size_t)n * sizeof(ord_t));
   float* areas = (float*)malloc((size_t)n * sizeof(float));
@@ -62,8 +72,14 @@ int64_t oracle_nms(const float* boxes, const float* scores, int64_t n, float iou
       if (!(w > 0.f)) w = 0.f;
       if (!(h > 0.f)) h = 0.f;
       const float inter = w * h;
-      const float ovr = inter / (iarea + areas[j] - inter);
-      if (ovr > iou_threshold) dead[_j] = 1;
+      const float uni = iarea + areas[j] - inter;
+      if (form) {
+        const float rhs = iou_threshold * uni;
+        if (inter > rhs) dead[_j] = 1;
+      } else {
+        const float ovr = inter / uni;
+        if (ovr > iou_threshold) dead[_j] = 1;
+      }
     }
   }
   free(order);

@@ -27,8 +27,10 @@ WORKER = textwrap.dedent('''
     from mmdet_yolov4_amd.flat_state import FlatState
     from mmdet_yolov4_amd.yolocsp_head import RawPredMap
     rank = int(os.environ['RANK'])
-    dist.init_process_group('gloo', rank=rank, world_size=2)
-    dev = torch.device('cuda', 0)
+    backend = os.environ['YV4_TEST_BACKEND']                # gloo: both ranks on cuda:0; nccl (= RCCL): rank r on cuda:r
+    dev = torch.device('cuda', rank if backend == 'nccl' else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=2, **(dict(device_id=dev) if backend == 'nccl' else {}))
 
     def build(norm):
         torch.manual_seed(0)
@@ -68,8 +70,15 @@ WORKER = textwrap.dedent('''
     det = build('SyncBN')
     start = {k: v.clone() for k, v in det.state_dict().items()}
     fs = FlatState(det)
-    red = D.GradReducer(fs, bucket_mb=0.05)
+    red = D.GradReducer(fs, bucket_mb=0.05, mode=os.environ['YV4_TEST_MODE'])
     img, boxes, labels = data(rank, sizes[rank])
+    # a local (not exchanged) backward first: the largest LOCAL gradient entry of every tensor over both ranks is what
+    # a 16-bit wire format's rounding error is relative to (per-rank gradients can cancel in the mean)
+    fs.zero_grad()
+    total(det(img=img, img_metas=[dict()] * sizes[rank], gt_bboxes=boxes, gt_labels=labels)).backward()
+    local_max = torch.stack([p.grad.abs().max() for p in det.parameters()])
+    dist.all_reduce(local_max, op=dist.ReduceOp.MAX)
+    det.load_state_dict(start)                              # undo the running-statistics update of that forward
     fs.zero_grad()
     red.arm()
     loss = total(det(img=img, img_metas=[dict()] * sizes[rank], gt_bboxes=boxes, gt_labels=labels))
@@ -77,6 +86,8 @@ WORKER = textwrap.dedent('''
     launched = all(red._launched)
     red.finish()
     torch.cuda.synchronize()
+    # the log variables of the step: ONE all-reduce + ONE device-to-host copy (detectors/base.py:197-202 semantics)
+    _, log_vars = det._parse_losses(dict(loss_a=loss.detach(), num=torch.tensor(float(rank), device=dev)))
 
     # ---- the same step by one process --------------------------------------------------------------
     ref = build('BN')
@@ -95,8 +106,9 @@ WORKER = textwrap.dedent('''
     tot.backward()
     worst, name = 0.0, ''
     errs = []
-    for (n, p), q in zip(det.named_parameters(), ref.parameters()):
-        e = float((p.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-12))
+    for i, ((n, p), q) in enumerate(zip(det.named_parameters(), ref.parameters())):
+        scale = float(local_max[i]) if os.environ['YV4_TEST_MODE'] == 'direct_bf16' else float(q.grad.abs().max())
+        e = float((p.grad - q.grad).abs().max() / (scale + 1e-12))
         errs.append((e, n, float(q.grad.abs().max())))
         if e > worst:
             worst, name = e, n
@@ -106,12 +118,26 @@ WORKER = textwrap.dedent('''
     stats = max(float((a - b).abs().max()) for (_, a), (_, b) in zip(det.named_buffers(), ref.named_buffers())
                 if a.dtype.is_floating_point)
     print('RESULT ' + json.dumps(dict(rank=rank, fwd_err=fwd_err, worst=worst, name=name, stats=stats, launched=launched,
-                                      nb=len(red.buckets), gsum=float(fs.grads.double().sum()))), flush=True)
+                                      nb=len(red.buckets), gsum=float(fs.grads.double().sum()), order=red.launch_order,
+                                      log_vars=log_vars, loss=float(loss))), flush=True)
     dist.destroy_process_group()
 ''')
 
 
-def test_two_rank_step_equals_one_process_big_batch(tmp_path):
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize('backend,mode', [('gloo', 'allreduce'), ('gloo', 'direct'), ('gloo', 'direct_bf16'),
+                                          ('nccl', 'allreduce'), ('nccl', 'direct'), ('nccl', 'direct_bf16')])
+def test_two_rank_step_equals_one_process_big_batch(tmp_path, backend, mode):
+    """backend 'nccl' is RCCL: one rank per GPU, needs two visible GPUs (skipped on the 1-GPU test boxes -- the
+    driver's multi-GPU node runs it); 'gloo' runs both ranks on cuda:0.  'direct_bf16' rounds every rank's gradients
+    to bf16 once and the reduced chunk once more (fp32 accumulation in between): 2^-8 of each tensor's largest LOCAL
+    entry over the ranks (per-rank gradients may cancel in the mean) instead of 1e-5 of the result's."""
+    if backend == 'nccl' and _gpus() < 2:
+        pytest.skip('RCCL with 2 ranks needs 2 GPUs (torch.cuda.device_count() < 2)')
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % ROOT)
     s = socket.socket()
@@ -120,8 +146,9 @@ def test_two_rank_step_equals_one_process_big_batch(tmp_path):
     s.close()
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank if backend == 'nccl' else 0), WORLD_SIZE='2',
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1', YV4_TEST_BACKEND=backend,
+                   YV4_TEST_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -131,8 +158,16 @@ def test_two_rank_step_equals_one_process_big_batch(tmp_path):
         if os.environ.get('YV4_TEST_VERBOSE'):
             print(out)
         outs.append(json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][0][7:]))
+    outs.sort(key=lambda o: o['rank'])
+    tol = 2.0 ** -8 if mode == 'direct_bf16' else 1e-5
     for o in outs:
         assert o['nb'] > 1 and o['launched']                  # buckets went out from the backward hooks
-        assert o['worst'] < 1e-5, o                           # exchanged gradients == one-process gradients
+        assert o['worst'] < tol, o                            # exchanged gradients == one-process gradients
         assert o['stats'] < 1e-5, o                           # running statistics == big-batch BatchNorm's
+        assert o['order'] == sorted(o['order'], reverse=True)
     assert outs[0]['gsum'] == outs[1]['gsum']                 # both ranks hold the same reduced arena
+    assert outs[0]['order'] == outs[1]['order']               # ... and enqueued their collectives in the same order
+    # _parse_losses: mean over ranks, identical on both ranks
+    assert outs[0]['log_vars'] == outs[1]['log_vars']
+    assert abs(outs[0]['log_vars']['loss_a'] - 0.5 * (outs[0]['loss'] + outs[1]['loss'])) <= 1e-5 * abs(outs[0]['loss'])
+    assert outs[0]['log_vars']['num'] == 0.5

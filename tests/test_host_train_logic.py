@@ -257,6 +257,71 @@ def test_grad_reducer_buckets_cover_the_arena_and_fire_in_backward():
     red.remove()
 
 
+def test_grad_reducer_launch_order_is_descending_and_unused_parameters_wait_for_finish():
+    """A rank that leaves a parameter unused must not reorder its collectives: buckets go out strictly in descending
+    index order, a ready bucket below a not-yet-ready one waits (for finish() at the latest)."""
+    torch.manual_seed(0)
+    model = Toy()
+    fs = FlatState(model)
+    red = GradReducer(fs, bucket_mb=4 * 4 / (1 << 20))           # 4 floats: one bucket per parameter
+    nb = len(red.buckets)
+    assert nb >= 3
+    red.arm()
+    # gradient-final events arrive bottom-up (the opposite of backward's order): nothing may launch before the top
+    # bucket is complete
+    order = [si for b in red.buckets for si in b[2]]
+    top = set(red.buckets[-1][2])
+    for si in order:
+        if si in top:
+            break
+        red._event(si)
+        assert red.launch_order == []
+    for si in red.buckets[-1][2][:-1]:
+        red._event(si)
+    assert red.launch_order == []
+    red._event(red.buckets[-1][2][-1])
+    assert red.launch_order == list(range(nb - 1, -1, -1))
+    red.finish()
+    # an unused parameter in the top bucket: everything is exchanged by finish(), still in descending order
+    red.arm()
+    for si in order:
+        if si != red.buckets[-1][2][0]:
+            red._event(si)
+    assert red.launch_order == []
+    red.finish()
+    assert red.launch_order == list(range(nb - 1, -1, -1))
+    red.remove()
+
+
+def test_grad_reducer_counts_a_parameter_once_and_refuses_late_gradients():
+    torch.manual_seed(0)
+    model = Toy()
+    fs = FlatState(model)
+    red = GradReducer(fs, bucket_mb=300 * 4 / (1 << 20))
+    red.arm()
+    last = red.buckets[-1][2]
+    red._event(last[0])
+    red._event(last[0])                                  # a second use of the same weight before the exchange: harmless
+    assert red._pending[-1] == len(last) - 1
+    for si in last[1:]:
+        red._event(si)
+    assert red.launch_order == [len(red.buckets) - 1]
+    with pytest.raises(RuntimeError, match='after its bucket was exchanged'):
+        red._event(last[0])
+    red.finish()
+    lazy = GradReducer(fs, bucket_mb=300 * 4 / (1 << 20), overlap=False)
+    lazy.arm()
+    for b in lazy.buckets:
+        for si in b[2]:
+            lazy._event(si)
+            lazy._event(si)
+    assert lazy.launch_order == []                       # overlap=False: everything goes out in finish()
+    lazy.finish()
+    assert lazy.launch_order == list(range(len(lazy.buckets) - 1, -1, -1))
+    lazy.remove()
+    red.remove()
+
+
 def test_syncbn_norm_cfg_builds_and_selects_group():
     """configs/yolov5_ddp: norm_cfg type 'SyncBN' -> torch.nn.SyncBatchNorm; the HIP BN path synchronises only
     for a training-mode SyncBatchNorm inside an initialised group of more than one rank."""

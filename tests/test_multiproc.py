@@ -7,6 +7,8 @@ import json
 import os
 import socket
 import subprocess
+
+import pytest
 import sys
 import textwrap
 
@@ -98,7 +100,7 @@ REDUCE_WORKER = textwrap.dedent('''
     torch.manual_seed(0)
     model = Toy()                                         # identical weights on both ranks
     fs = FlatState(model)
-    red = D.GradReducer(fs, bucket_mb=200 * 4 / (1 << 20))
+    red = D.GradReducer(fs, bucket_mb=200 * 4 / (1 << 20), mode=os.environ['YV4_TEST_MODE'])
     g = torch.Generator().manual_seed(100)
     xs = [torch.randn(2, 4, 6, 6, generator=g) for _ in range(4)]   # 2 ranks x 2 micro-batches
     mine = xs[2 * rank: 2 * rank + 2]
@@ -115,21 +117,26 @@ REDUCE_WORKER = textwrap.dedent('''
         for x in xs[2 * r: 2 * r + 2]:
             (ref(x).square().mean() / 2).backward()
     err = max(float((p.grad - q.grad).abs().max()) for p, q in zip(model.parameters(), ref.parameters()))
-    out = dict(rank=rank, nb=len(red.buckets), launched=launched_in_backward, err=err,
-               gsum=float(fs.grads.double().sum()))
+    scale = max(float(q.grad.abs().max()) for q in ref.parameters())
+    out = dict(rank=rank, nb=len(red.buckets), launched=launched_in_backward, err=err, scale=scale,
+               order=red.launch_order, gsum=float(fs.grads.double().sum()))
     print('RESULT ' + json.dumps(out), flush=True)
     D.finalize()
 ''')
 
 
-def test_grad_reducer_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize('mode', ['allreduce', 'direct', 'direct_bf16'])
+def test_grad_reducer_two_ranks_gloo(tmp_path, mode):
+    """The exchanged arena equals the mean over ranks of the per-rank gradient sums: exactly (1e-6) for the fp32 wire
+    formats, within two bf16 roundings (2^-8 of the largest gradient) for 'direct_bf16'; both ranks end bit-identical and
+    enqueue their collectives in the same (descending bucket) order."""
     script = tmp_path / 'reduce_worker.py'
     script.write_text(REDUCE_WORKER % (ROOT, ROOT))
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+                   MASTER_PORT=str(port), OMP_NUM_THREADS='1', YV4_TEST_MODE=mode)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -139,7 +146,9 @@ def test_grad_reducer_two_ranks_gloo(tmp_path):
         outs.append(json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][0][7:]))
     outs.sort(key=lambda o: o['rank'])
     assert outs[0]['nb'] >= 2 and all(o['launched'] for o in outs)
-    assert all(o['err'] < 1e-6 for o in outs), outs      # averaged sum of both ranks' gradients
+    tol = 2.0 ** -8 * outs[0]['scale'] if mode == 'direct_bf16' else 1e-6
+    assert all(o['err'] <= tol for o in outs), outs      # averaged sum of both ranks' gradients
+    assert outs[0]['order'] == outs[1]['order'] == sorted(outs[0]['order'], reverse=True)
     assert outs[0]['gsum'] == outs[1]['gsum']            # bit-identical arenas after the exchange
 
 

@@ -11,18 +11,7 @@ import mmdet_yolov4_amd as pkg
 from mmdet_yolov4_amd import dist as D
 
 
-def synthetic_gts(batch, size, seed, device):
-    g = torch.Generator().manual_seed(seed)
-    boxes, labels = [], []
-    for _ in range(batch):
-        n = max(1, int(torch.poisson(torch.tensor(12.0), generator=g)))
-        c = torch.rand(n, 2, generator=g) * size
-        wh = torch.exp(torch.rand(n, 2, generator=g) * (torch.log(torch.tensor(400.0)) - torch.log(torch.tensor(8.0))) +
-                       torch.log(torch.tensor(8.0)))
-        b = torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, size)
-        boxes.append(b.to(device))
-        labels.append(torch.randint(0, 80, (n,), generator=g).to(device))
-    return boxes, labels
+synthetic_gts = bench.synthetic_gts
 
 
 def main():
@@ -34,6 +23,8 @@ def main():
     ap.add_argument('--model', default='yolov4l')
     ap.add_argument('--accumulation', type=int, default=1)
     ap.add_argument('--torch-optim', action='store_true')
+    ap.add_argument('--grad-exchange', default=None, choices=['allreduce', 'direct', 'direct_bf16'],
+                    help='dist.GradReducer mode (default: YV4_GRAD_EXCHANGE or allreduce)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'],
                     help='activation / conv operand type (master weights, statistics and losses stay fp32)')
     a = ap.parse_args()
@@ -80,23 +71,22 @@ def main():
                                            priority='HIGH'))
         runner.register_hook(H.Fp16GradAccumulateOptimizerHook(accumulation=a.accumulation,
                                                                grad_clip=dict(max_norm=35, norm_type=2),
-                                                               loss_scale='dynamic'), 'ABOVE_NORMAL')
+                                                               loss_scale='dynamic', grad_exchange=a.grad_exchange),
+                             'ABOVE_NORMAL')
         runner.data_loader = H.BatchSource([data], a.batch)
         runner.call_hook('before_run')
         runner.call_hook('before_train_epoch')
         last = {}
 
         def step():
+            # exactly what the runner does per iteration (mmcv epoch_based_runner.run_iter): hooks around
+            # ``model.train_step`` -- including its log-variable exchange (one all-reduce, one D2H copy = one host
+            # synchronisation per step, single_stage._parse_losses)
             runner.call_hook('before_train_iter')
-            losses = det(**data)
-            # keep the loss on the device inside the timed loop (the reference's _parse_losses does
-            # one .item() per logged value = a host sync per step)
-            loss = sum(sum(x.mean() for x in v) if isinstance(v, (list, tuple)) else v.mean()
-                       for k, v in losses.items() if 'loss' in k)
-            runner.outputs = dict(loss=loss, num_samples=a.batch)
+            runner.outputs = det.train_step(data, opt)
             runner.call_hook('after_train_iter')
             runner.iter += 1
-            last['loss'] = loss.detach()
+            last['loss'] = runner.outputs['log_vars']['loss']
             return last['loss']
 
     for _ in range(a.warmup):
@@ -115,6 +105,7 @@ def main():
                               n_gpus=world, ms_per_step=round(el / a.steps * 1e3, 1), batch_per_gpu=a.batch,
                               dtype=a.dtype, loss_first=round(float(l0), 3), loss_last=round(float(l1), 3),
                               optimizer='torch SGD + DDP' if a.torch_optim else 'flat arenas + recipe hooks',
+                              backend=D.backend_name(), grad_exchange=D.exchange_name(a.grad_exchange, world),
                               approx_conv_tflops=round(fl * a.batch * world * a.steps / el / 1e12, 1),
                               peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))))
     D.finalize()
