@@ -372,7 +372,7 @@ def main():
             return 'stem3x3'
         if h16:
             t = d.tile if d.tile else pkg._lib.lib().yv4_conv_h16_pick_tile(__import__('ctypes').byref(d))
-            return {1: 'h16_128x128', 2: 'h16_128x64', 3: 'h16_64x64'}[t]
+            return pkg._lib.HTILE_NAMES[t]
         t = d.tile if d.tile else pkg._lib.lib().yv4_conv_pick_tile(__import__('ctypes').byref(d))
         return pkg._lib.TILE_NAMES[t]
 

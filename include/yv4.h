@@ -318,6 +318,10 @@ int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, i
 #define YV4_HTILE_128x128 1
 #define YV4_HTILE_128x64 2
 #define YV4_HTILE_64x64 3
+/* 3x3 / stride 1 / pad 1, Cin % 64 == 0 only (conv3x3_h16.hip): 256 pixels x 128 (64) channels on 8 waves, the three kw
+ * taps of a (chunk, kh) share one LDS image of the activations */
+#define YV4_HTILE_C3_256x128 4
+#define YV4_HTILE_C3_256x64 5
 int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x,
                             const void* w, const float* scale1, const float* shift1,
                             const float* scale2, const float* shift2, const void* residual,

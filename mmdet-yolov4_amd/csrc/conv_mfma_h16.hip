@@ -15,209 +15,9 @@
 // What the reference does at this precision (mmcv wrap_fp16_model / autocast around ConvModule,
 // darknetcsp.py:15-35): conv in half with fp32 accumulation -> round -> BN in fp32 -> round -> Mish ->
 // round.  Here the chain after the accumulator stays in fp32 and is rounded once.
-#include "yv4_common.h"
+#include "conv_h16_common.h"
 
 namespace yv4 {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int kHBK = 64;        // K slice in elements (128 bytes)
-constexpr int kHThreads = 256;
-
-struct ConvArgsH {
-  const void* x;
-  const void* w;
-  const float* s1;
-  const float* t1;
-  const float* s2;
-  const float* t2;
-  const void* res;
-  void* y;
-  int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
-  int x_cs, x_co, y_cs, y_co, r_cs, r_co;
-  int act1, act2;
-  float slope1, slope2;
-  int M, K, Kw;
-  int tiles_n;
-  int out_f32;    // store fp32 instead of the operand type (pred maps feeding the fp32 decode kernel)
-  int ys_on, ys_H, ys_W, ys_sh, ys_sw, ys_oh, ys_ow;   // scattered output, see conv_mfma_f32.hip
-  int ablate;     // measurement only (YV4_H16_ABLATE): 1 = issue no DMA after the first slice, 2 = no MFMA, 4 = no barrier
-  double* stats;  // training: per-channel [sum | sum of squares] of the STORED outputs, YV4_STATS_REPLICAS x 2*Cout
-  FastDiv fd_hw, fd_wo;   // m / (Ho*Wo), r / Wo (set by launch_h16)
-  FastDiv fd_cin, fd_kw;  // GENERAL_K: k / Cin, tap / KW, once per lane per slice
-};
-
-__device__ __forceinline__ int64_t out_row_h(const ConvArgsH& p, int m) {
-  if (!p.ys_on) return m;
-  const int hw = p.Ho * p.Wo;
-  const int n = m / hw;
-  const int r = m - n * hw;
-  const int ho = r / p.Wo;
-  const int wo = r - ho * p.Wo;
-  return ((int64_t)n * p.ys_H + ho * p.ys_sh + p.ys_oh) * p.ys_W + wo * p.ys_sw + p.ys_ow;
-}
-
-__device__ __forceinline__ void lds_dma16_h(u32x4_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :
-               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory");
-}
-__device__ __forceinline__ u32x4_t make_rsrc_h(const void* base, unsigned bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-  u32x4_t v;
-  v.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-  v.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-  v.z = __builtin_amdgcn_readfirstlane(bytes);
-  v.w = 0x00020000u;
-  return v;
-}
-
-template <bool BF16>
-struct Elem;
-template <>
-struct Elem<true> {
-  typedef __bf16 T;
-  typedef bf16x8 V8;
-  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <>
-struct Elem<false> {
-  typedef _Float16 T;
-  typedef f16x8 V8;
-  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-
-// Epilogue of one 32x32 accumulator tile through a wave-private LDS patch (fp32, pitch 36):
-// afterwards lane l owns 8 consecutive channels of rows (l>>2) and (l>>2)+16, i.e. one 16-byte
-// store of 16-bit outputs per row (two dwordx4 when the output is fp32).
-// the activation of 8 values with ONE (uniform) branch on the activation id: apply_act() inside the element
-// loop left a scalar compare-and-branch chain per element in the epilogue (the compiler does not unswitch it)
-__device__ __forceinline__ void act_row8(float (&v)[8], int act, float slope) {
-  switch (act) {
-    case YV4_ACT_MISH:
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = apply_act(v[u], YV4_ACT_MISH, 0.f);
-      break;
-    case YV4_ACT_LEAKY:
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = v[u] >= 0.f ? v[u] : v[u] * slope;
-      break;
-    case YV4_ACT_SWISH:
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = apply_act(v[u], YV4_ACT_SWISH, 0.f);
-      break;
-    default:
-      break;
-  }
-}
-
-// per-channel affine of a lane's 8 output columns (co .. co+7): two 16-byte loads per array when aligned
-struct AffH { float s1[8], t1[8], s2[8], t2[8]; };
-__device__ __forceinline__ void load_affine_h(const ConvArgsH& p, int co, bool has2, AffH& a) {
-  const bool al = (((uintptr_t)p.s1 | (uintptr_t)p.t1 | (uintptr_t)p.s2 | (uintptr_t)p.t2) & 15) == 0 && (co & 3) == 0;
-  if (al) {
-    const float4 a0 = *reinterpret_cast<const float4*>(p.s1 + co), a1 = *reinterpret_cast<const float4*>(p.s1 + co + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(p.t1 + co), b1 = *reinterpret_cast<const float4*>(p.t1 + co + 4);
-    a.s1[0] = a0.x; a.s1[1] = a0.y; a.s1[2] = a0.z; a.s1[3] = a0.w; a.s1[4] = a1.x; a.s1[5] = a1.y; a.s1[6] = a1.z; a.s1[7] = a1.w;
-    a.t1[0] = b0.x; a.t1[1] = b0.y; a.t1[2] = b0.z; a.t1[3] = b0.w; a.t1[4] = b1.x; a.t1[5] = b1.y; a.t1[6] = b1.z; a.t1[7] = b1.w;
-    if (has2) {
-      const float4 c0 = *reinterpret_cast<const float4*>(p.s2 + co), c1 = *reinterpret_cast<const float4*>(p.s2 + co + 4);
-      const float4 d0 = *reinterpret_cast<const float4*>(p.t2 + co), d1 = *reinterpret_cast<const float4*>(p.t2 + co + 4);
-      a.s2[0] = c0.x; a.s2[1] = c0.y; a.s2[2] = c0.z; a.s2[3] = c0.w; a.s2[4] = c1.x; a.s2[5] = c1.y; a.s2[6] = c1.z; a.s2[7] = c1.w;
-      a.t2[0] = d0.x; a.t2[1] = d0.y; a.t2[2] = d0.z; a.t2[3] = d0.w; a.t2[4] = d1.x; a.t2[5] = d1.y; a.t2[6] = d1.z; a.t2[7] = d1.w;
-    } else {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { a.s2[u] = 1.f; a.t2[u] = 0.f; }
-    }
-  } else {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      a.s1[u] = p.s1[co + u];
-      a.t1[u] = p.t1[co + u];
-      a.s2[u] = has2 ? p.s2[co + u] : 1.f;
-      a.t2[u] = has2 ? p.t2[co + u] : 0.f;
-    }
-  }
-}
-
-// `full` (lane-uniform per tile column group): the vector path applies, `af` holds the lane's affine
-template <bool BF16>
-__device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16& acc, float* ep, int lane, int m_base,
-                                                int co_base, bool full, bool has2, const AffH& af) {
-  typedef typename Elem<BF16>::T T;
-  typedef typename Elem<BF16>::V8 V8;
-  const int r = lane & 31, h = lane >> 5;
-  constexpr int kPitch = 36;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + 4 * h) * kPitch + r] = acc[e];
-  const int c8 = (lane & 3) * 8;
-  const int co = co_base + c8;
-  if (full) {
-    const float (&s1)[8] = af.s1; const float (&t1)[8] = af.t1; const float (&s2)[8] = af.s2; const float (&t2)[8] = af.t2;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int row = (lane >> 2) + 16 * k;
-      const int m = m_base + row;
-      const float4 a0 = *reinterpret_cast<const float4*>(ep + row * kPitch + c8);
-      const float4 a1 = *reinterpret_cast<const float4*>(ep + row * kPitch + c8 + 4);
-      if (m < p.M) {
-        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = v[u] * s1[u] + t1[u];
-        act_row8(v, p.act1, p.slope1);
-        if (p.res) {
-          const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.r_cs + p.r_co + co);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] += (float)rr[u];
-        }
-        if (has2) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = v[u] * s2[u] + t2[u];
-          act_row8(v, p.act2, p.slope2);
-        }
-        if (p.out_f32) {
-          float* dst = reinterpret_cast<float*>(p.y) + out_row_h(p, m) * p.y_cs + p.y_co + co;
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          V8 o;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) o[u] = (T)v[u];
-          *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.y) + out_row_h(p, m) * p.y_cs + p.y_co + co) = o;
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int row = (lane >> 2) + 16 * k;
-      const int m = m_base + row;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int c = co + u;
-        if (c < p.Cout) {
-          float v = ep[row * kPitch + c8 + u] * p.s1[c] + p.t1[c];
-          v = apply_act(v, p.act1, p.slope1);
-          if (p.res) v += (float)reinterpret_cast<const T*>(p.res)[(int64_t)m * p.r_cs + p.r_co + c];
-          if (has2) v = apply_act(v * p.s2[c] + p.t2[c], p.act2, p.slope2);
-          if (p.out_f32)
-            reinterpret_cast<float*>(p.y)[out_row_h(p, m) * p.y_cs + p.y_co + c] = v;
-          else
-            reinterpret_cast<T*>(p.y)[out_row_h(p, m) * p.y_cs + p.y_co + c] = (T)v;
-        }
-      }
-    }
-  }
-}
 
 // GENERAL_K = false: Cin % 64 == 0, a slice lies inside one (kh,kw) tap and the (tap, channel)
 //   walk is scalar.  GENERAL_K = true: Cin % 8 == 0 only (stem with C padded to 8, Cin = 32
@@ -526,6 +326,22 @@ static int dispatch_h16(const ConvArgsH& a, int tile, bool general, hipStream_t 
   return dispatch_h16_n<BF16, 2>(a, tile, general, s);
 }
 
+// conv3x3_h16.hip
+bool conv3x3_h16_applies(const ConvArgsH& a);
+int conv3x3_h16_launch(const ConvArgsH& a, bool bf16, int tile, hipStream_t s);
+
+// YV4_C3=1: the 3x3 / stride-1 kernel takes every layer in its domain that fills at least ~40 % of the chip with its
+// one-workgroup-per-CU tiles.  Off by default: measured on MI355X (profiles/r02_c3_ablation.md) it is within +-2 % of
+// the generic tiles on YOLOv4-L (inference 3531 vs 3585 images/s bf16, train step 768 vs 759) -- it removes the
+// L2 -> LDS fill cost it was built to remove (10 us of a 77 us layer instead of 23) but runs one workgroup per CU, so
+// its prologue / epilogue (25 us per two-round launch) no longer overlap another workgroup's K loop.
+static bool prefer_c3(const ConvArgsH& a) {
+  static const int mode = [] { const char* e = getenv("YV4_C3"); return e ? atoi(e) : 0; }();
+  if (!mode || !conv3x3_h16_applies(a)) return false;
+  const long long tiles = ((long long)a.M + 255) / 256 * ((a.Cout + (a.Cout > 64 ? 127 : 63)) / (a.Cout > 64 ? 128 : 64));
+  return tiles >= 100;
+}
+
 static int pick_tile_h16(long long M, int Cout, long long K) {
   // From the per-layer table of tools/conv_bench.py --dtype bf16 (YOLOv4-L, batch 32; after the prologue /
   // epilogue work of round 1 the 128x64 tile -- three workgroups per CU -- is the best or within 2 % of the best
@@ -542,6 +358,12 @@ using namespace yv4;
 
 extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
   if (!d) return YV4_TILE_AUTO;
+  {
+    ConvArgsH a{};
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.Cin = d->Cin; a.Cout = d->Cout; a.ys_on = 0; a.M = (int)((long long)d->N * d->Ho * d->Wo);
+    if (prefer_c3(a)) return d->Cout > 64 ? YV4_HTILE_C3_256x128 : YV4_HTILE_C3_256x64;
+  }
   return pick_tile_h16((long long)d->N * d->Ho * d->Wo, d->Cout, (long long)d->KH * d->KW * d->Cin);
 }
 
@@ -590,8 +412,11 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   a.ablate = ablate;
   a.stats = stats;
   const bool general = (d->Cin % kHBK) != 0;
-  const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const bool c3_id = d->tile == YV4_HTILE_C3_256x128 || d->tile == YV4_HTILE_C3_256x64;
+  if (c3_id) YV4_REQUIRE(conv3x3_h16_applies(a), "conv h16: the C3 tiles need a 3x3 / stride 1 / pad 1 conv with Cin %% 64 == 0, Cout >= 64");
+  if (c3_id || (d->tile == YV4_TILE_AUTO && prefer_c3(a))) return conv3x3_h16_launch(a, dtype == YV4_BF16, d->tile, s);
+  const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);
 }
 

@@ -144,7 +144,21 @@ class Fp16GradAccumulateOptimizerHook(Hook):
             self.scaler_cfg['init_scale'] = float(loss_scale)
             self.dynamic = False
         elif isinstance(loss_scale, dict):
-            self.scaler_cfg.update(loss_scale)
+            # torch.cuda.amp.GradScaler's keys, or mmcv's legacy LossScaler spelling that the reference's own
+            # yolov5_ddp configs use (configs/yolov5_ddp/*:21-23: init_scale, mode, scale_factor, scale_window)
+            ls = dict(loss_scale)
+            mode = ls.pop('mode', 'dynamic')
+            if 'scale_factor' in ls:
+                f = float(ls.pop('scale_factor'))
+                ls.setdefault('growth_factor', f)
+                ls.setdefault('backoff_factor', 1.0 / f)
+            if 'scale_window' in ls:
+                ls.setdefault('growth_interval', int(ls.pop('scale_window')))
+            unknown = set(ls) - set(self.scaler_cfg)
+            if unknown:
+                raise TypeError(f'loss_scale: unexpected keys {sorted(unknown)}')
+            self.scaler_cfg.update(ls)
+            self.dynamic = mode == 'dynamic' 
         else:
             raise ValueError(f'loss_scale must be of type float, dict, or "dynamic", got {loss_scale}')
         self.scale_state = None
@@ -248,6 +262,41 @@ class Fp16GradAccumulateOptimizerHook(Hook):
 
     def after_run(self, runner):
         self.sync_meta(runner)
+
+
+@HOOKS.register_module()
+class Fp16OptimizerHook(Fp16GradAccumulateOptimizerHook):
+    """mmcv's ``Fp16OptimizerHook`` (third party; the base class of the fork's accumulate hook,
+    accum_optim_hooks.py:9): what ``mmdet/apis/train.py:115-118`` builds from ``optimizer_config`` + the top-level
+    ``fp16`` block of configs/yolov5_ddp/*.  One optimizer step per iteration = the accumulate hook with a window of 1."""
+
+    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, loss_scale=512., distributed=True, **kw):
+        super().__init__(grad_clip=grad_clip, coalesce=coalesce, bucket_size_mb=bucket_size_mb, loss_scale=loss_scale,
+                         distributed=distributed, accumulation=1, **kw)
+
+
+@HOOKS.register_module()
+class OptimizerHook(Fp16GradAccumulateOptimizerHook):
+    """mmcv's plain ``OptimizerHook(grad_clip)`` (``apis/train.py:119-120``): no loss scaling -- the same fused
+    clip + step launches with a static scale of 1."""
+
+    def __init__(self, grad_clip=None, **kw):
+        kw.setdefault('distributed', True)
+        super().__init__(grad_clip=grad_clip, loss_scale=1.0, accumulation=1, **kw)
+
+
+def build_optimizer_hook(cfg, distributed=True):
+    """``mmdet/apis/train.py:115-122``: the optimizer hook a config asks for.  ``cfg`` needs ``optimizer_config`` and
+    optionally ``fp16`` (mapping or Config)."""
+    get = cfg.get if hasattr(cfg, 'get') else (lambda k, d=None: getattr(cfg, k, d))
+    oc = dict(get('optimizer_config') or {})
+    fp16 = get('fp16', None)
+    if fp16 is not None:
+        return Fp16OptimizerHook(**oc, **dict(fp16), distributed=distributed)
+    if 'type' not in oc:
+        return OptimizerHook(**oc)
+    from .registry import build_from_cfg
+    return build_from_cfg(oc, HOOKS)
 
 
 # ---- a23 ---------------------------------------------------------------------------------------------

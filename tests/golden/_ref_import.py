@@ -101,10 +101,10 @@ def install_shim(mish_ext):
     def build_norm_layer(cfg, num_features, postfix=''):
         cfg_ = dict(cfg)
         t = cfg_.pop('type')
-        assert t in ('BN', 'BN2d')
+        assert t in ('BN', 'BN2d', 'SyncBN')
         requires_grad = cfg_.pop('requires_grad', True)
         cfg_.setdefault('eps', 1e-5)
-        layer = nn.BatchNorm2d(num_features, **cfg_)
+        layer = (nn.SyncBatchNorm if t == 'SyncBN' else nn.BatchNorm2d)(num_features, **cfg_)
         for p in layer.parameters():
             p.requires_grad = requires_grad
         return 'bn' + str(postfix), layer

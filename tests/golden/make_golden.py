@@ -195,6 +195,179 @@ def make_nms(ref, out):
 
 
 
+def find_boundary_pairs(thr, rng, want=48):
+    """Box pairs whose IoU sits ON the fp32 threshold, found by search (all arithmetic in numpy fp32, in the order of
+    oracle/nms_ref.c).  Integer coordinates: areas, intersection and union are exact, so the only roundings are the one
+    division (mmcv's CPU kernel: ``inter / union > thr``) or the one product (mmcv's CUDA kernel:
+    ``inter > thr * union``).  Returns dict category -> list of (boxA, boxB):
+      'eq'       inter / union == thr exactly (division keeps B; the product form may or may not)
+      'div_only' division suppresses, product keeps
+      'mul_only' product suppresses, division keeps
+      'above'    one fp32 ulp above thr in both forms (suppressed), 'below' one ulp below (kept)"""
+    thr = np.float32(thr)
+    cats = {k: [] for k in ('eq', 'div_only', 'mul_only', 'above', 'below')}
+    tries = 0
+    while min(len(v) for v in cats.values()) < want and tries < 4000:
+        tries += 1
+        n = 20000
+        w1 = rng.randint(20, 400, n); h1 = rng.randint(20, 400, n)
+        w2 = rng.randint(20, 400, n); h2 = rng.randint(20, 400, n)
+        dx = rng.randint(0, 60, n); dy = rng.randint(0, 60, n)
+        a = np.stack([np.zeros(n), np.zeros(n), w1, h1], 1).astype(np.float32)
+        b = np.stack([dx, dy, dx + w2, dy + h2], 1).astype(np.float32)
+        iw = np.maximum(np.float32(0), np.minimum(a[:, 2], b[:, 2]) - np.maximum(a[:, 0], b[:, 0]))
+        ih = np.maximum(np.float32(0), np.minimum(a[:, 3], b[:, 3]) - np.maximum(a[:, 1], b[:, 1]))
+        inter = iw * ih
+        uni = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter
+        ovr = inter / uni
+        rhs = thr * uni
+        div, mul = ovr > thr, inter > rhs
+        up, dn = np.nextafter(thr, np.float32(1)), np.nextafter(thr, np.float32(0))
+        sel = {'eq': ovr == thr, 'div_only': div & ~mul, 'mul_only': mul & ~div,
+               'above': (ovr == up) & div & mul, 'below': (ovr == dn) & ~div & ~mul}
+        for k, m in sel.items():
+            for i in np.nonzero(m)[0]:
+                if len(cats[k]) < want:
+                    cats[k].append((a[i].copy(), b[i].copy()))
+    return cats
+
+
+def _fp32_predicates(a, b, thr):
+    """oracle/nms_ref.c's arithmetic on arrays of boxes (n,4) fp32: (ovr, division form, product form)."""
+    f0 = np.float32(0)
+    iw = np.maximum(f0, np.minimum(a[:, 2], b[:, 2]) - np.maximum(a[:, 0], b[:, 0]))
+    ih = np.maximum(f0, np.minimum(a[:, 3], b[:, 3]) - np.maximum(a[:, 1], b[:, 1]))
+    inter = iw * ih
+    uni = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter
+    ovr = inter / uni
+    return ovr, ovr > thr, inter > thr * uni
+
+
+def find_float_boundary_pairs(thr, rng, cells, want=24):
+    """The categories integer coordinates cannot reach ('div_only': the quotient rounds above thr while the product
+    rounds to >= inter -- needs |IoU - thr| < 4e-8): for a random pair placed IN its final grid cell, bisect B's x1 to
+    the threshold crossing, then walk the 8192 consecutive fp32 values of x1 around it and classify each."""
+    thr = np.float32(thr)
+    up, dn = np.nextafter(thr, np.float32(1)), np.nextafter(thr, np.float32(0))
+    cats = {k: [] for k in ('div_only', 'mul_only', 'eq', 'above', 'below')}
+    used = 0                                                     # one pair per cell: a cell is consumed on success only
+    for attempt in range(60000):
+        if min(len(v) for v in cats.values()) >= want or used >= len(cells):
+            break
+        ox, oy = cells[used]
+        w1, h1 = rng.uniform(40, 200, 2)                         # the pair stays inside its 520 x 520 cell
+        ax, ay = ox + rng.uniform(5, 60), oy + rng.uniform(5, 60)
+        a = np.array([ax, ay, ax + w1, ay + h1], np.float32)
+        w2, h2 = w1 * rng.uniform(0.9, 1.1), h1 * rng.uniform(0.9, 1.1)
+        by = np.float32(ay + rng.uniform(-0.05, 0.05) * h1)
+
+        def boxes_for(x1s):
+            x1s = x1s.astype(np.float32)
+            b = np.stack([x1s, np.full_like(x1s, by), x1s + np.float32(w2), np.full_like(x1s, by + np.float32(h2))], 1)
+            return np.repeat(a[None], len(x1s), 0), b.astype(np.float32)
+        lo, hi = float(ax), float(ax + 0.6 * w1)                 # IoU decreases as B moves right
+        A, B = boxes_for(np.array([lo, hi]))
+        o = _fp32_predicates(A, B, thr)[0]
+        if not (o[0] > thr > o[1]):
+            continue
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            A, B = boxes_for(np.array([mid]))
+            if _fp32_predicates(A, B, thr)[0][0] > thr:
+                lo = mid
+            else:
+                hi = mid
+        c = np.float32(lo)
+        xs = [c]
+        for _ in range(4096):
+            xs.append(np.nextafter(xs[-1], np.float32(1e9)))
+        x = c
+        for _ in range(4096):
+            x = np.nextafter(x, np.float32(-1e9))
+            xs.append(x)
+        A, B = boxes_for(np.array(xs, np.float32))
+        ovr, div, mul = _fp32_predicates(A, B, thr)
+        sel = {'div_only': div & ~mul, 'mul_only': mul & ~div, 'eq': ovr == thr,
+               'above': (ovr == up) & div & mul, 'below': (ovr == dn) & ~div & ~mul}
+        avail = [k for k, m in sel.items() if m.any() and len(cats[k]) < want]
+        if not avail:
+            continue
+        k = min(avail, key=lambda n: len(cats[n]))               # the category that still needs pairs most
+        i0 = np.nonzero(sel[k])[0][0]
+        cats[k].append((A[i0].copy(), B[i0].copy()))
+        used += 1
+    return cats
+
+
+def make_nms_boundary(ref, out):
+    """multiclass_nms on candidates whose pairwise IoU equals the threshold in fp32 or straddles it by one rounding:
+    the only inputs on which the definition's ``>`` vs ``>=`` and its division vs product form matter
+    (mmdet/core/post_processing/bbox_nms.py:84 -> mmcv nms).  Stored: what the documented definition (division, mmcv's
+    CPU kernel) returns AND what the product form (mmcv's CUDA kernel) returns, through the reference's own
+    multiclass_nms glue.  A GPU run of the reference (CUDA kernel) may differ from the division form on exactly the
+    'div_only' / 'mul_only' pairs below.
+    Layout: every pair sits alone in a 520 x 520 cell of a 12-wide grid.  Integer-coordinate pairs ('int_*') cycle
+    through the 4 classes (class offsets are integers: all arithmetic stays exact); float-coordinate pairs are class 0
+    (offset 0) so that batched_nms' ``boxes + label * (max + 1)`` does not re-round them."""
+    from oracle import yolov4_oracle as O
+    rng = np.random.RandomState(65)
+    thr = 0.65
+    C = 4
+    icats = find_boundary_pairs(thr, rng)
+    ncell_int = sum(len(v) for v in icats.values())
+    cells = [((c % 12) * 520.0, (c // 12) * 520.0) for c in range(ncell_int, ncell_int + 160)]
+    fcats = find_float_boundary_pairs(thr, rng, cells)
+    print('  integer-coordinate pairs:', {k: len(v) for k, v in icats.items()})
+    print('  float-coordinate pairs  :', {k: len(v) for k, v in fcats.items()})
+    boxes, scores, cat_of, pair_of, names = [], [], [], [], []
+    cell = 0
+
+    def add(a, b, cls, cname):
+        nonlocal cell
+        if cname not in names:
+            names.append(cname)
+        for j, bx in enumerate((a, b)):
+            boxes.append(bx)
+            sc = np.zeros(C + 1, np.float32)
+            sc[cls] = np.float32(0.9 - 0.001 * (cell % 50)) if j == 0 else np.float32(0.5 - 0.001 * (cell % 50))
+            scores.append(sc)
+            cat_of.append(names.index(cname))
+            pair_of.append(cell)
+        cell += 1
+    for k, v in icats.items():
+        for (a, b) in v:
+            ox, oy = (cell % 12) * 520.0, (cell // 12) * 520.0
+            sh = np.array([ox, oy, ox, oy], np.float32)
+            add(a + sh, b + sh, cell % C, 'int_' + k)
+    for k, v in fcats.items():
+        for (a, b) in v:
+            add(a, b, 0, k)                                   # already placed in their cells by the search
+    # one far-away low-score box pins boxes.max() + 1 to 32768 = 2^15: the class offsets label * 32768 are then exact
+    # for the integer-coordinate pairs
+    boxes.append(np.array([32700, 32700, 32767, 32767], np.float32))
+    sc = np.zeros(C + 1, np.float32)
+    sc[0] = 0.06
+    scores.append(sc)
+    names.append('anchor_box')
+    cat_of.append(names.index('anchor_box'))
+    pair_of.append(cell)
+    b = np.stack(boxes).astype(np.float32)
+    sc = np.stack(scores).astype(np.float32)
+    data = dict(boxes=b, scores=sc, thr=np.float32(0.05), iou_thr=np.float32(thr), category=np.array(cat_of),
+                pair=np.array(pair_of), category_names=np.array(names))
+    for form, tag in ((0, 'div'), (1, 'mul')):
+        O.NMS_IOU_FORM = form
+        try:
+            d, l, inds = ref.nms.multiclass_nms(torch.from_numpy(b), torch.from_numpy(sc), 0.05,
+                                                dict(type='nms', iou_threshold=thr), -1, return_inds=True)
+        finally:
+            O.NMS_IOU_FORM = 0
+        data[f'{tag}_dets'], data[f'{tag}_labels'], data[f'{tag}_inds'] = d.numpy(), l.numpy(), inds.numpy()
+        print(f'  nms boundary ({tag}): {b.shape[0]} candidates -> {d.shape[0]} kept')
+    np.savez_compressed(out, **data)
+    print('nms_boundary', out)
+
+
 def make_train(ref, out):
     """One training-mode forward + backward of the reference on a tiny v4 detector: loss dict,
     gradients (full for selected tensors, 3 checksums for every parameter), BN running statistics
@@ -351,6 +524,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'post':      # only the newest fixture
         make_post(ref, os.path.join(HERE, 'post_variants.npz'))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'nms_boundary':
+        make_nms_boundary(ref, os.path.join(HERE, 'nms_boundary.npz'))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'softfocal':
         make_softfocal(ref, os.path.join(HERE, 'softfocal.npz'))
         return
@@ -362,6 +538,7 @@ def main():
     run_detector(ref, 'tiny_v5', v5, [2, 3, 4], 'v5', [32, 64, 128], [32, 64, 128], 1, (64, 64), 5,
                  os.path.join(HERE, 'tiny_v5.npz'), obj_bias=-3.5, cls_bias=-4.0, head_std=12000)
     make_nms(ref, os.path.join(HERE, 'nms.npz'))
+    make_nms_boundary(ref, os.path.join(HERE, 'nms_boundary.npz'))
     make_train(ref, os.path.join(HERE, 'train_v4.npz'))
     make_post(ref, os.path.join(HERE, 'post_variants.npz'))
     make_softfocal(ref, os.path.join(HERE, 'softfocal.npz'))

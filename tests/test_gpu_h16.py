@@ -111,6 +111,71 @@ def test_h16_conv_epilogues(gpu_device, dtype, act):
     _h16_conv(gpu_device, dtype, 1, 9, 11, 40, 64, 3, 1, 1, act, 3, out_f32=True, y_off=4)
 
 
+C3_SHAPES = [
+    # N, H, W, Cin, Cout  (3x3, stride 1, pad 1): the domain of conv3x3_h16.hip, tiles 4 (256x128) and 5 (256x64)
+    (2, 19, 19, 64, 128),      # two images in three M tiles: image borders inside a tile, ragged last tile
+    (3, 7, 5, 128, 64),        # map narrower than a fragment row group: many left / right borders per tile
+    (1, 38, 38, 64, 192),      # Cout not a multiple of 128: half-empty last column tile
+    (2, 16, 16, 192, 72),      # three channel chunks, Cout tail inside a 32-column group
+    (1, 1, 300, 64, 64),       # one image row: every kh = 0 / 2 tap is padding
+    (5, 3, 3, 64, 64),         # tiny images: almost every tap is masked somewhere
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('tile', [4, 5])
+@pytest.mark.parametrize('shape', C3_SHAPES)
+def test_h16_conv3x3_kernel_shapes(gpu_device, dtype, tile, shape):
+    N, H, W, Cin, Cout = shape
+    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=tile)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+def test_h16_conv3x3_kernel_epilogues(gpu_device, dtype, act):
+    """Residual + two-stage epilogue + channel-offset views on both sides + fp32 output through the 3x3 kernel."""
+    _h16_conv(gpu_device, dtype, 2, 13, 13, 64, 72, 3, 1, 1, act, 4, residual=True, two_stage=True, x_off=8, y_off=16)
+    _h16_conv(gpu_device, dtype, 1, 20, 9, 128, 128, 3, 1, 1, act, 5, residual=True, x_off=16)
+    _h16_conv(gpu_device, dtype, 1, 9, 11, 64, 64, 3, 1, 1, act, 4, out_f32=True, y_off=4)
+
+
+def test_h16_conv3x3_kernel_is_refused_outside_its_domain(gpu_device):
+    for shape in [(1, 8, 8, 64, 64, 1, 1, 0), (1, 8, 8, 64, 64, 3, 2, 1), (1, 8, 8, 32, 64, 3, 1, 1)]:
+        with pytest.raises(L.Yv4Error):
+            _h16_conv(gpu_device, torch.bfloat16, *shape, act=1, tile=4)
+
+
+def test_h16_conv3x3_kernel_auto_choice_is_opt_in(gpu_device):
+    """YV4_C3=1 lets the auto tile choice take the 3x3 kernel for big layers (a child process: the switch is read once
+    per process); the default keeps the generic tiles (measured parity, profiles/r02_c3_ablation.md)."""
+    import subprocess
+    d = L.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 32, 38, 38, 256, 38, 38, 256
+    d.KH = d.KW = 3
+    d.stride, d.pad = 1, 1
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) in (1, 2, 3)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch; import test_gpu_h16 as T; "
+            "T._c3_auto_checks(torch.device('cuda:0'))") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                            os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, YV4_C3='1'), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _c3_auto_checks(gpu_device):
+    d = L.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 32, 38, 38, 256, 38, 38, 256
+    d.KH = d.KW = 3
+    d.stride, d.pad = 1, 1
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 4
+    d.Cout = 64
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 5
+    d.N = 1                                                  # 6 x 2 tiles: the generic tiles' occupancy wins
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) in (1, 2, 3)
+    _h16_conv(gpu_device, torch.bfloat16, 8, 38, 38, 128, 128, 3, 1, 1, act=1, tile=0)     # 46 x 1 tiles ... generic
+    _h16_conv(gpu_device, torch.bfloat16, 20, 38, 38, 64, 128, 3, 1, 1, act=1, tile=0)     # 113 tiles: the C3 kernel
+
+
 def test_h16_conv_big_k(gpu_device):
     _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 512, 64, 3, 1, 1, 1, 1)       # K = 4608
 

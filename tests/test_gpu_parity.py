@@ -495,3 +495,32 @@ def test_conf_topk_threshold_keys(gpu_device):
             assert int(got[n] & np.uint64(0xffffffff)) == order[k - 1], (k, n)
     assert L.yv4_conf_topk(levels, 2, N, A, ncls, total, work.data_ptr(), out.data_ptr(), None) != 0
     assert L.yv4_conf_topk(levels, 2, N, A, ncls, 0, work.data_ptr(), out.data_ptr(), None) != 0
+
+
+@pytest.mark.parametrize('form,tag', [('div', 'div'), ('mul', 'mul')])
+def test_nms_boundary_pairs_bit_exact(golden, gpu_device, form, tag):
+    """IoU == threshold (fp32) and one-rounding-off pairs, under both of mmcv's predicates (tests/golden/
+    nms_boundary.npz, see tests/test_oracle_golden.py::test_nms_boundary_fixture): the HIP kernels keep and drop
+    exactly what the reference glue + restated mmcv nms did -- `>` not `>=`, IEEE division for 'div', one fp32
+    product for 'mul', no contraction."""
+    g = golden('nms_boundary')
+    b, s = torch.from_numpy(g['boxes']), torch.from_numpy(g['scores'])
+    assert pkg.get_nms_iou_form() == 'div'                      # the documented default
+    pkg.set_nms_iou_form(form)
+    try:
+        d, l, inds = pkg.multiclass_nms(b.to(gpu_device), s.to(gpu_device), float(g['thr']),
+                                        dict(type='nms', iou_threshold=float(g['iou_thr'])), -1, return_inds=True)
+        # the per-class (n >= split_thr) branch must agree on the same pairs
+        d2, l2, inds2 = pkg.multiclass_nms(b.to(gpu_device), s.to(gpu_device), float(g['thr']),
+                                           dict(type='nms', iou_threshold=float(g['iou_thr']), split_thr=100), -1,
+                                           return_inds=True)
+    finally:
+        pkg.set_nms_iou_form('div')
+    np.testing.assert_array_equal(d.cpu().numpy(), g[f'{tag}_dets'])
+    np.testing.assert_array_equal(l.cpu().numpy(), g[f'{tag}_labels'])
+    np.testing.assert_array_equal(inds.cpu().numpy(), g[f'{tag}_inds'])
+    np.testing.assert_array_equal(d2.cpu().numpy(), g[f'{tag}_dets'])
+    np.testing.assert_array_equal(inds2.cpu().numpy(), g[f'{tag}_inds'])
+    assert not np.array_equal(g['div_inds'], g['mul_inds'])     # the two mmcv kernels really disagree on this input
+    with pytest.raises(Exception):
+        pkg.set_nms_iou_form('floor')

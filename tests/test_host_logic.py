@@ -206,3 +206,63 @@ def test_coco_test_annotation():
     import pytest
     with pytest.raises(KeyError):                          # the reference indexes cat2label before it could skip the box
         coco_test_annotation([dict(bbox=[0, 0, 1, 1], category_id=2, area=1)], cat_ids, cat2label)
+
+
+def _layout_digest(module):
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in module.state_dict().items():
+        h.update(f'{k}:{tuple(v.shape)}:{v.dtype}\n'.encode())
+    return h.hexdigest()
+
+
+def _n1():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'configs_n1.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('name', sorted(_n1()))
+def test_reference_configs_build_unchanged(name):
+    """N1 -- "configs/yolov4/* run unchanged": tests/golden/configs_n1.json holds, for each of the reference's 12
+    YOLOv4 / YOLOv5 config files, the blocks this package's Config.fromfile parsed from the FILE in the build container
+    and what the REFERENCE's own classes built from them (parameter counts, state-dict key order + shapes as a digest;
+    tests/golden/make_golden_configs.py).  Rebuilding through this package's registries must give the same detector
+    layout, one optimizer group per parameter (what DetailedLinearWarmUpHook requires, warmup_hooks.py:22-28), and the
+    recipe's hooks under the reference's names."""
+    from mmdet_yolov4_amd import hooks as H
+    from mmdet_yolov4_amd.optim import paramwise_groups
+    from mmdet_yolov4_amd.registry import HOOKS, build_from_cfg
+    e = _n1()[name]
+    det = pkg.build_detector(e['model'])
+    for part, want in e['reference_parts'].items():
+        m = getattr(det, part)
+        assert sum(p.numel() for p in m.parameters()) == want['params'], part
+        assert len(list(m.parameters())) == want['tensors'] and len(list(m.buffers())) == want['buffers'], part
+        assert _layout_digest(m) == want['layout_sha256'], f'{part}: state-dict keys / shapes differ from the reference'
+    syncbn = any(isinstance(m, torch.nn.SyncBatchNorm) for m in det.modules())
+    assert syncbn == name.startswith('yolov5_ddp/')
+    opt = dict(e['optimizer'])
+    assert opt.pop('type') == 'SGD'
+    groups = paramwise_groups(det, opt['lr'], opt['weight_decay'], opt.get('paramwise_cfg'))
+    assert len(groups) == len(list(det.parameters()))
+    for g, (n, p) in zip(groups, det.named_parameters()):
+        assert g['params'][0] is p
+        if n.endswith('.bias') or '.bn.' in n or n.endswith('bn.weight'):
+            assert g.get('weight_decay') == 0.0, n          # bias_decay_mult = norm_decay_mult = 0
+    # mmdet/apis/train.py:115-122: the fork's accumulate hook for configs/yolov4 + yolov5 (optimizer_config carries its
+    # type), mmcv's Fp16OptimizerHook from optimizer_config + the top-level fp16 block for configs/yolov5_ddp
+    hook = H.build_optimizer_hook(dict(optimizer_config=e['optimizer_config'], fp16=e['fp16']))
+    assert isinstance(hook, H.Fp16GradAccumulateOptimizerHook) and hook.dynamic and hook.grad_clip['max_norm'] == 35
+    if name.startswith('yolov5_ddp/'):
+        assert type(hook) is H.Fp16OptimizerHook and hook.accumulation == 1
+        assert hook.scaler_cfg == dict(init_scale=65536, growth_factor=2.0, backoff_factor=0.5, growth_interval=1000)
+    else:
+        assert type(hook) is H.Fp16GradAccumulateOptimizerHook and hook.nominal_batch_size == 64
+    kinds = [build_from_cfg({k: v for k, v in h.items() if k != 'priority'}, HOOKS) for h in e['custom_hooks']]
+    assert any(isinstance(k, H.StateEMAHook) for k in kinds) and any(isinstance(k, H.DetailedLinearWarmUpHook) for k in kinds)
+    spg = e['samples_per_gpu']
+    world = 8 if name.startswith('yolov5_ddp/') else 1
+    assert H.accumulation_steps(64, spg, world) == -(-64 // (spg * world))
+    tc = det.bbox_head.test_cfg
+    assert tc.score_thr == 0.001 and tc.nms['iou_threshold'] == 0.65 and tc.max_per_img == 300

@@ -119,6 +119,67 @@ def test_nms_c_equals_numpy_statement():
     assert O.nms_c(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 0.5).size == 0
 
 
+def _pair_predicates(b, iou_thr):
+    """Per boundary pair (rows 2k, 2k+1 of the fixture, class-offset applied): (ovr, division form, product form)
+    in numpy fp32, the arithmetic of oracle/nms_ref.c restated once more."""
+    a, c = b[0::2], b[1::2]
+    f0 = np.float32(0)
+    iw = np.maximum(f0, np.minimum(a[:, 2], c[:, 2]) - np.maximum(a[:, 0], c[:, 0]))
+    ih = np.maximum(f0, np.minimum(a[:, 3], c[:, 3]) - np.maximum(a[:, 1], c[:, 1]))
+    inter = iw * ih
+    uni = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (c[:, 2] - c[:, 0]) * (c[:, 3] - c[:, 1]) - inter
+    ovr = inter / uni
+    return ovr, ovr > iou_thr, inter > iou_thr * uni
+
+
+@pytest.mark.parametrize('form,tag', [(0, 'div'), (1, 'mul')])
+def test_nms_boundary_fixture(golden, form, tag):
+    """Pairs whose IoU equals the fp32 threshold or straddles it by one rounding (tests/golden/nms_boundary.npz, made
+    by the reference's multiclass_nms glue over the restated mmcv nms): the oracle under the documented definition
+    (division = mmcv's CPU kernel) and under mmcv's CUDA-kernel predicate (product) returns what the fixture holds; the
+    C loop and its numpy restatement agree; and every pair behaves as its category says -- including pairs on which
+    the two mmcv kernels disagree in BOTH directions, i.e. a GPU run of the reference may differ from the documented
+    definition exactly there."""
+    g = golden('nms_boundary')
+    b, s = torch.from_numpy(g['boxes']), torch.from_numpy(g['scores'])
+    iou_thr = np.float32(g['iou_thr'])
+    O.NMS_IOU_FORM = form
+    try:
+        d, l, inds = O.multiclass_nms(b, s, float(g['thr']), dict(type='nms', iou_threshold=float(g['iou_thr'])), -1,
+                                      return_inds=True)
+    finally:
+        O.NMS_IOU_FORM = 0
+    np.testing.assert_array_equal(d.numpy(), g[f'{tag}_dets'])
+    np.testing.assert_array_equal(l.numpy(), g[f'{tag}_labels'])
+    np.testing.assert_array_equal(inds.numpy(), g[f'{tag}_inds'])
+    # category semantics on the class-offset boxes batched_nms actually compares
+    names = [str(n) for n in g['category_names']]
+    cat = g['category'][:-1:2]                                  # one entry per pair (the last box is the anchor box)
+    labels = g['scores'][:-1, :-1].argmax(1)
+    off = (labels.astype(np.float32) * (g['boxes'].max() + np.float32(1)))[:, None]
+    ovr, div, mul = _pair_predicates(g['boxes'][:-1] + off, iou_thr)
+    want = {'eq': (False, None), 'int_eq': (False, None), 'div_only': (True, False), 'mul_only': (False, True),
+            'int_mul_only': (False, True), 'above': (True, True), 'below': (False, False)}
+    for k, (wd, wm) in want.items():
+        m = cat == names.index(k)
+        assert m.sum() >= 15, (k, int(m.sum()))
+        assert (div[m] == wd).all(), k
+        if wm is not None:
+            assert (mul[m] == wm).all(), k
+        if 'eq' in k:
+            assert (ovr[m] == iou_thr).all()
+    assert (div != mul).sum() >= 60 and (div & ~mul).sum() >= 15 and (mul & ~div).sum() >= 40
+    # the greedy loop in C and in numpy select identically on these boxes, either form
+    flat = g['scores'][:, :-1].max(1)
+    bo = np.concatenate([g['boxes'][:-1] + off, g['boxes'][-1:]], 0)
+    assert np.array_equal(O.nms_c(bo, flat, iou_thr, form=form), O.nms_numpy(bo, flat, iou_thr, form=form))
+    # B of a pair survives iff the form's predicate is false
+    kept = set(O.nms_c(bo, flat, iou_thr, form=form).tolist())
+    pred = mul if form else div
+    for k in range(len(pred)):
+        assert (2 * k + 1 in kept) == (not pred[k]) and 2 * k in kept
+
+
 def test_base_anchor_known_answers():
     """Known answers of the shared base-anchor formula (the reference's own test for the v3
     generator, tests/test_utils/test_anchor.py:148-188, pins the same formula)."""

@@ -36,11 +36,13 @@ def main():
     ap.add_argument('--filter', default='')
     ap.add_argument('--json', default='')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'])
+    ap.add_argument('--chain', type=int, default=1, help='launches per timed region (steady-state time per launch)')
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(',')]
     dev = torch.device('cuda:0')
     lib = pkg._lib.lib()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    NAMES = pkg._lib.HTILE_NAMES if a.dtype != 'f32' else TILE_NAMES
     rows = []
     tot = {t: 0.0 for t in tiles}
     best_tot = 0.0
@@ -74,19 +76,21 @@ def main():
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-                if h16:
-                    code = 1 if a.dtype == 'f16' else 2
-                    rc = lib.yv4_conv_bn_act_fwd_h16(C.byref(d), code, code, x.data_ptr(), w.data_ptr(), sc.data_ptr(),
+                for _c in range(a.chain):
+                    if h16:
+                        code = 1 if a.dtype == 'f16' else 2
+                        rc = lib.yv4_conv_bn_act_fwd_h16(C.byref(d), code, code, x.data_ptr(), w.data_ptr(),
+                                                         sc.data_ptr(), sh.data_ptr(), None, None, None, y.data_ptr(),
+                                                         stream)
+                    else:
+                        rc = lib.yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), sc.data_ptr(),
                                                      sh.data_ptr(), None, None, None, y.data_ptr(), stream)
-                else:
-                    rc = lib.yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                                                 None, None, None, y.data_ptr(), stream)
                 e1.record()
                 torch.cuda.synchronize()
                 if rc != 0:
                     break
                 if r:
-                    ts.append(e0.elapsed_time(e1) * 1e3)
+                    ts.append(e0.elapsed_time(e1) * 1e3 / a.chain)
             ts.sort()
             res[t] = ts[len(ts) // 2] if ts else float('inf')
             tot[t] += res[t] * cnt
@@ -95,10 +99,10 @@ def main():
         best = min(res, key=res.get)
         best_tot += res[best] * cnt
         line = f'{tag:28s} x{cnt:2d} ' + ' '.join(
-            f'{TILE_NAMES.get(t, t)}:{res[t]:7.0f}us {flops / res[t] / 1e6:6.1f}TF' for t in tiles)
-        print(line + f'  best={TILE_NAMES.get(best, best)} auto={TILE_NAMES.get(auto, auto)}', flush=True)
+            f'{NAMES.get(t, t)}:{res[t]:7.0f}us {flops / res[t] / 1e6:6.1f}TF' for t in tiles)
+        print(line + f'  best={NAMES.get(best, best)} auto={NAMES.get(auto, auto)}', flush=True)
         rows.append(dict(shape=[cin, cout, k, s, h], count=cnt, us=res, best=best, auto=auto))
-    print('weighted totals (us): ' + ' '.join(f'{TILE_NAMES.get(t, t)}:{v:.0f}' for t, v in tot.items()) +
+    print('weighted totals (us): ' + ' '.join(f'{NAMES.get(t, t)}:{v:.0f}' for t, v in tot.items()) +
           f' best-per-shape:{best_tot:.0f}')
     if a.json:
         json.dump(rows, open(a.json, 'w'))
