@@ -555,6 +555,44 @@ int yv4_match_coco_batched(const float* iou, const int64_t* det_off, const int64
                            const uint8_t* is_ignore, const uint8_t* is_crowd, int P, uint8_t* work,
                            int32_t* matched, void* stream);
 
+/* ---- train-side input pipeline (configs/yolov4/yolov4l_coco_mosaic.py:22-69) ----------------------------------
+ * Replaces, per batch: Resize(keep_ratio) of 4 source images + MosaicPipeline (mmdet/datasets/pipelines/
+ * transforms.py:1906-1983) + the Albu block [PadIfNeeded, RandomCrop, RandomScale, CenterCrop, HorizontalFlip]
+ * (albumentations, third party) + HueSaturationValueJitter (transforms.py:1986-2021) + GtBBoxesFilter
+ * (transforms.py:2024-2052) + Normalize + ImageToTensor/collate, which the reference runs in CPU dataloader workers.
+ * One yv4_aug_image per OUTPUT image describes its four sources and the random draws (made by the host):
+ *   src[i], sh/sw/pitch[i]  decoded 8-bit BGR source i (HWC, 3 channels, device memory), i = mosaic tile
+ *                           (0 top-left, 1 top-right, 2 bottom-left, 3 bottom-right, transforms.py:1943-1951)
+ *   rh/rw[i]                its size after Resize (mmcv rescale_size)
+ *   cxy                     mosaic centre = max(rh[0], rh[1], rw[0], rw[2]) (transforms.py:1934); canvas is 2cxy x 2cxy
+ *   left, top               PadIfNeeded offsets; x1, y1 RandomCrop origin in the padded canvas; C crop size (1280)
+ *   S                       size of the crop after RandomScale (int(C * scale)); o = (S - out) / 2 CenterCrop origin
+ *   flip                    HorizontalFlip applied; hsv_on + lut[3][256]: the hue / saturation / value LUTs of
+ *                           transforms.py:2004-2008 for this image's random gains. */
+typedef struct {
+  const void* src[4];
+  int32_t sh[4], sw[4], pitch[4];
+  int32_t rh[4], rw[4];
+  int32_t cxy, left, top, x1, y1, C, S, o, flip, hsv_on;
+  uint8_t lut[3][256];
+} yv4_aug_image;
+
+/* Pixels of N output images (out_size x out_size).  imgs: N descriptors in DEVICE memory.  out_u8 (optional):
+ * (N, out, out, 3) 8-bit BGR image after the geometric chain, before the colour jitter; out_nchw (optional):
+ * (N, 3, out, out) fp32 after jitter + (v - mean) * (1 / std) with the BGR -> RGB swap of to_rgb. */
+int yv4_mosaic_augment_u8(const yv4_aug_image* imgs, int N, int out_size, uint8_t* out_u8, float* out_nchw,
+                          const float* mean3, const float* std3, int to_rgb, int pad_val, void* stream);
+
+/* Boxes of the same N output images.  boxes (total, 4) pascal_voc in SOURCE image coordinates, labels / tile (total,)
+ * (tile = which of the 4 sources the box belongs to), seg (N + 1) ranges.  Per box: Resize scale + clip (float32),
+ * mosaic shift, the Albu chain in float64 with its BboxParams filter (clipped area > min_area, clipped / unclipped
+ * area > min_visibility), GtBBoxesFilter (w, h > min_size, aspect ratio < max_aspect_ratio).  Survivors are written in
+ * input order to out_boxes (N, cap, 4) / out_labels (N, cap), their number (<= cap) to out_count (N). */
+int yv4_augment_boxes(const yv4_aug_image* imgs, int N, int out_size, const float* boxes, const int32_t* labels,
+                      const int32_t* tile, const int64_t* seg, int cap, double min_area, double min_visibility,
+                      float min_size, float max_aspect_ratio, float* out_boxes, int32_t* out_labels,
+                      int32_t* out_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

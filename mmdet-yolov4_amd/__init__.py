@@ -22,6 +22,7 @@ from .single_stage import SingleStageDetector, bbox2result
 from .yolov3 import Darknet, DetectionBlock, ResBlock, YOLOBBoxCoder, YOLOV3, YOLOV3Head, YOLOV3Neck
 from .plan import Plan
 from .preprocess import FusedTestPipeline
+from .augment import FusedTrainPipeline
 from .apis import inference_detector, single_gpu_test, multi_gpu_test
 from .eval_utils import (coco_test_annotation, evaluate_fast_bbox, EVAL_BREAKDOWN, EVAL_IOU_CALCULATOR, EVAL_MATCHER, FlexibleStatisticsEval, IOU2DCoCo,
                          MatcherCoCo, ScaleBreakdown, average_precision, eval_map_flexible, iou_coco, match_coco)

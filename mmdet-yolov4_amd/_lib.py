@@ -61,7 +61,15 @@ class LossDesc(C.Structure):
                 ('gpos', C.c_void_p), ('sums', C.c_void_p)]
 
 
-_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+class AugImage(C.Structure):
+    """``yv4_aug_image``."""
+    _fields_ = [('src', C.c_void_p * 4), ('sh', C.c_int32 * 4), ('sw', C.c_int32 * 4), ('pitch', C.c_int32 * 4),
+                ('rh', C.c_int32 * 4), ('rw', C.c_int32 * 4)] + \
+               [(n, C.c_int32) for n in ('cxy', 'left', 'top', 'x1', 'y1', 'C', 'S', 'o', 'flip', 'hsv_on')] + \
+               [('lut', (C.c_uint8 * 256) * 3)]
+
+
+_vp, _i, _i64, _f, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
 
 #: every exported symbol: name -> (restype, argtypes).  tests/test_abi.py checks
 #: this table against include/yv4.h and against the built library.
@@ -130,6 +138,8 @@ SIGNATURES = {
     'yv4_pack_weight': (C.c_int, [_vp, _i64, _i64, _i64, _i64] + [_i] * 12 + [_vp, _i, _vp]),
     'yv4_yolo_loss_fwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
     'yv4_yolo_loss_bwd': (C.c_int, [C.POINTER(LossDesc), _vp, _vp]),
+    'yv4_mosaic_augment_u8': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'yv4_augment_boxes': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _f, _f, _vp, _vp, _vp, _vp]),
     'yv4_letterbox_u8': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _i64, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     'yv4_iou_coco_batched': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     'yv4_match_coco_batched': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
