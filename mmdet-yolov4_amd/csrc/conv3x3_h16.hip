@@ -307,11 +307,8 @@ static int launch_c3(const ConvArgsH& a, hipStream_t stream) {
   }
   const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 2, wb = (long long)p.Cout * p.Kw * 2;
   auto kern = conv3x3_h16_kernel<BF16, BN>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-      hipSuccess) {
-    set_error("conv3x3 h16: cannot reserve %zu bytes of LDS", lds);
-    return YV4_E_LAUNCH;
-  }
+  static LdsAttrOnce once;
+  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), lds, "conv3x3_h16")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kC3Threads), lds, stream, p, (unsigned)xb, (unsigned)wb);
   YV4_CHECK_LAUNCH("conv3x3_h16");
   return YV4_OK;

@@ -629,11 +629,8 @@ static int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
     return YV4_E_UNSUPPORTED;
   }
   auto kern = conv_mfma_f32_dma_kernel<BM, BN, WAVES_M, WAVES_N, NBUF>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static LdsAttrOnce once;
+  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), lds, "conv_mfma_f32_dma")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kThreads), lds, stream, p, (unsigned)xb, (unsigned)wb);
   YV4_CHECK_LAUNCH("conv_mfma_f32_dma");
   return YV4_OK;
@@ -820,14 +817,9 @@ static int launch_conv(const ConvArgs& a, bool uniform_tap, hipStream_t stream) 
   }
   auto kern_u = conv_mfma_f32_kernel<BM, BN, WAVES_M, WAVES_N, true>;
   auto kern_g = conv_mfma_f32_kernel<BM, BN, WAVES_M, WAVES_N, false>;
-  static bool attr_done = false;  // benign race: idempotent
-  if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern_u),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern_g),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static LdsAttrOnce once_u, once_g;
+  if (int rc = ensure_dyn_lds(once_u, reinterpret_cast<const void*>(kern_u), lds, "conv_mfma_f32")) return rc;
+  if (int rc = ensure_dyn_lds(once_g, reinterpret_cast<const void*>(kern_g), lds, "conv_mfma_f32")) return rc;
   if (uniform_tap)
     hipLaunchKernelGGL(kern_u, dim3((unsigned)tiles), dim3(kThreads), lds, stream, p);
   else

@@ -287,11 +287,8 @@ static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
   }
   const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 2, wb = (long long)p.Cout * p.Kw * 2;
   auto kern = conv_mfma_h16_kernel<BF16, BM, BN, 2, 2, GENERAL_K, NBUF>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static LdsAttrOnce once;
+  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), lds, "conv_mfma_h16")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kHThreads), lds, stream, p, (unsigned)xb, (unsigned)wb);
   YV4_CHECK_LAUNCH("conv_mfma_h16");
   return YV4_OK;

@@ -356,7 +356,8 @@ static int fill_args(const yv4_loss_desc* d, LossArgs& a, const char* who) {
     off += (long long)s.H * s.W * a.A;
     t.fd_hw = make_fastdiv((unsigned)(s.H * s.W));
     t.fd_cpr = make_fastdiv((unsigned)(s.Cp / ch));
-    YV4_REQUIRE((long long)d->N * s.H * s.W * (s.Cp / ch) < (1LL << 31), "%s: level %d: map too large", who, l);
+    // the dense backward walks 16-byte chunks with a 32-bit index that advances by up to 2048 * 256 per iteration
+    YV4_REQUIRE((long long)d->N * s.H * s.W * (s.Cp / ch) < (1LL << 31) - 2048LL * 256, "%s: level %d: map too large", who, l);
   }
   a.TA = off;
   a.fd_TA = make_fastdiv((unsigned)off);

@@ -24,11 +24,11 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const float4 v = reinterpret_cast<const float4*>(g)[i];
-    const float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    // inf*inf = inf, nan*nan = nan: s is finite iff all four are (overflow of a finite square to
-    // inf also counts -- such a gradient cannot be clipped in fp32 either)
-    bad += !(fabsf(s) <= 3.402823466e38f);
-    acc += (double)s;
+    // non-finite is decided on the VALUES (what GradScaler's unscale_ inspects): a finite gradient whose fp32
+    // square would overflow must not skip the step; the squares are formed and summed in double
+    bad += !(fabsf(v.x) <= 3.402823466e38f && fabsf(v.y) <= 3.402823466e38f && fabsf(v.z) <= 3.402823466e38f &&
+             fabsf(v.w) <= 3.402823466e38f);
+    acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
   }
   // wave reduction, then one atomic per wave
 #pragma unroll

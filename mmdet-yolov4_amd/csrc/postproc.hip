@@ -522,12 +522,8 @@ extern "C" int yv4_nms_images(uint64_t* keys, int64_t key_cap, const int32_t* co
   a.boxes_per_image = boxes_per_image; a.labels = labels; a.label_stride = label_stride;
   a.fused_classes = fused_classes; a.iou_thr = iou_thr; a.iou_form = nms_iou_form(); a.max_out = max_out; a.split_thr = split_thr;
   a.out_dets = out_dets; a.out_labels = out_labels; a.out_index = out_index; a.out_count = out_count;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(nms_images_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)kNmsLds);
-    attr_done = true;
-  }
+  static LdsAttrOnce once;
+  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(nms_images_kernel), kNmsLds, "nms_images")) return rc;
   hipLaunchKernelGGL(nms_images_kernel, dim3(N), dim3(kNmsThreads), kNmsLds, reinterpret_cast<hipStream_t>(stream), a);
   YV4_CHECK_LAUNCH("nms_images");
   return YV4_OK;

@@ -997,14 +997,9 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     a.rows_per_chunk = (int)rw;
     ch = (M + rw - 1) / rw;
     const size_t ldsh = (size_t)2 * 2 * kWhRows * 256;
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h16_kernel<true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h16_kernel<false>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh);
-      attr_done = true;
-    }
+    static LdsAttrOnce once_b, once_h;
+    if (int rc = ensure_dyn_lds(once_b, reinterpret_cast<const void*>(conv_wgrad_h16_kernel<true>), ldsh, "conv_wgrad_h16")) return rc;
+    if (int rc = ensure_dyn_lds(once_h, reinterpret_cast<const void*>(conv_wgrad_h16_kernel<false>), ldsh, "conv_wgrad_h16")) return rc;
     if (dtype == YV4_BF16)
       hipLaunchKernelGGL(conv_wgrad_h16_kernel<true>, dim3((unsigned)tl, (unsigned)ch), dim3(256), ldsh,
                          reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);

@@ -1,6 +1,8 @@
 // Shared helpers of the gfx950 YOLOv4 kernels (device math + host error plumbing).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -55,6 +57,27 @@ __device__ __forceinline__ unsigned long long tap_mask(int hi0, int wi0, int KH,
   for (int kh = 0; kh < KH; ++kh)
     if ((unsigned)(hi0 + kh) < (unsigned)H) mk |= (unsigned long long)colm << (kh * KW);
   return mk;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON ONE DEVICE: a process that launches on a second
+// GPU must set it there too.  One LdsAttrOnce per (call site, kernel) remembers the devices already done (bit per
+// device ordinal); thread-safe, and the status of hipFuncSetAttribute is checked.
+struct LdsAttrOnce { std::atomic<unsigned long long> done{0ull}; };
+static inline int ensure_dyn_lds(LdsAttrOnce& g, const void* fn, size_t bytes, const char* who) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error("%s: hipGetDevice failed", who);
+    return YV4_E_LAUNCH;
+  }
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (g.done.load(std::memory_order_acquire) & bit) return YV4_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: cannot reserve %zu bytes of dynamic LDS on device %d", who, bytes, dev);
+    return YV4_E_LAUNCH;
+  }
+  g.done.fetch_or(bit, std::memory_order_release);
+  return YV4_OK;
 }
 
 // ---- device math -------------------------------------------------------------

@@ -72,6 +72,13 @@ def paramwise_groups(model, base_lr, base_wd, paramwise_cfg=None):
 class FlatSGD:
     """``torch.optim.SGD`` semantics (dampening 0) on a :class:`FlatState`.
 
+    Parameters that took no part in a step: their slice of the gradient arena is zero (``zero_grad`` fills, it does
+    not detach), so they still receive weight decay and their momentum buffer still decays -- what
+    ``torch.optim.SGD`` does for a zero gradient TENSOR, i.e. the behaviour of the reference's stack (torch 1.x
+    ``zero_grad()`` zero-fills; mmcv 1.3 ``OptimizerHook`` calls exactly that).  torch >= 2.0's default
+    ``zero_grad(set_to_none=True)`` would skip such parameters instead; every parameter of the YOLOv4 / YOLOv5
+    detectors is used in every step, so the two agree on the recipes.
+
     ``params``: parameters or group dicts, exactly what ``torch.optim.SGD`` accepts; every
     trainable parameter of the model must be in exactly one group."""
 

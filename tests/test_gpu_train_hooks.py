@@ -92,6 +92,12 @@ def test_grad_prepare_norm_clip_and_overflow(gpu_device):
         _lib.check(L.yv4_grad_prepare(g2.data_ptr(), n, scale.data_ptr(), 35., work.data_ptr(), ctrl.data_ptr(),
                                       _sp()), 'prep')
         assert ctrl.tolist()[2] == 1.0
+    # a finite gradient whose fp32 SQUARE overflows is still finite: no skip, the norm comes out of the double sum
+    g3 = torch.zeros(n, device=gpu_device)
+    g3[7], g3[99] = 3e30, -4e30
+    _lib.check(L.yv4_grad_prepare(g3.data_ptr(), n, None, 0., work.data_ptr(), ctrl.data_ptr(), _sp()), 'prep')
+    c = ctrl.tolist()
+    assert c[2] == 0.0 and abs(c[1] - 5e30) <= 1e-6 * 5e30
     # invalid arguments are refused, not launched
     assert L.yv4_grad_prepare(g.data_ptr(), 6, None, 0., work.data_ptr(), ctrl.data_ptr(), _sp()) != 0
     assert L.yv4_grad_prepare(g.data_ptr() + 4, 8, None, 0., work.data_ptr(), ctrl.data_ptr(), _sp()) != 0
