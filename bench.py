@@ -287,6 +287,10 @@ def main():
     ap.add_argument('--train-batch', type=int, default=64, help='images per GPU per training step (configs[2])')
     ap.add_argument('--train-dtype', default='bf16', choices=['f32', 'f16', 'bf16'])
     ap.add_argument('--train-timeout', type=float, default=420.0, help='seconds the train-step child may take')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the launch list as ONE hipGraph per step (the batch-1 protocol of '
+                         'tools/analysis_tools/benchmark.py:83-109 is launch-bound otherwise); the per-conv HIP events of '
+                         'the roofline block then come from extra eager steps after the timed region')
     ap.add_argument('--event-every', type=int, default=4,
                     help='bracket the conv launches with HIP events in every n-th timed step (events cost ~2 %%)')
     args = ap.parse_args()
@@ -335,8 +339,18 @@ def main():
     host_labels = torch.empty(post['labels'].shape, dtype=torch.int32, pin_memory=True)
     host_count = torch.empty(post['count'].shape, dtype=torch.int32, pin_memory=True)
     plan.inputs[0]['src'] = img
+    if args.graph:
+        plan.capture()                                  # static input buffer + one graph of the whole launch list
+        plan.inputs[0]['src'].copy_(img)
+        torch.cuda.synchronize()
 
     def step(events=None):
+        if args.graph and events is None:
+            plan.graph.replay()
+            host_dets.copy_(post['dets'], non_blocking=True)
+            host_labels.copy_(post['labels'], non_blocking=True)
+            host_count.copy_(post['count'], non_blocking=True)
+            return
         for op in plan.ops:
             if events is not None and op.kind == 'conv':
                 e0 = torch.cuda.Event(enable_timing=True)
@@ -357,9 +371,13 @@ def main():
     events = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(events if i % max(args.event_every, 1) == 0 else None)
+        step(events if (i % max(args.event_every, 1) == 0 and not args.graph) else None)
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+    if args.graph:                                      # per-conv events: eager steps outside the timed region
+        for _ in range(max(2, args.steps // max(args.event_every, 1))):
+            step(events)
+        torch.cuda.synchronize()
     assert int(host_count.min()) >= 0, 'an image took the split NMS path; lower --candidates'
 
     # ---- roofline of the dominant kernel (the fused MFMA conv), from the timed region ------
@@ -470,6 +488,7 @@ def main():
                                   f'{MODELS[args.model].get("neck", "YOLOV4Neck")} + YOLOCSPHead, 80 classes) ') +
                                  f'{args.size}x{args.size} {dict(f32="fp32", f16="fp16", bf16="bf16")[args.dtype]} inference, batch {args.batch}/GPU: image -> '
                                  'fused conv path -> decode -> per-class NMS -> detections on host ' +
+                                 ('[one hipGraph replay per step] ' if args.graph else '') +
                                  ('(BASELINE.json configs[1])' if (args.model, args.size, args.batch, args.dtype) == ('yolov4l', 608, 32, 'f32')
                                   else '(not the headline configuration)'),
                         global_batch=args.batch * world, per_gpu_batch=args.batch, input=f'{args.size}x{args.size}',

@@ -555,6 +555,19 @@ int yv4_match_coco_batched(const float* iou, const int64_t* det_off, const int64
                            const uint8_t* is_ignore, const uint8_t* is_crowd, int P, uint8_t* work,
                            int32_t* matched, void* stream);
 
+/* ---- split-K form of yv4_conv_bn_act_fwd for single-image (latency) plans ---------------------------------------
+ * The reference's only published protocol is batch 1 (tools/analysis_tools/benchmark.py:83-109).  There the deep layers
+ * have a handful of output tiles and hundreds of K slices each; this entry splits K over several workgroups per tile
+ * (partials in per-split slabs of `workspace`, added in slab order by a finishing kernel that applies the epilogue:
+ * deterministic, no atomics).  The summation order differs from yv4_conv_bn_act_fwd's, so the two agree to fp32
+ * rounding, not bit for bit.  yv4_conv_splitk_workspace returns the bytes `workspace` must hold (0 and *ksplit = 1
+ * when the layer is not split: the call then forwards to yv4_conv_bn_act_fwd). */
+size_t yv4_conv_splitk_workspace(const yv4_conv_desc* d, int* ksplit);
+int yv4_conv_bn_act_fwd_splitk(const yv4_conv_desc* d, const float* x, const float* w, const float* scale1,
+                               const float* shift1, const float* scale2, const float* shift2,
+                               const float* residual, float* y, float* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* ---- train-side input pipeline (configs/yolov4/yolov4l_coco_mosaic.py:22-69) ----------------------------------
  * Replaces, per batch: Resize(keep_ratio) of 4 source images + MosaicPipeline (mmdet/datasets/pipelines/
  * transforms.py:1906-1983) + the Albu block [PadIfNeeded, RandomCrop, RandomScale, CenterCrop, HorizontalFlip]

@@ -83,6 +83,8 @@ SIGNATURES = {
     'yv4_nhwc_to_nchw': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_conv_bn_act_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp, _vp]),
+    'yv4_conv_splitk_workspace': (_sz, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
+    'yv4_conv_bn_act_fwd_splitk': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'yv4_conv_flops': (C.c_double, [C.POINTER(ConvDesc)]),
     'yv4_conv_pick_tile': (C.c_int, [C.POINTER(ConvDesc)]),
     'yv4_spp_pool_fwd': (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -48,6 +48,12 @@ struct ConvArgs {
   int ys_on, ys_H, ys_W, ys_sh, ys_sw, ys_oh, ys_ow;
   double* stats;   // training: [YV4_STATS_REPLICAS][sum (Cout) | sum of squares (Cout)] of the outputs, or null
   FastDiv fd_hw, fd_wo;   // m / (Ho*Wo), r / Wo (LDS-DMA kernels; set by launch_conv_dma)
+  // split-K (LDS-DMA kernels, single-image plans): workgroup (tile, split) reduces K slices
+  // [split * ks_slices, ...) and stores its RAW partial tile into slab `split` of ws ([ksplit][M][ws_cs]);
+  // splitk_finish_kernel adds the slabs in slab order and applies the epilogue.  ksplit <= 1: off.
+  int ksplit = 0, ks_slices = 0, ws_cs = 0;
+  float* ws = nullptr;
+  FastDiv fd_taps, fd_kw;   // slice -> (chunk, tap), tap -> (kh, kw) at a split's first slice
 };
 
 __device__ __forceinline__ int64_t out_row(const ConvArgs& p, int m) {
@@ -311,6 +317,18 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const f32x16& a
   for (int e = 0; e < 16; ++e) ep[((e & 3) + 8 * (e >> 2) + 4 * h) * kPitch + r] = acc[e];
   const int c4 = (lane & 7) * 4;
   const int co = co_base + c4;
+  if (p.ksplit > 1) {                       // split-K partial: raw accumulators, dense [M][ws_cs] slab (ws_cs % 4 == 0)
+    if (co < p.ws_cs) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = (lane >> 3) + 8 * k;
+        const int m = m_base + row;
+        if (m < p.M)
+          *reinterpret_cast<float4*>(p.y + (int64_t)m * p.ws_cs + co) = *reinterpret_cast<const float4*>(ep + row * kPitch + c4);
+      }
+    }
+    return;
+  }
   if (vec_ok && co + 3 < p.Cout) {
     const float4 s1 = *reinterpret_cast<const float4*>(p.s1 + co);
     const float4 t1 = *reinterpret_cast<const float4*>(p.t1 + co);
@@ -398,11 +416,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
   const unsigned nwg = gridDim.x;
   const unsigned bid = blockIdx.x;
   const unsigned xcd = bid & 7u, q8 = nwg >> 3, rem8 = nwg & 7u;
-  const unsigned tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (bid >> 3);
+  const unsigned tile_s = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (bid >> 3);
+  const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+  const unsigned tile = tile_s / (unsigned)ksplit;          // the splits of one tile are neighbours (same L2)
+  const int split = (int)(tile_s - tile * (unsigned)ksplit);
   const int tile_n = tile % p.tiles_n;
   const int tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
+  if (ksplit > 1) p.y = p.ws + (size_t)split * p.M * p.ws_cs;
 
   const u32x4_t rsA = make_rsrc(p.x, x_bytes);
   const u32x4_t rsB = make_rsrc(p.w, w_bytes);
@@ -451,6 +473,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
   const int ntaps = p.KH * p.KW;
   int s_tap = 0, s_c0 = 0, s_kh = 0, s_kw = 0;
   unsigned s_kb = 0;
+  const int slice0 = ksplit > 1 ? split * p.ks_slices : 0;      // first K slice of this workgroup
+  if (slice0) {
+    const int chunk = fd_div(slice0, p.fd_taps);
+    s_tap = slice0 - chunk * ntaps;
+    s_c0 = chunk * kBK;
+    s_kh = fd_div(s_tap, p.fd_kw);
+    s_kw = s_tap - s_kh * p.KW;
+    s_kb = (unsigned)((s_tap * p.Cin + s_c0) * 4);
+  }
 
 #define YV4_V3_DMA(BUF)                                                             \
   {                                                                                 \
@@ -529,7 +560,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                 \
   }
 
-  const int nk = p.K / kBK;
+  const int nk_all = p.K / kBK;
+  const int nk = ksplit > 1 ? (nk_all - slice0 < p.ks_slices ? nk_all - slice0 : p.ks_slices) : nk_all;
   int issued = 0;        // slices whose DMA has been issued
   int wbuf = 0;          // ring slot the next DMA goes to
 #pragma unroll
@@ -618,7 +650,9 @@ static int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
   p.tiles_n = (p.Cout + BN - 1) / BN;
   p.fd_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
   p.fd_wo = make_fastdiv((unsigned)p.Wo);
-  const long long tiles = (long long)tiles_m * p.tiles_n;
+  p.fd_taps = make_fastdiv((unsigned)(p.KH * p.KW));
+  p.fd_kw = make_fastdiv((unsigned)p.KW);
+  const long long tiles = (long long)tiles_m * p.tiles_n * (p.ksplit > 1 ? p.ksplit : 1);
   if (tiles <= 0 || tiles > 0x7fffffffLL) {
     set_error("conv: grid of %lld tiles out of range", tiles);
     return YV4_E_INVALID;
@@ -913,6 +947,7 @@ static int conv_f32_impl(const yv4_conv_desc* d, const float* x, const float* w,
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.Kw = a.K; a.tiles_n = 0;
   a.ys_on = 0;
   a.stats = nullptr;
+  a.ksplit = 0; a.ks_slices = 0; a.ws_cs = 0; a.ws = nullptr;
 
   const bool uniform = (d->Cin % kBK) == 0;
   // the LDS-DMA kernels address x and w through 32-bit buffer descriptors
@@ -947,6 +982,109 @@ extern "C" int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const
                                    const float* scale2, const float* shift2,
                                    const float* residual, float* y, void* stream) {
   return conv_f32_impl(d, x, w, scale1, shift1, scale2, shift2, residual, y, nullptr, nullptr, stream);
+}
+
+// ---- split-K: the single-image (latency) form of the LDS-DMA kernels ----------------------------------------------
+// At batch 1 the deep layers have a handful of tiles (512 -> 512 3x3 at 19x19: 6 x 8 tiles of 64 x 64 on 256 CUs) and
+// 144 K slices each: the chip idles while 48 workgroups walk K serially.  Splitting K over `ksplit` workgroups per tile
+// fills the CUs; partials go to per-split slabs (plain stores, no atomics) that one small kernel adds IN SLAB ORDER
+// before the usual epilogue, so the result is deterministic (but not bit-identical to the unsplit kernel's summation
+// order: plans use it for N == 1 only, where no cross-batch bit-exactness is claimed).
+namespace yv4 {
+__global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p) {
+  const int c4n = p.ws_cs >> 2;
+  const long long total = (long long)p.M * c4n;
+  const bool has2 = p.s2 != nullptr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / c4n);
+    const int co = (int)(i - (long long)m * c4n) * 4;
+    const float* src = p.ws + (int64_t)m * p.ws_cs + co;
+    const size_t slab = (size_t)p.M * p.ws_cs;
+    float4 a = *reinterpret_cast<const float4*>(src);
+    for (int s = 1; s < p.ksplit; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(src + s * slab);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = co + u;
+      if (c >= p.Cout) continue;
+      float t = v[u] * p.s1[c] + p.t1[c];
+      t = apply_act(t, p.act1, p.slope1);
+      if (p.res) t += p.res[(int64_t)m * p.r_cs + p.r_co + c];
+      if (has2) t = apply_act(t * p.s2[c] + p.t2[c], p.act2, p.slope2);
+      p.y[(int64_t)m * p.y_cs + p.y_co + c] = t;
+    }
+  }
+}
+
+// how many ways to split K for this layer on a 256-CU chip: enough workgroups to give every CU ~2, at least 4 slices
+// per split; 1 = do not split (enough tiles already, or a kernel without the split path)
+static int splitk_choice(const yv4_conv_desc* d, int* tile_out) {
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const int K = d->KH * d->KW * d->Cin;
+  if (d->Cin % kBK != 0 || stem_ok(d, false, false)) return 1;
+  if ((long long)d->N * d->H * d->W * d->x_cstride * 4 >= 0xFFFFFFF0LL || (long long)d->Cout * K * 4 >= 0xFFFFFFF0LL) return 1;
+  const int tile = YV4_TILE_DMA_64x64;
+  const long long tiles = ((M + 63) / 64) * ((d->Cout + 63) / 64);
+  const int nk = K / kBK;
+  static const long long target = [] { const char* e = getenv("YV4_SPLITK_TARGET"); return e ? atoll(e) : 512LL; }();
+  static const int min_slices = [] { const char* e = getenv("YV4_SPLITK_MINSL"); return e ? atoi(e) : 8; }();
+  int ks = 1;
+  while (tiles * ks < target && nk / (ks * 2) >= min_slices && ks < 32) ks *= 2;
+  if (tile_out) *tile_out = tile;
+  return ks;
+}
+}  // namespace yv4
+
+extern "C" size_t yv4_conv_splitk_workspace(const yv4_conv_desc* d, int* ksplit) {
+  if (!d) return 0;
+  const int ks = splitk_choice(d, nullptr);
+  if (ksplit) *ksplit = ks;
+  if (ks <= 1) return 0;
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  return (size_t)ks * (size_t)M * (size_t)((d->Cout + 3) / 4 * 4) * sizeof(float);
+}
+
+extern "C" int yv4_conv_bn_act_fwd_splitk(const yv4_conv_desc* d, const float* x, const float* w, const float* scale1,
+                                          const float* shift1, const float* scale2, const float* shift2,
+                                          const float* residual, float* y, float* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  YV4_REQUIRE(d, "conv splitk: null descriptor");
+  int tile = 0;
+  const int ks = splitk_choice(d, &tile);
+  if (ks <= 1) return yv4_conv_bn_act_fwd(d, x, w, scale1, shift1, scale2, shift2, residual, y, stream);
+  YV4_REQUIRE(x && w && scale1 && shift1 && y && workspace, "conv splitk: null argument");
+  YV4_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), "conv splitk: scale2/shift2 must come together");
+  YV4_REQUIRE(d->x_cstride % 4 == 0 && d->x_coff % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 &&
+              ((uintptr_t)workspace & 15) == 0, "conv splitk: alignment");
+  YV4_REQUIRE(d->x_coff + d->Cin <= d->x_cstride && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_cstride,
+              "conv splitk: view exceeds its pixel stride");
+  const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  YV4_REQUIRE(Ho == d->Ho && Wo == d->Wo, "conv splitk: Ho/Wo do not match the geometry");
+  if (residual) YV4_REQUIRE(d->r_coff >= 0 && d->r_coff + d->Cout <= d->r_cstride, "conv splitk: residual view");
+  YV4_REQUIRE(d->act1 >= 0 && d->act1 <= YV4_ACT_SWISH && d->act2 >= 0 && d->act2 <= YV4_ACT_SWISH, "conv splitk: activation id");
+  YV4_REQUIRE(workspace_bytes >= yv4_conv_splitk_workspace(d, nullptr), "conv splitk: workspace too small");
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  ConvArgs a;
+  a.x = x; a.w = w; a.s1 = scale1; a.t1 = shift1; a.s2 = scale2; a.t2 = shift2; a.res = residual; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff;
+  a.r_cs = d->r_cstride; a.r_co = d->r_coff;
+  a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
+  a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.Kw = a.K; a.tiles_n = 0; a.ys_on = 0; a.stats = nullptr;
+  const int nk = a.K / kBK;
+  a.ksplit = ks; a.ks_slices = (nk + ks - 1) / ks; a.ws_cs = (d->Cout + 3) / 4 * 4; a.ws = workspace;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (int rc = launch_conv_dma<64, 64, 2, 2, 2>(a, s)) return rc;
+  const long long work = M * (a.ws_cs / 4);
+  unsigned g = (unsigned)((work + 255) / 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3(g), dim3(256), 0, s, a);
+  YV4_CHECK_LAUNCH("conv splitk finish");
+  return YV4_OK;
 }
 
 int conv_stats_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w, const float* ones, const float* zeros,

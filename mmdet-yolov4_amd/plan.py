@@ -15,6 +15,7 @@ convs' epilogues; permute+reshape of the pred maps (yolocsp_head.py:264) -> NHWC
 already that layout.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -235,12 +236,32 @@ class Plan:
                     L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), stream),
                     'yv4_conv_bn_act_fwd_h16')
         else:
-            def fn(stream, L=L):
-                check(_lib.lib().yv4_conv_bn_act_fwd(
-                    C.byref(L['d']), L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(), L['t1'].data_ptr(),
-                    L['s2'].data_ptr() if L['s2'] is not None else None,
-                    L['t2'].data_ptr() if L['t2'] is not None else None,
-                    L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), stream), 'yv4_conv_bn_act_fwd')
+            # single-image plans (the reference's benchmark protocol, tools/analysis_tools/benchmark.py:83-109): the
+            # deep layers have too few output tiles for 256 CUs; split their K loop (yv4_conv_bn_act_fwd_splitk).
+            # Batched plans never split, so their results stay bit-identical across batch sizes.
+            ks = C.c_int(1)
+            ws_bytes = 0
+            if x.N == 1 and d.tile == _lib.TILE_AUTO and os.environ.get('YV4_SPLITK', '1') != '0':
+                ws_bytes = int(_lib.lib().yv4_conv_splitk_workspace(C.byref(d), C.byref(ks)))
+            if ws_bytes:
+                self._splitk_bytes = max(getattr(self, '_splitk_bytes', 0), ws_bytes)
+                L['ksplit'] = ks.value
+
+                def fn(stream, L=L):
+                    ws = self._splitk_ws
+                    check(_lib.lib().yv4_conv_bn_act_fwd_splitk(
+                        C.byref(L['d']), L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(), L['t1'].data_ptr(),
+                        L['s2'].data_ptr() if L['s2'] is not None else None,
+                        L['t2'].data_ptr() if L['t2'] is not None else None,
+                        L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), ws.data_ptr(),
+                        ws.numel() * 4, stream), 'yv4_conv_bn_act_fwd_splitk')
+            else:
+                def fn(stream, L=L):
+                    check(_lib.lib().yv4_conv_bn_act_fwd(
+                        C.byref(L['d']), L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(), L['t1'].data_ptr(),
+                        L['s2'].data_ptr() if L['s2'] is not None else None,
+                        L['t2'].data_ptr() if L['t2'] is not None else None,
+                        L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), stream), 'yv4_conv_bn_act_fwd')
         M = x.N * Ho * Wo
         flops = 2.0 * M * Cout * KH * KW * Cin          # algorithmic: real Cin, not the padded one
         es = float(self.esize)
@@ -412,6 +433,8 @@ class Plan:
     def finalize(self):
         for b in self.bufs:
             b.tensor = torch.empty(b.numel, dtype=b.dtype, device=self.device)
+        if getattr(self, '_splitk_bytes', 0):          # one workspace shared by the split-K layers (they run in turn)
+            self._splitk_ws = torch.empty(self._splitk_bytes // 4, dtype=torch.float32, device=self.device)
         if getattr(self, 'post', None) is not None:
             self.post['_alloc']()
         self.finalized = True
