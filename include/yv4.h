@@ -351,6 +351,13 @@ int yv4_spp_pool_fwd_h16(void* buf, int N, int H, int W, int C, int cstride, int
  * with the channel arguments halved. */
 int yv4_conv_wgrad_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* dy,
                        float* dw, void* stream);
+/* Deterministic weight gradient (round 2): same contract as yv4_conv_wgrad / yv4_conv_wgrad_h16 (dw += the weight
+ * gradient, dtype YV4_F32 / YV4_F16 / YV4_BF16 operands), but the chunks of the N*Ho*Wo reduction store their partial
+ * sums to slabs of `workspace` (yv4_conv_wgrad_workspace bytes; 0 = a single chunk, no workspace needed) and a small
+ * kernel adds the slabs to dw in chunk order: run-to-run bit-identical, no float atomics. */
+size_t yv4_conv_wgrad_workspace(const yv4_conv_desc* d, int dtype);
+int yv4_conv_wgrad_det(const yv4_conv_desc* d, int dtype, const void* x, const void* dy, float* dw,
+                       float* workspace, size_t workspace_bytes, void* stream);
 int yv4_bn_train_stats_h16(const void* x, int dtype, int64_t M, int C, int x_cstride, int x_coff,
                            float eps, float momentum, double* work, float* mean, float* invstd,
                            float* running_mean, float* running_var, void* stream);

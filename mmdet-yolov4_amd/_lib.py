@@ -109,6 +109,8 @@ SIGNATURES = {
     'yv4_nms_set_iou_form': (C.c_int, [_i]),
     'yv4_nms_get_iou_form': (C.c_int, []),
     'yv4_conv_wgrad': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    'yv4_conv_wgrad_workspace': (_sz, [C.POINTER(ConvDesc), _i]),
+    'yv4_conv_wgrad_det': (C.c_int, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'yv4_dilate2_fwd': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_bn_train_stats': (C.c_int, [_vp, _i64, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'yv4_bn_act_fwd': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i64, _i, _i, _f, _vp]),

@@ -78,6 +78,10 @@ struct WgradArgs {
   int M, K;
   int tiles_k, rows_per_chunk;
   FastDiv fd_hw, fd_wo;     // m / (Ho*Wo), r / Wo: the per-slice row decode sits inside the pipelined loop
+  // deterministic form: chunk c of the M reduction stores its partial dW to slab c of ws ([chunks][Cout][K], plain
+  // stores); wgrad_reduce_kernel then adds the slabs to dw in chunk order.  ws == nullptr: float atomics into dw.
+  float* ws = nullptr;
+  long long ws_stride = 0;
 };
 
 constexpr int kWgRows = 32;   // reduction rows per slice
@@ -186,7 +190,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p, unsigne
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (co < p.Cout) atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[e]);
+      if (co < p.Cout) {
+        if (p.ws) p.ws[(size_t)blockIdx.y * p.ws_stride + (size_t)co * p.K + kcol] = acc[e];
+        else atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[e]);
+      }
     }
   }
 }
@@ -364,9 +371,56 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(WgradArgs p, uns
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int co = co0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h5;
-        if (co < p.Cout) atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[a][b][e]);
+        if (co < p.Cout) {
+          if (p.ws) p.ws[(size_t)blockIdx.y * p.ws_stride + (size_t)co * p.K + kcol] = acc[a][b][e];
+          else atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[a][b][e]);
+        }
       }
     }
+}
+
+// dw[i] += sum over chunks of slab_c[i], in a FIXED order: the deterministic tail of the weight gradient.
+// A workgroup owns 16 float4 columns; its 16 chunk lanes q each add the slabs c = q, q + 16, q + 32, ... in ascending
+// order (independent loads, 4 in flight), the 16 lane sums are then added in lane order.  (One thread per column
+// walking all chunks serially was latency-bound on the 1x1 layers: 361 chunks of a 64 KB dW took 100 us.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int chunks, long long stride,
+                                                           long long n, float* __restrict__ dw) {
+  __shared__ float4 part[16][16];
+  const long long n4 = n >> 2;
+  const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const long long col = (long long)blockIdx.x * 16 + cl;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < n4) {
+    const float* base = ws + 4 * col;
+    int c = q;
+    for (; c + 48 < chunks; c += 64) {
+      const float4 b0 = *reinterpret_cast<const float4*>(base + (size_t)c * stride);
+      const float4 b1 = *reinterpret_cast<const float4*>(base + (size_t)(c + 16) * stride);
+      const float4 b2 = *reinterpret_cast<const float4*>(base + (size_t)(c + 32) * stride);
+      const float4 b3 = *reinterpret_cast<const float4*>(base + (size_t)(c + 48) * stride);
+      a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+      a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+      a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+      a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+    }
+    for (; c < chunks; c += 16) {
+      const float4 b = *reinterpret_cast<const float4*>(base + (size_t)c * stride);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+  }
+  part[q][cl] = a;
+  __syncthreads();
+  if (q == 0 && col < n4) {
+    float4 t = part[0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 b = part[k][cl];
+      t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+    }
+    float4 d = reinterpret_cast<float4*>(dw)[col];
+    d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+    reinterpret_cast<float4*>(dw)[col] = d;
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -955,7 +1009,39 @@ using namespace yv4;
 // 16-bit MFMA one (YV4_WGRAD_WIDEN=1 in the environment)
 static const bool g_wgrad_widen = [] { const char* e = getenv("YV4_WGRAD_WIDEN"); return e && e[0] == '1'; }();
 
-static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const void* dy, float* dw, void* stream) {
+// split of the M reduction into chunks (shared by the launch and by yv4_conv_wgrad_workspace)
+static void wgrad_chunks(const yv4_conv_desc* d, int dtype, long long* chunks, long long* rows) {
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const int K = d->KH * d->KW * d->Cin;
+  if (dtype != YV4_F32 && !g_wgrad_widen) {
+    const long long tl = (long long)((K + kWhTile - 1) / kWhTile) * ((d->Cout + kWhTile - 1) / kWhTile);
+    static const int wg_target = [] { const char* e = getenv("YV4_WGRAD_WGS"); return e ? atoi(e) : 1024; }();
+    static const int min_slices = [] { const char* e = getenv("YV4_WGRAD_MINSL"); return e ? atoi(e) : 16; }();
+    long long ch = (wg_target + tl - 1) / tl;             // default: ~2 rounds of 2 workgroups per CU
+    const long long mx = (M + min_slices * kWhRows - 1) / (min_slices * kWhRows);   // at least min_slices per chunk
+    if (ch > mx) ch = mx;
+    if (ch < 1) ch = 1;
+    if (ch > 65535) ch = 65535;
+    long long rw = (M + ch - 1) / ch;
+    rw = (rw + kWhRows - 1) / kWhRows * kWhRows;
+    *rows = rw;
+    *chunks = (M + rw - 1) / rw;
+    return;
+  }
+  const long long tiles = (long long)((K + 63) / 64) * ((d->Cout + 63) / 64);
+  long long ch = (256 * 4 + tiles - 1) / tiles;            // ~4 workgroups per CU, at least 8 slices each
+  const long long mx = (M + 8 * kWgRows - 1) / (8 * kWgRows);
+  if (ch > mx) ch = mx;
+  if (ch < 1) ch = 1;
+  if (ch > 65535) ch = 65535;
+  long long rw = (M + ch - 1) / ch;
+  rw = (rw + kWgRows - 1) / kWgRows * kWgRows;
+  *rows = rw;
+  *chunks = (M + rw - 1) / rw;
+}
+
+static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const void* dy, float* dw, void* stream,
+                      float* ws = nullptr, size_t ws_bytes = 0) {
   YV4_REQUIRE(d && x && dy && dw, "wgrad: null argument");
   YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "wgrad: dtype must be f32, f16 or bf16");
   const int al = dtype == YV4_F32 ? 4 : 8;
@@ -979,23 +1065,32 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin;
   a.fd_hw = make_fastdiv((unsigned)(d->Ho * d->Wo));
   a.fd_wo = make_fastdiv((unsigned)d->Wo);
+  long long ch = 1, rw = M;
+  wgrad_chunks(d, dtype, &ch, &rw);
+  a.rows_per_chunk = (int)rw;
+  const long long dw_elems = (long long)a.Cout * a.K;
+  if (ws && ch > 1) {
+    YV4_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)dw & 15) == 0 && dw_elems % 4 == 0,
+                "wgrad: workspace / dw must be 16-byte aligned and Cout*K a multiple of 4");
+    YV4_REQUIRE(ws_bytes >= (size_t)ch * dw_elems * sizeof(float), "wgrad: workspace too small (%zu bytes for %lld chunks)",
+                ws_bytes, ch);
+    a.ws = ws;
+    a.ws_stride = dw_elems;
+  }
+  auto finish = [&]() -> int {
+    if (!a.ws) return YV4_OK;
+    const long long g = (dw_elems / 4 + 15) / 16;
+    if (g > 0x7fffffffLL) { set_error("wgrad: dW too large"); return YV4_E_INVALID; }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a.ws, (int)ch,
+                       a.ws_stride, dw_elems, dw);
+    YV4_CHECK_LAUNCH("conv_wgrad reduce");
+    return YV4_OK;
+  };
   if (dtype != YV4_F32 && !g_wgrad_widen) {
     // 16-bit MFMA form: 128 x 128 tiles of dW, 64-row slices
     a.tiles_k = (a.K + kWhTile - 1) / kWhTile;
     const int tc = (a.Cout + kWhTile - 1) / kWhTile;
     const long long tl = (long long)a.tiles_k * tc;
-    static const int wg_target = [] { const char* e = getenv("YV4_WGRAD_WGS"); return e ? atoi(e) : 1024; }();
-    static const int min_slices = [] { const char* e = getenv("YV4_WGRAD_MINSL"); return e ? atoi(e) : 16; }();
-    long long ch = (wg_target + tl - 1) / tl;             // default: ~2 rounds of 2 workgroups per CU
-    const long long mx = (M + min_slices * kWhRows - 1) / (min_slices * kWhRows);   // at least min_slices (16) per chunk: fewer, longer chunks
-    // amortise a workgroup's fixed cost and its 16 K atomics on the shallow (1x1) layers
-    if (ch > mx) ch = mx;
-    if (ch < 1) ch = 1;
-    if (ch > 65535) ch = 65535;
-    long long rw = (M + ch - 1) / ch;
-    rw = (rw + kWhRows - 1) / kWhRows * kWhRows;
-    a.rows_per_chunk = (int)rw;
-    ch = (M + rw - 1) / rw;
     const size_t ldsh = (size_t)2 * 2 * kWhRows * 256;
     static LdsAttrOnce once_b, once_h;
     if (int rc = ensure_dyn_lds(once_b, reinterpret_cast<const void*>(conv_wgrad_h16_kernel<true>), ldsh, "conv_wgrad_h16")) return rc;
@@ -1007,26 +1102,17 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
       hipLaunchKernelGGL(conv_wgrad_h16_kernel<false>, dim3((unsigned)tl, (unsigned)ch), dim3(256), ldsh,
                          reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
     YV4_CHECK_LAUNCH("conv_wgrad_h16");
-    return YV4_OK;
+    return finish();
   }
   a.tiles_k = (a.K + 63) / 64;
   const int tiles_c = (a.Cout + 63) / 64;
   const long long tiles = (long long)a.tiles_k * tiles_c;
-  // enough chunks of the reduction to fill ~4 workgroups per CU, at least 8 slices each
-  long long chunks = (256 * 4 + tiles - 1) / tiles;
-  const long long max_chunks = (M + 8 * kWgRows - 1) / (8 * kWgRows);
-  if (chunks > max_chunks) chunks = max_chunks;
-  if (chunks < 1) chunks = 1;
-  if (chunks > 65535) chunks = 65535;
-  long long rows = (M + chunks - 1) / chunks;
-  rows = (rows + kWgRows - 1) / kWgRows * kWgRows;
-  a.rows_per_chunk = (int)rows;
-  chunks = (M + rows - 1) / rows;
+  const long long chunks = ch;
   const size_t lds = (size_t)4 * kWgRows * 64 * es;
   YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(conv_wgrad_kernel<T>, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds,
                                            reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db));
   YV4_CHECK_LAUNCH("conv_wgrad");
-  return YV4_OK;
+  return finish();
 }
 
 // phase: 0 = sums + finalize (one rank), 1 = sums only (SyncBN: the caller all-reduces `work`)
@@ -1119,6 +1205,22 @@ extern "C" int yv4_conv_wgrad_h16(const yv4_conv_desc* d, int dtype, const void*
                                   void* stream) {
   YV4_REQUIRE(dtype == YV4_F16 || dtype == YV4_BF16, "wgrad_h16: dtype must be YV4_F16 or YV4_BF16");
   return wgrad_impl(d, dtype, x, dy, dw, stream);
+}
+
+// Deterministic weight gradient: the chunks of the M reduction store their partials to slabs of `workspace` and one
+// small kernel adds them to dw in chunk order -- same accumulate-into-dw contract as yv4_conv_wgrad[_h16], run-to-run
+// bit-identical, and the partial exchange moves at store speed instead of the ~1.3 TB/s of float atomics.
+extern "C" size_t yv4_conv_wgrad_workspace(const yv4_conv_desc* d, int dtype) {
+  if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+  long long ch = 1, rw = 0;
+  wgrad_chunks(d, dtype, &ch, &rw);
+  if (ch <= 1) return 0;
+  return (size_t)ch * (size_t)d->Cout * (size_t)(d->KH * d->KW * d->Cin) * sizeof(float);
+}
+extern "C" int yv4_conv_wgrad_det(const yv4_conv_desc* d, int dtype, const void* x, const void* dy, float* dw,
+                                  float* workspace, size_t workspace_bytes, void* stream) {
+  YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "wgrad_det: dtype must be f32, f16 or bf16");
+  return wgrad_impl(d, dtype, x, dy, dw, stream, workspace, workspace_bytes);
 }
 
 extern "C" int yv4_dilate2_fwd(const float* src, float* dst, int N, int H, int W, int C, int src_cstride, int src_coff,

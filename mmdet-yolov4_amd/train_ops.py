@@ -17,6 +17,7 @@ mmdet/models/backbones/darknetcsp.py:15-64, mmdet/ops/mish_cuda/mish.py:18-36).
                                                        input: SURVEY Q17)
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -245,6 +246,23 @@ def _direct_grad_target(weight, cp):
     return g
 
 
+# YV4_WGRAD_ATOMIC=1: the round-1 weight gradient (split-M partials added with float atomics: not run-to-run
+# deterministic); default: partials in a workspace + ordered reduction (yv4_conv_wgrad_det)
+_WGRAD_ATOMIC = os.environ.get('YV4_WGRAD_ATOMIC', '0') == '1'
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(nbytes, device):
+    """One growing fp32 scratch per device, shared by all layers (kernels on one stream run in order)."""
+    if not nbytes:
+        return None
+    ws = _WGRAD_WS.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _WGRAD_WS[device] = ws
+    return ws
+
+
 class ConvFunction(torch.autograd.Function):
     """``dtype``: torch.float32, or torch.float16 / torch.bfloat16 -- then x, y and their gradients are
     that type (fp32 accumulation in every kernel) while ``weight`` and its gradient stay fp32 (the
@@ -292,12 +310,19 @@ class ConvFunction(torch.autograd.Function):
             d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, cp, Ho, Wo, Cout
             d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
             d.x_cstride, d.y_cstride = cp, dy_cs
-            if h16:
-                check(L.yv4_conv_wgrad_h16(C.byref(d), code, x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), stream_ptr()),
-                      'yv4_conv_wgrad_h16')
+            if _WGRAD_ATOMIC:
+                if h16:
+                    check(L.yv4_conv_wgrad_h16(C.byref(d), code, x.data_ptr(), dy.data_ptr(), dwp.data_ptr(),
+                                               stream_ptr()), 'yv4_conv_wgrad_h16')
+                else:
+                    check(L.yv4_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), stream_ptr()),
+                          'yv4_conv_wgrad')
             else:
-                check(L.yv4_conv_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), stream_ptr()),
-                      'yv4_conv_wgrad')
+                # deterministic form: partial sums of the reduction chunks in a workspace, added in chunk order
+                need = int(L.yv4_conv_wgrad_workspace(C.byref(d), code))
+                ws = _wgrad_workspace(need, x.device)
+                check(L.yv4_conv_wgrad_det(C.byref(d), code, x.data_ptr(), dy.data_ptr(), dwp.data_ptr(),
+                                           ws.data_ptr() if need else None, need, stream_ptr()), 'yv4_conv_wgrad_det')
             if target is None:
                 dw = dwp.view(Cout, KH, KW, cp)[..., :Cin].permute(0, 3, 1, 2)
                 if cp != Cin:

@@ -302,3 +302,51 @@ def test_pack_weight_forms(gpu_device, dtype, layout):
             for tb, lb in (((1, 1, 1), [1]), ((2, -2, 2), [2, 0])):
                 got, _ = T.packed_weight(w, dtype, taps=(ta, tb))
                 assert torch.equal(got, pack_ref(w[:, :, la][:, :, :, lb].permute(1, 0, 2, 3)))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_wgrad_deterministic_form(gpu_device, dtype):
+    """yv4_conv_wgrad_det: the chunks of the N*Ho*Wo reduction go to workspace slabs that are added to dw in chunk
+    order.  Same accumulate-into-dw contract and the same value (fp32 reassociation apart) as the atomic form, and
+    run-to-run bit-identical where the atomic form is not guaranteed to be."""
+    import ctypes
+    from mmdet_yolov4_amd import _lib
+    from mmdet_yolov4_amd._lib import ConvDesc
+    lib = _lib.lib()
+    torch.manual_seed(0)
+    N, H, W, Cin, Cout, k = 6, 38, 38, 64, 72, 3
+    code = 0 if dtype == torch.float32 else 2
+    x = torch.randn(N, H, W, Cin, device=gpu_device).to(dtype)
+    dy = torch.randn(N, H, W, Cout, device=gpu_device).to(dtype)
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, H, W, Cout
+    d.KH = d.KW = k
+    d.stride, d.pad = 1, 1
+    d.x_cstride, d.y_cstride = Cin, Cout
+    need = int(lib.yv4_conv_wgrad_workspace(ctypes.byref(d), code))
+    assert need > 0 and need % (Cout * k * k * Cin * 4) == 0                       # several chunks
+    ws = torch.empty(need // 4, device=gpu_device)
+    s = torch.cuda.current_stream().cuda_stream
+    base = torch.randn(Cout, k * k * Cin, device=gpu_device)                       # dw is accumulated into
+    outs = []
+    for _ in range(3):
+        dw = base.clone()
+        _lib.check(lib.yv4_conv_wgrad_det(ctypes.byref(d), code, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                          need, s), 'wgrad_det')
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    dwa = base.clone()
+    if dtype == torch.float32:
+        _lib.check(lib.yv4_conv_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dwa.data_ptr(), s), 'wgrad')
+    else:
+        _lib.check(lib.yv4_conv_wgrad_h16(ctypes.byref(d), code, x.data_ptr(), dy.data_ptr(), dwa.data_ptr(), s), 'wgrad')
+    ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (Cout, Cin, k, k), dy.double().permute(0, 3, 1, 2),
+                                      stride=1, padding=1).permute(0, 2, 3, 1).reshape(Cout, -1) + base.double()
+    scale = float(ref.abs().max())
+    assert float((outs[0].double() - ref).abs().max()) <= 2e-5 * scale
+    assert float((outs[0] - dwa).abs().max()) <= 2e-5 * scale
+    # too small a workspace is refused, none at all falls back to the atomic form
+    assert lib.yv4_conv_wgrad_det(ctypes.byref(d), code, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), 64, s) != 0
+    dwn = base.clone()
+    _lib.check(lib.yv4_conv_wgrad_det(ctypes.byref(d), code, x.data_ptr(), dy.data_ptr(), dwn.data_ptr(), None, 0, s), 'x')
+    assert float((dwn - dwa).abs().max()) <= 2e-5 * scale

@@ -15,6 +15,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--chain', type=int, default=10)
     ap.add_argument('--filter', default='')
+    ap.add_argument('--det', action='store_true', help='the deterministic form (workspace slabs + ordered reduction)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = pkg._lib.lib()
@@ -36,12 +37,17 @@ def main():
         d.KH = d.KW = k
         d.stride, d.pad = s, pad
         d.x_cstride, d.y_cstride = cp, co
+        need = int(lib.yv4_conv_wgrad_workspace(C.byref(d), 2)) if a.det else 0
+        ws = torch.empty(max(need // 4, 4), device=dev)
         ts = []
         for r in range(4):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.chain):
-                rc = lib.yv4_conv_wgrad_h16(C.byref(d), 2, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), stream)
+                if a.det:
+                    rc = lib.yv4_conv_wgrad_det(C.byref(d), 2, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), need, stream)
+                else:
+                    rc = lib.yv4_conv_wgrad_h16(C.byref(d), 2, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), stream)
             e1.record()
             torch.cuda.synchronize()
             assert rc == 0, lib.yv4_last_error()
