@@ -30,7 +30,7 @@ constexpr int kC3PA = kC3ARows / 64;
 constexpr int kC3ZeroRow = 304;     // any row in [258, 320): never written with data
 constexpr int kC3NB = 4;            // weight ring slots
 
-template <bool BF16, int BN>
+template <bool BF16, int BN, bool PP>
 __global__ __launch_bounds__(kC3Threads, 2) void conv3x3_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes) {
   typedef typename Elem<BF16>::V8 V8;
   static_assert(BN == 128 || BN == 64, "BN is 128 or 64");
@@ -201,6 +201,48 @@ __global__ __launch_bounds__(kC3Threads, 2) void conv3x3_h16_kernel(ConvArgsH p,
 
 #define YV4_C3_WAIT(NEWER) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEWER) : "memory")
 
+  // ---- ping-pong form (PP): the 16 fragments of a stage are read into registers in a LOAD phase, the 16 MFMAs run in
+  // the next phase, two barriers per stage, and waves 4-7 run one phase behind waves 0-3 (one extra barrier up front):
+  // on every SIMD one wave is in its MFMA phase while its partner reads LDS and issues DMA (MI355X_MICROARCH.md "Two
+  // waves per SIMD"; the 256^2 8-phase GEMM template of cdna_hip_programming.md is built the same way).  Reads of a
+  // stage are retired (lgkmcnt(0)) BEFORE the barrier that ends their phase, so the DMA the other group issues one
+  // phase later into the same ring slot cannot overtake them.
+  V8 fa4[4][TM], fb4[4][TN];
+#define YV4_C3_LOAD(KW, ABUF, BSLOT, MK)                                                            \
+  {                                                                                                 \
+    const char* as_ = As + (ABUF) * (kC3ARows * kRowB);                                             \
+    const char* bs_ = Bs + (BSLOT) * (BN * kRowB);                                                  \
+    unsigned ar[TM];                                                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+        ar[i] = ((MK[i] >> (KW)) & 1u) ? a_rd[i][KW] : zero_rd;                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
+          fa4[j][i] = *reinterpret_cast<const V8*>(as_ + (ar[i] ^ (unsigned)(j << 5)));             \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                \
+          fb4[j][i] = *reinterpret_cast<const V8*>(bs_ + (b_rd[i] ^ (unsigned)(j << 5)));           \
+    }                                                                                               \
+  }
+#define YV4_C3_MFMA()                                                                               \
+  {                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
+        _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                           \
+            acc[i][jn] = Elem<BF16>::mfma(fa4[j][i], fb4[j][jn], acc[i][jn]);                       \
+  }
+#define YV4_C3_PP_STAGE(KW, NEWER)                                                                  \
+  {                                                                                                 \
+    YV4_C3_ISSUE();                                                                                 \
+    YV4_C3_LOAD(KW, ab, (t0 + (KW)) & 3, mk3);                                                      \
+    YV4_C3_WAIT(NEWER);                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                  \
+    YV4_C3_MFMA();                                                                                  \
+    __builtin_amdgcn_s_setprio(0);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    __builtin_amdgcn_s_barrier();                                                                   \
+  }
+
   // prologue: stages 0, 1, 2 in flight, then wait for stage 0 (weights 0 + activation group 0; newer: weights 1, 2)
   YV4_C3_ISSUE();
   YV4_C3_ISSUE();
@@ -208,6 +250,21 @@ __global__ __launch_bounds__(kC3Threads, 2) void conv3x3_h16_kernel(ConvArgsH p,
   YV4_C3_WAIT(2 * PB);
   __builtin_amdgcn_s_barrier();
 
+  if (PP) {
+    if (wm >= 2) __builtin_amdgcn_s_barrier();         // waves 4-7 run one phase behind waves 0-3
+    for (int g = 0; g < G; ++g) {
+      const int kh = g - 3 * (g / 3);
+      unsigned mk3[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) mk3[i] = mask9[i] >> (3 * kh);
+      const int ab = g & 1;
+      const int t0 = 3 * g;
+      YV4_C3_PP_STAGE(0, 2 * PB + kC3PA);
+      YV4_C3_PP_STAGE(1, 2 * PB + kC3PA);
+      YV4_C3_PP_STAGE(2, 2 * PB);
+    }
+    if (wm < 2) __builtin_amdgcn_s_barrier();          // same number of barriers for both halves
+  } else
   for (int g = 0; g < G; ++g) {
     const int kh = g - 3 * (g / 3);
     unsigned mk3[TM];
@@ -239,6 +296,9 @@ __global__ __launch_bounds__(kC3Threads, 2) void conv3x3_h16_kernel(ConvArgsH p,
     if (!(p.ablate & 8)) YV4_C3_WAIT(2 * PB);
     if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
   }
+#undef YV4_C3_PP_STAGE
+#undef YV4_C3_MFMA
+#undef YV4_C3_LOAD
 #undef YV4_C3_ISSUE
 #undef YV4_C3_COMPUTE
 #undef YV4_C3_WAIT
@@ -292,7 +352,7 @@ __global__ __launch_bounds__(kC3Threads, 2) void conv3x3_h16_kernel(ConvArgsH p,
   }
 }
 
-template <bool BF16, int BN>
+template <bool BF16, int BN, bool PP>
 static int launch_c3(const ConvArgsH& a, hipStream_t stream) {
   constexpr size_t lds = (size_t)(2 * kC3ARows + kC3NB * BN) * 128;
   ConvArgsH p = a;
@@ -306,7 +366,7 @@ static int launch_c3(const ConvArgsH& a, hipStream_t stream) {
     return YV4_E_INVALID;
   }
   const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 2, wb = (long long)p.Cout * p.Kw * 2;
-  auto kern = conv3x3_h16_kernel<BF16, BN>;
+  auto kern = conv3x3_h16_kernel<BF16, BN, PP>;
   static LdsAttrOnce once;
   if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), lds, "conv3x3_h16")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kC3Threads), lds, stream, p, (unsigned)xb, (unsigned)wb);
@@ -322,8 +382,14 @@ bool conv3x3_h16_applies(const ConvArgsH& a) {
 
 int conv3x3_h16_launch(const ConvArgsH& a, bool bf16, int tile, hipStream_t s) {
   const bool wide = tile == YV4_HTILE_C3_256x128 || (tile != YV4_HTILE_C3_256x64 && a.Cout > 64);
-  if (bf16) return wide ? launch_c3<true, 128>(a, s) : launch_c3<true, 64>(a, s);
-  return wide ? launch_c3<false, 128>(a, s) : launch_c3<false, 64>(a, s);
+  // YV4_C3_PP=0: the lock-step form (all eight waves in the same phase), kept for A/B measurement
+  static const bool pp = [] { const char* e = getenv("YV4_C3_PP"); return !(e && e[0] == '0'); }();
+  if (pp) {
+    if (bf16) return wide ? launch_c3<true, 128, true>(a, s) : launch_c3<true, 64, true>(a, s);
+    return wide ? launch_c3<false, 128, true>(a, s) : launch_c3<false, 64, true>(a, s);
+  }
+  if (bf16) return wide ? launch_c3<true, 128, false>(a, s) : launch_c3<true, 64, false>(a, s);
+  return wide ? launch_c3<false, 128, false>(a, s) : launch_c3<false, 64, false>(a, s);
 }
 
 }  // namespace yv4
