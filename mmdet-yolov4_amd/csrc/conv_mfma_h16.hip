@@ -339,6 +339,19 @@ static bool prefer_c3(const ConvArgsH& a) {
   return tiles >= 100;
 }
 
+// conv1x1_ws_h16.hip
+bool conv1x1_ws_applies(const ConvArgsH& a);
+int conv1x1_ws_launch(const ConvArgsH& a, bool bf16, hipStream_t s);
+
+// The weight-stationary pointwise kernel takes the 1x1 layers in its domain that give each of its persistent waves
+// at least YV4_WS_MINSTRIPS strips of 32 pixels (YV4_WS=0 switches it off).
+static bool prefer_ws(const ConvArgsH& a) {
+  static const int mode = [] { const char* e = getenv("YV4_WS"); return e ? atoi(e) : 1; }();
+  static const int min_strips = [] { const char* e = getenv("YV4_WS_MINSTRIPS"); return e ? atoi(e) : 2; }();
+  if (!mode || !conv1x1_ws_applies(a)) return false;
+  return ((long long)a.M + 31) / 32 >= (long long)min_strips * 2048;
+}
+
 static int pick_tile_h16(long long M, int Cout, long long K) {
   // From the per-layer table of tools/conv_bench.py --dtype bf16 (YOLOv4-L, batch 32; after the prologue /
   // epilogue work of round 1 the 128x64 tile -- three workgroups per CU -- is the best or within 2 % of the best
@@ -360,6 +373,8 @@ extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
     a.Cin = d->Cin; a.Cout = d->Cout; a.ys_on = 0; a.M = (int)((long long)d->N * d->Ho * d->Wo);
     if (prefer_c3(a)) return d->Cout > 64 ? YV4_HTILE_C3_256x128 : YV4_HTILE_C3_256x64;
+    a.K = a.Kw = d->KH * d->KW * d->Cin; a.res = nullptr; a.out_f32 = 0;
+    if (prefer_ws(a)) return YV4_HTILE_WS_1x1;
   }
   return pick_tile_h16((long long)d->N * d->Ho * d->Wo, d->Cout, (long long)d->KH * d->KW * d->Cin);
 }
@@ -413,6 +428,10 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   const bool c3_id = d->tile == YV4_HTILE_C3_256x128 || d->tile == YV4_HTILE_C3_256x64;
   if (c3_id) YV4_REQUIRE(conv3x3_h16_applies(a), "conv h16: the C3 tiles need a 3x3 / stride 1 / pad 1 conv with Cin %% 64 == 0, Cout >= 64");
   if (c3_id || (d->tile == YV4_TILE_AUTO && prefer_c3(a))) return conv3x3_h16_launch(a, dtype == YV4_BF16, d->tile, s);
+  if (d->tile == YV4_HTILE_WS_1x1)
+    YV4_REQUIRE(conv1x1_ws_applies(a), "conv h16: the weight-stationary tile needs a 1x1 / stride 1 conv with Cin 64, 128 or 256, "
+                "Cout >= 32, 16-bit output and no residual");
+  if (d->tile == YV4_HTILE_WS_1x1 || (d->tile == YV4_TILE_AUTO && prefer_ws(a))) return conv1x1_ws_launch(a, dtype == YV4_BF16, s);
   const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);
 }

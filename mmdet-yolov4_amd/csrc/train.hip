@@ -659,109 +659,129 @@ struct BnArgs {
   int publish;       // the apply pass writes dgamma / dbeta from `sums` (not when `sums` were all-reduced)
 };
 
-// Elementwise passes use the reductions' thread map too: a thread keeps ONE channel quad (its
+// Elementwise passes use the reductions' thread map too: a thread keeps ONE channel group of V channels (its
 // mean / invstd / gamma / beta live in registers) and walks rows -- no per-element index division,
-// kBnUnroll independent row loads in flight.
-template <typename T>
+// kBnUnroll independent row loads in flight.  V = 4 channels per thread (V = 8 for 16-bit rows: YV4_BN_VEC8=1).
+template <typename T, int V> struct RowVec {
+  typedef T raw __attribute__((ext_vector_type(V)));
+  static __device__ __forceinline__ raw ld(const T* p) { return *reinterpret_cast<const raw*>(p); }
+  static __device__ __forceinline__ void st(T* p, const float (&v)[V]) {
+    raw o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = (T)v[k];
+    *reinterpret_cast<raw*>(p) = o;
+  }
+  static __device__ __forceinline__ raw zero() {
+    raw o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = (T)0.f;
+    return o;
+  }
+};
+
+template <typename T, int V>
 __global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_fwd_kernel(BnArgs p) {
+  typedef RowVec<T, V> RV;
   const T* px = reinterpret_cast<const T*>(p.x);
   const T* pres = reinterpret_cast<const T*>(p.res);
   T* py = reinterpret_cast<T*>(p.y);
-  const int C4 = p.C >> 2;
-  const RedMap mp = red_map(C4);
+  const int CV = p.C / V;
+  const RedMap mp = red_map(CV);
   const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
   const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
   if (!mp.active) return;
-  for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
-    const int c = cq * 4;
-    const float4 mu = *reinterpret_cast<const float4*>(p.mean + c);
-    const float4 is = *reinterpret_cast<const float4*>(p.invstd + c);
-    const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c);
-    const float4 be = *reinterpret_cast<const float4*>(p.beta + c);
-    // z = x * a + b
-    const float4 sa = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
+  for (int cq = mp.cq0; cq < CV; cq += mp.cq_step) {
+    const int c = cq * V;
+    float mu[V], sa[V], be[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {       // z = (x - mu) * sa + be
+      mu[k] = p.mean[c + k]; sa[k] = p.invstd[c + k] * p.gamma[c + k]; be[k] = p.beta[c + k];
+    }
     for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnUnroll) {
-      float4 v[kBnUnroll], rs[kBnUnroll];
+      typename RV::raw v[kBnUnroll], rs[kBnUnroll];
 #pragma unroll
       for (int u = 0; u < kBnUnroll; ++u) {
         const int64_t row = rr + (int64_t)u * mp.rstep;
         const bool ok = row < r1;
-        v[u] = ok ? El<T>::ld4(px + row * p.x_cs + p.x_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        rs[u] = (ok && pres) ? El<T>::ld4(pres + row * p.r_cs + p.r_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = ok ? RV::ld(px + row * p.x_cs + p.x_co + c) : RV::zero();
+        rs[u] = (ok && pres) ? RV::ld(pres + row * p.r_cs + p.r_co + c) : RV::zero();
       }
 #pragma unroll
       for (int u = 0; u < kBnUnroll; ++u) {
         const int64_t row = rr + (int64_t)u * mp.rstep;
         if (row >= r1) continue;
-        float4 o;
-        o.x = apply_act((v[u].x - mu.x) * sa.x + be.x, p.act, p.slope) + rs[u].x;
-        o.y = apply_act((v[u].y - mu.y) * sa.y + be.y, p.act, p.slope) + rs[u].y;
-        o.z = apply_act((v[u].z - mu.z) * sa.z + be.z, p.act, p.slope) + rs[u].z;
-        o.w = apply_act((v[u].w - mu.w) * sa.w + be.w, p.act, p.slope) + rs[u].w;
-        El<T>::st4(py + row * p.y_cs + p.y_co + c, o);
+        float o[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = apply_act(((float)v[u][k] - mu[k]) * sa[k] + be[k], p.act, p.slope) + (float)rs[u][k];
+        RV::st(py + row * p.y_cs + p.y_co + c, o);
       }
     }
   }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256, YV4_BN_RED_WAVES) void bn_act_bwd_reduce_kernel(BnArgs p) {
+  typedef RowVec<T, V> RV;
   extern __shared__ double part[];   // [2][C]: dbeta | dgamma
   const T* px = reinterpret_cast<const T*>(p.x);
   const T* pdy = reinterpret_cast<const T*>(p.dy);
-  const int C4 = p.C >> 2;
+  const int CV = p.C / V;
   for (int i = threadIdx.x; i < 2 * p.C; i += 256) part[i] = 0.0;
   __syncthreads();
-  const RedMap mp = red_map(C4);
+  const RedMap mp = red_map(CV);
   const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
   const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
   if (mp.active) {
-    for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
-      const int c = cq * 4;
-      const float mu[4] = {p.mean[c], p.mean[c + 1], p.mean[c + 2], p.mean[c + 3]};
-      const float is[4] = {p.invstd[c], p.invstd[c + 1], p.invstd[c + 2], p.invstd[c + 3]};
-      const float ga[4] = {p.gamma[c], p.gamma[c + 1], p.gamma[c + 2], p.gamma[c + 3]};
-      const float be[4] = {p.beta[c], p.beta[c + 1], p.beta[c + 2], p.beta[c + 3]};
+    for (int cq = mp.cq0; cq < CV; cq += mp.cq_step) {
+      const int c = cq * V;
+      float mu[V], is[V], ga[V], be[V];
       // fp32 running sums over this thread's rows (at most rows_per_block / rows-per-pass, a few hundred terms):
       // double registers here cost a wave of occupancy (135 -> 119 VGPRs) and 35 % of the kernel's speed
-      float db[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0};
+      float db[V], dg[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        mu[k] = p.mean[c + k]; is[k] = p.invstd[c + k]; ga[k] = p.gamma[c + k]; be[k] = p.beta[c + k];
+        db[k] = 0.f; dg[k] = 0.f;
+      }
       for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnRedUnroll) {
-        float4 xv[kBnRedUnroll], gv[kBnRedUnroll];
+        typename RV::raw xv[kBnRedUnroll], gv[kBnRedUnroll];
 #pragma unroll
         for (int u = 0; u < kBnRedUnroll; ++u) {
           const int64_t row = rr + (int64_t)u * mp.rstep;
           const bool ok = row < r1;
-          xv[u] = ok ? El<T>::ld4(px + row * p.x_cs + p.x_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-          gv[u] = ok ? El<T>::ld4(pdy + row * p.dy_cs + p.dy_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          xv[u] = ok ? RV::ld(px + row * p.x_cs + p.x_co + c) : RV::zero();
+          gv[u] = ok ? RV::ld(pdy + row * p.dy_cs + p.dy_co + c) : RV::zero();   // zero beyond r1 -> contributes nothing
         }
 #pragma unroll
         for (int u = 0; u < kBnRedUnroll; ++u) {
-          const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-          const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};   // zero beyond r1 -> contributes nothing
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float xhat = (xs[k] - mu[k]) * is[k];
-            const float g = gs[k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
+          for (int k = 0; k < V; ++k) {
+            const float xhat = ((float)xv[u][k] - mu[k]) * is[k];
+            const float g = (float)gv[u][k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
             db[k] += g;
             dg[k] += g * xhat;
           }
         }
       }
-      const double ddb[4] = {db[0], db[1], db[2], db[3]}, ddg[4] = {dg[0], dg[1], dg[2], dg[3]};
-      red_flush(part, p.C, c, ddb, ddg, true);
+#pragma unroll
+      for (int h = 0; h < V; h += 4) {
+        const double ddb[4] = {db[h], db[h + 1], db[h + 2], db[h + 3]}, ddg[4] = {dg[h], dg[h + 1], dg[h + 2], dg[h + 3]};
+        red_flush(part, p.C, c + h, ddb, ddg, true);
+      }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * p.C; i += 256) atomicAdd(&p.sums[i], part[i]);
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_bwd_apply_kernel(BnArgs p) {
+  typedef RowVec<T, V> RV;
   const T* px = reinterpret_cast<const T*>(p.x);
   const T* pdy = reinterpret_cast<const T*>(p.dy);
   T* pdx = reinterpret_cast<T*>(p.dx);
-  const int C4 = p.C >> 2;
-  const RedMap mp = red_map(C4);
+  const int CV = p.C / V;
+  const RedMap mp = red_map(CV);
   const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
   const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
   if (blockIdx.x == 0 && p.publish) {   // the reduction kernel has completed (stream order): publish dbeta / dgamma as fp32
@@ -777,38 +797,38 @@ __global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_bwd_apply_kern
   }
   if (!mp.active) return;
   const double invM = 1.0 / (p.rows ? *p.rows : (double)p.M_total);
-  for (int cq = mp.cq0; cq < C4; cq += mp.cq_step) {
-    const int c = cq * 4;
-    float mu[4], is[4], ga[4], be[4], dbm[4], dgm[4];
+  for (int cq = mp.cq0; cq < CV; cq += mp.cq_step) {
+    const int c = cq * V;
+    // dx = k1 * (g - dbm - xhat * dgm),  xhat = (x - mu) * is,  z = xhat * ga + be
+    float mu[V], is[V], ga[V], be[V], k1[V], dbm[V], dgm[V];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < V; ++k) {
       mu[k] = p.mean[c + k]; is[k] = p.invstd[c + k]; ga[k] = p.gamma[c + k]; be[k] = p.beta[c + k];
-      dbm[k] = (float)(p.sums[c + k] * invM);
-      dgm[k] = (float)(p.sums[p.C + c + k] * invM);
+      k1[k] = ga[k] * is[k];
+      dbm[k] = p.eval_mode ? 0.f : (float)(p.sums[c + k] * invM);
+      dgm[k] = p.eval_mode ? 0.f : (float)(p.sums[p.C + c + k] * invM);
     }
     for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnUnroll) {
-      float4 xv[kBnUnroll], gv[kBnUnroll];
+      typename RV::raw xv[kBnUnroll], gv[kBnUnroll];
 #pragma unroll
       for (int u = 0; u < kBnUnroll; ++u) {
         const int64_t row = rr + (int64_t)u * mp.rstep;
         const bool ok = row < r1;
-        xv[u] = ok ? El<T>::ld4(px + row * p.x_cs + p.x_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        gv[u] = ok ? El<T>::ld4(pdy + row * p.dy_cs + p.dy_co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[u] = ok ? RV::ld(px + row * p.x_cs + p.x_co + c) : RV::zero();
+        gv[u] = ok ? RV::ld(pdy + row * p.dy_cs + p.dy_co + c) : RV::zero();
       }
 #pragma unroll
       for (int u = 0; u < kBnUnroll; ++u) {
         const int64_t row = rr + (int64_t)u * mp.rstep;
         if (row >= r1) continue;
-        const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-        const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
-        float o[4];
+        float o[V];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float xhat = (xs[k] - mu[k]) * is[k];
-          const float g = gs[k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
-          o[k] = p.eval_mode ? ga[k] * is[k] * g : ga[k] * is[k] * (g - dbm[k] - xhat * dgm[k]);
+        for (int k = 0; k < V; ++k) {
+          const float xhat = ((float)xv[u][k] - mu[k]) * is[k];
+          const float g = (float)gv[u][k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
+          o[k] = p.eval_mode ? k1[k] * g : k1[k] * (g - dbm[k] - xhat * dgm[k]);
         }
-        El<T>::st4(pdx + row * p.dx_cs + p.dx_co + c, make_float4(o[0], o[1], o[2], o[3]));
+        RV::st(pdx + row * p.dx_cs + p.dx_co + c, o);
       }
     }
   }
@@ -1005,6 +1025,18 @@ using namespace yv4;
     default: { typedef __bf16 T; CALL; } break;        \
   }
 
+// ... and the vector width of the BN row passes: 4 channels for fp32, 8 for 16-bit operands whose strides allow it
+#define YV4_DISPATCH_TV(dtype, v8, CALL)                                          \
+  switch (dtype) {                                                                \
+    case YV4_F32: { typedef float T; constexpr int V = 4; CALL; } break;          \
+    case YV4_F16: { typedef _Float16 T; if (v8) { constexpr int V = 8; CALL; } else { constexpr int V = 4; CALL; } } break; \
+    default: { typedef __bf16 T; if (v8) { constexpr int V = 8; CALL; } else { constexpr int V = 4; CALL; } } break;        \
+  }
+// (ablation switch, off by default: 8 channels per thread -- 16-byte accesses on 16-bit rows -- measured no faster on the
+// forward pass and 20 % SLOWER on the backward apply pass over YOLOv4-L's shapes, tools/bn_bench.py --kernels: the
+// passes are bound by bytes in flight per CU, which the extra registers reduce)
+static const bool g_bn_vec8 = [] { const char* e = getenv("YV4_BN_VEC8"); return e && e[0] == '1'; }();
+
 // test / ablation switch: route 16-bit inputs through the widening fp32-MFMA kernel instead of the
 // 16-bit MFMA one (YV4_WGRAD_WIDEN=1 in the environment)
 static const bool g_wgrad_widen = [] { const char* e = getenv("YV4_WGRAD_WIDEN"); return e && e[0] == '1'; }();
@@ -1150,8 +1182,11 @@ static int bn_fwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   a.M = M; a.C = C; a.act = act; a.slope = slope;
   YV4_REQUIRE(C <= 4096, "bn_act_fwd: more than 4096 channels");
   a.rows_per_block = bn_rows_per_block(M);
-  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block)),
-                                           dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a));
+  const dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
+  const bool v8 = dtype != YV4_F32 && g_bn_vec8 && ((C | x_cstride | x_coff | y_cstride | y_coff) & 7) == 0 &&
+                  (!residual || ((r_cstride | r_coff) & 7) == 0);
+  YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_fwd_kernel<T, V>), grid, dim3(256), 0,
+                                                reinterpret_cast<hipStream_t>(stream), a));
   YV4_CHECK_LAUNCH("bn_act_fwd");
   return YV4_OK;
 }
@@ -1186,13 +1221,14 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   a.rows = phase == 2 ? rows_dev : nullptr;
   a.rows_per_block = bn_rows_per_block(M);
   dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
+  const bool v8 = dtype != YV4_F32 && g_bn_vec8 && ((C | x_cstride | x_coff | dy_cstride | dy_coff | dx_cstride | dx_coff) & 7) == 0;
   if (phase != 2)
-    YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s, a));
+    YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, V>), grid, dim3(256), sizeof(double) * 2 * C, s, a));
   if (phase == 1) {
     hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
     hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
   } else {
-    YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, grid, dim3(256), 0, s, a));
+    YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, a));
   }
   YV4_CHECK_LAUNCH("bn_act_bwd");
   return YV4_OK;

@@ -176,6 +176,44 @@ def _c3_auto_checks(gpu_device):
     _h16_conv(gpu_device, torch.bfloat16, 20, 38, 38, 64, 128, 3, 1, 1, act=1, tile=0)     # 113 tiles: the C3 kernel
 
 
+WS_SHAPES = [
+    # N, H, W, Cin, Cout  (1x1, stride 1): the domain of conv1x1_ws_h16.hip, tile 6
+    (2, 19, 19, 128, 128),     # ragged last strip (722 pixels), one slab
+    (1, 76, 76, 64, 64),       # more strips than one round of waves: Cin = one stage
+    (3, 40, 33, 256, 128),     # four stages per strip, slab of 64 columns x 2
+    (1, 31, 7, 256, 256),      # four column slabs reading the same strips
+    (2, 64, 64, 64, 32),       # narrowest slab (one 32-column tile)
+    (1, 5, 5, 128, 96),        # fewer pixels than one strip; Cout 96 = a full 64-column slab and a half-empty one
+    (4, 152, 152, 64, 64),     # 2 888 strips: every wave walks its ring across several strips
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', WS_SHAPES)
+def test_h16_conv1x1_ws_kernel_shapes(gpu_device, dtype, shape):
+    N, H, W, Cin, Cout = shape
+    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 1, 1, 0, act=1, tile=6)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+def test_h16_conv1x1_ws_kernel_epilogues(gpu_device, dtype, act):
+    """Two-stage epilogue + channel-offset views on both sides through the weight-stationary kernel."""
+    _h16_conv(gpu_device, dtype, 2, 23, 17, 128, 64, 1, 1, 0, act, 6, two_stage=True, x_off=8, y_off=16)
+    _h16_conv(gpu_device, dtype, 1, 50, 50, 64, 128, 1, 1, 0, act, 6, x_off=64, y_off=3 * 8)
+
+
+def test_h16_conv1x1_ws_kernel_is_refused_outside_its_domain(gpu_device):
+    for shape in [(1, 8, 8, 64, 64, 3, 1, 1), (1, 8, 8, 192, 64, 1, 1, 0), (1, 8, 8, 512, 64, 1, 1, 0),
+                  (1, 8, 8, 64, 16, 1, 1, 0)]:
+        with pytest.raises(L.Yv4Error):
+            _h16_conv(gpu_device, torch.bfloat16, *shape, act=1, tile=6)
+    with pytest.raises(L.Yv4Error):
+        _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 64, 1, 1, 0, act=1, tile=6, residual=True)
+    with pytest.raises(L.Yv4Error):
+        _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 64, 1, 1, 0, act=1, tile=6, out_f32=True)
+
+
 def test_h16_conv_big_k(gpu_device):
     _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 512, 64, 3, 1, 1, 1, 1)       # K = 4608
 
