@@ -386,6 +386,8 @@ def main():
 
     def tile_of(op):
         d = op.info['desc']
+        if op.info.get('fused'):
+            return op.info['fused']
         if op.info.get('stem32'):
             return 'stem3x3'
         if h16:

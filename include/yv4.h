@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YV4_ABI_VERSION 3
+#define YV4_ABI_VERSION 4
 
 /* error codes */
 #define YV4_OK 0
@@ -335,6 +335,19 @@ int yv4_conv_h16_pick_tile(const yv4_conv_desc* d);
 int yv4_conv_stem_fwd(const yv4_conv_desc* d, const float* x, const float* w,
                       const float* scale1, const float* shift1, void* y, int out_dtype,
                       void* stream);
+
+/* The first two layers of CSPDarknet as one launch for the 16-bit inference plans (stem_down_h16.hip): the stem
+ * Conv(3 -> C1, 3x3, s1) + BN + act (darknetcsp.py:357-366) and the next stage's conv_downscale Conv(C1 -> C2, 3x3, s2)
+ * + BN + act (darknetcsp.py:290-300), straight from the NCHW fp32 image (N, 3, H, W) to the NHWC 16-bit map
+ * (N, ceil(H/2), ceil(W/2), C2) at channel offset y_coff of pixels of y_cstride channels.  w1: the fp32 stem weights
+ * as yv4_conv_stem_fwd takes them, (C1, 9 taps x 4 channels); the stem is computed on 16-bit MFMAs with a three-term
+ * hi / lo split of the fp32 products (result = the fp32 stem's to fp32 accumulation noise) and rounded to `dtype`
+ * like its stored output; w2: (C2, 9 * C1) in `dtype`, as yv4_conv_bn_act_fwd_h16 takes it.  C1 in {16, 32},
+ * C2 in {32, 64}. */
+int yv4_stem_down_fwd_h16(int dtype, const float* x_nchw, int N, int H, int W, const float* w1,
+                          const float* scale1, const float* shift1, int C1, int act1, float slope1,
+                          const void* w2, const float* scale2, const float* shift2, int C2, int act2,
+                          float slope2, void* y, int y_cstride, int y_coff, void* stream);
 
 /* 16-bit forms of the layout adaptors and the SPP pools (same argument meaning as the fp32
  * entries; the boundary tensors stay fp32 NCHW like the reference's, the NHWC side is `dtype`).

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('YV4_LIB_PATH') or os.path.join(LIB_DIR, 'libyv4_hip.s
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 # ---- constants mirrored from include/yv4.h -------------------------------------
-ABI_VERSION = 3
+ABI_VERSION = 4
 STATS_REPLICAS = 64        # YV4_STATS_REPLICAS
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_MISH, ACT_LEAKY, ACT_SWISH = 0, 1, 2, 3
@@ -119,6 +119,8 @@ SIGNATURES = {
     'yv4_conv_bn_act_fwd_h16': (C.c_int, [C.POINTER(ConvDesc), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'yv4_conv_stem_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'yv4_conv_h16_pick_tile': (C.c_int, [C.POINTER(ConvDesc)]),
+    'yv4_stem_down_fwd_h16': (C.c_int, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i,
+                                        _vp]),
     'yv4_nchw_to_nhwc_h16': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_nhwc_to_nchw_h16': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_spp_pool_fwd_h16': (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

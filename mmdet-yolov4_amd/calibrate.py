@@ -43,6 +43,9 @@ def _set_stats(bn, lo, hi, x2d):
 def calibrate_bn(plan, *inputs):
     """Run ``plan`` once on ``inputs`` while fitting every folded BN to the batch."""
     assert plan.finalized and plan.graph is None
+    assert not any(op.info.get('fused') for op in plan.ops), \
+        'calibrate_bn walks single-conv launches: calibrate through the fp32 plan (the statistics live in the modules) ' \
+        'or compile the 16-bit plan with YV4_STEM_FUSE=0'
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for slot, t in zip(plan.inputs, inputs):
         slot['src'] = t.contiguous()

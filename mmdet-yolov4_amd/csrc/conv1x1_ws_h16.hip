@@ -18,7 +18,8 @@
 //   * a lane owns one output channel per 32-column tile (the MFMA's C layout), so the per-channel affine is four
 //     registers, the BatchNorm statistics of the training forward accumulate in registers over ALL of a wave's strips
 //     (two atomics per channel per wave at the very end instead of two per tile), and the 16-bit outputs go out as
-//     64-byte segments (32 consecutive channels of a pixel per half-wave).
+//     dwords after one DPP swap between the lanes of adjacent channels (pair_pack16: sub-dword stores were the
+//     first version's bottleneck), 64-byte segments per pixel.
 //
 // Epilogue = the common one minus the residual: affine1 -> act1 -> (affine2 -> act2) -> store at a channel offset,
 // or (stats != nullptr) identity + statistics of the rounded outputs.  Residual, fp32 output and scattered output
@@ -36,8 +37,7 @@ constexpr int kWsGrid = 256;          // one workgroup per CU
 __device__ __forceinline__ void act_row16_h(float (&v)[16], int act, float slope) {
   switch (act) {
     case YV4_ACT_MISH:
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = apply_act(v[e], YV4_ACT_MISH, 0.f);
+      mish_fast_row(v);
       break;
     case YV4_ACT_LEAKY:
 #pragma unroll
@@ -222,14 +222,19 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
           act_row16_h(v, p.act2, p.slope2);
         }
       }
-      T* yb = reinterpret_cast<T*>(p.y) + ((int64_t)(m0 + 4 * h) * p.y_cs + p.y_co + c);
+      // dword stores: the even lane of a channel pair takes rows 0-3 / 8-11 (+4h), the odd lane rows 16-19 / 24-27
+      const bool odd = r & 1;
+      unsigned pk[8];
+      pair_pack16<T>(v, odd, pk);
+      const int rb = 4 * h + (odd ? 16 : 0);
+      T* yb = reinterpret_cast<T*>(p.y) + ((int64_t)(m0 + rb) * p.y_cs + p.y_co + (c & ~1));
       if (full) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) yb[(int64_t)((e & 3) + 8 * (e >> 2)) * p.y_cs] = (T)v[e];
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned*>(yb + (int64_t)((j & 3) + 8 * (j >> 2)) * p.y_cs) = pk[j];
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (m0 + (e & 3) + 8 * (e >> 2) + 4 * h < p.M) yb[(int64_t)((e & 3) + 8 * (e >> 2)) * p.y_cs] = (T)v[e];
+        for (int j = 0; j < 8; ++j)
+          if (m0 + rb + (j & 3) + 8 * (j >> 2) < p.M) *reinterpret_cast<unsigned*>(yb + (int64_t)((j & 3) + 8 * (j >> 2)) * p.y_cs) = pk[j];
       }
     }
   }
@@ -269,7 +274,8 @@ static int ws_slab_cols(const ConvArgsH& a) {
 // Is this layer in the kernel's domain?
 bool conv1x1_ws_applies(const ConvArgsH& a) {
   return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.ys_on && !a.out_f32 && a.res == nullptr &&
-         (a.Cin == 64 || a.Cin == 128 || a.Cin == 256) && a.Kw == a.Cin && a.Cout >= 32 && ws_slab_cols(a) > 0;
+         (a.Cin == 64 || a.Cin == 128 || a.Cin == 256) && a.Kw == a.Cin && a.Cout >= 32 && (a.Cout & 1) == 0 &&
+         ((a.y_cs | a.y_co) & 1) == 0 && ws_slab_cols(a) > 0;
 }
 
 template <bool BF16, int NT>

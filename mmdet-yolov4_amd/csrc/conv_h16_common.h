@@ -90,8 +90,7 @@ struct Elem<false> {
 __device__ __forceinline__ void act_row8(float (&v)[8], int act, float slope) {
   switch (act) {
     case YV4_ACT_MISH:
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = apply_act(v[u], YV4_ACT_MISH, 0.f);
+      mish_fast_row(v);       // packed pairs (yv4_common.h)
       break;
     case YV4_ACT_LEAKY:
 #pragma unroll
@@ -103,6 +102,26 @@ __device__ __forceinline__ void act_row8(float (&v)[8], int act, float slope) {
       break;
     default:
       break;
+  }
+}
+
+// Stores from the MFMA's C layout (lane (r, h) = output channel r of the rows (e & 3) + 8 (e >> 2) + 4 h): a 16-bit
+// value per lane and store is a sub-dword write per lane, which the memory pipeline handles at a fraction of the dword
+// rate (measured: the persistent kernels that store this way were bound by it).  Two lanes that own adjacent
+// channels (r even / odd) of the same 16 rows trade halves through one DPP swap per value pair, so that each stores
+// full dwords: afterwards out[j] (j = 0..7) is, on the even lane, channels (c, c+1) of row (j & 3) + 8 (j >> 2) + 4 h,
+// on the odd lane channels (c-1, c) of row 16 + (j & 3) + 8 (j >> 2) + 4 h.
+template <typename T>
+__device__ __forceinline__ void pair_pack16(const float (&v)[16], bool odd, unsigned (&out)[8]) {
+  typedef T T2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float send = odd ? v[j] : v[j + 8];
+    const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));
+    T2 pk;
+    pk[0] = (T)(odd ? recv : v[j]);
+    pk[1] = (T)(odd ? v[j + 8] : recv);
+    out[j] = __builtin_bit_cast(unsigned, pk);
   }
 }
 

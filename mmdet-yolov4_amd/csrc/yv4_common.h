@@ -103,6 +103,42 @@ __device__ __forceinline__ float mish_fast_f32(float x) {
   return x >= 20.f ? x : y;
 }
 
+// Two at a time for the epilogues that store 16-bit values: the multiplies and adds become packed fp32 instructions
+// (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, two elements per lane and issue slot), leaving the two quarter-rate
+// transcendentals per element as the bulk of the cost: ~46 issue cycles per element and wave instead of ~64 -- these
+// epilogues are VALU-bound on the HBM-bound layers.  The x >= 20 branch is replaced by clamping the exponent
+// (for x >= 20 the ratio n / (n + 2) rounds to 1): the result may differ from mish_fast_f32's by one fp32 ulp there,
+// invisible after the rounding to 16 bits.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t mish_fast2_f32(f32x2_t x) {
+  const f32x2_t xs = x * 1.44269504088896340736f;
+  f32x2_t e;
+  e.x = __builtin_amdgcn_exp2f(fminf(xs.x, 28.853900817779268f));   // e^20
+  e.y = __builtin_amdgcn_exp2f(fminf(xs.y, 28.853900817779268f));
+  const f32x2_t n = e * (e + 2.f);
+  const f32x2_t d = n + 2.f;
+  f32x2_t r;
+  r.x = __builtin_amdgcn_rcpf(d.x);
+  r.y = __builtin_amdgcn_rcpf(d.y);
+  return x * (n * r);
+}
+template <int N>
+__device__ __forceinline__ void mish_fast_row(float (&v)[N]) {
+  static_assert(N % 2 == 0, "pairs");
+#ifdef YV4_SCALAR_MISH      // A/B build: the scalar form in the same places
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] = mish_fast_f32(v[u]);
+  return;
+#endif
+#pragma unroll
+  for (int u = 0; u < N; u += 2) {
+    f32x2_t a;
+    a.x = v[u]; a.y = v[u + 1];
+    a = mish_fast2_f32(a);
+    v[u] = a.x; v[u + 1] = a.y;
+  }
+}
+
 __device__ __forceinline__ float sigmoid_f32(float x) {
   return 1.f / (1.f + expf(-x));
 }

@@ -517,6 +517,8 @@ class DarknetCSP(HipModule):
             x = getattr(self, layer_name).emit(plan, x)
             if i in self.out_indices:
                 outs.append(x)
+            elif i == 0:
+                plan.hint_single_consumer(x)         # the stem's map is read by the next stage's first conv only
         return tuple(outs)
 
     def fwd(self, x):

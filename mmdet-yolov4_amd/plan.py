@@ -168,7 +168,7 @@ class Plan:
                 src = slot['src']
                 check(_lib.lib().yv4_nchw_to_nhwc(src.data_ptr(), v.buf.ptr(), v.N, C_, v.H, v.W, cp, 0,
                                                   cp - C_, stream), 'yv4_nchw_to_nhwc')
-        self.ops.append(Op('to_nhwc', name, fn, nbytes=(4.0 + (2 if h16 else 4)) * N * C_ * H * W))
+        self.ops.append(Op('to_nhwc', name, fn, nbytes=(4.0 + (2 if h16 else 4)) * N * C_ * H * W, info=dict(slot=slot)))
         return v
 
     # ---- ops ---------------------------------------------------------------------
@@ -430,8 +430,56 @@ class Plan:
         return res
 
     # ---- lifecycle ---------------------------------------------------------------
+    def hint_single_consumer(self, view):
+        """The emitter's promise that exactly one later op reads this view's buffer (lets finalize() fuse the
+        producer into that consumer and drop the buffer)."""
+        view.buf.single_consumer = True
+        return view
+
+    def _fuse_stem_down(self):
+        """16-bit plans: [NCHW fp32 image -> NHWC4 repack, fp32 3x3 stem, 3x3 / stride-2 conv] -> ONE launch of
+        yv4_stem_down_fwd_h16 (stem_down_h16.hip) when the three ops follow each other, the widths are the kernel's
+        (C1 in {16, 32}, C2 in {32, 64}) and the two intermediate buffers have no other reader.  The replaced ops
+        stay reachable through ``info['parts']``; the launch reads their parameter records, so refreshed scale /
+        shift / weight tensors are picked up.  YV4_STEM_FUSE=0 keeps the three launches."""
+        if not self.h16 or os.environ.get('YV4_STEM_FUSE', '1') == '0':
+            return
+        for i in range(len(self.ops) - 2):
+            o0, o1, o2 = self.ops[i:i + 3]
+            if not (o0.kind == 'to_nhwc' and o1.kind == 'conv' and o2.kind == 'conv' and o1.info.get('stem32')):
+                continue
+            slot = o0.info.get('slot')
+            L1, L2 = o1.info['launch'], o2.info['launch']
+            d1, d2 = L1['d'], L2['d']
+            v0, v1 = slot['view'], o1.info['out']
+            ok = (L1['x'] is v0.buf and L2['x'] is v1.buf and getattr(v0.buf, 'single_consumer', False)
+                  and getattr(v1.buf, 'single_consumer', False) and v1.coff == 0 and v1.cstride == v1.C
+                  and (d2.KH, d2.KW, d2.stride, d2.pad) == (3, 3, 2, 1) and d1.Cout in (16, 32) and d2.Cin == d1.Cout
+                  and d2.Cout in (32, 64) and L2['res'] is None and L2['s2'] is None
+                  and o2.info['out'].buf.dtype == self.dtype and slot['C'] == 3)
+            if not ok:
+                continue
+            out = o2.info['out']
+
+            def fn(stream, slot=slot, L1=L1, L2=L2, d1=d1, d2=d2):
+                check(_lib.lib().yv4_stem_down_fwd_h16(
+                    self.dcode, slot['src'].data_ptr(), d1.N, d1.H, d1.W, L1['w'].data_ptr(), L1['s1'].data_ptr(),
+                    L1['t1'].data_ptr(), d1.Cout, d1.act1, d1.slope1, L2['w'].data_ptr(), L2['s1'].data_ptr(),
+                    L2['t1'].data_ptr(), d2.Cout, d2.act1, d2.slope1, L2['y'].ptr(), d2.y_cstride, d2.y_coff, stream),
+                    'yv4_stem_down_fwd_h16')
+            es = float(self.esize)
+            nbytes = 4.0 * d1.N * 3 * d1.H * d1.W + es * d2.N * d2.Ho * d2.Wo * d2.Cout + 4.0 * d1.Cout * 27 + es * d2.Cout * 9 * d2.Cin
+            info = dict(o2.info)
+            info.update(Cin=3, H=d1.H, W=d1.W, stem32=True, fused='stem_down', parts=[o0, o1, o2], bn1=None, bn2=None)
+            self.ops[i:i + 3] = [Op('conv', 'stem_down', fn, o1.flops + o2.flops, nbytes, info)]
+            v0.buf.unused = v1.buf.unused = True          # never allocated
+            return
+
     def finalize(self):
+        self._fuse_stem_down()
         for b in self.bufs:
+            if getattr(b, 'unused', False):
+                continue
             b.tensor = torch.empty(b.numel, dtype=b.dtype, device=self.device)
         if getattr(self, '_splitk_bytes', 0):          # one workspace shared by the split-K layers (they run in turn)
             self._splitk_ws = torch.empty(self._splitk_bytes // 4, dtype=torch.float32, device=self.device)

@@ -83,6 +83,7 @@ class SingleStageDetector(HipModule):
                       and conv0.stride == (1, 1) and conv0.padding == (1, 1) and conv0.in_channels == 3
                       and conv0.out_channels <= 64 and conv0.out_channels % 8 == 0)
             x = plan.add_input_nchw(batch, 3, height, width, name='img', dtype=torch.float32 if stem32 else None)
+            plan.hint_single_consumer(x)             # the image feeds the backbone's first conv and nothing else
             preds = self.emit(plan, x)
             self.bbox_head.emit_postprocess(plan, preds, rescale=rescale)
             plan.pred_views = preds
