@@ -445,6 +445,20 @@ int yv4_pack_weight(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kh, in
                     int Cin, int KH, int KW, int KHo, int KWo, int kh0, int kh_step, int kw0,
                     int kw_step, int transpose, int pad_to, void* dst, int dtype, void* stream);
 
+/* yv4_pack_weight over a table of weights in ONE launch (a training step packs every conv weight twice -- forward
+ * operand and data-gradient operand -- 750 launches of a few microseconds each on YOLOv4-L; the table is built once and
+ * replayed after every optimizer step).  The table lives in DEVICE memory; descriptor i serves workgroups
+ * [first_block, first_block + nblocks), rows_per_block output rows each (the caller lays the ranges out back to
+ * back, total_blocks = their sum); the other fields are yv4_pack_weight's arguments. */
+typedef struct yv4_pack_desc {
+  const float* w;
+  int64_t s_co, s_ci, s_kh, s_kw;
+  void* dst;
+  int32_t Cout, Cin, KHo, KWo, kh0, kh_step, kw0, kw_step, transpose, pad_to, dtype;
+  int32_t first_block, nblocks, rows_per_block;
+} yv4_pack_desc;
+int yv4_pack_weights_multi(const yv4_pack_desc* table_dev, int n, int total_blocks, void* stream);
+
 /* One parity class of the data gradient of a stride-2 convolution: a stride-1 convolution of dY whose
  * output pixel (n, ho, wo) is stored at y[n, ho*sh + oh, wo*sw + ow, y_coff + c] of an
  * (N, Hy, Wy, y_cstride) tensor.  d->Ho / d->Wo are taken as given (rows past the input's edge read

@@ -69,6 +69,14 @@ class AugImage(C.Structure):
                [('lut', (C.c_uint8 * 256) * 3)]
 
 
+class PackDesc(C.Structure):
+    """yv4_pack_desc (include/yv4.h)."""
+    _fields_ = [('w', C.c_void_p), ('s_co', C.c_int64), ('s_ci', C.c_int64), ('s_kh', C.c_int64), ('s_kw', C.c_int64),
+                ('dst', C.c_void_p)] + [(k, C.c_int32) for k in (
+                    'Cout', 'Cin', 'KHo', 'KWo', 'kh0', 'kh_step', 'kw0', 'kw_step', 'transpose', 'pad_to', 'dtype',
+                    'first_block', 'nblocks', 'rows_per_block')]
+
+
 _vp, _i, _i64, _f, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
 
 #: every exported symbol: name -> (restype, argtypes).  tests/test_abi.py checks
@@ -142,6 +150,7 @@ SIGNATURES = {
     'yv4_bn_act_bwd_sums': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp]),
     'yv4_bn_act_bwd_apply': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i64, _vp, _i, _i, _f, _vp]),
     'yv4_pack_weight': (C.c_int, [_vp, _i64, _i64, _i64, _i64] + [_i] * 12 + [_vp, _i, _vp]),
+    'yv4_pack_weights_multi': (C.c_int, [_vp, _i, _i, _vp]),
     'yv4_yolo_loss_fwd': (C.c_int, [C.POINTER(LossDesc), _vp]),
     'yv4_yolo_loss_bwd': (C.c_int, [C.POINTER(LossDesc), _vp, _vp]),
     'yv4_mosaic_augment_u8': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),

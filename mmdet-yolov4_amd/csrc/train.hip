@@ -1001,6 +1001,45 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   }
 }
 
+// The same pass over a TABLE of weights in one launch (yv4_pack_weights_multi): workgroup b serves the descriptor whose
+// [first_block, first_block + nblocks) range holds b, rows_per_block output rows of it.
+template <typename T>
+__device__ __forceinline__ void pack_rows(const yv4_pack_desc& d, int row0, int row1) {
+  const int tf = d.transpose;
+  const int IC = tf ? d.Cout : d.Cin;
+  const int ICp = (IC + d.pad_to - 1) / d.pad_to * d.pad_to;
+  const int taps = d.KHo * d.KWo;
+  const long long s_ic = tf ? d.s_co : d.s_ci;
+  T* dst = reinterpret_cast<T*>(d.dst);
+  for (int row = row0; row < row1; ++row) {
+    const int r = row / taps;
+    const int tap = row - r * taps;
+    const int kh = tap / d.KWo, kw = tap - kh * d.KWo;
+    const float* src = d.w + (d.kh0 + kh * d.kh_step) * d.s_kh + (d.kw0 + kw * d.kw_step) * d.s_kw + (tf ? r * d.s_ci : r * d.s_co);
+    T* o = dst + (size_t)row * ICp;
+    for (int ic = threadIdx.x; ic < ICp; ic += 256) o[ic] = (T)(ic < IC ? src[ic * s_ic] : 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const yv4_pack_desc* __restrict__ table, int n) {
+  // binary search of the descriptor (uniform per workgroup)
+  int lo = 0, hi = n - 1;
+  const int b = (int)blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const yv4_pack_desc d = table[lo];
+  const int R = d.transpose ? d.Cin : d.Cout;
+  const int nrows = R * d.KHo * d.KWo;
+  const int row0 = (b - d.first_block) * d.rows_per_block;
+  const int row1 = row0 + d.rows_per_block < nrows ? row0 + d.rows_per_block : nrows;
+  switch (d.dtype) {
+    case YV4_F32: pack_rows<float>(d, row0, row1); break;
+    case YV4_F16: pack_rows<_Float16>(d, row0, row1); break;
+    default: pack_rows<__bf16>(d, row0, row1); break;
+  }
+}
+
 __global__ void sums_to_float_kernel(const double* __restrict__ sums, int n, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (float)sums[i];
@@ -1383,6 +1422,14 @@ extern "C" int yv4_pack_weight(const float* w, int64_t s_co, int64_t s_ci, int64
                                            (long long)s_kh, (long long)s_kw, Cout, Cin, KHo, KWo, kh0, kh_step, kw0, kw_step,
                                            transpose ? 1 : 0, ICp, reinterpret_cast<T*>(dst), (int)nrows));
   YV4_CHECK_LAUNCH("pack_weight");
+  return YV4_OK;
+}
+
+extern "C" int yv4_pack_weights_multi(const yv4_pack_desc* table_dev, int n, int total_blocks, void* stream) {
+  YV4_REQUIRE(table_dev && n > 0 && total_blocks > 0, "pack_weights_multi: bad argument");
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     table_dev, n);
+  YV4_CHECK_LAUNCH("pack_weights_multi");
   return YV4_OK;
 }
 

@@ -100,12 +100,97 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None,
     return d
 
 
+# ---- packed weight operands, replayed in one launch per optimizer step -----------------------------------------------
+# A training step needs every conv weight twice as a packed 16-bit (or fp32) operand: (Cout, K) for the forward, the
+# transposed / mirrored form for the data gradient (plus one per parity class of a stride-2 layer) -- 750 launches of
+# ``yv4_pack_weight`` per YOLOv4-L step.  The operands only change when the weights do, so the requests of the first
+# step are recorded in a table (``yv4_pack_desc``) and from then on ONE ``yv4_pack_weights_multi`` launch refreshes all
+# of them the first time any operand is asked for after the weights' version counter moved.  The version is torch's
+# (views of the flat arena share the arena's counter; ``FlatSGD.step`` bumps it for its raw-pointer kernel).
+# YV4_PACK_CACHE=0 packs per call as before.
+_PACK_CACHE_ON = os.environ.get('YV4_PACK_CACHE', '1') != '0'
+
+
+class _PackCache:
+    ROWS_TARGET = 4096          # output elements per workgroup
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}       # key -> dict(weight=weakref, desc fields, dst, version)
+        self.table = None       # device copy of the descriptor table (rebuilt when entries were added)
+        self.dirty_table = True
+        self.total_blocks = 0
+
+    @staticmethod
+    def key(weight, dtype, mode):
+        return (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), dtype, mode)
+
+    def lookup(self, weight, dtype, mode):
+        e = self.entries.get(self.key(weight, dtype, mode))
+        if e is None:
+            return None
+        if e['version'] != weight._version:
+            self.refresh(weight)
+        return e
+
+    def add(self, weight, dtype, mode, fields, dst, cp):
+        if len(self.entries) >= 4096:       # many models came and went: start over rather than keep their weights alive
+            self.entries.clear()
+        e = dict(fields=fields, dst=dst, cp=cp, version=weight._version, wref=weight)
+        self.entries[self.key(weight, dtype, mode)] = e
+        self.dirty_table = True
+        return e
+
+    def _build(self):
+        n = len(self.entries)
+        tab = (_lib.PackDesc * n)()
+        blk = 0
+        for i, e in enumerate(self.entries.values()):
+            d = tab[i]
+            for k, v in e['fields'].items():
+                setattr(d, k, v)
+            d.dst = e['dst'].data_ptr()
+            rows = (d.Cin if d.transpose else d.Cout) * d.KHo * d.KWo
+            icp = ((d.Cout if d.transpose else d.Cin) + d.pad_to - 1) // d.pad_to * d.pad_to
+            d.rows_per_block = max(1, self.ROWS_TARGET // icp)
+            d.nblocks = (rows + d.rows_per_block - 1) // d.rows_per_block
+            d.first_block = blk
+            blk += d.nblocks
+        self.total_blocks = blk
+        raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8)
+        self.table = raw.to(self.device)
+        self.dirty_table = False
+
+    def refresh(self, _weight):
+        """Re-pack every recorded operand in one launch (the weights move together at an optimizer step)."""
+        live = {k: e for k, e in self.entries.items() if e['wref'].data_ptr() == k[0]}
+        if len(live) != len(self.entries):
+            self.entries = live
+            self.dirty_table = True
+        if not self.entries:
+            return
+        if self.dirty_table:
+            self._build()
+        check(_lib.lib().yv4_pack_weights_multi(self.table.data_ptr(), len(self.entries), self.total_blocks, stream_ptr()),
+              'yv4_pack_weights_multi')
+        for e in self.entries.values():
+            e['version'] = e['wref']._version
+
+
+_PACK_CACHES = {}
+
+
+def clear_pack_cache():
+    _PACK_CACHES.clear()
+
+
 def packed_weight(weight, dtype, transpose_flip=False, taps=None):
     """The conv kernels' weight operand from an fp32 (Cout, Cin, KH, KW) parameter in one launch (``yv4_pack_weight``):
     rows x (KH'*KW'*Cp), K ordered (kh, kw, channel), channels zero-padded to a 16-byte chunk, cast to ``dtype``.
     ``transpose_flip``: the data gradient's operand (rows = Cin, channels = Cout, taps mirrored).  ``taps``:
     ((kh0, kh_step, KH'), (kw0, kw_step, KW')) selects source taps explicitly (rows = Cin, channels = Cout): the
-    operand of one parity class of a stride-2 data gradient.  Returns (w, Cp)."""
+    operand of one parity class of a stride-2 data gradient.  Returns (w, Cp).  The result is a cached buffer that the
+    next refresh overwrites: use it on the current stream before the weights change again (the conv launches do)."""
     Cout, Cin, KH, KW = weight.shape
     al = 4 if dtype == torch.float32 else 8
     transpose = bool(transpose_flip or taps is not None)
@@ -118,6 +203,16 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None):
     else:
         kh0, khs, KHo, kw0, kws, KWo = 0, 1, KH, 0, 1, KW
     w = weight.detach()
+    cacheable = _PACK_CACHE_ON and w.dtype == torch.float32 and w.is_cuda
+    cache = None
+    mode = (bool(transpose_flip), taps)
+    if cacheable:
+        cache = _PACK_CACHES.get(w.device)
+        if cache is None:
+            cache = _PACK_CACHES[w.device] = _PackCache(w.device)
+        e = cache.lookup(w, dtype, mode)
+        if e is not None:
+            return e['dst'], e['cp']
     if w.dtype != torch.float32:
         w = w.float()
     out = torch.empty((rows, KHo * KWo * cp), device=w.device, dtype=dtype)
@@ -125,6 +220,10 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None):
     check(_lib.lib().yv4_pack_weight(w.data_ptr(), st[0], st[1], st[2], st[3], Cout, Cin, KH, KW, KHo, KWo, kh0, khs, kw0,
                                      kws, int(transpose), al, out.data_ptr(), _DCODE[dtype], stream_ptr()),
           'yv4_pack_weight')
+    if cacheable:
+        cache.add(w, dtype, mode, dict(w=w.data_ptr(), s_co=st[0], s_ci=st[1], s_kh=st[2], s_kw=st[3], Cout=Cout, Cin=Cin,
+                                       KHo=KHo, KWo=KWo, kh0=kh0, kh_step=khs, kw0=kw0, kw_step=kws,
+                                       transpose=int(transpose), pad_to=al, dtype=_DCODE[dtype]), out, cp)
     return out, cp
 
 

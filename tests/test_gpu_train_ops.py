@@ -350,3 +350,39 @@ def test_wgrad_deterministic_form(gpu_device, dtype):
     dwn = base.clone()
     _lib.check(lib.yv4_conv_wgrad_det(ctypes.byref(d), code, x.data_ptr(), dy.data_ptr(), dwn.data_ptr(), None, 0, s), 'x')
     assert float((dwn - dwa).abs().max()) <= 2e-5 * scale
+
+
+def test_packed_weight_cache_follows_the_weights(gpu_device):
+    """The recorded operands are re-packed in one launch when the weight's version counter moves (an in-place update,
+    an optimizer step), and an operand asked for after that is the fresh one -- for the forward, the data-gradient and
+    a stride-2 parity-class form."""
+    from mmdet_yolov4_amd import train_ops as T
+    T.clear_pack_cache()
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(16, 8, 3, 3, device=gpu_device)),
+          torch.nn.Parameter(torch.randn(24, 16, 3, 3, device=gpu_device))]
+    modes = [dict(), dict(transpose_flip=True), dict(taps=((2, -2, 2), (1, 1, 1)))]
+
+    def pack_all(cached):
+        out = []
+        for w in ws:
+            for m in modes:
+                if not cached:
+                    T.clear_pack_cache()
+                out.append(T.packed_weight(w.detach(), torch.bfloat16, **m)[0].clone())
+        return out
+
+    first = pack_all(True)
+    again = pack_all(True)                      # served from the table, no change
+    for a, b in zip(first, again):
+        assert torch.equal(a, b)
+    cache = T._PACK_CACHES[gpu_device]
+    assert len(cache.entries) == 6
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(-0.5).add_(0.25)             # in-place: the version counters move
+    fresh = pack_all(True)
+    ref = pack_all(False)                       # per-call packing of the new values
+    for a, b, c in zip(fresh, ref, first):
+        assert torch.equal(a, b) and not torch.equal(a, c)
+    T.clear_pack_cache()
