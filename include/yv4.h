@@ -122,6 +122,9 @@ typedef struct yv4_conv_desc {
 #define YV4_TILE_DMA_128x128 7
 /* register-only kernel for the 3x3/s1/p1 stem (Cin padded to 4, Cout <= 64) */
 #define YV4_TILE_STEM 8
+/* 1x1 / stride 1, Cin 64 / 128 / 256, Cout >= 32, no residual: one persistent 8-wave workgroup per CU, the weight slab
+ * resident in LDS, wave-private rings of 32-pixel strips; same summation order as the DMA tiles (bit-identical) */
+#define YV4_TILE_WS_1x1 9
 
 int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const float* w,
                         const float* scale1, const float* shift1,

@@ -862,6 +862,266 @@ static int launch_conv(const ConvArgs& a, bool uniform_tap, hipStream_t stream) 
   return YV4_OK;
 }
 
+// ---- 1x1 / stride 1, weight-stationary and persistent (the fp32 form of conv1x1_ws_h16.hip) ---------------------------
+// The pointwise layers with Cin <= 256 run at 50-57 % of the fp32 matrix peak on the tiles above (profiles/
+// r02_layers.json): a tile's K loop is 2-8 slices, so a workgroup's life is mostly its first-slice latency and its
+// epilogue.  Here one 8-wave workgroup per CU keeps its weight slab (BN x Cin floats, <= 64 KB) in LDS for the whole
+// layer and every wave walks its own strips of 32 pixels with a private 3-stage LDS-DMA ring (stage = 32 pixels x 32
+// channels) that runs on across strips; no barrier after the slab has landed.  The summation order of an output is
+// EXACTLY the tile kernels' (slices of 32 channels in order; inside a slice the MFMA K pairs (8j+i, 8j+4+i), i = 0..3;
+// two accumulator sets alternating with j, added once at the end), so a layer gives the same bits whichever kernel a
+// batch size selects -- the plans' cross-batch bit-exactness (bench.py's output check) holds.
+constexpr int kWsfWaves = 8;
+constexpr int kWsfThreads = kWsfWaves * 64;
+constexpr int kWsfStages = 3;
+constexpr int kWsfStageBytes = 4096;   // 32 pixels x 32 channels x 4 bytes
+constexpr int kWsfGrid = 256;
+
+template <int NT>
+__global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes, int ncol,
+                                                                        int nstrips, int cpr_shift) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  constexpr int BN = NT * 32;
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* smem_c = reinterpret_cast<char*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  const int kc_n = p.Cin >> 5;          // 32-channel stages per strip
+  const int cpr = 1 << cpr_shift;       // 16-byte chunks per weight row (Cin / 4 >= 16)
+  const int wpitch = p.Cin * 4;
+
+  char* Ws = smem_c;
+  char* ring = smem_c + BN * wpitch + wave * (kWsfStages * kWsfStageBytes);
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem;
+  const unsigned ring_lds = lds_base + (unsigned)(BN * wpitch + wave * (kWsfStages * kWsfStageBytes));
+
+  const unsigned b = blockIdx.x;
+  const int xcd = (int)(b & 7u), local = (int)(b >> 3);
+  const int col = local % ncol;
+  const int walker = (local / ncol) * 8 + xcd;
+  const int nwalkers = ((int)(gridDim.x >> 3) / ncol) * 8;
+  const int NW = nwalkers * kWsfWaves;
+  const int gw = walker * kWsfWaves + wave;
+  const int n0 = col * BN;
+
+  const u32x4_t rsA = make_rsrc(p.x, x_bytes);
+  const u32x4_t rsB = make_rsrc(p.w, w_bytes);
+
+  // the weight slab, once: rows of Cin floats, 16-byte chunks XOR-swizzled with row & 15
+  {
+    const int groups = (BN * cpr) >> 6;
+    for (int g = wave; g < groups; g += kWsfWaves) {
+      const int c = g * 64 + lane;
+      const int row = c >> cpr_shift;
+      const int pch = c & (cpr - 1);
+      const int co = n0 + row;
+      const unsigned voff = co < p.Cout ? (unsigned)(((int64_t)co * p.Kw + (pch ^ (row & 15)) * 4) * 4) : kOOB;
+      lds_dma16(rsB, lds_base + (unsigned)(g * 1024), voff, 0u);
+    }
+  }
+
+  float s1[NT], t1[NT], s2[NT], t2[NT];
+  const bool has2 = p.s2 != nullptr;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int c = n0 + t * 32 + r;
+    const bool ok = c < p.Cout;
+    s1[t] = ok ? p.s1[c] : 0.f;
+    t1[t] = ok ? p.t1[c] : 0.f;
+    s2[t] = (ok && has2) ? p.s2[c] : 1.f;
+    t2[t] = (ok && has2) ? p.t2[c] : 0.f;
+  }
+
+  const unsigned a_rd = (unsigned)(r * 128 + ((h ^ ((r >> 1) & 7)) << 4));
+  unsigned w_rd[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int row = t * 32 + r;
+    w_rd[t] = (unsigned)(row * wpitch + ((h ^ (row & 15)) << 4));
+  }
+
+  const int my_n = gw < nstrips ? (nstrips - gw + NW - 1) / NW : 0;
+  const int lrow = lane >> 3;
+  const unsigned lch_even = (unsigned)(((lane & 7) ^ ((lane >> 4) & 7)) * 4);
+  const unsigned lch_odd = (unsigned)(((lane & 7) ^ (((lane >> 4) + 4) & 7)) * 4);
+  int iss_i = 0, iss_kc = 0, iss_slot = 0;
+#define YV4_WSF_ISSUE()                                                                                     \
+  {                                                                                                         \
+    const int row0_ = (gw + iss_i * NW) * 32 + lrow;                                                        \
+    const bool live_ = iss_i < my_n;                                                                        \
+    const unsigned lds_ = ring_lds + (unsigned)(iss_slot * kWsfStageBytes);                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+      const int row_ = row0_ + 8 * j;                                                                       \
+      const unsigned lch_ = (j & 1) ? lch_odd : lch_even;                                                   \
+      const unsigned voff_ = (live_ && row_ < p.M)                                                          \
+                                 ? (unsigned)(((int64_t)row_ * p.x_cs + p.x_co + iss_kc * 32 + (int)lch_) * 4) \
+                                 : kOOB;                                                                    \
+      lds_dma16(rsA, lds_ + (unsigned)(j * 1024), voff_, 0u);                                               \
+    }                                                                                                       \
+    iss_kc += 1;                                                                                            \
+    const int wrap_ = iss_kc == kc_n ? 1 : 0;                                                               \
+    iss_kc = wrap_ ? 0 : iss_kc;                                                                            \
+    iss_i += wrap_;                                                                                         \
+    iss_slot = iss_slot + 1 == kWsfStages ? 0 : iss_slot + 1;                                               \
+  }
+
+  YV4_WSF_ISSUE();
+  YV4_WSF_ISSUE();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  float st_su[NT], st_sq[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { st_su[t] = 0.f; st_sq[t] = 0.f; }
+
+  int rslot = 0;
+  for (int i = 0; i < my_n; ++i) {
+    f32x16 acc[NT], acc2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[t][e] = 0.f; acc2[t][e] = 0.f; }
+
+    for (int kc = 0; kc < kc_n; ++kc) {
+      YV4_WSF_ISSUE();
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // stage q landed: only the two younger stages may be out
+      const char* st = ring + rslot * kWsfStageBytes;
+      const unsigned kx = (unsigned)(kc << 7);               // (kc * 8) << 4: chunk index inside the weight row
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 fa = *reinterpret_cast<const float4*>(st + (a_rd ^ (unsigned)(j << 5)));
+        float4 fb[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fb[t] = *reinterpret_cast<const float4*>(Ws + ((w_rd[t] ^ (unsigned)(j << 5)) ^ kx));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          f32x16& ac_ = (j & 1) ? acc2[t] : acc[t];
+          ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[t].x, ac_, 0, 0, 0);
+          ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[t].y, ac_, 0, 0, 0);
+          ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[t].z, ac_, 0, 0, 0);
+          ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[t].w, ac_, 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      rslot = rslot + 1 == kWsfStages ? 0 : rslot + 1;
+    }
+
+    // epilogue: lane (r, h) holds channel n0 + 32t + r of pixels m0 + (e&3) + 8(e>>2) + 4h; the arithmetic is
+    // epilogue_tile's, operation for operation
+    const int m0 = (gw + i * NW) * 32;
+    const bool full = m0 + 32 <= p.M;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int c = n0 + t * 32 + r;
+      if (c >= p.Cout) continue;
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = acc[t][e] + acc2[t][e];
+      if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool in = full || (m0 + (e & 3) + 8 * (e >> 2) + 4 * h < p.M);
+          st_su[t] += in ? v[e] : 0.f;
+          st_sq[t] += in ? v[e] * v[e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = __builtin_fmaf(v[e], s1[t], t1[t]);     // epilogue_tile's a * s + t is an fma
+      act_row16(v, p.act1, p.slope1);
+      if (has2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = __builtin_fmaf(v[e], s2[t], t2[t]);
+        act_row16(v, p.act2, p.slope2);
+      }
+      float* yb = p.y + ((int64_t)(m0 + 4 * h) * p.y_cs + p.y_co + c);
+      if (full) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yb[(int64_t)((e & 3) + 8 * (e >> 2)) * p.y_cs] = v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (m0 + (e & 3) + 8 * (e >> 2) + 4 * h < p.M) yb[(int64_t)((e & 3) + 8 * (e >> 2)) * p.y_cs] = v[e];
+      }
+    }
+  }
+#undef YV4_WSF_ISSUE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's out-of-range stage DMAs still write this wave's ring
+
+  if (p.stats && my_n > 0) {
+    double* rep = p.stats + (size_t)(gw & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float su = st_su[t], sq = st_sq[t];
+      su += __shfl_xor(su, 32);
+      sq += __shfl_xor(sq, 32);
+      const int c = n0 + t * 32 + r;
+      if (h == 0 && c < p.Cout) {
+        atomicAdd(&rep[c], (double)su);
+        atomicAdd(&rep[p.Cout + c], (double)sq);
+      }
+    }
+  }
+}
+
+static int wsf_slab_cols(const ConvArgs& a) {
+  const int cout32 = (a.Cout + 31) / 32 * 32;
+  for (int bn = 128; bn >= 32; bn >>= 1) {
+    if (bn > cout32) continue;
+    if ((long long)bn * a.Cin * 4 + kWsfWaves * kWsfStages * kWsfStageBytes > 160 * 1024) continue;
+    const int ncol = (a.Cout + bn - 1) / bn;
+    if (32 % ncol != 0) continue;
+    return bn;
+  }
+  return 0;
+}
+
+static bool conv1x1_ws_f32_applies(const ConvArgs& a) {
+  return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.ys_on && a.res == nullptr && a.ksplit <= 1 &&
+         (a.Cin == 64 || a.Cin == 128 || a.Cin == 256) && a.Kw == a.Cin && a.Cout >= 32 && wsf_slab_cols(a) > 0;
+}
+
+template <int NT>
+static int launch_wsf(const ConvArgs& a, hipStream_t stream) {
+  constexpr int BN = NT * 32;
+  const int ncol = (a.Cout + BN - 1) / BN;
+  const size_t lds = (size_t)BN * a.Cin * 4 + (size_t)kWsfWaves * kWsfStages * kWsfStageBytes;
+  const int nstrips = (a.M + 31) / 32;
+  int cpr_shift = 0;
+  while ((4 << cpr_shift) < a.Cin) ++cpr_shift;
+  const long long xb = (long long)a.N * a.H * a.W * a.x_cs * 4, wb = (long long)a.Cout * a.Kw * 4;
+  auto kern = conv1x1_ws_f32_kernel<NT>;
+  static LdsAttrOnce once;
+  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024, "conv1x1_ws_f32")) return rc;
+  hipLaunchKernelGGL(kern, dim3(kWsfGrid), dim3(kWsfThreads), lds, stream, a, (unsigned)xb, (unsigned)wb, ncol, nstrips,
+                     cpr_shift);
+  YV4_CHECK_LAUNCH("conv1x1_ws_f32");
+  return YV4_OK;
+}
+
+static int conv1x1_ws_f32_launch(const ConvArgs& a, hipStream_t s) {
+  switch (wsf_slab_cols(a)) {
+    case 128: return launch_wsf<4>(a, s);
+    case 64: return launch_wsf<2>(a, s);
+    case 32: return launch_wsf<1>(a, s);
+    default: break;
+  }
+  set_error("conv1x1 ws f32: no weight slab of this layer fits the LDS");
+  return YV4_E_UNSUPPORTED;
+}
+
+// the pointwise layers in the kernel's domain that give each persistent wave at least YV4_WS_MINSTRIPS strips
+static bool prefer_ws_f32(const ConvArgs& a) {
+  static const int mode = [] { const char* e = getenv("YV4_WS"); return e ? atoi(e) : 1; }();
+  static const int min_strips = [] { const char* e = getenv("YV4_WS_MINSTRIPS"); return e ? atoi(e) : 2; }();
+  if (!mode || !conv1x1_ws_f32_applies(a)) return false;
+  return ((long long)a.M + 31) / 32 >= (long long)min_strips * 2048;
+}
+
 static bool stem_ok(const yv4_conv_desc* d, bool has_res, bool has2) {
   return d->Cin == 4 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cout <= 64 && !has_res &&
          !has2 && d->x_coff % 2 == 0 && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL;
@@ -905,6 +1165,12 @@ extern "C" int yv4_conv_pick_tile(const yv4_conv_desc* d) {
   const bool fast_ok = d->Cin % kBK == 0 && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL &&
                        (long long)d->Cout * d->KH * d->KW * d->Cin * 4 < 0xFFFFFFF0LL;
   if (stem_ok(d, false, false)) return YV4_TILE_STEM;
+  {
+    ConvArgs a{};
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.K = a.Kw = d->KH * d->KW * d->Cin; a.M = (int)((long long)d->N * d->Ho * d->Wo);
+    if (fast_ok && prefer_ws_f32(a)) return YV4_TILE_WS_1x1;     // (a residual, unknown here, keeps the tile kernels)
+  }
   return pick_tile((long long)d->N * d->Ho * d->Wo, d->Cout, fast_ok, (long long)d->KH * d->KW * d->Cin);
 }
 
@@ -954,9 +1220,16 @@ static int conv_f32_impl(const yv4_conv_desc* d, const float* x, const float* w,
   const bool fast_ok = uniform && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL &&
                        (long long)d->Cout * a.K * 4 < 0xFFFFFFF0LL;
   const bool can_stem = stem_ok(d, residual != nullptr, scale2 != nullptr);
-  int tile = d->tile == YV4_TILE_AUTO ? (can_stem ? YV4_TILE_STEM : pick_tile(M, d->Cout, fast_ok, a.K)) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (stats_done) *stats_done = false;
+  if (d->tile == YV4_TILE_WS_1x1)
+    YV4_REQUIRE(fast_ok && conv1x1_ws_f32_applies(a), "conv: the weight-stationary tile needs a 1x1 / stride 1 conv with Cin 64, "
+                "128 or 256, Cout >= 32 and no residual");
+  if (d->tile == YV4_TILE_WS_1x1 || (d->tile == YV4_TILE_AUTO && fast_ok && prefer_ws_f32(a))) {
+    if (stats) { a.stats = stats; *stats_done = true; }
+    return conv1x1_ws_f32_launch(a, s);
+  }
+  int tile = d->tile == YV4_TILE_AUTO ? (can_stem ? YV4_TILE_STEM : pick_tile(M, d->Cout, fast_ok, a.K)) : d->tile;
   if (stats && fast_ok && (tile == YV4_TILE_DMA_64x64 || tile == YV4_TILE_DMA_128x64 || tile == YV4_TILE_DMA_128x128)) {
     a.stats = stats;
     *stats_done = true;

@@ -97,6 +97,10 @@ __device__ __forceinline__ float mish_f32(float x) {
 // vs mish_f32 is < 2e-6 over the whole range (tests/test_gpu_parity.py::test_conv_*), far inside
 // the 1e-4 parity budget.
 __device__ __forceinline__ float mish_fast_f32(float x) {
+  // no contraction in here: whether  n + 2  became fma(e, e + 2, 2) used to depend on the loop around the call, so two
+  // kernels with the same accumulator could round an output differently (the fp32 plans promise the same bits from
+  // every tile kernel, tests/test_gpu_parity.py::test_conv1x1_ws_kernel_f32)
+#pragma clang fp contract(off)
   const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
   const float n = e * (e + 2.f);
   const float y = x * n * __builtin_amdgcn_rcpf(n + 2.f);

@@ -74,7 +74,7 @@ def test_mish_empty(gpu_device):
 # fused conv, op level
 # ---------------------------------------------------------------------------------------------
 def _conv_case(dev, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=False, two_stage=False, x_off=0,
-               y_off=0, seed=0):
+               y_off=0, seed=0, raw=False):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5
@@ -113,6 +113,8 @@ def _conv_case(dev, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=Fals
     torch.cuda.synchronize()
     full = out_buf.buf.tensor.view(N, Ho, Wo, -1)
     assert bool((full[..., :y_off] == 7.0).all()) and bool((full[..., y_off + Cout:] == 7.0).all())
+    if raw:
+        return got.clone()
     return close(got, ref, 1e-4, f'conv {N}x{Cin}x{H}x{W}->{Cout} k{k}s{stride} tile{tile}')
 
 
@@ -141,6 +143,37 @@ def test_conv_shapes_and_tiles(gpu_device, shape, tile):
 def test_conv_epilogues(gpu_device, act):
     _conv_case(gpu_device, 2, 13, 13, 32, 96, 3, 1, 1, act, 0, residual=True, two_stage=True, x_off=8, y_off=4)
     _conv_case(gpu_device, 1, 13, 13, 64, 64, 1, 1, 0, act, 0, residual=False, two_stage=True, y_off=8)
+
+
+WS_SHAPES_F32 = [
+    # N, H, W, Cin, Cout  (1x1, stride 1): the domain of conv1x1_ws_f32_kernel, tile 9
+    (2, 19, 19, 128, 128),     # ragged last strip, one slab (64 KB of weights)
+    (1, 76, 76, 64, 64),       # more strips than one round of waves
+    (3, 40, 33, 256, 128),     # eight stages per strip, two slabs of 64 columns
+    (1, 31, 7, 256, 256),      # four slabs reading the same strips
+    (2, 64, 64, 64, 32),       # narrowest slab
+    (1, 5, 5, 128, 96),        # fewer pixels than one strip, half-empty second slab
+]
+
+
+@pytest.mark.parametrize('shape', WS_SHAPES_F32)
+def test_conv1x1_ws_kernel_f32(gpu_device, shape):
+    """The persistent weight-stationary pointwise kernel: within 1e-4 of the fp64 convolution AND bit-identical to the
+    LDS-DMA tiles (same summation order), which is what lets a plan pick either by batch size."""
+    N, H, W, Cin, Cout = shape
+    _conv_case(gpu_device, N, H, W, Cin, Cout, 1, 1, 0, act=1, tile=L.TILE_WS_1x1)
+    outs = []
+    for tile in (L.TILE_WS_1x1, L.TILE_DMA_64x64, L.TILE_DMA_128x64):
+        outs.append(_conv_case(gpu_device, N, H, W, Cin, Cout, 1, 1, 0, act=1, tile=tile, two_stage=True, y_off=4, raw=True))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_conv1x1_ws_kernel_f32_is_refused_outside_its_domain(gpu_device):
+    for shape in [(1, 8, 8, 64, 64, 3, 1, 1), (1, 8, 8, 96, 64, 1, 1, 0), (1, 8, 8, 512, 64, 1, 1, 0), (1, 8, 8, 64, 16, 1, 1, 0)]:
+        with pytest.raises(L.Yv4Error):
+            _conv_case(gpu_device, *shape, act=1, tile=L.TILE_WS_1x1)
+    with pytest.raises(L.Yv4Error):
+        _conv_case(gpu_device, 1, 8, 8, 64, 64, 1, 1, 0, act=1, tile=L.TILE_WS_1x1, residual=True)
 
 
 def test_conv_big_k_accuracy(gpu_device):
