@@ -209,6 +209,26 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
         }
       }
     }
+  } else if (p.out_f32) {
+    // fp32 rows that are not 16-byte aligned (the 255-channel pred maps): lane (r, h) takes channel co_base + r of the
+    // rows 2k + h, so a store instruction writes two runs of 32 consecutive floats -- coalesced whatever the row's
+    // alignment (eight scattered dwords per lane and instruction took 3.7x the pred convs' byte floor)
+    const int c = co_base + r;
+    if (c < p.Cout) {
+      const float sc1 = p.s1[c], sh1 = p.t1[c];
+      const float sc2 = has2 ? p.s2[c] : 1.f, sh2 = has2 ? p.t2[c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int row = 2 * k + h;
+        const int m = m_base + row;
+        if (m >= p.M) continue;
+        float v = ep[row * kPitch + r] * sc1 + sh1;
+        v = apply_act(v, p.act1, p.slope1);
+        if (p.res) v += (float)reinterpret_cast<const T*>(p.res)[(int64_t)m * p.r_cs + p.r_co + c];
+        if (has2) v = apply_act(v * sc2 + sh2, p.act2, p.slope2);
+        reinterpret_cast<float*>(p.y)[out_row_h(p, m) * p.y_cs + p.y_co + c] = v;
+      }
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {

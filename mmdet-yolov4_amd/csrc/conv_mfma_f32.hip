@@ -357,21 +357,23 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const f32x16& a
       }
     }
   } else {
+    // rows that are not 16-byte aligned (the 255-channel pred maps) or a ragged column tile: lane (r, h) takes channel
+    // co_base + r of the rows 2k + h, so a store instruction writes two runs of 32 consecutive floats (coalesced
+    // whatever the row's alignment).  Same arithmetic, element for element, as the vector path.
+    const int c = co_base + r;
+    if (c < p.Cout) {
+      const float sc1 = p.s1[c], sh1 = p.t1[c];
+      const float sc2 = has2 ? p.s2[c] : 1.f, sh2 = has2 ? p.t2[c] : 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = (lane >> 3) + 8 * k;
-      const int m = m_base + row;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = co + u;
-        if (c < p.Cout) {
-          float v = ep[row * kPitch + c4 + u] * p.s1[c] + p.t1[c];
-          v = apply_act(v, p.act1, p.slope1);
-          if (p.res) v += p.res[(int64_t)m * p.r_cs + p.r_co + c];
-          if (has2) v = apply_act(v * p.s2[c] + p.t2[c], p.act2, p.slope2);
-          p.y[out_row(p, m) * p.y_cs + p.y_co + c] = v;
-        }
+      for (int k = 0; k < 16; ++k) {
+        const int row = 2 * k + h;
+        const int m = m_base + row;
+        if (m >= p.M) continue;
+        float v = ep[row * kPitch + r] * sc1 + sh1;
+        v = apply_act(v, p.act1, p.slope1);
+        if (p.res) v += p.res[(int64_t)m * p.r_cs + p.r_co + c];
+        if (has2) v = apply_act(v * sc2 + sh2, p.act2, p.slope2);
+        p.y[out_row(p, m) * p.y_cs + p.y_co + c] = v;
       }
     }
   }
