@@ -92,7 +92,9 @@ class Conv(HipModule):
                          name=name or f'conv{self.kernel_size}x{self.kernel_size}',
                          bn1=(self.norm, 0, self.out_channels) if self.with_norm else None, bn2=bn2)
 
-    def fwd(self, x, residual=None):
+    def fwd(self, x, residual=None, sink=None, res_sink=None):
+        """``sink`` / ``res_sink``: a ``train_ops.GradSink`` this conv's data gradient consumes / the residual's
+        gradient is parked in (both ends of a Bottleneck's shortcut, see ``Bottleneck.fwd``)."""
         w = self.conv.weight
         dt = T.train_dtype(self, x)
         al = 4 if dt == torch.float32 else 8
@@ -110,8 +112,8 @@ class Conv(HipModule):
                 if stats is None or stats.device != x.device or stats.numel() != T.stats_numel(w.shape[0]):
                     stats = self._yv4_stats = T.conv_stats_buffer(w.shape[0], x.device, persistent=True)
             try:
-                y = T.conv2d(x, w, self.stride, self.padding, dtype=dt, stats=stats)
-                return T.bn_act(y, bn, act_id(self.activate), residual, sums=stats)
+                y = T.conv2d(x, w, self.stride, self.padding, dtype=dt, stats=stats, sink=sink)
+                return T.bn_act(y, bn, act_id(self.activate), residual, sums=stats, res_sink=res_sink)
             except Exception:
                 self._yv4_stats = None       # a half-used statistics buffer is not clean: drop it
                 raise
@@ -169,7 +171,13 @@ class Bottleneck(HipModule):
         return self.conv2.emit(plan, y, out=out, residual=x if self.shortcut else None, post=post)
 
     def fwd(self, x):
-        return self.conv2.fwd(self.conv1.fwd(x), residual=x if self.shortcut else None)
+        if not self.shortcut:
+            return self.conv2.fwd(self.conv1.fwd(x))
+        # out = x + f(x): d_out reaches x twice; the second path is added inside conv1's data-gradient launch
+        # (train_ops.GradSink) instead of by autograd's add kernel -- when both convs run the fused BN path
+        sink = T.grad_sink_for(x) if (self.conv1.with_norm and self.conv2.with_norm and self.conv1.stride == 1
+                                      and T.train_dtype(self, x) == x.dtype) else None
+        return self.conv2.fwd(self.conv1.fwd(x, sink=sink), residual=x, res_sink=sink)
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')

@@ -70,7 +70,7 @@ def _identity_affine(device, C_):
 _DCODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
-def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None, x_cs=None):
+def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None, x_cs=None, residual=None, res_cs=None):
     """Identity-epilogue conv of a channels_last tensor; fp32, or fp16 / bf16 operands (fp32 accumulate).
     ``stats``: a float64 buffer of ``STATS_REPLICAS * 2 * Cout`` entries that receives the BatchNorm sums of the
     output (``yv4_conv_fwd_stats``: accumulated in the conv kernel's epilogue)."""
@@ -80,6 +80,10 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None,
     d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin_p, Ho, Wo, Cout
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.x_cstride, d.y_cstride = (x_cs if x_cs is not None else Cin_p), Cout
+    if residual is not None:        # out = conv + residual (a gradient that joins this one: see GradSink)
+        assert stats is None and residual.dtype == x.dtype
+        d.r_cstride, d.r_coff = (res_cs if res_cs is not None else Cout), 0
+    rptr = residual.data_ptr() if residual is not None else None
     ones, zeros = _identity_affine(x.device, Cout)
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.numel() >= _lib.STATS_REPLICAS * 2 * Cout
@@ -90,14 +94,37 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None,
         return d
     if x.dtype == torch.float32:
         check(_lib.lib().yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w_packed.data_ptr(), ones.data_ptr(),
-                                             zeros.data_ptr(), None, None, None, out.data_ptr(), stream_ptr()),
+                                             zeros.data_ptr(), None, None, rptr, out.data_ptr(), stream_ptr()),
               'yv4_conv_bn_act_fwd')
     else:
         code = _DCODE[x.dtype]
         check(_lib.lib().yv4_conv_bn_act_fwd_h16(C.byref(d), code, code, x.data_ptr(), w_packed.data_ptr(),
-                                                 ones.data_ptr(), zeros.data_ptr(), None, None, None, out.data_ptr(),
+                                                 ones.data_ptr(), zeros.data_ptr(), None, None, rptr, out.data_ptr(),
                                                  stream_ptr()), 'yv4_conv_bn_act_fwd_h16')
     return d
+
+
+class GradSink:
+    """Joins two gradient paths of one tensor without autograd's add kernel.  For  out = x + f(x)  (a Bottleneck
+    with shortcut, darknetcsp.py:60-64) the gradient of x is  d_out + f'(d_out): the BN + act + residual Function at
+    the end of f parks d_out here instead of returning it for the residual, and the FIRST convolution of f -- whose
+    backward runs last -- adds it in the epilogue of its data-gradient launch (``residual=`` of the conv kernels).
+    Saves one read-read-write pass over the activation per bottleneck and step.  YV4_GRAD_SINK=0 switches it off."""
+    __slots__ = ('value', 'cs')
+
+    def __init__(self):
+        self.value = None
+        self.cs = None
+
+
+_GRAD_SINK_ON = os.environ.get('YV4_GRAD_SINK', '1') != '0'
+
+
+def grad_sink_for(x):
+    """A sink for the residual path of ``x``, or None when the fusion does not apply (no gradient wanted)."""
+    if _GRAD_SINK_ON and torch.is_grad_enabled() and x.requires_grad:
+        return GradSink()
+    return None
 
 
 # ---- packed weight operands, replayed in one launch per optimizer step -----------------------------------------------
@@ -227,7 +254,7 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None):
     return out, cp
 
 
-def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None):
+def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None, residual=None, res_cs=None):
     """dX = correlate(dY zero-dilated by `stride`, W flipped in (kh,kw) and transposed in (co,ci)), pad k-1-p."""
     N, Cin, H, W = xshape
     Cout, _, KH, KW = weight.shape
@@ -252,7 +279,9 @@ def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None):
     Hx = Hs + 2 * p2 - KH + 1
     Wx = Ws + 2 * p2 - KW + 1
     dxf = torch.empty((N, Cin, Hx, Wx), device=dy.device, dtype=dtype, memory_format=torch.channels_last)
-    _conv_launch(src, wtp, Cout, Cin, KH, KW, 1, p2, dxf, x_cs=src_cs)
+    if residual is not None:
+        assert (Hx, Wx) == (H, W)
+    _conv_launch(src, wtp, Cout, Cin, KH, KW, 1, p2, dxf, x_cs=src_cs, residual=residual, res_cs=res_cs)
     if (Hx, Wx) != (H, W):
         # stride 2 with odd input size: the dilated grid is one row/column larger or smaller
         dx = torch.empty((N, Cin, H, W), device=dy.device, dtype=dtype, memory_format=torch.channels_last).zero_()
@@ -368,11 +397,12 @@ class ConvFunction(torch.autograd.Function):
     master copy the optimizer steps; autocast semantics of the reference's Fp16 hook)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, dtype, stats=None, direct=None):
+    def forward(ctx, x, weight, stride, pad, dtype, stats=None, direct=None, sink=None):
         """``direct``: a ``_ParamRef`` to the parameter whose ``.grad`` receives dW in place (then ``weight`` is the
         detached parameter: autograd does not track it through this Function, see ``conv2d``)."""
         _need_cuda(x, 'x')
         ctx.direct = direct
+        ctx.sink = sink if stride == 1 else None     # (the stride-2 parity form has no residual input)
         Cout, Cin, KH, KW = weight.shape
         al = 4 if dtype == torch.float32 else 8
         assert x.shape[1] == Cin and Cout % al == 0 and Cin % al == 0, \
@@ -434,12 +464,24 @@ class ConvFunction(torch.autograd.Function):
                 for cb in _direct_grad_listeners:
                     cb(prm)
         if ctx.needs_input_grad[0]:
+            joined = jcs = None
+            if ctx.sink is not None and ctx.sink.value is not None:
+                joined, jcs = ctx.sink.value, ctx.sink.cs
+                ctx.sink.value = None
+                if joined.dtype != dtype or tuple(joined.shape) != (N, Cin, H, W):
+                    joined = to_nhwc(joined.to(dtype))
+                    jcs = None
             if stride == 2 and (KH, KW, pad) == (3, 3, 1) and Cout % (8 if h16 else 32) == 0:
                 dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype, dy_cs)
             else:
-                dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype, dy_cs)
+                dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype, dy_cs, residual=joined, res_cs=jcs)
+                joined = None
+            if joined is not None:
+                dx = dx + joined
             dx = dx.to(ctx.x_dtype)
-        return dx, dw, None, None, None, None, None
+        elif ctx.sink is not None and ctx.sink.value is not None:
+            dx, ctx.sink.value = ctx.sink.value, None       # nobody wants this conv's share: hand the parked one on
+        return dx, dw, None, None, None, None, None, None
 
 
 def train_dtype(module, x):
@@ -451,7 +493,7 @@ def train_dtype(module, x):
     return x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
 
 
-def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None):
+def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None, sink=None):
     """``dtype`` None: follow ``x`` (a 16-bit activation keeps the path 16-bit, anything else is fp32).
     ``stats``: see ``_conv_launch`` / ``conv_stats_buffer``; pass the same buffer to ``bn_act(..., sums=)``."""
     if dtype is None:
@@ -460,8 +502,8 @@ def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None):
             and _direct_grad_target(weight, weight.shape[1]) is not None
             and weight.shape[1] % (4 if dtype == torch.float32 else 8) == 0):
         # dW goes straight into weight.grad (see the note above ConvFunction): the Function sees the detached weight
-        return ConvFunction.apply(x, weight.detach(), stride, pad, dtype, stats, _ParamRef(weight))
-    return ConvFunction.apply(x, weight, stride, pad, dtype, stats, None)
+        return ConvFunction.apply(x, weight.detach(), stride, pad, dtype, stats, _ParamRef(weight), sink)
+    return ConvFunction.apply(x, weight, stride, pad, dtype, stats, None, sink)
 
 
 def stats_numel(cout):
@@ -485,7 +527,7 @@ class BNActFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual, training=True,
-                sync_group=None, sums=None, direct=None):
+                sync_group=None, sums=None, direct=None, res_sink=None):
         """``sync_group``: None, or a (process group or 'world') to synchronise the batch statistics over
         (torch.nn.SyncBatchNorm semantics: statistics over all ranks' rows, local dgamma / dbeta).
         ``sums``: the replicated [sum | sum of squares] buffer the producing conv filled (``conv2d(stats=)``):
@@ -558,6 +600,7 @@ class BNActFunction(torch.autograd.Function):
         ctx.act = (int(act), float(slope))
         ctx.training = bool(training)
         ctx.has_res = residual is not None
+        ctx.res_sink = res_sink if residual is not None else None      # GradSink: the residual's gradient is parked
         return y
 
     @staticmethod
@@ -608,6 +651,9 @@ class BNActFunction(torch.autograd.Function):
                          dgamma.data_ptr(), dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope,
                          stream_ptr()), 'yv4_bn_act_bwd')
         dres = dy if ctx.has_res else None
+        if dres is not None and ctx.res_sink is not None:
+            ctx.res_sink.value, ctx.res_sink.cs = dy, dcs       # added by the data-gradient launch that consumes the sink
+            dres = None
         if ctx.direct is not None:   # autograd does not track gamma / beta through this Function
             if ctx.rows is not None or gw is None:
                 for ref, gr in zip(ctx.direct, (dgamma, dbeta)):
@@ -616,7 +662,7 @@ class BNActFunction(torch.autograd.Function):
                 for cb in _direct_grad_listeners:
                     cb(ref.p)
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None, None, None
 
 
 def _sync_group(bn):
@@ -634,7 +680,7 @@ def _sync_group(bn):
     return group if group is not None else 'world'
 
 
-def bn_act(x, bn, act=(0, 0.0), residual=None, sums=None):
+def bn_act(x, bn, act=(0, 0.0), residual=None, sums=None, res_sink=None):
     """``bn``: a torch BatchNorm2d; in training mode it normalises with batch statistics and updates
     the running ones, in eval mode (``norm_eval`` / frozen stages inside a training graph) with the
     running statistics as constants.  act = (YV4_ACT_*, slope)."""
@@ -650,7 +696,7 @@ def bn_act(x, bn, act=(0, 0.0), residual=None, sums=None):
     out = BNActFunction.apply(x, gamma, beta, bn.running_mean if bn.track_running_stats else None,
                               bn.running_var if bn.track_running_stats else None, bn.eps, mom, act[0], act[1],
                               residual, use_batch, _sync_group(bn) if use_batch else None,
-                              sums if use_batch else None, direct)
+                              sums if use_batch else None, direct, res_sink)
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         if _fwd_depth[0] > 0:        # inside a registered module's training forward: one multi-tensor add at its end
             _nbt_pending.append(bn.num_batches_tracked)
