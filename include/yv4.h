@@ -325,7 +325,7 @@ int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, i
  * taps of a (chunk, kh) share one LDS image of the activations */
 #define YV4_HTILE_C3_256x128 4
 #define YV4_HTILE_C3_256x64 5
-/* 1x1 / stride 1, Cin 64 / 128 / 256, Cout >= 32, 16-bit output, no residual (conv1x1_ws_h16.hip): one persistent
+/* 1x1 / stride 1, Cin <= 256, even Cout >= 16, 16-bit output, no residual (conv1x1_ws_h16.hip): one persistent
  * 8-wave workgroup per CU, the weight slab resident in LDS, wave-private rings of 32-pixel strips */
 #define YV4_HTILE_WS_1x1 6
 int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x,

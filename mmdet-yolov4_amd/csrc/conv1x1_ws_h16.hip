@@ -21,6 +21,7 @@
 //     dwords after one DPP swap between the lanes of adjacent channels (pair_pack16: sub-dword stores were the
 //     first version's bottleneck), 64-byte segments per pixel.
 //
+// Any Cin % 8 == 0 up to 256 (laid out as 64 / 128 / 256 channels, zero-padded) and Cout >= 16.
 // Epilogue = the common one minus the residual: affine1 -> act1 -> (affine2 -> act2) -> store at a channel offset,
 // or (stats != nullptr) identity + statistics of the rounded outputs.  Residual, fp32 output and scattered output
 // stay with the generic tiles.
@@ -68,9 +69,13 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31;
   const int h = lane >> 5;
-  const int kc_n = p.Cin >> 6;          // 64-channel stages per strip
-  const int cpr = 1 << cpr_shift;       // 16-byte chunks per weight row (Cin / 8)
-  const int wpitch = p.Cin * 2;
+  // The LDS images are laid out for Cin rounded up to 64 / 128 / 256 channels; the chunks beyond the real Cin are
+  // zero-filled by out-of-range DMA offsets (Cin = 32: half of every stage and of every weight row is padding --
+  // these layers are HBM-bound, the idle half of the MFMA K steps costs nothing that shows)
+  const int cpr = 1 << cpr_shift;       // 16-byte chunks per weight row in LDS
+  const int kc_n = cpr >> 3;            // 64-channel stages per strip
+  const int wpitch = cpr * 16;
+  const int cin_chunks = p.Cin >> 3;    // real chunks per row
 
   char* Ws = smem_ws;                                                   // [BN][Cin] 16-bit, chunks XOR-swizzled
   char* ring = smem_ws + BN * wpitch + wave * (kWsStages * kWsStageBytes);
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
       const int pch = c & (cpr - 1);
       const int swz = cpr >= 16 ? (row & 15) : ((row >> 1) & 7);
       const int co = n0 + row;
-      const unsigned voff = co < p.Cout ? (unsigned)(((int64_t)co * p.Kw + (pch ^ swz) * 8) * 2) : kOOB;
+      const int lch = pch ^ swz;
+      const unsigned voff = (co < p.Cout && lch < cin_chunks) ? (unsigned)(((int64_t)co * p.Kw + lch * 8) * 2) : kOOB;
       lds_dma16_h(rsB, lds_base + (unsigned)(g * 1024), voff, 0u);
     }
   }
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
       const int row_ = row0_ + 8 * j;                                                                       \
       const unsigned lch_ = (j & 1) ? lch_odd : lch_even;                                                   \
-      const unsigned voff_ = (live_ && row_ < p.M)                                                          \
+      const unsigned voff_ = (live_ && row_ < p.M && iss_kc * 64 + (int)lch_ < p.Cin)                       \
                                  ? (unsigned)(((int64_t)row_ * p.x_cs + p.x_co + iss_kc * 64 + (int)lch_) * 2) \
                                  : kOOB;                                                                    \
       lds_dma16_h(rsA, lds_ + (unsigned)(j * 1024), voff_, 0u);                                             \
@@ -259,11 +265,13 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
 }
 
 // Slab width: the widest of 128 / 64 / 32 columns whose Cin-deep slab fits 64 KB beside the rings
+static int ws_cin_lds(int Cin) { return Cin <= 64 ? 64 : (Cin <= 128 ? 128 : 256); }
+
 static int ws_slab_cols(const ConvArgsH& a) {
   const int cout32 = (a.Cout + 31) / 32 * 32;
   for (int bn = 128; bn >= 32; bn >>= 1) {
     if (bn > cout32) continue;
-    if ((long long)bn * a.Cin * 2 + kWsWaves * kWsStages * kWsStageBytes > 160 * 1024) continue;
+    if ((long long)bn * ws_cin_lds(a.Cin) * 2 + kWsWaves * kWsStages * kWsStageBytes > 160 * 1024) continue;
     const int ncol = (a.Cout + bn - 1) / bn;
     if (32 % ncol != 0) continue;
     return bn;
@@ -274,7 +282,7 @@ static int ws_slab_cols(const ConvArgsH& a) {
 // Is this layer in the kernel's domain?
 bool conv1x1_ws_applies(const ConvArgsH& a) {
   return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.ys_on && !a.out_f32 && a.res == nullptr &&
-         (a.Cin == 64 || a.Cin == 128 || a.Cin == 256) && a.Kw == a.Cin && a.Cout >= 32 && (a.Cout & 1) == 0 &&
+         a.Cin >= 16 && a.Cin <= 256 && (a.Cin & 7) == 0 && a.Kw == a.Cin && a.Cout >= 16 && (a.Cout & 1) == 0 &&
          ((a.y_cs | a.y_co) & 1) == 0 && ws_slab_cols(a) > 0;
 }
 
@@ -282,10 +290,11 @@ template <bool BF16, int NT>
 static int launch_ws(const ConvArgsH& a, hipStream_t stream) {
   constexpr int BN = NT * 32;
   const int ncol = (a.Cout + BN - 1) / BN;
-  const size_t lds = (size_t)BN * a.Cin * 2 + (size_t)kWsWaves * kWsStages * kWsStageBytes;
+  const int cin_lds = ws_cin_lds(a.Cin);
+  const size_t lds = (size_t)BN * cin_lds * 2 + (size_t)kWsWaves * kWsStages * kWsStageBytes;
   const int nstrips = (a.M + 31) / 32;
   int cpr_shift = 0;
-  while ((8 << cpr_shift) < a.Cin) ++cpr_shift;
+  while ((8 << cpr_shift) < cin_lds) ++cpr_shift;
   const long long xb = (long long)a.N * a.H * a.W * a.x_cs * 2, wb = (long long)a.Cout * a.Kw * 2;
   auto kern = conv1x1_ws_kernel<BF16, NT>;
   static LdsAttrOnce once;

@@ -429,8 +429,8 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   if (c3_id) YV4_REQUIRE(conv3x3_h16_applies(a), "conv h16: the C3 tiles need a 3x3 / stride 1 / pad 1 conv with Cin %% 64 == 0, Cout >= 64");
   if (c3_id || (d->tile == YV4_TILE_AUTO && prefer_c3(a))) return conv3x3_h16_launch(a, dtype == YV4_BF16, d->tile, s);
   if (d->tile == YV4_HTILE_WS_1x1)
-    YV4_REQUIRE(conv1x1_ws_applies(a), "conv h16: the weight-stationary tile needs a 1x1 / stride 1 conv with Cin 64, 128 or 256, "
-                "Cout >= 32, 16-bit output and no residual");
+    YV4_REQUIRE(conv1x1_ws_applies(a), "conv h16: the weight-stationary tile needs a 1x1 / stride 1 conv with Cin <= 256, "
+                "even Cout >= 16, 16-bit output and no residual");
   if (d->tile == YV4_HTILE_WS_1x1 || (d->tile == YV4_TILE_AUTO && prefer_ws(a))) return conv1x1_ws_launch(a, dtype == YV4_BF16, s);
   const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);

@@ -185,6 +185,9 @@ WS_SHAPES = [
     (2, 64, 64, 64, 32),       # narrowest slab (one 32-column tile)
     (1, 5, 5, 128, 96),        # fewer pixels than one strip; Cout 96 = a full 64-column slab and a half-empty one
     (4, 152, 152, 64, 64),     # 2 888 strips: every wave walks its ring across several strips
+    (2, 52, 52, 32, 16),       # the v4s widths: Cin 32 laid out as 64 (zero chunks), Cout 16 = half a column tile
+    (1, 40, 40, 96, 48),       # the v4m widths: Cin 96 laid out as 128
+    (1, 33, 33, 192, 96),      # Cin 192 laid out as 256
 ]
 
 
@@ -204,8 +207,8 @@ def test_h16_conv1x1_ws_kernel_epilogues(gpu_device, dtype, act):
 
 
 def test_h16_conv1x1_ws_kernel_is_refused_outside_its_domain(gpu_device):
-    for shape in [(1, 8, 8, 64, 64, 3, 1, 1), (1, 8, 8, 192, 64, 1, 1, 0), (1, 8, 8, 512, 64, 1, 1, 0),
-                  (1, 8, 8, 64, 16, 1, 1, 0)]:
+    for shape in [(1, 8, 8, 64, 64, 3, 1, 1), (1, 8, 8, 320, 64, 1, 1, 0), (1, 8, 8, 512, 64, 1, 1, 0),
+                  (1, 8, 8, 64, 8, 1, 1, 0)]:
         with pytest.raises(L.Yv4Error):
             _h16_conv(gpu_device, torch.bfloat16, *shape, act=1, tile=6)
     with pytest.raises(L.Yv4Error):
