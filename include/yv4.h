@@ -328,6 +328,10 @@ int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, i
 /* 1x1 / stride 1, Cin <= 256, even Cout >= 16, 16-bit output, no residual (conv1x1_ws_h16.hip): one persistent
  * 8-wave workgroup per CU, the weight slab resident in LDS, wave-private rings of 32-pixel strips */
 #define YV4_HTILE_WS_1x1 6
+/* 3x3 / stride 1 / pad 1 with few channels -- Cin 16, 32 or 64, even Cout in [16, 64], 16-bit output
+ * (conv3x3_small_h16.hip): one persistent 8-wave workgroup per CU on 16 x 16 output tiles, the weights resident in LDS,
+ * the 18 x 18 input tile double-buffered through LDS-DMA */
+#define YV4_HTILE_S3x3 7
 int yv4_conv_bn_act_fwd_h16(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x,
                             const void* w, const float* scale1, const float* shift1,
                             const float* scale2, const float* shift2, const void* residual,

@@ -352,6 +352,22 @@ static bool prefer_ws(const ConvArgsH& a) {
   return ((long long)a.M + 31) / 32 >= (long long)min_strips * 2048;
 }
 
+// conv3x3_small_h16.hip
+bool conv3x3_small_applies(const ConvArgsH& a);
+int conv3x3_small_launch(const ConvArgsH& a, bool bf16, hipStream_t s);
+
+// The few-channel 3x3 kernel takes the layers in its domain with at least YV4_S3_MINTILES 16 x 16 output tiles
+// (YV4_S3=0 switches it off).
+static bool prefer_s3(const ConvArgsH& a) {
+  static const int mode = [] { const char* e = getenv("YV4_S3"); return e ? atoi(e) : 1; }();
+  static const int min_tiles = [] { const char* e = getenv("YV4_S3_MINTILES"); return e ? atoi(e) : 1024; }();
+  if (!mode || !conv3x3_small_applies(a)) return false;
+  const long long ty = (a.Ho + 15) / 16, tx = (a.Wo + 15) / 16;
+  // at 64 input channels the generic tiles are close (0.9-1.2x, measured): only maps that fill their 16 x 16 tiles
+  if (a.Cin == 64 && (long long)a.Ho * a.Wo * 100 < ty * tx * 256 * 85) return false;
+  return (long long)a.N * ty * tx >= min_tiles;
+}
+
 static int pick_tile_h16(long long M, int Cout, long long K) {
   // From the per-layer table of tools/conv_bench.py --dtype bf16 (YOLOv4-L, batch 32; after the prologue /
   // epilogue work of round 1 the 128x64 tile -- three workgroups per CU -- is the best or within 2 % of the best
@@ -375,6 +391,8 @@ extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
     if (prefer_c3(a)) return d->Cout > 64 ? YV4_HTILE_C3_256x128 : YV4_HTILE_C3_256x64;
     a.K = a.Kw = d->KH * d->KW * d->Cin; a.res = nullptr; a.out_f32 = 0;
     if (prefer_ws(a)) return YV4_HTILE_WS_1x1;
+    a.N = d->N; a.stats = nullptr; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = d->r_cstride; a.r_co = d->r_coff;
+    if (prefer_s3(a)) return YV4_HTILE_S3x3;
   }
   return pick_tile_h16((long long)d->N * d->Ho * d->Wo, d->Cout, (long long)d->KH * d->KW * d->Cin);
 }
@@ -432,6 +450,10 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
     YV4_REQUIRE(conv1x1_ws_applies(a), "conv h16: the weight-stationary tile needs a 1x1 / stride 1 conv with Cin <= 256, "
                 "even Cout >= 16, 16-bit output and no residual");
   if (d->tile == YV4_HTILE_WS_1x1 || (d->tile == YV4_TILE_AUTO && prefer_ws(a))) return conv1x1_ws_launch(a, dtype == YV4_BF16, s);
+  if (d->tile == YV4_HTILE_S3x3)
+    YV4_REQUIRE(conv3x3_small_applies(a), "conv h16: the few-channel 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with Cin 16, 32 "
+                "or 64, even Cout in [16, 64], 16-bit output and no statistics");
+  if (d->tile == YV4_HTILE_S3x3 || (d->tile == YV4_TILE_AUTO && prefer_s3(a))) return conv3x3_small_launch(a, dtype == YV4_BF16, s);
   const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);
 }

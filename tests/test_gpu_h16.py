@@ -217,6 +217,42 @@ def test_h16_conv1x1_ws_kernel_is_refused_outside_its_domain(gpu_device):
         _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 64, 1, 1, 0, act=1, tile=6, out_f32=True)
 
 
+S3_SHAPES = [
+    # N, H, W, Cin, Cout  (3x3, stride 1, pad 1): the domain of conv3x3_small_h16.hip, tile 7
+    (2, 32, 32, 16, 32),       # 2 x 2 full tiles per image, the v4s widths
+    (1, 40, 56, 32, 64),       # ragged tiles on both axes, the v4l widths
+    (3, 19, 23, 64, 64),       # odd sizes, four chunks per pixel pair ... Cin 64
+    (1, 16, 300, 32, 32),      # one tile row: every top / bottom tap row is padding
+    (5, 5, 5, 16, 16),         # images smaller than a tile, Cout 16 = half a column tile
+    (2, 304, 304, 32, 64),     # 722 tiles: more than one round of the persistent grid, double-buffered prefetch
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', S3_SHAPES)
+def test_h16_conv3x3_small_kernel_shapes(gpu_device, dtype, shape):
+    N, H, W, Cin, Cout = shape
+    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=7)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+def test_h16_conv3x3_small_kernel_epilogues(gpu_device, dtype, act):
+    """Residual + two-stage epilogue + channel-offset views on both sides through the few-channel 3x3 kernel."""
+    _h16_conv(gpu_device, dtype, 2, 23, 37, 32, 64, 3, 1, 1, act, 7, residual=True, two_stage=True, x_off=8, y_off=16)
+    _h16_conv(gpu_device, dtype, 1, 50, 18, 16, 32, 3, 1, 1, act, 7, residual=True, x_off=16)
+    _h16_conv(gpu_device, dtype, 1, 20, 20, 64, 48, 3, 1, 1, act, 7, y_off=8)
+
+
+def test_h16_conv3x3_small_kernel_is_refused_outside_its_domain(gpu_device):
+    for shape in [(1, 8, 8, 32, 64, 1, 1, 0), (1, 8, 8, 32, 64, 3, 2, 1), (1, 8, 8, 128, 64, 3, 1, 1), (1, 8, 8, 32, 128, 3, 1, 1),
+                  (1, 8, 8, 24, 32, 3, 1, 1)]:
+        with pytest.raises(L.Yv4Error):
+            _h16_conv(gpu_device, torch.bfloat16, *shape, act=1, tile=7)
+    with pytest.raises(L.Yv4Error):
+        _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 32, 64, 3, 1, 1, act=1, tile=7, out_f32=True)
+
+
 def test_h16_conv_big_k(gpu_device):
     _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 512, 64, 3, 1, 1, 1, 1)       # K = 4608
 
