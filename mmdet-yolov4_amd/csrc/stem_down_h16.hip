@@ -240,26 +240,47 @@ __global__ __launch_bounds__(kSdThreads, 1) void stem_down_kernel(StemDownArgs p
       if (pix < kSdSR * kSdSC) {
         const int ay = 2 * oy0 - 1 + sy, ax = 2 * ox0 - 1 + sx;
         const bool inside = (unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W;
-        float v[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {         // channels 8g + 4h .. +3
-          const float4 sc = *reinterpret_cast<const float4*>(Al + (8 * g + 4 * h) * 4);
-          const float4 sh = *reinterpret_cast<const float4*>(Al + (32 + 8 * g + 4 * h) * 4);
-          v[4 * g + 0] = acc[4 * g + 0] * sc.x + sh.x;
-          v[4 * g + 1] = acc[4 * g + 1] * sc.y + sh.y;
-          v[4 * g + 2] = acc[4 * g + 2] * sc.z + sh.z;
-          v[4 * g + 3] = acc[4 * g + 3] * sc.w + sh.w;
-        }
-        if (!(p.ablate & 4)) sd_act16(v, p.act1, p.slope1);
         const int q = ((sx & 1) * kSdSR + sy) * kSdSCols + (sx >> 1);
         const int swz = C1H == 2 ? ((q >> 2) & 3) : ((q >> 3) & 1);
         char* sp = Sl + q * SPix;
+        if (inside) {
+          // only the 8 C1H accumulator registers that hold real channels (C1 = 16: MFMA rows 16-31 are padding)
+          float v[8 * C1H];
 #pragma unroll
-        for (int g = 0; g < 2 * C1H; ++g) {     // channels 8g + 4h .. +3: chunk g, half h
+          for (int g = 0; g < 2 * C1H; ++g) {         // channels 8g + 4h .. +3
+            const float4 sc = *reinterpret_cast<const float4*>(Al + (8 * g + 4 * h) * 4);
+            const float4 sh = *reinterpret_cast<const float4*>(Al + (32 + 8 * g + 4 * h) * 4);
+            v[4 * g + 0] = acc[4 * g + 0] * sc.x + sh.x;
+            v[4 * g + 1] = acc[4 * g + 1] * sc.y + sh.y;
+            v[4 * g + 2] = acc[4 * g + 2] * sc.z + sh.z;
+            v[4 * g + 3] = acc[4 * g + 3] * sc.w + sh.w;
+          }
+          if (!(p.ablate & 4)) {
+            switch (p.act1) {
+              case YV4_ACT_MISH: mish_fast_row(v); break;
+              case YV4_ACT_LEAKY:
+#pragma unroll
+                for (int e = 0; e < 8 * C1H; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope1;
+                break;
+              case YV4_ACT_SWISH:
+#pragma unroll
+                for (int e = 0; e < 8 * C1H; ++e) v[e] = apply_act(v[e], YV4_ACT_SWISH, 0.f);
+                break;
+              default: break;
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < 2 * C1H; ++g) {         // chunk g, half h
+            T4 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = (T)v[4 * g + u];
+            *reinterpret_cast<T4*>(sp + ((g ^ swz) << 4) + h * 8) = o;
+          }
+        } else {                                       // outside the image: the stride-2 conv's zero padding
           T4 o;
+          o[0] = (T)0.f; o[1] = (T)0.f; o[2] = (T)0.f; o[3] = (T)0.f;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) o[u] = inside ? (T)v[4 * g + u] : (T)0.f;
-          *reinterpret_cast<T4*>(sp + ((g ^ swz) << 4) + h * 8) = o;
+          for (int g = 0; g < 2 * C1H; ++g) *reinterpret_cast<T4*>(sp + ((g ^ swz) << 4) + h * 8) = o;
         }
       }
     }
