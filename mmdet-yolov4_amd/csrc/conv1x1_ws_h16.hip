@@ -183,9 +183,11 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
     for (int kc = 0; kc < kc_n; ++kc) {
       // slot (q+2) % 3 was read one iteration ago; its fragments have been consumed by issued MFMAs
       YV4_WS_ISSUE();
-      // stage q landed when at most the two younger stages (8 DMA instructions) are outstanding.  (Stores of the
-      // previous epilogue count too and complete out of order with loads: the count is then conservative, not wrong.)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // The first two stages of a strip were confirmed by the wait in front of the previous strip's stores (below);
+      // a later stage has landed when at most the two younger stages (8 DMA instructions) are outstanding -- by then
+      // the previous strip's stores, which count in vmcnt too, are long complete.  (A counted wait right after the
+      // stores made every strip wait for their acknowledgement: 1-2 us per strip.)
+      if (kc >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       const char* st = ring + rslot * kWsStageBytes;
       const unsigned kx = (unsigned)(kc << 7);   // (kc * 8) << 4: chunk index of the weight row
 #pragma unroll
@@ -232,6 +234,9 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
       const bool odd = r & 1;
       unsigned pk[8];
       pair_pack16<T>(v, odd, pk);
+      // the two stages in flight (the next strip's first ones) have had this strip's last MFMAs and the epilogue
+      // arithmetic to land: confirm them here, BEFORE the stores join the counter
+      if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int rb = 4 * h + (odd ? 16 : 0);
       T* yb = reinterpret_cast<T*>(p.y) + ((int64_t)(m0 + rb) * p.y_cs + p.y_co + (c & ~1));
       if (full) {

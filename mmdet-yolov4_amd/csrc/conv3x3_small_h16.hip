@@ -111,10 +111,10 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
 
   int tile = (int)blockIdx.x;
   if (tile < ntiles) issue_tile(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // tile 0 (this wave's share) and the weights
   int buf = 0;
   for (; tile < ntiles; tile += (int)gridDim.x, buf ^= 1) {
-    // this wave's share of the tile has landed (and the weights, the first time) ... everybody's
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // every wave confirmed its share of this tile before its previous stores (below) ... now everybody's is in
     __builtin_amdgcn_s_barrier();
     // every wave has finished reading the other buffer (tile - grid): refill it with the next tile
     if (tile + (int)gridDim.x < ntiles) issue_tile(tile + (int)gridDim.x, buf ^ 1);
@@ -226,6 +226,9 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
       }
       unsigned pk[8];
       pair_pack16<T>(v, odd, pk);
+      // the next tile's DMA has had the whole tile to land: confirm it BEFORE the stores join vmcnt (a wait after
+      // them would sit out their acknowledgement once per tile)
+      if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       T* yb = reinterpret_cast<T*>(p.y) + (pix0 * p.y_cs + p.y_co + (c & ~1));
 #pragma unroll
       for (int j = 0; j < 8; ++j) {

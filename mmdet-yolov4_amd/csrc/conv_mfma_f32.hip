@@ -991,7 +991,9 @@ __global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs
 
     for (int kc = 0; kc < kc_n; ++kc) {
       YV4_WSF_ISSUE();
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // stage q landed: only the two younger stages may be out
+      // stages 0 and 1 of a strip were confirmed in front of the previous strip's stores; later ones by count
+      // (see conv1x1_ws_h16.hip)
+      if (kc >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       const char* st = ring + rslot * kWsfStageBytes;
       const unsigned kx = (unsigned)(kc << 7);               // (kc * 8) << 4: chunk index inside the weight row
 #pragma unroll
@@ -1041,6 +1043,7 @@ __global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs
         act_row16(v, p.act2, p.slope2);
       }
       float* yb = p.y + ((int64_t)(m0 + 4 * h) * p.y_cs + p.y_co + c);
+      if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stages in flight, before the stores join the counter
       if (full) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) yb[(int64_t)((e & 3) + 8 * (e >> 2)) * p.y_cs] = v[e];
