@@ -108,6 +108,11 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
     whs[t] = (unsigned)wswz(row);
   }
   const bool odd = r & 1;
+  // training forward (identity epilogue): BatchNorm sums of the stored values, kept in registers over all of this
+  // wave's tiles -- two atomics per channel and wave at the very end
+  float st_su[NT], st_sq[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { st_su[t] = 0.f; st_sq[t] = 0.f; }
 
   int tile = (int)blockIdx.x;
   if (tile < ntiles) issue_tile(tile, 0);
@@ -175,6 +180,16 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
       float v[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = acc[t][e] * s1[t] + t1[t];
+      if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          v[e] = (float)(T)v[e];
+          const int m = (e & 3) + 8 * (e >> 2) + 4 * h;       // this wave's pixel: row 2w + (m >> 4), column m & 15
+          const bool in = oy0 + 2 * wave + (m >> 4) < p.Ho && ox0 + (m & 15) < p.Wo;
+          st_su[t] += in ? v[e] : 0.f;
+          st_sq[t] += in ? v[e] * v[e] : 0.f;
+        }
+      }
       switch (p.act1) {
         case YV4_ACT_MISH: mish_fast_row(v); break;
         case YV4_ACT_LEAKY:
@@ -238,6 +253,20 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (p.stats) {
+    double* rep = p.stats + (size_t)((blockIdx.x * 8 + wave) & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float su = st_su[t], sq = st_sq[t];
+      su += __shfl_xor(su, 32);
+      sq += __shfl_xor(sq, 32);
+      const int c = t * 32 + r;
+      if (h == 0 && c < p.Cout) {
+        atomicAdd(&rep[c], (double)su);
+        atomicAdd(&rep[p.Cout + c], (double)sq);
+      }
+    }
+  }
 }
 
 static size_t s3_lds_bytes(int Cin, int Cout) {
@@ -248,7 +277,7 @@ static size_t s3_lds_bytes(int Cin, int Cout) {
 // Is this layer in the kernel's domain?
 bool conv3x3_small_applies(const ConvArgsH& a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && !a.ys_on && !a.out_f32 &&
-         a.stats == nullptr && (a.Cin == 16 || a.Cin == 32 || a.Cin == 64) && a.Kw == 9 * a.Cin && a.Cout >= 16 &&
+         (a.Cin == 16 || a.Cin == 32 || a.Cin == 64) && a.Kw == 9 * a.Cin && a.Cout >= 16 &&
          a.Cout <= 64 && (a.Cout & 1) == 0 && ((a.y_cs | a.y_co) & 1) == 0 &&
          (a.res == nullptr || ((a.r_cs | a.r_co) & 1) == 0) && s3_lds_bytes(a.Cin, a.Cout) <= 160 * 1024;
 }

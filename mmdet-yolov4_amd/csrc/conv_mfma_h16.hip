@@ -452,7 +452,7 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   if (d->tile == YV4_HTILE_WS_1x1 || (d->tile == YV4_TILE_AUTO && prefer_ws(a))) return conv1x1_ws_launch(a, dtype == YV4_BF16, s);
   if (d->tile == YV4_HTILE_S3x3)
     YV4_REQUIRE(conv3x3_small_applies(a), "conv h16: the few-channel 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with Cin 16, 32 "
-                "or 64, even Cout in [16, 64], 16-bit output and no statistics");
+                "or 64, even Cout in [16, 64] and 16-bit output");
   if (d->tile == YV4_HTILE_S3x3 || (d->tile == YV4_TILE_AUTO && prefer_s3(a))) return conv3x3_small_launch(a, dtype == YV4_BF16, s);
   const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);
