@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--json', default='')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'])
     ap.add_argument('--chain', type=int, default=1, help='launches per timed region (steady-state time per launch)')
+    ap.add_argument('--zeros', action='store_true', help='all-zero operands: the clock the chip holds on trivial data (DVFS check)')
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(',')]
     dev = torch.device('cuda:0')
@@ -57,6 +58,9 @@ def main():
         ho = (h + 2 * pad - k) // s + 1
         x = torch.randn(a.batch * h * h * cp, device=dev).to(tdt)
         w = (torch.randn(cout * k * k * cp, device=dev) * 0.05).to(tdt)
+        if a.zeros:
+            x.zero_()
+            w.zero_()
         ycs = (cout + 7) // 8 * 8 if h16 else cout
         y = torch.empty(a.batch * ho * ho * ycs, device=dev, dtype=tdt)
         sc = torch.ones(cout, device=dev)
