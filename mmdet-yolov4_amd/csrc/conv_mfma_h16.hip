@@ -163,10 +163,31 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+// All of a slice's fragments are requested FIRST, then its MFMAs run (fenced: left to itself hipcc puts every
+// ds_read_b128 and an s_waitcnt right in front of the MFMA that uses it -- four exposed LDS latencies per slice of 4 x
+// 64 matrix-pipe cycles).  YV4_H16_STAGED=0 at build time restores the interleaved form for A/B measurement.
+#ifndef YV4_H16_STAGED
+#define YV4_H16_STAGED 1
+#endif
 #define YV4_H_COMPUTE(BUF)                                                                       \
   {                                                                                              \
     const char* as_ = As + (BUF) * BM * kRowB;                                                   \
     const char* bs_ = Bs + (BUF) * BN * kRowB;                                                   \
+    if (YV4_H16_STAGED && TM * TN <= 2) {                                                        \
+      V8 fa[4][TM], fb[4][TN];                                                                   \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+            fa[j][i] = *reinterpret_cast<const V8*>(as_ + (a_rd[i] ^ (unsigned)(j << 5)));       \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i)                                           \
+            fb[j][i] = *reinterpret_cast<const V8*>(bs_ + (b_rd[i] ^ (unsigned)(j << 5)));       \
+      }                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+          _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                      \
+              acc[i][jn] = Elem<BF16>::mfma(fa[j][i], fb[j][jn], acc[i][jn]);                    \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    } else {                                                                                     \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
       V8 fa[TM], fb[TN];                                                                         \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
@@ -176,6 +197,7 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
         _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                        \
             acc[i][jn] = Elem<BF16>::mfma(fa[i], fb[jn], acc[i][jn]);                            \
+    }                                                                                            \
     }                                                                                            \
   }
 
