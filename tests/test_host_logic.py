@@ -85,6 +85,48 @@ def test_v4l_plan_fusion_and_flops():
     assert plan.post['total_anchors'] == 22743
 
 
+def test_16_bit_plan_fuses_the_first_two_layers_at_finalize(monkeypatch):
+    """Host logic of Plan._fuse_stem_down (no launch): a 16-bit plan of YOLOv4-L replaces [repack, fp32 stem, stride-2
+    conv] by ONE op that carries their FLOPs, keeps the replaced ops reachable, drops the two intermediate buffers
+    from the allocation, and leaves the rest of the launch list alone; YV4_STEM_FUSE=0 and fp32 plans keep the three
+    launches; calibrate_bn refuses a fused plan with a message that says what to do."""
+    det = pkg.build_detector(V4L).eval()
+
+    def build(dtype):
+        plan = pkg.Plan('cpu', dtype=dtype)
+        x = plan.add_input_nchw(1, 3, 608, 608, dtype=torch.float32)
+        plan.hint_single_consumer(x)
+        preds = det.emit(plan, x)
+        det.bbox_head.emit_postprocess(plan, preds)
+        flops = plan.total_flops()
+        plan.finalize()
+        return plan, flops
+
+    plan, flops = build(torch.bfloat16)
+    kinds = [o.kind for o in plan.ops]
+    assert kinds.count('to_nhwc') == 0 and kinds.count('conv') == 114
+    fused = plan.ops[0]
+    assert fused.name == 'stem_down' and fused.info['fused'] == 'stem_down'
+    assert [o.kind for o in fused.info['parts']] == ['to_nhwc', 'conv', 'conv']
+    assert abs(plan.total_flops() - flops) < 1.0                          # same algorithmic work
+    assert (fused.info['Cin'], fused.info['Cout'], fused.info['stride'], fused.info['H']) == (3, 64, 2, 608)
+    unused = [b for b in plan.bufs if getattr(b, 'unused', False)]
+    assert len(unused) == 2 and all(b.tensor is None for b in unused)
+    from mmdet_yolov4_amd.calibrate import calibrate_bn
+    with pytest.raises(AssertionError, match='fp32 plan'):
+        calibrate_bn(plan, torch.zeros(1, 3, 608, 608))
+    monkeypatch.setenv('YV4_STEM_FUSE', '0')
+    plain, _ = build(torch.bfloat16)
+    assert [o.kind for o in plain.ops[:3]] == ['to_nhwc', 'conv', 'conv'] and not any(o.info.get('fused') for o in plain.ops)
+    monkeypatch.delenv('YV4_STEM_FUSE')
+    plan32 = pkg.Plan('cpu')
+    x = plan32.add_input_nchw(1, 3, 608, 608)
+    plan32.hint_single_consumer(x)
+    det.emit(plan32, x)
+    plan32.finalize()
+    assert not any(o.info.get('fused') for o in plan32.ops)
+
+
 def test_bn_fold_equals_batch_norm():
     bn = torch.nn.BatchNorm2d(16, eps=1e-3).eval()
     with torch.no_grad():
