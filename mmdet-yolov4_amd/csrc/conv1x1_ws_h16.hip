@@ -22,9 +22,9 @@
 //     first version's bottleneck), 64-byte segments per pixel.
 //
 // Any Cin % 8 == 0 up to 256 (laid out as 64 / 128 / 256 channels, zero-padded) and Cout >= 16.
-// Epilogue = the common one minus the residual: affine1 -> act1 -> (affine2 -> act2) -> store at a channel offset,
-// or (stats != nullptr) identity + statistics of the rounded outputs.  Residual, fp32 output and scattered output
-// stay with the generic tiles.
+// Epilogue = the common one minus the residual: affine1 -> act1 -> (affine2 -> act2) -> store at a channel offset
+// (16-bit, or fp32 for the pred maps), or (stats != nullptr) identity + statistics of the rounded outputs.  Residual
+// and scattered output stay with the generic tiles.
 #include "conv_h16_common.h"
 
 namespace yv4 {
@@ -230,6 +230,16 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
           act_row16_h(v, p.act2, p.slope2);
         }
       }
+      if (p.out_f32) {
+        // fp32 output (the pred maps feeding decode): a lane owns one channel, a store instruction writes two runs of
+        // 32 consecutive floats -- coalesced whatever the row pitch (255 channels) is
+        if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* yf = reinterpret_cast<float*>(p.y) + ((int64_t)(m0 + 4 * h) * p.y_cs + p.y_co + c);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (full || m0 + (e & 3) + 8 * (e >> 2) + 4 * h < p.M) yf[(int64_t)((e & 3) + 8 * (e >> 2)) * p.y_cs] = v[e];
+        continue;
+      }
       // dword stores: the even lane of a channel pair takes rows 0-3 / 8-11 (+4h), the odd lane rows 16-19 / 24-27
       const bool odd = r & 1;
       unsigned pk[8];
@@ -286,9 +296,9 @@ static int ws_slab_cols(const ConvArgsH& a) {
 
 // Is this layer in the kernel's domain?
 bool conv1x1_ws_applies(const ConvArgsH& a) {
-  return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.ys_on && !a.out_f32 && a.res == nullptr &&
-         a.Cin >= 16 && a.Cin <= 256 && (a.Cin & 7) == 0 && a.Kw == a.Cin && a.Cout >= 16 && (a.Cout & 1) == 0 &&
-         ((a.y_cs | a.y_co) & 1) == 0 && ws_slab_cols(a) > 0;
+  const bool store_ok = a.out_f32 ? a.stats == nullptr : ((a.Cout & 1) == 0 && ((a.y_cs | a.y_co) & 1) == 0);
+  return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.ys_on && a.res == nullptr && a.Cin >= 16 &&
+         a.Cin <= 256 && (a.Cin & 7) == 0 && a.Kw == a.Cin && a.Cout >= 16 && store_ok && ws_slab_cols(a) > 0;
 }
 
 template <bool BF16, int NT>

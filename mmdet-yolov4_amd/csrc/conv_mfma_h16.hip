@@ -411,7 +411,7 @@ extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
     a.Cin = d->Cin; a.Cout = d->Cout; a.ys_on = 0; a.M = (int)((long long)d->N * d->Ho * d->Wo);
     if (prefer_c3(a)) return d->Cout > 64 ? YV4_HTILE_C3_256x128 : YV4_HTILE_C3_256x64;
-    a.K = a.Kw = d->KH * d->KW * d->Cin; a.res = nullptr; a.out_f32 = 0;
+    a.K = a.Kw = d->KH * d->KW * d->Cin; a.res = nullptr; a.out_f32 = (d->Cout & 1) ? 1 : 0;   // (odd Cout: a pred map)
     if (prefer_ws(a)) return YV4_HTILE_WS_1x1;
     a.N = d->N; a.stats = nullptr; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = d->r_cstride; a.r_co = d->r_coff;
     if (prefer_s3(a)) return YV4_HTILE_S3x3;
@@ -470,7 +470,7 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   if (c3_id || (d->tile == YV4_TILE_AUTO && prefer_c3(a))) return conv3x3_h16_launch(a, dtype == YV4_BF16, d->tile, s);
   if (d->tile == YV4_HTILE_WS_1x1)
     YV4_REQUIRE(conv1x1_ws_applies(a), "conv h16: the weight-stationary tile needs a 1x1 / stride 1 conv with Cin <= 256, "
-                "even Cout >= 16, 16-bit output and no residual");
+                "Cout >= 16 (even unless the output is fp32) and no residual");
   if (d->tile == YV4_HTILE_WS_1x1 || (d->tile == YV4_TILE_AUTO && prefer_ws(a))) return conv1x1_ws_launch(a, dtype == YV4_BF16, s);
   if (d->tile == YV4_HTILE_S3x3)
     YV4_REQUIRE(conv3x3_small_applies(a), "conv h16: the few-channel 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with Cin 16, 32 "

@@ -214,7 +214,16 @@ def test_h16_conv1x1_ws_kernel_is_refused_outside_its_domain(gpu_device):
     with pytest.raises(L.Yv4Error):
         _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 64, 1, 1, 0, act=1, tile=6, residual=True)
     with pytest.raises(L.Yv4Error):
-        _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 64, 1, 1, 0, act=1, tile=6, out_f32=True)
+        _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 63, 1, 1, 0, act=1, tile=6)          # odd Cout needs fp32 output
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_h16_conv1x1_ws_kernel_fp32_pred_maps(gpu_device, dtype):
+    """The head convs: fp32 output, 255 channels (odd pitch), bias as the shift -- through the weight-stationary kernel
+    with two and four column slabs."""
+    _h16_conv(gpu_device, dtype, 2, 26, 26, 128, 255, 1, 1, 0, act=0, tile=6, out_f32=True)
+    _h16_conv(gpu_device, dtype, 1, 19, 23, 256, 255, 1, 1, 0, act=0, tile=6, out_f32=True)
+    _h16_conv(gpu_device, dtype, 1, 9, 11, 64, 18, 1, 1, 0, act=1, tile=6, out_f32=True, y_off=4)
 
 
 S3_SHAPES = [
