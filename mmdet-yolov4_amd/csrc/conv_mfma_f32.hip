@@ -890,7 +890,7 @@ constexpr int kP3NB = 6;            // weight slots: ping-pong form a ring of 4,
 // activation rows and its three taps' weights are requested a whole group (3 x 32 MFMAs per wave = 6 144 matrix-pipe
 // cycles) ahead into the other halves of the buffers, the waves run the group's 96 MFMAs free (fragment reads of step
 // j + 1 issued before the MFMAs of step j, the SIMD's two waves interleaving as they come) and meet once per group.  A
-// barrier costs ~250 cycles of a 2 048-cycle ping-pong phase (11 % in a bare skeleton, tools/scratch/mfma/pp_rate.hip:
+// barrier costs ~250 cycles of a 2 048-cycle ping-pong phase (11 % in a bare skeleton, tools/microbench/pp_rate.hip:
 // 134.8 vs 151.2 TFLOP/s); per group it is 2 %.
 template <bool GB>
 __global__ __launch_bounds__(kP3Threads, 1) void conv3x3_pp_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes) {
