@@ -1289,10 +1289,11 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3x3_pg_f32_kernel(ConvArgs 
     const char* bs_ = Bs + (3 * (BH) + kw_) * (kP3BN * kRowB);                                      \
     if (!(ablate & 8)) {                                                                            \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                \
-      const unsigned ar_ = ((MK[i] >> kw_) & 1u) ? a_rd[i][kw_] : zero_rd;                           \
+      unsigned ar_ = ((MK[i] >> kw_) & 1u) ? a_rd[i][kw_] : zero_rd;                                 \
+      if (ablate & 16) ar_ = (unsigned)(lane * 16 + i * 4096);    /* measurement: conflict-free linear reads */ \
       ga[SET][i] = *reinterpret_cast<const float4*>(as_ + (ar_ ^ (unsigned)(j_ << 5)));             \
     }                                                                                               \
-    gb[SET] = *reinterpret_cast<const float4*>(bs_ + (b_rd ^ (unsigned)(j_ << 5)));                 \
+    gb[SET] = *reinterpret_cast<const float4*>(bs_ + (((ablate & 16) ? (unsigned)(lane * 16) : b_rd) ^ (unsigned)(j_ << 5))); \
     }                                                                                               \
   }
 #define YV4_PG_MFMASTEP(S, SET)                                                                     \

@@ -30,7 +30,7 @@
 
 namespace yv4 {
 
-constexpr int kSdThreads = 512;
+// 8 waves per workgroup; the narrow variant (C1 = 16) runs two 4-wave workgroups per CU (template parameter NW)
 constexpr int kSdTx = 16;                       // output tile columns; rows: template parameter TY (15 or 16)
 constexpr int kSdSC = 2 * kSdTx + 1;            // stem tile columns (33)
 constexpr int kSdPC = kSdSC + 2;                // input patch columns (35)
@@ -71,16 +71,20 @@ __device__ __forceinline__ void sd_act16(float (&v)[16], int act, float slope) {
   }
 }
 
-// C1H = C1 / 16 (1 or 2), NT2 = C2 / 32 (1 or 2), TY = output rows per tile
-template <bool BF16, int C1H, int NT2, int TY>
-__global__ __launch_bounds__(kSdThreads, 1) void stem_down_kernel(StemDownArgs p) {
+// C1H = C1 / 16 (1 or 2), NT2 = C2 / 32 (1 or 2), TY = output rows per tile, NW = waves per workgroup (8 or 4).
+// NW = 4: half the waves per workgroup and (LDS permitting: C1 = 16 needs 66 KB) two workgroups per CU, which drift out
+// of phase -- one in its stem phase while the other convolves -- instead of eight waves meeting at every barrier.
+template <bool BF16, int C1H, int NT2, int TY, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void stem_down_kernel(StemDownArgs p) {
+  constexpr int kSdThreads = NW * 64;
+  constexpr int kPasses = (( (2 * TY + 3) * kSdPC) + kSdThreads - 1) / kSdThreads;      // phase A passes over the patch
   constexpr int kSdTy = TY;
   constexpr int kSdSR = 2 * TY + 1;               // stem tile rows
   constexpr int kSdPR = kSdSR + 2;                // input patch rows
   constexpr int kSdPPlane = sd_plane_bytes(TY);
   constexpr int kSdSPix = sd_stem_pixels(TY);
   constexpr int kRowTiles = (kSdSR * kSdSC + 31) / 32;
-  static_assert(kSdPR * kSdPC <= 3 * kSdThreads, "phase A covers the patch in three passes");
+  static_assert(kSdPR * kSdPC <= kPasses * kSdThreads, "phase A covers the patch");
   typedef typename Elem<BF16>::T T;
   typedef typename Elem<BF16>::V8 V8;
   typedef T T4 __attribute__((ext_vector_type(4)));
@@ -154,17 +158,17 @@ __global__ __launch_bounds__(kSdThreads, 1) void stem_down_kernel(StemDownArgs p
 #pragma unroll
   for (int t = 0; t < NT2; ++t) { sb[t] = p.s2[t * 32 + r]; tb[t] = p.t2[t * 32 + r]; }
 
-  // phase A thread map: patch pixels tid, tid + 512, tid + 1024 (< 33 * 35 = 1155)
-  int a_py[3], a_px[3];
+  // phase A thread map: patch pixels tid, tid + threads, ...
+  int a_py[kPasses], a_px[kPasses];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < kPasses; ++k) {
     const int q = tid + k * kSdThreads;
     a_py[k] = q / kSdPC;
     a_px[k] = q - a_py[k] * kSdPC;
   }
   const size_t plane = (size_t)p.H * p.W;
 
-  float pre[3][3];
+  float pre[kPasses][3];
   auto load_patch = [&](int tile) {
     const int n = fd_div(tile, p.fd_ty);                   // tile / (tiles_x * tiles_y)
     const int rem = tile - n * (p.tiles_x * p.tiles_y);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(kSdThreads, 1) void stem_down_kernel(StemDownArgs p
     const int iy0 = 2 * ty * kSdTy - 2, ix0 = 2 * tx * kSdTx - 2;
     const float* xb = p.x + (size_t)n * 3 * plane;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < kPasses; ++k) {
       const int iy = iy0 + a_py[k], ix = ix0 + a_px[k];
       const bool ok = tid + k * kSdThreads < kSdPR * kSdPC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       const size_t o = ok ? (size_t)iy * p.W + ix : 0;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(kSdThreads, 1) void stem_down_kernel(StemDownArgs p
 
     // ---- A: split and store the patch; prefetch the next one
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < kPasses; ++k) {
       if (tid + k * kSdThreads < kSdPR * kSdPC) {
         T4 hi, lo;
 #pragma unroll
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(kSdThreads, 1) void stem_down_kernel(StemDownArgs p
     __syncthreads();
 
     // ---- B: the stem on 31 x 33 pixels, 32 per row tile, four row tiles per wave
-    for (int rt = wave; rt < kRowTiles && !(p.ablate & 1); rt += 8) {
+    for (int rt = wave; rt < kRowTiles && !(p.ablate & 1); rt += NW) {
       const int pix = rt * 32 + r;
       const int sy = pix / kSdSC, sx = pix - sy * kSdSC;
       const char* pb = Pl + (sy * kSdPPitch + sx) * 8;
@@ -288,8 +292,9 @@ __global__ __launch_bounds__(kSdThreads, 1) void stem_down_kernel(StemDownArgs p
 
     // ---- C: the stride-2 conv on the tile; wave w owns output rows 2w, 2w + 1 (32 pixels; row 15 is not part of
     // the tile: computed on whatever the LDS holds and never stored)
-    if (!(p.ablate & 2)) {
-      const int oyl = 2 * wave + (r >> 4), oxl = r & 15;
+    if (!(p.ablate & 2))
+    for (int wv = wave; wv < 8; wv += NW) {          // "wave row" wv = output rows 2 wv, 2 wv + 1
+      const int oyl = 2 * wv + (r >> 4), oxl = r & 15;
       const int q0 = (2 * oyl) * kSdSCols + oxl;
       f32x16 acc[NT2];
 #pragma unroll
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(kSdThreads, 1) void stem_down_kernel(StemDownArgs p
       // exchange the even lane of a channel pair stores output row 2w, the odd lane row 2w + 1, columns
       // (j & 3) + 8 (j >> 2) + 4 h, as dwords (two channels).
       const bool odd = r & 1;
-      const int orow = 2 * wave + (odd ? 1 : 0);
+      const int orow = 2 * wv + (odd ? 1 : 0);
       const bool row_ok = orow < kSdTy && oy0 + orow < p.Ho;
       const bool full_x = ox0 + kSdTx <= p.Wo;
 #pragma unroll
@@ -361,16 +366,17 @@ __global__ __launch_bounds__(kSdThreads, 1) void stem_down_kernel(StemDownArgs p
   }
 }
 
-template <bool BF16, int C1H, int NT2, int TY>
+template <bool BF16, int C1H, int NT2, int TY, int NW>
 static int launch_sd_ty(const StemDownArgs& a, hipStream_t stream) {
   constexpr int C1 = C1H * 16, C2 = NT2 * 32;
   const size_t lds = 2 * (size_t)sd_plane_bytes(TY) + (((size_t)sd_stem_pixels(TY) * C1 * 2 + 15) & ~(size_t)15) +
                      (size_t)C2 * 9 * C1 * 2 + 256;
-  auto kern = stem_down_kernel<BF16, C1H, NT2, TY>;
+  auto kern = stem_down_kernel<BF16, C1H, NT2, TY, NW>;
   static LdsAttrOnce once;
   if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), lds, "stem_down_h16")) return rc;
-  const int grid = a.ntiles < 256 ? a.ntiles : 256;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kSdThreads), lds, stream, a);
+  const int slots = NW == 4 ? 512 : 256;
+  const int grid = a.ntiles < slots ? a.ntiles : slots;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
   YV4_CHECK_LAUNCH("stem_down_h16");
   return YV4_OK;
 }
@@ -382,7 +388,10 @@ static int launch_sd(StemDownArgs a, hipStream_t stream) {
   a.tiles_y = (a.Ho + g_sd_ty - 1) / g_sd_ty;
   a.ntiles = a.N * a.tiles_x * a.tiles_y;
   a.fd_ty = make_fastdiv((unsigned)(a.tiles_x * a.tiles_y));
-  return g_sd_ty == 15 ? launch_sd_ty<BF16, C1H, NT2, 15>(a, stream) : launch_sd_ty<BF16, C1H, NT2, 16>(a, stream);
+  // YV4_SD_WAVES=8 keeps one 8-wave workgroup per CU for the narrow variant too (A/B measurement)
+  static const bool narrow4 = [] { const char* e = getenv("YV4_SD_WAVES"); return !(e && atoi(e) == 8); }();
+  if (C1H == 1 && narrow4 && g_sd_ty == 16) return launch_sd_ty<BF16, C1H, NT2, 16, 4>(a, stream);
+  return g_sd_ty == 15 ? launch_sd_ty<BF16, C1H, NT2, 15, 8>(a, stream) : launch_sd_ty<BF16, C1H, NT2, 16, 8>(a, stream);
 }
 
 }  // namespace yv4
