@@ -20,14 +20,15 @@
 
 namespace yv4 {
 
-constexpr int kS3Threads = 512;
+// 8 waves per workgroup, or 4 (template parameter NW) with several workgroups per CU when the LDS footprint allows
 constexpr int kS3T = 16;                 // output tile edge
 constexpr int kS3I = kS3T + 2;           // input tile edge (18)
 constexpr int kS3Pix = kS3I * kS3I;      // 324
 
-// CINH = Cin / 16 (1, 2, 4), NT = Cout / 32 (1, 2)
-template <bool BF16, int CINH, int NT>
-__global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH p, unsigned x_bytes, int tiles_x, int tiles_y,
+// CINH = Cin / 16 (1, 2, 4), NT = Cout / 32 (1, 2), NW = waves per workgroup (8 or 4: then a wave takes two of the
+// tile's eight row pairs and two to four workgroups share a CU and drift out of phase)
+template <bool BF16, int CINH, int NT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_small_kernel(ConvArgsH p, unsigned x_bytes, int tiles_x, int tiles_y,
                                                                       int ntiles, FastDiv fd_tx, FastDiv fd_txy) {
   typedef typename Elem<BF16>::T T;
   typedef typename Elem<BF16>::V8 V8;
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
   constexpr int XBytes = (kS3Pix * PixB + 1023) & ~1023;     // one input tile, rounded to whole DMA instructions
   constexpr int NGroups = XBytes / 1024;
   constexpr unsigned kOOB = 0xFFFFFFF0u;
+  constexpr int kS3Threads = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem_s3[];
   char* Xl = smem_s3;                      // [2][324 pixels][Cin], chunks XOR-swizzled with the pixel index
   char* Wl = smem_s3 + 2 * XBytes;         // [Cout][K], chunks XOR-swizzled with the row index
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
     const int ty = fd_div(rem, fd_tx);
     const int tx = rem - ty * tiles_x;
     const int iy0 = ty * kS3T - 1, ix0 = tx * kS3T - 1;
-    for (int g = wave; g < NGroups; g += 8) {
+    for (int g = wave; g < NGroups; g += NW) {
       const int c = g * 64 + lane;
       const int q = c / Cpp, pch = c - q * Cpp;
       const int py = q / kS3I, px = q - py * kS3I;
@@ -98,8 +100,6 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
   };
 
   // fragment read bases.  A operand: pixel (oyl + dy, oxl + dx) of the input tile; B operand: weight row 32 t + r.
-  const int oyl = 2 * wave + (r >> 4), oxl = r & 15;
-  const int q0 = oyl * kS3I + oxl;
   unsigned wrow[NT], whs[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -131,6 +131,9 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
     const int oy0 = ty * kS3T, ox0 = tx * kS3T;
     const char* Xb = Xl + buf * XBytes;
 
+    for (int wv = wave; wv < 8; wv += NW) {          // "wave row" wv = output rows 2 wv, 2 wv + 1 of the tile
+    const int oyl = 2 * wv + (r >> 4), oxl = r & 15;
+    const int q0 = oyl * kS3I + oxl;
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
     // ---- epilogue: lane (r, h) holds channel 32 t + r of this wave's pixels m = (e & 3) + 8 (e >> 2) + 4 h.  After the
     // pair exchange the even lane of a channel pair owns output row 2w, the odd lane row 2w + 1, columns
     // (j & 3) + 8 (j >> 2) + 4 h, two channels per dword -- for the residual loads and for the stores.
-    const int orow = 2 * wave + (odd ? 1 : 0);
+    const int orow = 2 * wv + (odd ? 1 : 0);
     const bool row_ok = oy0 + orow < p.Ho;
     const bool full_x = ox0 + kS3T <= p.Wo;
     const size_t pix0 = (size_t)(n * p.Ho + oy0 + orow) * p.Wo + ox0 + 4 * h;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
         for (int e = 0; e < 16; ++e) {
           v[e] = (float)(T)v[e];
           const int m = (e & 3) + 8 * (e >> 2) + 4 * h;       // this wave's pixel: row 2w + (m >> 4), column m & 15
-          const bool in = oy0 + 2 * wave + (m >> 4) < p.Ho && ox0 + (m & 15) < p.Wo;
+          const bool in = oy0 + 2 * wv + (m >> 4) < p.Ho && ox0 + (m & 15) < p.Wo;
           st_su[t] += in ? v[e] : 0.f;
           st_sq[t] += in ? v[e] * v[e] : 0.f;
         }
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
       pair_pack16<T>(v, odd, pk);
       // the next tile's DMA has had the whole tile to land: confirm it BEFORE the stores join vmcnt (a wait after
       // them would sit out their acknowledgement once per tile)
-      if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (t == 0 && wv == wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       T* yb = reinterpret_cast<T*>(p.y) + (pix0 * p.y_cs + p.y_co + (c & ~1));
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -251,10 +254,11 @@ __global__ __launch_bounds__(kS3Threads, 1) void conv3x3_small_kernel(ConvArgsH 
         if (row_ok && (full_x || ox0 + col + 4 * h < p.Wo)) *reinterpret_cast<unsigned*>(yb + (size_t)col * p.y_cs) = pk[j];
       }
     }
+    }   // wave rows
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (p.stats) {
-    double* rep = p.stats + (size_t)((blockIdx.x * 8 + wave) & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+    double* rep = p.stats + (size_t)((blockIdx.x * NW + wave) & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float su = st_su[t], sq = st_sq[t];
@@ -282,8 +286,8 @@ bool conv3x3_small_applies(const ConvArgsH& a) {
          (a.res == nullptr || ((a.r_cs | a.r_co) & 1) == 0) && s3_lds_bytes(a.Cin, a.Cout) <= 160 * 1024;
 }
 
-template <bool BF16, int CINH, int NT>
-static int launch_s3(const ConvArgsH& a, hipStream_t stream) {
+template <bool BF16, int CINH, int NT, int NW>
+static int launch_s3_nw(const ConvArgsH& a, hipStream_t stream) {
   const int tiles_x = (a.Wo + kS3T - 1) / kS3T, tiles_y = (a.Ho + kS3T - 1) / kS3T;
   const long long nt = (long long)a.N * tiles_x * tiles_y;
   if (nt >= (1LL << 31)) {
@@ -292,14 +296,30 @@ static int launch_s3(const ConvArgsH& a, hipStream_t stream) {
   }
   const size_t lds = s3_lds_bytes(CINH * 16, NT * 32);
   const long long xb = (long long)a.N * a.H * a.W * a.x_cs * 2;
-  auto kern = conv3x3_small_kernel<BF16, CINH, NT>;
+  auto kern = conv3x3_small_kernel<BF16, CINH, NT, NW>;
   static LdsAttrOnce once;
   if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), lds, "conv3x3_small_h16")) return rc;
-  const int grid = nt < 256 ? (int)nt : 256;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kS3Threads), lds, stream, a, (unsigned)xb, tiles_x, tiles_y, (int)nt,
+  // workgroups per CU: by LDS (160 KB) and, for the 4-wave form, at most 4 (16 waves, <= 128 VGPRs each)
+  int per_cu = 1;
+  if (NW == 4) {
+    per_cu = (int)(160 * 1024 / lds);
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+  }
+  const long long slots = 256LL * per_cu;
+  const int grid = nt < slots ? (int)nt : (int)slots;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, a, (unsigned)xb, tiles_x, tiles_y, (int)nt,
                      make_fastdiv((unsigned)tiles_x), make_fastdiv((unsigned)(tiles_x * tiles_y)));
   YV4_CHECK_LAUNCH("conv3x3_small_h16");
   return YV4_OK;
+}
+
+// 4-wave workgroups when at least two fit a CU (the 16- and 32-channel layers); YV4_S3_WAVES=8 keeps one of 8
+template <bool BF16, int CINH, int NT>
+static int launch_s3(const ConvArgsH& a, hipStream_t stream) {
+  static const bool allow4 = [] { const char* e = getenv("YV4_S3_WAVES"); return !(e && atoi(e) == 8); }();
+  if (allow4 && 2 * s3_lds_bytes(CINH * 16, NT * 32) <= 160 * 1024) return launch_s3_nw<BF16, CINH, NT, 4>(a, stream);
+  return launch_s3_nw<BF16, CINH, NT, 8>(a, stream);
 }
 
 int conv3x3_small_launch(const ConvArgsH& a, bool bf16, hipStream_t s) {
