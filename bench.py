@@ -367,6 +367,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # no garbage collection inside the timed region: an instrumented step allocates ~230 event objects, and a
+    # generation-0 pass of the collector between a start event and its launch showed up as a 170 us "kernel" at the
+    # same layer of every such step (profiles/r02_layers_bf16.json before this line)
+    import gc
+    gc.collect()
+    gc.disable()
     D.barrier()
     events = []
     t0 = time.perf_counter()
@@ -374,6 +380,7 @@ def main():
         step(events if (i % max(args.event_every, 1) == 0 and not args.graph) else None)
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+    gc.enable()
     if args.graph:                                      # per-conv events: eager steps outside the timed region
         for _ in range(max(2, args.steps // max(args.event_every, 1))):
             step(events)
