@@ -353,8 +353,9 @@ def main():
             return
         for op in plan.ops:
             if events is not None and op.kind == 'conv':
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
+                # events come from a pool created before the timed region: creating two per launch inside it made the
+                # instrumented 16-bit steps host-bound, and the gap where the GPU caught up read as one slow kernel
+                e0, e1 = ev_pool.pop() if ev_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 e0.record(stream)
                 op.fn(sptr)
                 e1.record(stream)
@@ -365,6 +366,9 @@ def main():
         host_labels.copy_(post['labels'], non_blocking=True)
         host_count.copy_(post['count'], non_blocking=True)
 
+    n_instr = (args.steps + max(args.event_every, 1) - 1) // max(args.event_every, 1) + 2
+    ev_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(n_instr * len(conv_ops))]
     for _ in range(args.warmup):
         step()
     # no garbage collection inside the timed region: an instrumented step allocates ~230 event objects, and a
