@@ -32,7 +32,22 @@ WORKER = textwrap.dedent('''
     torch.cuda.set_device(dev)
     dist.init_process_group(backend, rank=rank, world_size=2, **(dict(device_id=dev) if backend == 'nccl' else {}))
 
+    FULL = os.environ.get('YV4_TEST_MODEL', 'toy') == 'yolov5l'   # configs/yolov5_ddp/yolov5l_coco_mosaic_8x8.py:3-13
+    SIZE, NCLS = (640, 80) if FULL else (64, 4)
+
+    def build_full(norm):
+        import bench
+        torch.manual_seed(0)
+        cfg = bench.model_cfg('yolov5l')
+        for part in ('backbone', 'neck', 'bbox_head'):
+            cfg[part]['norm_cfg'] = dict(type=norm, requires_grad=True, eps=0.001, momentum=0.03)
+        det = pkg.build_detector(cfg)
+        det.init_weights()
+        return det.train().to(dev)
+
     def build(norm):
+        if FULL:
+            return build_full(norm)
         torch.manual_seed(0)
         det = pkg.build_detector(dict(
             type='SingleStageDetector',
@@ -50,27 +65,27 @@ WORKER = textwrap.dedent('''
 
     def data(r, n):
         g = torch.Generator().manual_seed(50 + r)
-        img = torch.randn(n, 3, 64, 64, generator=g).to(dev)
+        img = torch.randn(n, 3, SIZE, SIZE, generator=g).to(dev)
         boxes, labels = [], []
         for _ in range(n):
-            k = int(torch.randint(1, 4, (1,), generator=g))
-            c = torch.rand(k, 2, generator=g) * 64
-            wh = torch.rand(k, 2, generator=g) * 30 + 6
-            boxes.append(torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, 64).to(dev))
-            labels.append(torch.randint(0, 4, (k,), generator=g).to(dev))
+            k = int(torch.randint(1, 4, (1,), generator=g)) * (4 if FULL else 1)
+            c = torch.rand(k, 2, generator=g) * SIZE
+            wh = torch.rand(k, 2, generator=g) * (30 * SIZE // 64) + 6
+            boxes.append(torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, SIZE).to(dev))
+            labels.append(torch.randint(0, NCLS, (k,), generator=g).to(dev))
         return img, boxes, labels
 
     def total(losses):
         return sum(sum(x.mean() for x in v) if isinstance(v, (list, tuple)) else v.mean()
                    for k, v in losses.items() if 'loss' in k)
 
-    sizes = [2, 3]                                          # ragged shards
+    sizes = [1, 2] if FULL else [2, 3]                      # ragged shards
     # (no 'sppv4' stage: the reference's SPPV4Stage builds its SPPV4 without the norm_cfg, darknetcsp.py:313-314,
     # so those BatchNorms stay per-rank under a SyncBN config -- mirrored by this package, and not what is tested here)
     det = build('SyncBN')
     start = {k: v.clone() for k, v in det.state_dict().items()}
     fs = FlatState(det)
-    red = D.GradReducer(fs, bucket_mb=0.05, mode=os.environ['YV4_TEST_MODE'])
+    red = D.GradReducer(fs, bucket_mb=64 if FULL else 0.05, mode=os.environ['YV4_TEST_MODE'])
     img, boxes, labels = data(rank, sizes[rank])
     # a local (not exchanged) backward first: the largest LOCAL gradient entry of every tensor over both ranks is what
     # a 16-bit wire format's rounding error is relative to (per-rank gradients can cancel in the mean)
@@ -129,15 +144,7 @@ def _gpus():
     return torch.cuda.device_count()
 
 
-@pytest.mark.parametrize('backend,mode', [('gloo', 'allreduce'), ('gloo', 'direct'), ('gloo', 'direct_bf16'),
-                                          ('nccl', 'allreduce'), ('nccl', 'direct'), ('nccl', 'direct_bf16')])
-def test_two_rank_step_equals_one_process_big_batch(tmp_path, backend, mode):
-    """backend 'nccl' is RCCL: one rank per GPU, needs two visible GPUs (skipped on the 1-GPU test boxes -- the
-    driver's multi-GPU node runs it); 'gloo' runs both ranks on cuda:0.  'direct_bf16' rounds every rank's gradients
-    to bf16 once and the reduced chunk once more (fp32 accumulation in between): 2^-8 of each tensor's largest LOCAL
-    entry over the ranks (per-rank gradients may cancel in the mean) instead of 1e-5 of the result's."""
-    if backend == 'nccl' and _gpus() < 2:
-        pytest.skip('RCCL with 2 ranks needs 2 GPUs (torch.cuda.device_count() < 2)')
+def _run_two_ranks(tmp_path, backend, mode, model='toy'):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % ROOT)
     s = socket.socket()
@@ -148,7 +155,7 @@ def test_two_rank_step_equals_one_process_big_batch(tmp_path, backend, mode):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank if backend == 'nccl' else 0), WORLD_SIZE='2',
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1', YV4_TEST_BACKEND=backend,
-                   YV4_TEST_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   YV4_TEST_MODE=mode, YV4_TEST_MODEL=model, HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -159,11 +166,12 @@ def test_two_rank_step_equals_one_process_big_batch(tmp_path, backend, mode):
             print(out)
         outs.append(json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][0][7:]))
     outs.sort(key=lambda o: o['rank'])
-    tol = 2.0 ** -8 if mode == 'direct_bf16' else 1e-5
+    return outs
+
+
+def _check_common(outs):
     for o in outs:
         assert o['nb'] > 1 and o['launched']                  # buckets went out from the backward hooks
-        assert o['worst'] < tol, o                            # exchanged gradients == one-process gradients
-        assert o['stats'] < 1e-5, o                           # running statistics == big-batch BatchNorm's
         assert o['order'] == sorted(o['order'], reverse=True)
     assert outs[0]['gsum'] == outs[1]['gsum']                 # both ranks hold the same reduced arena
     assert outs[0]['order'] == outs[1]['order']               # ... and enqueued their collectives in the same order
@@ -171,3 +179,38 @@ def test_two_rank_step_equals_one_process_big_batch(tmp_path, backend, mode):
     assert outs[0]['log_vars'] == outs[1]['log_vars']
     assert abs(outs[0]['log_vars']['loss_a'] - 0.5 * (outs[0]['loss'] + outs[1]['loss'])) <= 1e-5 * abs(outs[0]['loss'])
     assert outs[0]['log_vars']['num'] == 0.5
+
+
+@pytest.mark.parametrize('backend,mode', [('gloo', 'allreduce'), ('gloo', 'direct'), ('gloo', 'direct_bf16'),
+                                          ('nccl', 'allreduce'), ('nccl', 'direct'), ('nccl', 'direct_bf16')])
+def test_two_rank_step_equals_one_process_big_batch(tmp_path, backend, mode):
+    """backend 'nccl' is RCCL: one rank per GPU, needs two visible GPUs (skipped on the 1-GPU test boxes -- the
+    driver's multi-GPU node runs it); 'gloo' runs both ranks on cuda:0.  'direct_bf16' rounds every rank's gradients
+    to bf16 once and the reduced chunk once more (fp32 accumulation in between): 2^-8 of each tensor's largest LOCAL
+    entry over the ranks (per-rank gradients may cancel in the mean) instead of 1e-5 of the result's."""
+    if backend == 'nccl' and _gpus() < 2:
+        pytest.skip('RCCL with 2 ranks needs 2 GPUs (torch.cuda.device_count() < 2)')
+    outs = _run_two_ranks(tmp_path, backend, mode)
+    tol = 2.0 ** -8 if mode == 'direct_bf16' else 1e-5
+    for o in outs:
+        assert o['worst'] < tol, o                            # exchanged gradients == one-process gradients
+        assert o['stats'] < 1e-5, o                           # running statistics == big-batch BatchNorm's
+    _check_common(outs)
+
+
+def test_two_rank_syncbn_step_at_yolov5l_width(tmp_path):
+    """configs/yolov5_ddp/yolov5l_coco_mosaic_8x8.py:3-13 at its real width, depth and input size: YOLOv5-L 640x640,
+    SyncBN in backbone / neck / head, ragged shards (1 + 2 images), two ranks on cuda:0 over gloo, 64 MB buckets.
+    The exchanged gradients equal ONE process running BatchNorm over the 3 concatenated images.  Both sides are the
+    same fp32 kernels; what differs is the order of the statistics' reduction (per-rank partial sums in double, then
+    an all-reduce) -- a last-bit difference of a mean amplified through ~100 batch-statistics layers, so the bound is
+    TOL_FULL of each tensor's largest entry rather than the toy's 1e-5 (measured value printed)."""
+    TOL_FULL = 2e-3
+    outs = _run_two_ranks(tmp_path, 'gloo', 'allreduce', model='yolov5l')
+    print('yolov5l SyncBN 2-rank: worst |g_ddp - g_one| / max|g| =', [(o['worst'], o['name']) for o in outs],
+          'fwd_err', [o['fwd_err'] for o in outs], 'stats', [o['stats'] for o in outs], 'buckets', outs[0]['nb'])
+    for o in outs:
+        assert o['fwd_err'] < 1e-4, o
+        assert o['worst'] < TOL_FULL, o
+        assert o['stats'] < 1e-4, o
+    _check_common(outs)

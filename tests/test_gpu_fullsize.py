@@ -20,18 +20,28 @@ pytestmark = pytest.mark.gpu
 SIZE = 608
 
 
-@pytest.fixture(scope='module')
-def v4l(gpu_device):
+def _make(gpu_device, batch, size):
     torch.manual_seed(0)
     det = pkg.build_detector(bench.model_cfg('yolov4l'))
     det.init_weights()
     det.eval().to(gpu_device)
-    img = bench.synthetic_images(2, SIZE, 1000, gpu_device)
-    plan = det.compile(2, SIZE, SIZE, device=gpu_device, rescale=True)
+    img = bench.synthetic_images(batch, size, 1000, gpu_device)
+    plan = det.compile(batch, size, size, device=gpu_device, rescale=True)
     calibrate_bn(plan, img)                               # BN statistics fitted on the batch (modules updated)
     ncand = bench.init_head(det, plan, img, 1500.0)       # ~1500 NMS candidates per image
     assert 500 < ncand < 5000
     return det, img
+
+
+@pytest.fixture(scope='module')
+def v4l(gpu_device):
+    return _make(gpu_device, 2, SIZE)
+
+
+@pytest.fixture(scope='module')
+def v4l_416(gpu_device):
+    """BASELINE.json configs[0]'s workload: YOLOv4-L (CSPDarknet53-class backbone), 416x416, a single image."""
+    return _make(gpu_device, 1, 416)
 
 
 def _ious(b):
@@ -42,14 +52,18 @@ def _ious(b):
     return inter / (area[:, None] + area[None, :] - inter)
 
 
-def test_fullsize_parity_with_the_oracle_on_one_image(v4l):
-    """115 layers deep, two correct fp32 implementations no longer agree to 1e-4 on every logit: the
+@pytest.mark.parametrize('case', ['608', '416_single_image'])
+def test_fullsize_parity_with_the_oracle_on_one_image(request, case):
+    """Case 416_single_image is BASELINE.json configs[0]'s workload (416x416, one image) through the HIP path.
+
+    115 layers deep, two correct fp32 implementations no longer agree to 1e-4 on every logit: the
     rounding differences of each layer (summation order inside a K = 4608 dot product) are amplified by
     the layers after it.  The honest statement at full depth is therefore relative to the truth: the
     oracle evaluated in float64.  The HIP path must be as close to it as the fp32 CPU oracle (= the
     reference's own arithmetic) is; and what the north star names -- scores and box coordinates -- must
     agree with the fp32 oracle to 1e-4 for all but a vanishing fraction of entries."""
-    det, img = v4l
+    det, img = request.getfixturevalue('v4l' if case == '608' else 'v4l_416')
+    SIZE = img.shape[-1]
     sd = {k: v.detach().cpu() for k, v in det.state_dict().items()}
     sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
     stages, reps = O.ARCH['v4l5p']

@@ -304,3 +304,82 @@ def test_cfg3_batch_independence_and_nms_invariants(v4s):
                 iou = inter / (area[:, None] + area[None, :] - inter)
                 np.fill_diagonal(iou, 0)
                 assert iou.max() <= cfg['nms']['iou_threshold'] + 1e-6
+
+
+# ---- fp32 train step at full depth vs the CPU oracle's autograd (the pinned arithmetic) --------------------------
+def _oracle_train_grads(sd0, img, gtb, gtl, arch, neck, out_indices, dtype):
+    """forward_train + autograd of the CPU oracle (oracle/yolov4_oracle.py:717 = single_stage.py:51-79 +
+    yolocsp_head.py:384-575 restated) in `dtype`; returns (loss terms, total, {name: grad as float64})."""
+    stages, reps = O.ARCH[arch]
+    sd, params = {}, {}
+    for k, v in sd0.items():
+        v = v.detach().cpu()
+        if v.is_floating_point():
+            v = v.to(dtype)
+        if v.is_floating_point() and 'running_' not in k:
+            sd[k] = v.clone().requires_grad_(True)
+            params[k] = sd[k]
+        else:
+            sd[k] = v.clone()
+    L = O.forward_train(img.cpu().to(dtype), sd, stages, reps, out_indices, [b.cpu().to(dtype) for b in gtb],
+                        [l.cpu() for l in gtl], neck=neck)
+    total = O.total_loss(L)
+    total.backward()
+    terms = {k: float(sum(x.sum() for x in v)) for k, v in L.items() if k.startswith('loss')}
+    stats = {k: v.detach().double() for k, v in sd.items() if 'running_' in k}
+    return terms, float(total), {k: p.grad.double() for k, p in params.items()}, stats
+
+
+@pytest.mark.parametrize('model,size,arch,neck,outs', [('yolov4l', 608, 'v4l5p', 'v4', [3, 4, 5]),
+                                                        ('yolov5l', 640, 'v5l5p', 'v5', [2, 3, 4])],
+                         ids=['yolov4l_608', 'yolov5l_640'])
+def test_fullsize_fp32_train_step_vs_oracle_autograd(gpu_device, model, size, arch, neck, outs):
+    """The fp32 HIP training step (forward, fused loss, data / weight gradients, train-mode BN backward) at the real
+    depth and input size of configs[2] / configs[4], batch 2, against the ORACLE's forward_train + torch autograd on
+    the CPU -- the arithmetic test_oracle_train_golden.py pins to the reference's own step.  At this depth two fp32
+    evaluations of the same gradient differ by reassociation noise amplified through ~110 batch-statistics layers, so
+    the statement is relative to the truth (the oracle in float64): per parameter tensor, the HIP gradient's distance
+    from the float64 gradient (L2, relative to the float64 norm) is at most K_REL x the fp32 CPU oracle's own distance
+    (+ a floor for tensors whose fp32 CPU error happens to be tiny); loss terms within 2e-4 of the float64 oracle."""
+    K_REL, FLOOR = 3.0, 1e-4       # measured on MI355X: HIP 7.8e-4 / 1.0e-4 (median, v4l / v5l) vs the fp32 CPU oracle's 1.45e-3 / 7.6e-5
+    B = 2
+    torch.manual_seed(0)
+    det = pkg.build_detector(bench.model_cfg(model))
+    det.init_weights()
+    det.train().to(gpu_device)
+    img = bench.synthetic_images(B, size, 1000, gpu_device)
+    gtb, gtl = bench.synthetic_gts(B, size, 2000, gpu_device)
+    data = dict(img=img, img_metas=[dict() for _ in range(B)], gt_bboxes=gtb, gt_labels=gtl)
+    sd0 = {k: v.detach().clone() for k, v in det.state_dict().items()}
+    log, raws, total, _ = _train_step(det, data)
+    total.backward()
+    got = {n: p.grad.detach().double().cpu() for n, p in det.named_parameters()}
+    t32, tot32, g32, _ = _oracle_train_grads(sd0, img, gtb, gtl, arch, neck, outs, torch.float32)
+    t64, tot64, g64, st64 = _oracle_train_grads(sd0, img, gtb, gtl, arch, neck, outs, torch.float64)
+    assert list(got) == list(g64)                                  # same parameter set, same order
+    for k in ('loss_cls', 'loss_conf', 'loss_bbox'):
+        np.testing.assert_allclose(log[k], t64[k], rtol=2e-4, err_msg=f'{k}: HIP fp32 step vs float64 oracle')
+        np.testing.assert_allclose(t32[k], t64[k], rtol=2e-4, err_msg=f'{k}: fp32 oracle vs float64 oracle')
+    np.testing.assert_allclose(log['loss'], tot64, rtol=2e-4)
+    worst = (0.0, None)
+    e_hip, e_cpu = [], []
+    for n, t in g64.items():
+        den = float(t.norm()) + 1e-30
+        eh = float((got[n] - t).norm()) / den
+        ec = float((g32[n] - t).norm()) / den
+        e_hip.append(eh); e_cpu.append(ec)
+        ratio = eh / (K_REL * ec + FLOOR)
+        if ratio > worst[0]:
+            worst = (ratio, n, eh, ec)
+    e_hip, e_cpu = np.array(e_hip), np.array(e_cpu)
+    print(f'{model} {size} fp32 step, {len(g64)} parameter tensors, |g - g64| / |g64|: HIP median {np.median(e_hip):.2e} '
+          f'p90 {np.quantile(e_hip, 0.9):.2e} max {e_hip.max():.2e} | CPU fp32 oracle median {np.median(e_cpu):.2e} '
+          f'p90 {np.quantile(e_cpu, 0.9):.2e} max {e_cpu.max():.2e} | worst ratio {worst}')
+    assert worst[0] <= 1.0, worst
+    assert np.median(e_hip) <= 2.0 * np.median(e_cpu) + 1e-6
+    # BatchNorm running statistics after the step (momentum 0.03 / SPP block 0.1, Q1; unbiased variance) vs the
+    # float64 oracle's in-place updated buffers
+    bufs = dict(det.named_buffers())
+    assert len(st64) >= 190                                        # 2 x (108 BatchNorms of YOLOv4-L / 99 of YOLOv5-L)
+    for n, t in st64.items():
+        np.testing.assert_allclose(bufs[n].double().cpu().numpy(), t.numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
