@@ -151,6 +151,8 @@ class FlatState:
             torch.autograd.graph.increment_version(p)
         torch.autograd.graph.increment_version(self.values)
         torch.autograd.graph.increment_version(self.ints)
+        from . import train_ops          # the packed conv operands of the training step are stale too
+        train_ops.invalidate_packed_weights()
 
     # ---- tables for the kernels ------------------------------------------------------------
     def segment_offsets(self):

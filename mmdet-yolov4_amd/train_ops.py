@@ -18,6 +18,7 @@ mmdet/models/backbones/darknetcsp.py:15-64, mmdet/ops/mish_cuda/mish.py:18-36).
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -156,14 +157,16 @@ class _PackCache:
         e = self.entries.get(self.key(weight, dtype, mode))
         if e is None:
             return None
-        if e['version'] != weight._version:
+        if e['wref']() is None:             # the first owner died, the same storage lives on under another tensor object
+            e['wref'] = weakref.ref(weight)
+        if e['version'] != weight._version or e['gen'] != _PACK_GENERATION[0]:
             self.refresh(weight)
         return e
 
     def add(self, weight, dtype, mode, fields, dst, cp):
-        if len(self.entries) >= 4096:       # many models came and went: start over rather than keep their weights alive
-            self.entries.clear()
-        e = dict(fields=fields, dst=dst, cp=cp, version=weight._version, wref=weight)
+        """Only PERSISTENT weights come here (``packed_weight``: leaves of the autograd graph, i.e. parameters); the
+        entry holds a weak reference, so a model that is dropped takes its entries with it at the next refresh."""
+        e = dict(fields=fields, dst=dst, cp=cp, version=weight._version, gen=_PACK_GENERATION[0], wref=weakref.ref(weight))
         self.entries[self.key(weight, dtype, mode)] = e
         self.dirty_table = True
         return e
@@ -190,7 +193,11 @@ class _PackCache:
 
     def refresh(self, _weight):
         """Re-pack every recorded operand in one launch (the weights move together at an optimizer step)."""
-        live = {k: e for k, e in self.entries.items() if e['wref'].data_ptr() == k[0]}
+        live = {}
+        for k, e in self.entries.items():
+            w = e['wref']()
+            if w is not None and w.data_ptr() == k[0]:
+                live[k] = e
         if len(live) != len(self.entries):
             self.entries = live
             self.dirty_table = True
@@ -201,10 +208,19 @@ class _PackCache:
         check(_lib.lib().yv4_pack_weights_multi(self.table.data_ptr(), len(self.entries), self.total_blocks, stream_ptr()),
               'yv4_pack_weights_multi')
         for e in self.entries.values():
-            e['version'] = e['wref']._version
+            e['version'] = e['wref']()._version
+            e['gen'] = _PACK_GENERATION[0]
 
 
 _PACK_CACHES = {}
+# Staleness is detected through torch's version counters; an update that bypasses them (``p.data.copy_()``, a
+# raw-pointer kernel) must call ``invalidate_packed_weights()`` -- FlatSGD.step, load_state_dict of a FlatState model and
+# the EMA swap do (they also bump the versions) -- which makes the next request re-pack everything.
+_PACK_GENERATION = [0]
+
+
+def invalidate_packed_weights():
+    _PACK_GENERATION[0] += 1
 
 
 def clear_pack_cache():
@@ -230,7 +246,10 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None):
     else:
         kh0, khs, KHo, kw0, kws, KWo = 0, 1, KH, 0, 1, KW
     w = weight.detach()
-    cacheable = _PACK_CACHE_ON and w.dtype == torch.float32 and w.is_cuda
+    # temporaries (the stem weight zero-padded to a 16-byte chunk in every step, darknetcsp.Conv.fwd: a fresh non-leaf
+    # tensor each time) take the per-call launch below: cached, each step would add an entry that is never hit again
+    persistent = weight.is_leaf and (weight.requires_grad or isinstance(weight, torch.nn.Parameter))
+    cacheable = _PACK_CACHE_ON and persistent and w.dtype == torch.float32 and w.is_cuda
     cache = None
     mode = (bool(transpose_flip), taps)
     if cacheable:
@@ -248,7 +267,7 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None):
                                      kws, int(transpose), al, out.data_ptr(), _DCODE[dtype], stream_ptr()),
           'yv4_pack_weight')
     if cacheable:
-        cache.add(w, dtype, mode, dict(w=w.data_ptr(), s_co=st[0], s_ci=st[1], s_kh=st[2], s_kw=st[3], Cout=Cout, Cin=Cin,
+        cache.add(weight, dtype, mode, dict(w=w.data_ptr(), s_co=st[0], s_ci=st[1], s_kh=st[2], s_kw=st[3], Cout=Cout, Cin=Cin,
                                        KHo=KHo, KWo=KWo, kh0=kh0, kh_step=khs, kw0=kw0, kw_step=kws,
                                        transpose=int(transpose), pad_to=al, dtype=_DCODE[dtype]), out, cp)
     return out, cp

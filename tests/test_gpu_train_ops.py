@@ -371,7 +371,7 @@ def test_packed_weight_cache_follows_the_weights(gpu_device):
             for m in modes:
                 if not cached:
                     T.clear_pack_cache()
-                out.append(T.packed_weight(w.detach(), torch.bfloat16, **m)[0].clone())
+                out.append(T.packed_weight(w, torch.bfloat16, **m)[0].clone())
         return out
 
     first = pack_all(True)
@@ -387,4 +387,31 @@ def test_packed_weight_cache_follows_the_weights(gpu_device):
     ref = pack_all(False)                       # per-call packing of the new values
     for a, b, c in zip(fresh, ref, first):
         assert torch.equal(a, b) and not torch.equal(a, c)
+    # an update that bypasses the version counters (p.data.copy_, a raw-pointer kernel) + invalidate_packed_weights()
+    pack_all(True)
+    for w in ws:
+        w.data.mul_(2.0)
+    assert all(torch.equal(a, b) for a, b in zip(pack_all(True), fresh))        # stale by contract ...
+    T.invalidate_packed_weights()
+    for a, b in zip(pack_all(True), pack_all(False)):                           # ... fresh after the call
+        assert torch.equal(a, b)
+    # temporaries are not recorded (the stem weight is re-padded in every step -- a fresh non-leaf tensor
+    # whose entry would never be hit again and whose storage the table would pin)
+    cache = T._PACK_CACHES[gpu_device]
+    n0 = len(cache.entries)
+    for _ in range(3):
+        tmp = torch.nn.functional.pad(ws[0], (0, 0, 0, 0, 0, 5))
+        got, cp = T.packed_weight(tmp, torch.bfloat16)
+        assert cp == 16 and got.shape == (16, 9 * 16)
+        got2, _ = T.packed_weight(ws[0].detach() * 1.0, torch.bfloat16)
+    assert len(cache.entries) == n0
+    # a dropped parameter takes its entries with it at the next refresh (weak references)
+    w = tmp = None
+    del ws[1]
+    import gc
+    gc.collect()
+    with torch.no_grad():
+        ws[0].add_(1.0)
+    T.packed_weight(ws[0], torch.bfloat16)
+    assert len(cache.entries) == 3
     T.clear_pack_cache()

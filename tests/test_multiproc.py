@@ -98,11 +98,23 @@ REDUCE_WORKER = textwrap.dedent('''
     from mmdet_yolov4_amd.flat_state import FlatState
     rank, local_rank, world = D.init(backend='gloo')
     torch.manual_seed(0)
-    model = Toy()                                         # identical weights on both ranks
+    class Odd(Toy):
+        """Toy + a tail whose parameter counts (91, 7, 33, 3) are multiples of neither 4 nor 8: bucket sizes that
+        the chunked exchange has to pad (dist.py _staging) and bucket tails that do not divide by the world size."""
+        def __init__(self):
+            super().__init__()
+            self.fc1 = torch.nn.Linear(13, 7)
+            self.fc2 = torch.nn.Linear(11, 3)
+        def forward(self, x):
+            y = super().forward(x)
+            f = y.flatten(1)
+            return y.mean() + self.fc1(f[:, :13]).square().mean() + self.fc2(f[:, 13:24]).square().mean()
+    model = Odd() if os.environ.get('YV4_TEST_ODD') else Toy()   # identical weights on every rank
     fs = FlatState(model)
-    red = D.GradReducer(fs, bucket_mb=200 * 4 / (1 << 20), mode=os.environ['YV4_TEST_MODE'])
+    red = D.GradReducer(fs, bucket_mb=float(os.environ.get('YV4_TEST_BUCKET_FLOATS', '200')) * 4 / (1 << 20),
+                        mode=os.environ['YV4_TEST_MODE'])
     g = torch.Generator().manual_seed(100)
-    xs = [torch.randn(2, 4, 6, 6, generator=g) for _ in range(4)]   # 2 ranks x 2 micro-batches
+    xs = [torch.randn(2, 4, 6, 6, generator=g) for _ in range(2 * world)]   # world ranks x 2 micro-batches
     mine = xs[2 * rank: 2 * rank + 2]
     # accumulation window of 2 micro-batches: only the last one is exchanged
     fs.zero_grad()
@@ -112,17 +124,53 @@ REDUCE_WORKER = textwrap.dedent('''
     launched_in_backward = all(red._launched)
     red.finish()
     # what the exchange must produce: mean over ranks of the per-rank SUM of micro-batch gradients
-    ref = Toy(); ref.load_state_dict({k: v for k, v in model.state_dict().items()})
-    for r in range(2):
+    ref = type(model)(); ref.load_state_dict({k: v for k, v in model.state_dict().items()})
+    for r in range(world):
         for x in xs[2 * r: 2 * r + 2]:
-            (ref(x).square().mean() / 2).backward()
+            (ref(x).square().mean() / world).backward()
     err = max(float((p.grad - q.grad).abs().max()) for p, q in zip(model.parameters(), ref.parameters()))
     scale = max(float(q.grad.abs().max()) for q in ref.parameters())
+    # a 16-bit wire format rounds every rank's LOCAL gradient sum: its error is relative to the largest local entry over
+    # the ranks (per-rank gradients can cancel in the mean), cf. tests/test_gpu_ddp.py
+    loc = type(model)(); loc.load_state_dict({k: v for k, v in ref.state_dict().items()})
+    for x in mine:
+        loc(x).square().mean().backward()
+    lmax = torch.tensor(max(float(q.grad.abs().max()) for q in loc.parameters()))
+    torch.distributed.all_reduce(lmax, op=torch.distributed.ReduceOp.MAX)
+    scale = max(scale, float(lmax))
     out = dict(rank=rank, nb=len(red.buckets), launched=launched_in_backward, err=err, scale=scale,
-               order=red.launch_order, gsum=float(fs.grads.double().sum()))
+               order=red.launch_order, gsum=float(fs.grads.double().sum()),
+               sizes=[b[1] - b[0] for b in red.buckets], chunks=[st['chunk'] for st in red._stage.values()])
     print('RESULT ' + json.dumps(out), flush=True)
     D.finalize()
 ''')
+
+
+def _run_reduce(tmp_path, mode, world, **extra):
+    script = tmp_path / 'reduce_worker.py'
+    script.write_text(REDUCE_WORKER % (ROOT, ROOT))
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), OMP_NUM_THREADS='1', YV4_TEST_MODE=mode, **extra)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=480)
+        assert p.returncode == 0, out
+        outs.append(json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][0][7:]))
+    outs.sort(key=lambda o: o['rank'])
+    return outs
+
+
+def _check_reduce(outs, mode):
+    assert outs[0]['nb'] >= 2 and all(o['launched'] for o in outs)
+    tol = 2.0 ** -8 * outs[0]['scale'] if mode == 'direct_bf16' else 1e-6
+    assert all(o['err'] <= tol for o in outs), outs      # averaged sum of all ranks' gradients
+    assert all(o['order'] == outs[0]['order'] for o in outs) and outs[0]['order'] == sorted(outs[0]['order'], reverse=True)
+    assert all(o['gsum'] == outs[0]['gsum'] for o in outs)   # bit-identical arenas after the exchange
 
 
 @pytest.mark.parametrize('mode', ['allreduce', 'direct', 'direct_bf16'])
@@ -130,26 +178,24 @@ def test_grad_reducer_two_ranks_gloo(tmp_path, mode):
     """The exchanged arena equals the mean over ranks of the per-rank gradient sums: exactly (1e-6) for the fp32 wire
     formats, within two bf16 roundings (2^-8 of the largest gradient) for 'direct_bf16'; both ranks end bit-identical and
     enqueue their collectives in the same (descending bucket) order."""
-    script = tmp_path / 'reduce_worker.py'
-    script.write_text(REDUCE_WORKER % (ROOT, ROOT))
-    port = _free_port()
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), OMP_NUM_THREADS='1', YV4_TEST_MODE=mode)
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT, text=True))
-    outs = []
-    for p in procs:
-        out, _ = p.communicate(timeout=240)
-        assert p.returncode == 0, out
-        outs.append(json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][0][7:]))
-    outs.sort(key=lambda o: o['rank'])
-    assert outs[0]['nb'] >= 2 and all(o['launched'] for o in outs)
-    tol = 2.0 ** -8 * outs[0]['scale'] if mode == 'direct_bf16' else 1e-6
-    assert all(o['err'] <= tol for o in outs), outs      # averaged sum of both ranks' gradients
-    assert outs[0]['order'] == outs[1]['order'] == sorted(outs[0]['order'], reverse=True)
-    assert outs[0]['gsum'] == outs[1]['gsum']            # bit-identical arenas after the exchange
+    _check_reduce(_run_reduce(tmp_path, mode, 2), mode)
+
+
+@pytest.mark.parametrize('mode', ['allreduce', 'direct', 'direct_bf16'])
+def test_grad_reducer_eight_ranks_gloo_ragged_buckets(tmp_path, mode):
+    """The node's world size (8, mmdet/apis/train.py:74-82 + tools/dist_train.sh:8-10) over gloo on the CPU with an arena
+    whose buckets are multiples of neither 8 floats nor the world size: every bucket's per-rank chunk is padded
+    (dist.py _staging: ceil(n / 8) rounded up to 8 elements) and the pad must neither leak into the gradients nor
+    desynchronise the ranks."""
+    outs = _run_reduce(tmp_path, mode, 8, YV4_TEST_ODD='1', YV4_TEST_BUCKET_FLOATS='100')
+    assert len(outs) == 8
+    sizes = outs[0]['sizes']
+    assert len(sizes) >= 3 and any(n % 8 for n in sizes), sizes
+    if mode != 'allreduce':
+        for n, c in zip(sorted(sizes), sorted(outs[0]['chunks'])):
+            assert c % 8 == 0 and 8 * c >= n
+        assert any(8 * c != n for n, c in zip(sorted(sizes), sorted(outs[0]['chunks'])))       # a padded tail was exchanged
+    _check_reduce(outs, mode)
 
 
 # ---- result gather of a distributed test run: ragged per-image results, 2 ranks -------------------
