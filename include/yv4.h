@@ -125,9 +125,8 @@ typedef struct yv4_conv_desc {
 /* 1x1 / stride 1, Cin 64 / 128 / 256, Cout >= 32, no residual: one persistent 8-wave workgroup per CU, the weight slab
  * resident in LDS, wave-private rings of 32-pixel strips; same summation order as the DMA tiles (bit-identical) */
 #define YV4_TILE_WS_1x1 9
-/* 3x3 / stride 1 / pad 1, Cin % 32 == 0, Cout >= 64: 256 x 64 tiles on 8 waves in ping-pong (waves 4-7 one phase behind
- * waves 0-3), the three kw taps of a (chunk, kh) from one LDS image; same summation order as the DMA tiles */
-#define YV4_TILE_PP_3x3 10
+/* (id 10 was the fp32 ping-pong 3x3 form of round 2: measured at the same 117-125 TFLOP/s plateau as the DMA tiles on
+ * every layer, DESIGN 9.12, and removed in round 3; the id is refused) */
 
 int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const float* w,
                         const float* scale1, const float* shift1,

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kC3Threads, 2) void conv3x3_h16_kernel(ConvArgsH p,
   }
 
   const int nchunks = p.Cin >> 6;
-  const int G = (p.ablate & 32) ? 0 : 3 * nchunks;   // (chunk, kh) groups; stage t = 3 g + kw  (ablate 32: measurement only)
+  const int G = YV4_ABLATE(p.ablate, 32) ? 0 : 3 * nchunks;   // (chunk, kh) groups; stage t = 3 g + kw  (ablate 32: measurement only)
   // issue-side walk: next stage to issue is (i_c0, i_kh, i_kw), its group index i_g
   int i_c0 = 0, i_kh = 0, i_kw = 0, i_g = 0, i_t = 0;
 
@@ -274,27 +274,27 @@ __global__ __launch_bounds__(kC3Threads, 2) void conv3x3_h16_kernel(ConvArgsH p,
     const int t0 = 3 * g;
     // kw = 0: issue stage t+3 (weights + the NEXT group's activations), compute, wait for stage t+1:
     //         newer than what it needs = weights t+2, weights t+3, activations g+1
-    if (!(p.ablate & 1)) YV4_C3_ISSUE();
+    if (!YV4_ABLATE(p.ablate, 1)) YV4_C3_ISSUE();
     __builtin_amdgcn_s_setprio(1);
-    if (!(p.ablate & 2)) YV4_C3_COMPUTE(0, ab, (t0 + 0) & 3, mk3);
+    if (!YV4_ABLATE(p.ablate, 2)) YV4_C3_COMPUTE(0, ab, (t0 + 0) & 3, mk3);
     __builtin_amdgcn_s_setprio(0);
-    if (!(p.ablate & 8)) YV4_C3_WAIT(2 * PB + kC3PA);
-    if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
+    if (!YV4_ABLATE(p.ablate, 8)) YV4_C3_WAIT(2 * PB + kC3PA);
+    if (!YV4_ABLATE(p.ablate, 4)) __builtin_amdgcn_s_barrier();
     // kw = 1: newer = weights t+2 + activations g+1 (issued at kw = 0 ... no: issued with stage t+2 = 3g+3 at kw = 0 of
     //         this group), weights t+3
-    if (!(p.ablate & 1)) YV4_C3_ISSUE();
+    if (!YV4_ABLATE(p.ablate, 1)) YV4_C3_ISSUE();
     __builtin_amdgcn_s_setprio(1);
-    if (!(p.ablate & 2)) YV4_C3_COMPUTE(1, ab, (t0 + 1) & 3, mk3);
+    if (!YV4_ABLATE(p.ablate, 2)) YV4_C3_COMPUTE(1, ab, (t0 + 1) & 3, mk3);
     __builtin_amdgcn_s_setprio(0);
-    if (!(p.ablate & 8)) YV4_C3_WAIT(2 * PB + kC3PA);
-    if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
+    if (!YV4_ABLATE(p.ablate, 8)) YV4_C3_WAIT(2 * PB + kC3PA);
+    if (!YV4_ABLATE(p.ablate, 4)) __builtin_amdgcn_s_barrier();
     // kw = 2: the next stage opens group g+1 and needs its activations: newer = weights t+2, weights t+3 only
-    if (!(p.ablate & 1)) YV4_C3_ISSUE();
+    if (!YV4_ABLATE(p.ablate, 1)) YV4_C3_ISSUE();
     __builtin_amdgcn_s_setprio(1);
-    if (!(p.ablate & 2)) YV4_C3_COMPUTE(2, ab, (t0 + 2) & 3, mk3);
+    if (!YV4_ABLATE(p.ablate, 2)) YV4_C3_COMPUTE(2, ab, (t0 + 2) & 3, mk3);
     __builtin_amdgcn_s_setprio(0);
-    if (!(p.ablate & 8)) YV4_C3_WAIT(2 * PB);
-    if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
+    if (!YV4_ABLATE(p.ablate, 8)) YV4_C3_WAIT(2 * PB);
+    if (!YV4_ABLATE(p.ablate, 4)) __builtin_amdgcn_s_barrier();
   }
 #undef YV4_C3_PP_STAGE
 #undef YV4_C3_MFMA
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kC3Threads, 2) void conv3x3_h16_kernel(ConvArgsH p,
       }
     }
   }
-  if (p.ablate & 64) return;                 // measurement only: no epilogue at all
+  if (YV4_ABLATE(p.ablate, 64)) return;                 // measurement only: no epilogue at all
   // every accumulator tile of the wave gets its own 32 x 36 fp32 patch (8 waves x TM*TN x 4608 B <= the K-loop carve):
   // stage all of them, then finish all of them
   float* ep = reinterpret_cast<float*>(smem_c3) + wave * (TM * TN * 32 * 36);
@@ -383,7 +383,7 @@ bool conv3x3_h16_applies(const ConvArgsH& a) {
 int conv3x3_h16_launch(const ConvArgsH& a, bool bf16, int tile, hipStream_t s) {
   const bool wide = tile == YV4_HTILE_C3_256x128 || (tile != YV4_HTILE_C3_256x64 && a.Cout > 64);
   // YV4_C3_PP=0: the lock-step form (all eight waves in the same phase), kept for A/B measurement
-  static const bool pp = [] { const char* e = getenv("YV4_C3_PP"); return !(e && e[0] == '0'); }();
+  static const bool pp = YV4_ENV_INT("YV4_C3_PP", 1) != 0;
   if (pp) {
     if (bf16) return wide ? launch_c3<true, 128, true>(a, s) : launch_c3<true, 64, true>(a, s);
     return wide ? launch_c3<false, 128, true>(a, s) : launch_c3<false, 64, true>(a, s);

@@ -317,7 +317,7 @@ static int launch_s3_nw(const ConvArgsH& a, hipStream_t stream) {
 // 4-wave workgroups when at least two fit a CU (the 16- and 32-channel layers); YV4_S3_WAVES=8 keeps one of 8
 template <bool BF16, int CINH, int NT>
 static int launch_s3(const ConvArgsH& a, hipStream_t stream) {
-  static const bool allow4 = [] { const char* e = getenv("YV4_S3_WAVES"); return !(e && atoi(e) == 8); }();
+  static const bool allow4 = YV4_ENV_INT("YV4_S3_WAVES", 4) != 8;
   if (allow4 && 2 * s3_lds_bytes(CINH * 16, NT * 32) <= 160 * 1024) return launch_s3_nw<BF16, CINH, NT, 4>(a, stream);
   return launch_s3_nw<BF16, CINH, NT, 8>(a, stream);
 }

@@ -195,7 +195,7 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
           for (int u = 0; u < 8; ++u) v[u] = v[u] * s2[u] + t2[u];
           act_row8(v, p.act2, p.slope2);
         }
-        if (p.ablate & 16) {
+        if (YV4_ABLATE(p.ablate, 16)) {
           if (v[0] == 12345.678f) reinterpret_cast<float*>(p.y)[0] = v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7];
         } else if (p.out_f32) {
           float* dst = reinterpret_cast<float*>(p.y) + out_row_h(p, m) * p.y_cs + p.y_co + co;

@@ -864,626 +864,6 @@ static int launch_conv(const ConvArgs& a, bool uniform_tap, hipStream_t stream) 
   return YV4_OK;
 }
 
-// ---- 3x3 / stride 1 / pad 1, Cin % 32 == 0: 256 x 64 tiles on 8 waves in ping-pong (the fp32 form of conv3x3_h16.hip) ----
-// The LDS-DMA tiles above plateau at 117-121 TFLOP/s on every 3x3 layer, whatever the tile shape (76.5 % of the matrix
-// peak at the 2 396 MHz the chip holds under this load, tools/clock_probe.py): the plateau is the two-barrier phase
-// structure -- load-and-wait, barrier, MFMAs, barrier -- in which a SIMD's two resident waves wait and compute at the
-// same times (+17 % without the barriers, +22 % without the DMA in the round-1 ablation).  Here one 8-wave workgroup
-// per CU works on a 256-pixel x 64-channel tile; a stage is one (32-channel chunk, kh, kw) tap: a LOAD phase reads
-// the stage's 12 operand fragments into registers (and issues the DMA three stages ahead), an MFMA phase runs its 32
-// MFMAs from registers, and waves 4-7 run one phase behind waves 0-3: on every SIMD one wave computes while its partner
-// reads LDS, issues DMA and waits.  The three kw taps of a (chunk, kh) share ONE LDS image of the 258 source pixels
-// (fragment row = output row + kw; what a shifted row must not see is masked by redirecting the read to a zero row), so
-// the activations are fetched 3 instead of 9 times per chunk.
-// The summation order of an output is EXACTLY the tile kernels': chunks in order, taps (kh, kw) in order inside a chunk,
-// K pairs (8j+i, 8j+4+i) inside a tap's 32 channels, two accumulator sets alternating with j, added once at the end --
-// a layer gives the same bits whichever kernel a batch size selects.
-constexpr int kP3Threads = 512;
-constexpr int kP3BM = 256;
-constexpr int kP3BN = 64;
-constexpr int kP3ARows = 320;       // BM + 2 source pixels, padded to 5 DMA passes of 64 rows; rows >= 258 stay zero
-constexpr int kP3PA = kP3ARows / 64;
-constexpr int kP3ZeroRow = 304;
-constexpr int kP3NB = 6;            // weight slots: ping-pong form a ring of 4, group form 2 groups x 3 taps
-
-// GB = false: the ping-pong form described above.  GB = true: ONE barrier per (chunk, kh) group -- the group's 258
-// activation rows and its three taps' weights are requested a whole group (3 x 32 MFMAs per wave = 6 144 matrix-pipe
-// cycles) ahead into the other halves of the buffers, the waves run the group's 96 MFMAs free (fragment reads of step
-// j + 1 issued before the MFMAs of step j, the SIMD's two waves interleaving as they come) and meet once per group.  A
-// barrier costs ~250 cycles of a 2 048-cycle ping-pong phase (11 % in a bare skeleton, tools/microbench/pp_rate.hip:
-// 134.8 vs 151.2 TFLOP/s); per group it is 2 %.
-template <bool GB>
-__global__ __launch_bounds__(kP3Threads, 1) void conv3x3_pp_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes) {
-  constexpr int TM = 2;                    // wave tile 64 pixels x 32 channels
-  constexpr int kRowB = 128;               // 32 floats
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  char* smem_c = reinterpret_cast<char*>(smem);
-  char* As = smem_c;                                   // [2][kP3ARows][128 B]
-  char* Bs = smem_c + 2 * kP3ARows * kRowB;            // [kP3NB][64][128 B]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1;                // 0..3
-  const int wn = wave & 1;
-  const int r = lane & 31;
-  const int h = lane >> 5;
-
-  const unsigned nwg = gridDim.x;
-  const unsigned bid = blockIdx.x;
-  const unsigned xcd = bid & 7u, q8 = nwg >> 3, rem8 = nwg & 7u;
-  const unsigned tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (bid >> 3);
-  const int tile_n = tile % p.tiles_n;
-  const int tile_m = tile / p.tiles_n;
-  const int m0 = tile_m * kP3BM;
-  const int n0 = tile_n * kP3BN;
-
-  const u32x4_t rsA = make_rsrc(p.x, x_bytes);
-  const u32x4_t rsB = make_rsrc(p.w, w_bytes);
-  constexpr unsigned kOOB = 0xFFFFFFF0u;
-  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem;
-  const int NHW = p.N * p.H * p.W;
-
-  // staging lanes: a DMA instruction of a wave fills 8 LDS rows (lane / 8) x 8 chunks of 4 floats (lane % 8)
-  const int srow = 8 * wave + (lane >> 3);               // 0..63, + 64 per pass
-  const int pc = lane & 7;
-  const int lc = pc ^ ((srow >> 1) & 7);
-  int a_s[kP3PA];
-  unsigned a_off[kP3PA];
-#pragma unroll
-  for (int q = 0; q < kP3PA; ++q) {
-    const int row = srow + 64 * q;
-    a_s[q] = row < kP3BM + 2 ? m0 - 1 + row : (int)0x40000000;
-    a_off[q] = (unsigned)((((int64_t)(m0 - 1 + row)) * p.x_cs + p.x_co + lc * 4) * 4);
-  }
-  const int co_s = n0 + srow;
-  const unsigned b_off = co_s < p.Cout ? (unsigned)(((int64_t)co_s * p.Kw + lc * 4) * 4) : kOOB;
-
-  // fragment read addresses
-  unsigned a_rd[TM][3];
-  unsigned mask9[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int rr = wm * 64 + i * 32 + r;
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int row = rr + kw;
-      a_rd[i][kw] = (unsigned)(row * kRowB + ((((row >> 1) & 7) ^ h) << 4));
-    }
-    const int m = m0 + rr;
-    unsigned mk = 0u;
-    if (m < p.M) {
-      const int hw = p.H * p.W;
-      const int n = fd_div(m, p.fd_hw);
-      const int rm = m - n * hw;
-      const int ho = fd_div(rm, p.fd_wo);
-      const int wo = rm - ho * p.W;
-      mk = (unsigned)tap_mask(ho - 1, wo - 1, 3, 3, p.H, p.W);
-    }
-    mask9[i] = mk;
-  }
-  const unsigned zero_rd = (unsigned)(kP3ZeroRow * kRowB);
-  const int brow = wn * 32 + r;
-  const unsigned b_rd = (unsigned)(brow * kRowB + ((((brow >> 1) & 7) ^ h) << 4));
-
-  f32x16 acc[TM], acc2[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { acc[i][e] = 0.f; acc2[i][e] = 0.f; }
-
-  const int nchunks = p.Cin >> 5;
-  const int G = 3 * nchunks;               // (chunk, kh) groups; stage t = 3 g + kw
-  int i_c0 = 0, i_kh = 0, i_kw = 0, i_g = 0, i_t = 0;
-
-#define YV4_P3_ISSUE()                                                                              \
-  {                                                                                                 \
-    const bool live = i_g < G;                                                                      \
-    const unsigned lb_ = lds_base + (unsigned)((2 * kP3ARows + (i_t & 3) * kP3BN + 8 * wave) * kRowB); \
-    const unsigned kb = (unsigned)((((i_kh * 3 + i_kw) * p.Cin) + i_c0) * 4);                        \
-    lds_dma16(rsB, lb_, live ? b_off : kOOB, live ? kb : 0u);                                        \
-    if (i_kw == 0) {                                                                                \
-      const unsigned la_ = lds_base + (unsigned)(((i_g & 1) * kP3ARows + 8 * wave) * kRowB);         \
-      const int ds = (i_kh - 1) * p.W;                                                              \
-      const unsigned step = (unsigned)(((int64_t)ds * p.x_cs + i_c0) * 4);                          \
-      _Pragma("unroll") for (int q = 0; q < kP3PA; ++q) {                                           \
-        const bool ok = live && (unsigned)(a_s[q] + ds) < (unsigned)NHW;                            \
-        lds_dma16(rsA, la_ + 64 * q * kRowB, ok ? a_off[q] + step : kOOB, 0u);                       \
-      }                                                                                             \
-    }                                                                                               \
-    i_t += 1;                                                                                       \
-    i_kw += 1;                                                                                      \
-    if (i_kw == 3) {                                                                                \
-      i_kw = 0;                                                                                     \
-      i_g += 1;                                                                                     \
-      i_kh += 1;                                                                                    \
-      if (i_kh == 3) { i_kh = 0; i_c0 += kBK; }                                                     \
-    }                                                                                               \
-  }
-
-  float4 fa4[4][TM], fb4[4];
-#define YV4_P3_LOAD(KW, ABUF, BSLOT, MK)                                                            \
-  {                                                                                                 \
-    const char* as_ = As + (ABUF) * (kP3ARows * kRowB);                                             \
-    const char* bs_ = Bs + (BSLOT) * (kP3BN * kRowB);                                               \
-    unsigned ar[TM];                                                                                \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
-        ar[i] = ((MK[i] >> (KW)) & 1u) ? a_rd[i][KW] : zero_rd;                                      \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
-          fa4[j][i] = *reinterpret_cast<const float4*>(as_ + (ar[i] ^ (unsigned)(j << 5)));         \
-      fb4[j] = *reinterpret_cast<const float4*>(bs_ + (b_rd ^ (unsigned)(j << 5)));                 \
-    }                                                                                               \
-  }
-#define YV4_P3_MFMA()                                                                               \
-  {                                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                              \
-        f32x16& ac_ = (j & 1) ? acc2[i] : acc[i];                                                   \
-        ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa4[j][i].x, fb4[j].x, ac_, 0, 0, 0);            \
-        ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa4[j][i].y, fb4[j].y, ac_, 0, 0, 0);            \
-        ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa4[j][i].z, fb4[j].z, ac_, 0, 0, 0);            \
-        ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa4[j][i].w, fb4[j].w, ac_, 0, 0, 0);            \
-      }                                                                                             \
-  }
-#define YV4_P3_WAIT(NEWER) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEWER) : "memory")
-  // a stage: issue the DMA three stages ahead, read this stage's fragments, retire them and this wave's share of the
-  // NEXT stage's DMA (NEWER younger instructions may stay in flight), barrier; MFMAs; barrier.  The reads are retired
-  // before the barrier that ends their phase, so the DMA the other group issues one phase later into the same ring slot
-  // cannot overtake them.
-#define YV4_P3_STAGE(KW, NEWER)                                                                     \
-  {                                                                                                 \
-    YV4_P3_ISSUE();                                                                                 \
-    YV4_P3_LOAD(KW, ab, (t0 + (KW)) & 3, mk3);                                                      \
-    YV4_P3_WAIT(NEWER);                                                                             \
-    __builtin_amdgcn_s_barrier();                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                              \
-    __builtin_amdgcn_s_setprio(1);                                                                  \
-    YV4_P3_MFMA();                                                                                  \
-    __builtin_amdgcn_s_setprio(0);                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                              \
-    __builtin_amdgcn_s_barrier();                                                                   \
-  }
-
-  if (GB) {
-    // issue group gi: activation rows into buffer gi & 1, the three taps' weights into slots 3 (gi & 1) + kw
-#define YV4_P3_ISSUE_GROUP(GI)                                                                      \
-  {                                                                                                 \
-    const int gi_ = (GI);                                                                           \
-    const bool live = gi_ < G;                                                                      \
-    const int c_ = gi_ / 3, kh_ = gi_ - 3 * c_;                                                     \
-    const unsigned la_ = lds_base + (unsigned)(((gi_ & 1) * kP3ARows + 8 * wave) * kRowB);           \
-    const int ds = (kh_ - 1) * p.W;                                                                 \
-    const unsigned step = (unsigned)(((int64_t)ds * p.x_cs + c_ * kBK) * 4);                        \
-    _Pragma("unroll") for (int q = 0; q < kP3PA; ++q) {                                             \
-      const bool ok = live && (unsigned)(a_s[q] + ds) < (unsigned)NHW;                              \
-      lds_dma16(rsA, la_ + 64 * q * kRowB, ok ? a_off[q] + step : kOOB, 0u);                         \
-    }                                                                                               \
-    _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                              \
-      const unsigned lb_ = lds_base + (unsigned)((2 * kP3ARows + (3 * (gi_ & 1) + kw) * kP3BN + 8 * wave) * kRowB); \
-      const unsigned kb = (unsigned)((((kh_ * 3 + kw) * p.Cin) + c_ * kBK) * 4);                     \
-      lds_dma16(rsB, lb_, live ? b_off : kOOB, live ? kb : 0u);                                      \
-    }                                                                                               \
-  }
-    // one tap: 4 K groups of 8 channels, fragments of group j + 1 requested before the MFMAs of group j
-#define YV4_P3_TAP(KW, ABUF, MK)                                                                    \
-  {                                                                                                 \
-    const char* as_ = As + (ABUF) * (kP3ARows * kRowB);                                             \
-    const char* bs_ = Bs + (3 * (ABUF) + (KW)) * (kP3BN * kRowB);                                   \
-    unsigned ar[TM];                                                                                \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
-        ar[i] = ((MK[i] >> (KW)) & 1u) ? a_rd[i][KW] : zero_rd;                                      \
-    float4 ga[2][TM], gb[2];                                                                        \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) ga[0][i] = *reinterpret_cast<const float4*>(as_ + ar[i]); \
-    gb[0] = *reinterpret_cast<const float4*>(bs_ + b_rd);                                           \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
-      if (j < 3) {                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-            ga[(j + 1) & 1][i] = *reinterpret_cast<const float4*>(as_ + (ar[i] ^ (unsigned)((j + 1) << 5))); \
-        gb[(j + 1) & 1] = *reinterpret_cast<const float4*>(bs_ + (b_rd ^ (unsigned)((j + 1) << 5)));         \
-      }                                                                                             \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                              \
-        f32x16& ac_ = (j & 1) ? acc2[i] : acc[i];                                                   \
-        ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j & 1][i].x, gb[j & 1].x, ac_, 0, 0, 0);      \
-        ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j & 1][i].y, gb[j & 1].y, ac_, 0, 0, 0);      \
-        ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j & 1][i].z, gb[j & 1].z, ac_, 0, 0, 0);      \
-        ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j & 1][i].w, gb[j & 1].w, ac_, 0, 0, 0);      \
-      }                                                                                             \
-    }                                                                                               \
-  }
-    YV4_P3_ISSUE_GROUP(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int g = 0; g < G; ++g) {
-      YV4_P3_ISSUE_GROUP(g + 1);           // into the halves last read in group g - 1 (every wave is past that barrier)
-      const int kh = g - 3 * (g / 3);
-      unsigned mk3[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) mk3[i] = mask9[i] >> (3 * kh);
-      const int ab = g & 1;
-      __builtin_amdgcn_s_setprio(1);
-      YV4_P3_TAP(0, ab, mk3);
-      YV4_P3_TAP(1, ab, mk3);
-      YV4_P3_TAP(2, ab, mk3);
-      __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // group g + 1 landed (this wave's share), reads retired
-      __builtin_amdgcn_s_barrier();
-    }
-#undef YV4_P3_TAP
-#undef YV4_P3_ISSUE_GROUP
-  } else {
-  // prologue: stages 0, 1, 2 in flight, then wait for stage 0 (weights 0 + activation group 0; newer: weights 1, 2)
-  YV4_P3_ISSUE();
-  YV4_P3_ISSUE();
-  YV4_P3_ISSUE();
-  YV4_P3_WAIT(2);
-  __builtin_amdgcn_s_barrier();
-
-  if (wm >= 2) __builtin_amdgcn_s_barrier();         // waves 4-7 run one phase behind waves 0-3
-  for (int g = 0; g < G; ++g) {
-    const int kh = g - 3 * (g / 3);
-    unsigned mk3[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) mk3[i] = mask9[i] >> (3 * kh);
-    const int ab = g & 1;
-    const int t0 = 3 * g;
-    // younger than what the NEXT stage needs: kw = 0, 1: weights t+2, t+3 and the next group's activation rows
-    // (issued with stage 3g+3 at kw = 0 of this group); kw = 2: the next stage opens group g+1 and needs those rows
-    YV4_P3_STAGE(0, 2 + kP3PA);
-    YV4_P3_STAGE(1, 2 + kP3PA);
-    YV4_P3_STAGE(2, 2);
-  }
-  if (wm < 2) __builtin_amdgcn_s_barrier();          // same number of barriers for both halves
-  }
-#undef YV4_P3_STAGE
-#undef YV4_P3_MFMA
-#undef YV4_P3_LOAD
-#undef YV4_P3_ISSUE
-#undef YV4_P3_WAIT
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the zero-filling tail DMAs
-  __builtin_amdgcn_s_barrier();
-
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] += acc2[i][e];
-  if (p.stats) {
-    double* rep = p.stats + (size_t)(tile_m & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
-    float su = 0.f, sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + wm * 64 + i * 32 + 4 * h;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float v = acc[i][e];
-        if (mb + (e & 3) + 8 * (e >> 2) < p.M) { su += v; sq += v * v; }
-      }
-    }
-    su += __shfl_xor(su, 32);
-    sq += __shfl_xor(sq, 32);
-    const int col = n0 + wn * 32 + r;
-    if (h == 0 && col < p.Cout) {
-      atomicAdd(&rep[col], (double)su);
-      atomicAdd(&rep[p.Cout + col], (double)sq);
-    }
-  }
-  const bool has2 = p.s2 != nullptr;
-  const bool vec_ok = ((p.y_cs | p.y_co) & 3) == 0 && (p.res == nullptr || ((p.r_cs | p.r_co) & 3) == 0);
-  float* ep = smem + wave * (32 * 36);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-    epilogue_tile(p, acc[i], ep, lane, m0 + wm * 64 + i * 32, n0 + wn * 32, vec_ok, has2);
-}
-
-// The group form made PERSISTENT: 256 workgroups (one per CU) walk the tiles of their XCD's share; the first group of
-// the NEXT tile is requested before the epilogue of the current one, the epilogue goes straight from the accumulators
-// (a lane owns one output channel: 128-byte runs per pixel, no LDS patch -- the buffers belong to the next tile by
-// then), and the DMA is confirmed between the epilogue's arithmetic and its stores.  What the one-tile-per-workgroup
-// forms pay per tile -- a first-group memory latency and an epilogue with nothing in flight, ~10 us of 150 -- overlaps.
-// Same arithmetic, operation for operation, as epilogue_tile: the result is bit-identical to every other fp32 kernel.
-__global__ __launch_bounds__(kP3Threads, 1) void conv3x3_pg_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes, int ntiles,
-                                                                        int ablate /* measurement only: 1 no in-loop DMA, 2 no in-loop barrier */) {
-  constexpr int TM = 2;
-  constexpr int kRowB = 128;
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  char* smem_c = reinterpret_cast<char*>(smem);
-  char* As = smem_c;                                   // [2][kP3ARows][128 B]
-  char* Bs = smem_c + 2 * kP3ARows * kRowB;            // [2 groups x 3 taps][64][128 B]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1;
-  const int wn = wave & 1;
-  const int r = lane & 31;
-  const int h = lane >> 5;
-  const u32x4_t rsA = make_rsrc(p.x, x_bytes);
-  const u32x4_t rsB = make_rsrc(p.w, w_bytes);
-  constexpr unsigned kOOB = 0xFFFFFFF0u;
-  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem;
-  const int NHW = p.N * p.H * p.W;
-
-  // this workgroup's tiles: XCD x (= blockIdx % 8) owns a contiguous eighth of the tile list, so the column tiles of
-  // one 256-pixel block are neighbours in one L2; its 32 workgroups take every 32nd tile of it
-  const int xcd = (int)(blockIdx.x & 7u), local = (int)(blockIdx.x >> 3), per_xcd = (int)(gridDim.x >> 3);
-  const int q8 = ntiles >> 3, rem8 = ntiles & 7;
-  const int t_lo = xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8;
-  const int t_hi = t_lo + q8 + (xcd < rem8 ? 1 : 0);
-
-  const int srow = 8 * wave + (lane >> 3);
-  const int pc = lane & 7;
-  const int lc = pc ^ ((srow >> 1) & 7);
-  unsigned a_rd[TM][3];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int row = wm * 64 + i * 32 + r + kw;
-      a_rd[i][kw] = (unsigned)(row * kRowB + ((((row >> 1) & 7) ^ h) << 4));
-    }
-  const unsigned zero_rd = (unsigned)(kP3ZeroRow * kRowB);
-  const int brow = wn * 32 + r;
-  const unsigned b_rd = (unsigned)(brow * kRowB + ((((brow >> 1) & 7) ^ h) << 4));
-  const int nchunks = p.Cin >> 5;
-  const int G = 3 * nchunks;
-  const bool has2 = p.s2 != nullptr;
-
-  // per-tile state, for the tile being computed (c_*) and the one being prefetched (n_*)
-  struct TileState { int m0, n0; int a_s[kP3PA]; unsigned a_off[kP3PA]; unsigned b_off; unsigned mask9[TM]; };
-  auto set_tile = [&](int t, TileState& ts) {
-    const int tile_n = t % p.tiles_n;
-    const int tile_m = t / p.tiles_n;
-    ts.m0 = tile_m * kP3BM;
-    ts.n0 = tile_n * kP3BN;
-#pragma unroll
-    for (int q = 0; q < kP3PA; ++q) {
-      const int row = srow + 64 * q;
-      ts.a_s[q] = row < kP3BM + 2 ? ts.m0 - 1 + row : (int)0x40000000;
-      ts.a_off[q] = (unsigned)((((int64_t)(ts.m0 - 1 + row)) * p.x_cs + p.x_co + lc * 4) * 4);
-    }
-    const int co_s = ts.n0 + srow;
-    ts.b_off = co_s < p.Cout ? (unsigned)(((int64_t)co_s * p.Kw + lc * 4) * 4) : kOOB;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = ts.m0 + wm * 64 + i * 32 + r;
-      unsigned mk = 0u;
-      if (m < p.M) {
-        const int hw = p.H * p.W;
-        const int n = fd_div(m, p.fd_hw);
-        const int rm = m - n * hw;
-        const int ho = fd_div(rm, p.fd_wo);
-        const int wo = rm - ho * p.W;
-        mk = (unsigned)tap_mask(ho - 1, wo - 1, 3, 3, p.H, p.W);
-      }
-      ts.mask9[i] = mk;
-    }
-  };
-  // group gi of tile state TS into buffer half BH
-#define YV4_PG_ISSUE_GROUP(TS, GI, BH)                                                              \
-  {                                                                                                 \
-    const int gi_ = (GI);                                                                           \
-    const int c_ = gi_ / 3, kh_ = gi_ - 3 * c_;                                                     \
-    const unsigned la_ = lds_base + (unsigned)(((BH) * kP3ARows + 8 * wave) * kRowB);                \
-    const int ds = (kh_ - 1) * p.W;                                                                 \
-    const unsigned step = (unsigned)(((int64_t)ds * p.x_cs + c_ * kBK) * 4);                        \
-    _Pragma("unroll") for (int q = 0; q < kP3PA; ++q) {                                             \
-      const bool ok = (unsigned)((TS).a_s[q] + ds) < (unsigned)NHW;                                 \
-      lds_dma16(rsA, la_ + 64 * q * kRowB, ok ? (TS).a_off[q] + step : kOOB, 0u);                    \
-    }                                                                                               \
-    _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                              \
-      const unsigned lb_ = lds_base + (unsigned)((2 * kP3ARows + (3 * (BH) + kw) * kP3BN + 8 * wave) * kRowB); \
-      const unsigned kb = (unsigned)((((kh_ * 3 + kw) * p.Cin) + c_ * kBK) * 4);                     \
-      lds_dma16(rsB, lb_, (TS).b_off, kb);       /* out-of-range rows: the range check is on the lane offset */ \
-    }                                                                                               \
-  }
-// One (chunk, kh) group = 12 steps (3 taps x 4 K groups of 8 channels).  The fragments of step s + 1 are requested
-// BEFORE the MFMAs of step s and the order is fenced: left to itself hipcc reads every fragment into the same
-// registers right in front of its four MFMAs (ds_read_b128, s_waitcnt lgkmcnt(0), 4 dependent MFMAs: an LDS latency
-// exposed per 256 matrix-pipe cycles -- the 120 TFLOP/s plateau of every fp32 kernel in this file until then).
-#define YV4_PG_LOADSTEP(S, SET, BH, MK)                                                             \
-  {                                                                                                 \
-    constexpr int kw_ = (S) / 4, j_ = (S) % 4;                                                      \
-    const char* as_ = As + (BH) * (kP3ARows * kRowB);                                               \
-    const char* bs_ = Bs + (3 * (BH) + kw_) * (kP3BN * kRowB);                                      \
-    if (!(ablate & 8)) {                                                                            \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                \
-      unsigned ar_ = ((MK[i] >> kw_) & 1u) ? a_rd[i][kw_] : zero_rd;                                 \
-      if (ablate & 16) ar_ = (unsigned)(lane * 16 + i * 4096);    /* measurement: conflict-free linear reads */ \
-      ga[SET][i] = *reinterpret_cast<const float4*>(as_ + (ar_ ^ (unsigned)(j_ << 5)));             \
-    }                                                                                               \
-    gb[SET] = *reinterpret_cast<const float4*>(bs_ + (((ablate & 16) ? (unsigned)(lane * 16) : b_rd) ^ (unsigned)(j_ << 5))); \
-    }                                                                                               \
-  }
-#define YV4_PG_MFMASTEP(S, SET)                                                                     \
-  {                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                \
-      f32x16& ac_ = ((S) & 1) ? acc2[i] : acc[i];                                                   \
-      ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[SET][i].x, gb[SET].x, ac_, 0, 0, 0);            \
-      ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[SET][i].y, gb[SET].y, ac_, 0, 0, 0);            \
-      ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[SET][i].z, gb[SET].z, ac_, 0, 0, 0);            \
-      ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[SET][i].w, gb[SET].w, ac_, 0, 0, 0);            \
-    }                                                                                               \
-  }
-#define YV4_PG_STEP(S, BH, MK)                                                                      \
-  {                                                                                                 \
-    if ((S) + 1 < 12) YV4_PG_LOADSTEP(((S) + 1 < 12 ? (S) + 1 : 0), ((S) + 1) & 1, BH, MK);          \
-    __builtin_amdgcn_sched_barrier(0);                                                              \
-    YV4_PG_MFMASTEP(S, (S) & 1);                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                              \
-  }
-#define YV4_PG_GROUP(BH, MK)                                                                        \
-  {                                                                                                 \
-    float4 ga[2][TM], gb[2];                                                                        \
-    if (ablate & 8) { ga[0][0] = ga[0][1] = ga[1][0] = ga[1][1] = gb[0] = gb[1] = make_float4(1.f, 2.f, 3.f, (float)lane); } \
-    YV4_PG_LOADSTEP(0, 0, BH, MK);                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                              \
-    YV4_PG_STEP(0, BH, MK) YV4_PG_STEP(1, BH, MK) YV4_PG_STEP(2, BH, MK) YV4_PG_STEP(3, BH, MK)      \
-    YV4_PG_STEP(4, BH, MK) YV4_PG_STEP(5, BH, MK) YV4_PG_STEP(6, BH, MK) YV4_PG_STEP(7, BH, MK)      \
-    YV4_PG_STEP(8, BH, MK) YV4_PG_STEP(9, BH, MK) YV4_PG_STEP(10, BH, MK) YV4_PG_STEP(11, BH, MK)    \
-  }
-
-  int t = t_lo + local;
-  if (t >= t_hi) return;                       // (whole workgroup: t is uniform)
-  TileState cur, nxt;
-  set_tile(t, cur);
-  int bh = 0;                                  // buffer half of the group being computed
-  YV4_PG_ISSUE_GROUP(cur, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  for (;;) {
-    f32x16 acc[TM], acc2[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { acc[i][e] = 0.f; acc2[i][e] = 0.f; }
-    const int t_next = t + per_xcd;
-    const bool more = t_next < t_hi;
-    for (int g = 0; g < G; ++g) {
-      const bool last = g + 1 == G;
-      if (!last) {
-        if (!(ablate & 1)) YV4_PG_ISSUE_GROUP(cur, g + 1, bh ^ 1);
-      } else if (more) {                       // the next tile's first group rides under this tile's last group + epilogue
-        set_tile(t_next, nxt);
-        YV4_PG_ISSUE_GROUP(nxt, 0, bh ^ 1);
-      }
-      const int kh = g - 3 * (g / 3);
-      unsigned mk3[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) mk3[i] = cur.mask9[i] >> (3 * kh);
-      YV4_PG_GROUP(bh, mk3);
-      if (!last) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (!(ablate & 2)) __builtin_amdgcn_s_barrier();
-      }
-      if (!(ablate & 4)) bh ^= 1;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-    // ---- epilogue from the accumulators: lane (r, h) = channel n0 + 32 wn + r of rows (e & 3) + 8 (e >> 2) + 4 h
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] += acc2[i][e];
-    const int c = cur.n0 + wn * 32 + r;
-    const bool c_ok = c < p.Cout;
-    if (p.stats) {
-      double* rep = p.stats + (size_t)((cur.m0 / kP3BM) & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
-      float su = 0.f, sq = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mb = cur.m0 + wm * 64 + i * 32 + 4 * h;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[i][e];
-          if (mb + (e & 3) + 8 * (e >> 2) < p.M) { su += v; sq += v * v; }
-        }
-      }
-      su += __shfl_xor(su, 32);
-      sq += __shfl_xor(sq, 32);
-      if (h == 0 && c_ok) {
-        atomicAdd(&rep[c], (double)su);
-        atomicAdd(&rep[p.Cout + c], (double)sq);
-      }
-    }
-    const float sc1 = c_ok ? p.s1[c] : 0.f, sh1 = c_ok ? p.t1[c] : 0.f;
-    const float sc2 = (c_ok && has2) ? p.s2[c] : 1.f, sh2 = (c_ok && has2) ? p.t2[c] : 0.f;
-    float v[TM][16];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = cur.m0 + wm * 64 + i * 32 + 4 * h;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[i][e] = __builtin_fmaf(acc[i][e], sc1, sh1);
-      act_row16(v[i], p.act1, p.slope1);
-      if (p.res && c_ok) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mb + (e & 3) + 8 * (e >> 2);
-          if (m < p.M) v[i][e] += p.res[(int64_t)m * p.r_cs + p.r_co + c];
-        }
-      }
-      if (has2) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[i][e] = __builtin_fmaf(v[i][e], sc2, sh2);
-        act_row16(v[i], p.act2, p.slope2);
-      }
-    }
-    // the next tile's first group (and the residual loads) before the stores join the counter; then everybody's
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (c_ok) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mb = cur.m0 + wm * 64 + i * 32 + 4 * h;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mb + (e & 3) + 8 * (e >> 2);
-          if (m < p.M) p.y[(int64_t)m * p.y_cs + p.y_co + c] = v[i][e];
-        }
-      }
-    }
-    if (!more) break;
-    __builtin_amdgcn_s_barrier();
-    cur = nxt;
-    t = t_next;
-  }
-#undef YV4_PG_GROUP
-#undef YV4_PG_STEP
-#undef YV4_PG_MFMASTEP
-#undef YV4_PG_LOADSTEP
-#undef YV4_PG_ISSUE_GROUP
-}
-
-static bool conv3x3_pp_f32_applies(const ConvArgs& a) {
-  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && (a.Cin & 31) == 0 &&
-         !a.ys_on && a.ksplit <= 1 && a.Cout >= 64;
-}
-
-static int conv3x3_pp_f32_launch(const ConvArgs& a, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(2 * kP3ARows + kP3NB * kP3BN) * 128;
-  ConvArgs p = a;
-  const int tiles_m = (p.M + kP3BM - 1) / kP3BM;
-  p.tiles_n = (p.Cout + kP3BN - 1) / kP3BN;
-  p.fd_hw = make_fastdiv((unsigned)(p.H * p.W));
-  p.fd_wo = make_fastdiv((unsigned)p.W);
-  const long long tiles = (long long)tiles_m * p.tiles_n;
-  if (tiles <= 0 || tiles > 0x7fffffffLL) {
-    set_error("conv3x3 pp f32: grid of %lld tiles out of range", tiles);
-    return YV4_E_INVALID;
-  }
-  const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 4, wb = (long long)p.Cout * p.Kw * 4;
-  // YV4_P3_FORM=pp: the ping-pong form (two barriers per tap); =group: one barrier per group, one tile per workgroup;
-  // default: the persistent group form when there is more than one tile per CU
-  static const int form = [] { const char* e = getenv("YV4_P3_FORM"); return !e ? 2 : (e[0] == 'p' ? 0 : (e[0] == 'g' ? 1 : 2)); }();
-  const bool gb = form != 0;
-  static LdsAttrOnce once_g, once_p, once_s;
-  if (form == 2 && tiles > 256) {
-    if (int rc = ensure_dyn_lds(once_s, reinterpret_cast<const void*>(conv3x3_pg_f32_kernel), lds, "conv3x3_pg_f32")) return rc;
-    static const int ablate = [] { const char* e = getenv("YV4_P3_ABLATE"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL(conv3x3_pg_f32_kernel, dim3(256), dim3(kP3Threads), lds, stream, p, (unsigned)xb, (unsigned)wb, (int)tiles,
-                       ablate);
-  } else if (gb) {
-    if (int rc = ensure_dyn_lds(once_g, reinterpret_cast<const void*>(conv3x3_pp_f32_kernel<true>), lds, "conv3x3_pp_f32")) return rc;
-    hipLaunchKernelGGL(conv3x3_pp_f32_kernel<true>, dim3((unsigned)tiles), dim3(kP3Threads), lds, stream, p, (unsigned)xb, (unsigned)wb);
-  } else {
-    if (int rc = ensure_dyn_lds(once_p, reinterpret_cast<const void*>(conv3x3_pp_f32_kernel<false>), lds, "conv3x3_pp_f32")) return rc;
-    hipLaunchKernelGGL(conv3x3_pp_f32_kernel<false>, dim3((unsigned)tiles), dim3(kP3Threads), lds, stream, p, (unsigned)xb, (unsigned)wb);
-  }
-  YV4_CHECK_LAUNCH("conv3x3_pp_f32");
-  return YV4_OK;
-}
-
-// The ping-pong 3x3 kernel takes the layers in its domain whose 256 x 64 tiles fill the one-workgroup-per-CU rounds
-// (YV4_P3=0 switches it off)
-static bool prefer_p3_f32(const ConvArgs& a) {
-  static const int mode = [] { const char* e = getenv("YV4_P3"); return e ? atoi(e) : 0; }();
-  if (!mode || !conv3x3_pp_f32_applies(a)) return false;
-  const long long tiles = ((long long)a.M + kP3BM - 1) / kP3BM * ((a.Cout + kP3BN - 1) / kP3BN);
-  const long long rounds = (tiles + 255) / 256;
-  return tiles >= 256 && tiles * 100 >= rounds * 256 * 88;
-}
-
 // ---- 1x1 / stride 1, weight-stationary and persistent (the fp32 form of conv1x1_ws_h16.hip) ---------------------------
 // The pointwise layers with Cin <= 256 run at 50-57 % of the fp32 matrix peak on the tiles above (profiles/
 // r02_layers.json): a tile's K loop is 2-8 slices, so a workgroup's life is mostly its first-slice latency and its
@@ -1741,8 +1121,8 @@ static int conv1x1_ws_f32_launch(const ConvArgs& a, hipStream_t s) {
 
 // the pointwise layers in the kernel's domain that give each persistent wave at least YV4_WS_MINSTRIPS strips
 static bool prefer_ws_f32(const ConvArgs& a) {
-  static const int mode = [] { const char* e = getenv("YV4_WS"); return e ? atoi(e) : 1; }();
-  static const int min_strips = [] { const char* e = getenv("YV4_WS_MINSTRIPS"); return e ? atoi(e) : 2; }();
+  static const int mode = YV4_ENV_INT("YV4_WS", 1);
+  static const int min_strips = YV4_ENV_INT("YV4_WS_MINSTRIPS", 2);
   if (!mode || !conv1x1_ws_f32_applies(a)) return false;
   return ((long long)a.M + 31) / 32 >= (long long)min_strips * 2048;
 }
@@ -1795,8 +1175,6 @@ extern "C" int yv4_conv_pick_tile(const yv4_conv_desc* d) {
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.Cin = d->Cin; a.Cout = d->Cout;
     a.K = a.Kw = d->KH * d->KW * d->Cin; a.M = (int)((long long)d->N * d->Ho * d->Wo);
     if (fast_ok && prefer_ws_f32(a)) return YV4_TILE_WS_1x1;     // (a residual, unknown here, keeps the tile kernels)
-    a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
-    if (fast_ok && prefer_p3_f32(a)) return YV4_TILE_PP_3x3;
   }
   return pick_tile((long long)d->N * d->Ho * d->Wo, d->Cout, fast_ok, (long long)d->KH * d->KW * d->Cin);
 }
@@ -1849,13 +1227,6 @@ static int conv_f32_impl(const yv4_conv_desc* d, const float* x, const float* w,
   const bool can_stem = stem_ok(d, residual != nullptr, scale2 != nullptr);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (stats_done) *stats_done = false;
-  if (d->tile == YV4_TILE_PP_3x3)
-    YV4_REQUIRE(fast_ok && conv3x3_pp_f32_applies(a), "conv: the ping-pong tile needs a 3x3 / stride 1 / pad 1 conv with "
-                "Cin %% 32 == 0 and Cout >= 64");
-  if (d->tile == YV4_TILE_PP_3x3 || (d->tile == YV4_TILE_AUTO && fast_ok && prefer_p3_f32(a))) {
-    if (stats) { a.stats = stats; *stats_done = true; }
-    return conv3x3_pp_f32_launch(a, s);
-  }
   if (d->tile == YV4_TILE_WS_1x1)
     YV4_REQUIRE(fast_ok && conv1x1_ws_f32_applies(a), "conv: the weight-stationary tile needs a 1x1 / stride 1 conv with Cin 64, "
                 "128 or 256, Cout >= 32 and no residual");
@@ -1936,8 +1307,8 @@ static int splitk_choice(const yv4_conv_desc* d, int* tile_out) {
   const int tile = YV4_TILE_DMA_64x64;
   const long long tiles = ((M + 63) / 64) * ((d->Cout + 63) / 64);
   const int nk = K / kBK;
-  static const long long target = [] { const char* e = getenv("YV4_SPLITK_TARGET"); return e ? atoll(e) : 512LL; }();
-  static const int min_slices = [] { const char* e = getenv("YV4_SPLITK_MINSL"); return e ? atoi(e) : 8; }();
+  static const long long target = (long long)YV4_ENV_INT("YV4_SPLITK_TARGET", (int)(512LL));
+  static const int min_slices = YV4_ENV_INT("YV4_SPLITK_MINSL", 8);
   int ks = 1;
   while (tiles * ks < target && nk / (ks * 2) >= min_slices && ks < 32) ks *= 2;
   if (tile_out) *tile_out = tile;

@@ -226,17 +226,17 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
   int rbuf = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (issued < nk) {     // slot wbuf was last read before the previous barrier
-      if (!(p.ablate & 1)) YV4_H_DMA(wbuf);
+      if (!YV4_ABLATE(p.ablate, 1)) YV4_H_DMA(wbuf);
       ++issued;
       wbuf = wbuf + 1 == NBUF ? 0 : wbuf + 1;
     }
     __builtin_amdgcn_s_setprio(1);
-    if (!(p.ablate & 2)) YV4_H_COMPUTE(rbuf);
+    if (!YV4_ABLATE(p.ablate, 2)) YV4_H_COMPUTE(rbuf);
     __builtin_amdgcn_s_setprio(0);
     rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
     if (kt + 1 < nk) {
       YV4_H_WAIT(issued - (kt + 2));
-      if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
+      if (!YV4_ABLATE(p.ablate, 4)) __builtin_amdgcn_s_barrier();
     }
   }
 #undef YV4_H_WAIT
@@ -355,7 +355,7 @@ int conv3x3_h16_launch(const ConvArgsH& a, bool bf16, int tile, hipStream_t s);
 // L2 -> LDS fill cost it was built to remove (10 us of a 77 us layer instead of 23) but runs one workgroup per CU, so
 // its prologue / epilogue (25 us per two-round launch) no longer overlap another workgroup's K loop.
 static bool prefer_c3(const ConvArgsH& a) {
-  static const int mode = [] { const char* e = getenv("YV4_C3"); return e ? atoi(e) : 0; }();
+  static const int mode = YV4_ENV_INT("YV4_C3", 0);
   if (!mode || !conv3x3_h16_applies(a)) return false;
   const long long tiles = ((long long)a.M + 255) / 256 * ((a.Cout + (a.Cout > 64 ? 127 : 63)) / (a.Cout > 64 ? 128 : 64));
   return tiles >= 100;
@@ -368,8 +368,8 @@ int conv1x1_ws_launch(const ConvArgsH& a, bool bf16, hipStream_t s);
 // The weight-stationary pointwise kernel takes the 1x1 layers in its domain that give each of its persistent waves
 // at least YV4_WS_MINSTRIPS strips of 32 pixels (YV4_WS=0 switches it off).
 static bool prefer_ws(const ConvArgsH& a) {
-  static const int mode = [] { const char* e = getenv("YV4_WS"); return e ? atoi(e) : 1; }();
-  static const int min_strips = [] { const char* e = getenv("YV4_WS_MINSTRIPS"); return e ? atoi(e) : 2; }();
+  static const int mode = YV4_ENV_INT("YV4_WS", 1);
+  static const int min_strips = YV4_ENV_INT("YV4_WS_MINSTRIPS", 2);
   if (!mode || !conv1x1_ws_applies(a)) return false;
   return ((long long)a.M + 31) / 32 >= (long long)min_strips * 2048;
 }
@@ -381,8 +381,8 @@ int conv3x3_small_launch(const ConvArgsH& a, bool bf16, hipStream_t s);
 // The few-channel 3x3 kernel takes the layers in its domain with at least YV4_S3_MINTILES 16 x 16 output tiles
 // (YV4_S3=0 switches it off).
 static bool prefer_s3(const ConvArgsH& a) {
-  static const int mode = [] { const char* e = getenv("YV4_S3"); return e ? atoi(e) : 1; }();
-  static const int min_tiles = [] { const char* e = getenv("YV4_S3_MINTILES"); return e ? atoi(e) : 1024; }();
+  static const int mode = YV4_ENV_INT("YV4_S3", 1);
+  static const int min_tiles = YV4_ENV_INT("YV4_S3_MINTILES", 1024);
   if (!mode || !conv3x3_small_applies(a)) return false;
   const long long ty = (a.Ho + 15) / 16, tx = (a.Wo + 15) / 16;
   // at 64 input channels the generic tiles are close (0.9-1.2x, measured): only maps that fill their 16 x 16 tiles
@@ -460,7 +460,7 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0;
   a.out_f32 = out_dtype == YV4_F32 ? 1 : 0;
   a.ys_on = 0;
-  static const int ablate = [] { const char* e = getenv("YV4_H16_ABLATE"); return e ? atoi(e) : 0; }();
+  static const int ablate = YV4_ENV_INT("YV4_H16_ABLATE", 0);
   a.ablate = ablate;
   a.stats = stats;
   const bool general = (d->Cin % kHBK) != 0;

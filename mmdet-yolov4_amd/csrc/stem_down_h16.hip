@@ -213,11 +213,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void stem_down_kernel(Ste
         *reinterpret_cast<T4*>(Pl + kSdPPlane + o) = lo;
       }
     }
-    if (tile + (int)gridDim.x < p.ntiles && !(p.ablate & 16)) load_patch(tile + (int)gridDim.x);
+    if (tile + (int)gridDim.x < p.ntiles && !YV4_ABLATE(p.ablate, 16)) load_patch(tile + (int)gridDim.x);
     __syncthreads();
 
     // ---- B: the stem on 31 x 33 pixels, 32 per row tile, four row tiles per wave
-    for (int rt = wave; rt < kRowTiles && !(p.ablate & 1); rt += NW) {
+    for (int rt = wave; rt < kRowTiles && !YV4_ABLATE(p.ablate, 1); rt += NW) {
       const int pix = rt * 32 + r;
       const int sy = pix / kSdSC, sx = pix - sy * kSdSC;
       const char* pb = Pl + (sy * kSdPPitch + sx) * 8;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void stem_down_kernel(Ste
             v[4 * g + 2] = acc[4 * g + 2] * sc.z + sh.z;
             v[4 * g + 3] = acc[4 * g + 3] * sc.w + sh.w;
           }
-          if (!(p.ablate & 4)) {
+          if (!YV4_ABLATE(p.ablate, 4)) {
             switch (p.act1) {
               case YV4_ACT_MISH: mish_fast_row(v); break;
               case YV4_ACT_LEAKY:
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void stem_down_kernel(Ste
 
     // ---- C: the stride-2 conv on the tile; wave w owns output rows 2w, 2w + 1 (32 pixels; row 15 is not part of
     // the tile: computed on whatever the LDS holds and never stored)
-    if (!(p.ablate & 2))
+    if (!YV4_ABLATE(p.ablate, 2))
     for (int wv = wave; wv < 8; wv += NW) {          // "wave row" wv = output rows 2 wv, 2 wv + 1
       const int oyl = 2 * wv + (r >> 4), oxl = r & 15;
       const int q0 = (2 * oyl) * kSdSCols + oxl;
@@ -349,14 +349,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void stem_down_kernel(Ste
         float v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = acc[t][e] * sb[t] + tb[t];
-        if (!(p.ablate & 4)) sd_act16(v, p.act2, p.slope2);
+        if (!YV4_ABLATE(p.ablate, 4)) sd_act16(v, p.act2, p.slope2);
         unsigned pk[8];
         pair_pack16<T>(v, odd, pk);
         T* yb = reinterpret_cast<T*>(p.y) + (((size_t)(n * p.Ho + oy0 + orow) * p.Wo + ox0 + 4 * h) * p.y_cs + p.y_co + t * 32 + (r & ~1));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int col = (j & 3) + 8 * (j >> 2);
-          if (row_ok && (full_x || ox0 + col + 4 * h < p.Wo) && (!(p.ablate & 8) || pk[j] == 0x12345678u))
+          if (row_ok && (full_x || ox0 + col + 4 * h < p.Wo) && (!YV4_ABLATE(p.ablate, 8) || pk[j] == 0x12345678u))
             *reinterpret_cast<unsigned*>(yb + col * p.y_cs) = pk[j];
         }
       }
@@ -382,14 +382,14 @@ static int launch_sd_ty(const StemDownArgs& a, hipStream_t stream) {
 }
 
 // rows per tile: 16 (default) or 15 (YV4_SD_TY=15: 32 instead of 35 stem row tiles per tile, but 7 % more tiles)
-static const int g_sd_ty = [] { const char* e = getenv("YV4_SD_TY"); return e && atoi(e) == 15 ? 15 : 16; }();
+static const int g_sd_ty = YV4_ENV_INT("YV4_SD_TY", 16) == 15 ? 15 : 16;
 template <bool BF16, int C1H, int NT2>
 static int launch_sd(StemDownArgs a, hipStream_t stream) {
   a.tiles_y = (a.Ho + g_sd_ty - 1) / g_sd_ty;
   a.ntiles = a.N * a.tiles_x * a.tiles_y;
   a.fd_ty = make_fastdiv((unsigned)(a.tiles_x * a.tiles_y));
   // YV4_SD_WAVES=8 keeps one 8-wave workgroup per CU for the narrow variant too (A/B measurement)
-  static const bool narrow4 = [] { const char* e = getenv("YV4_SD_WAVES"); return !(e && atoi(e) == 8); }();
+  static const bool narrow4 = YV4_ENV_INT("YV4_SD_WAVES", 4) != 8;
   if (C1H == 1 && narrow4 && g_sd_ty == 16) return launch_sd_ty<BF16, C1H, NT2, 16, 4>(a, stream);
   return g_sd_ty == 15 ? launch_sd_ty<BF16, C1H, NT2, 15, 8>(a, stream) : launch_sd_ty<BF16, C1H, NT2, 16, 8>(a, stream);
 }
@@ -419,7 +419,7 @@ extern "C" int yv4_stem_down_fwd_h16(int dtype, const float* x_nchw, int N, int 
   const long long nt = (long long)N * a.tiles_x * a.tiles_y;
   YV4_REQUIRE(nt < (1LL << 31) && (long long)N * a.Ho * a.Wo < (1LL << 31), "stem_down: too many tiles / pixels");
   a.ntiles = (int)nt;
-  static const int ablate = [] { const char* e = getenv("YV4_SD_ABLATE"); return e ? atoi(e) : 0; }();
+  static const int ablate = YV4_ENV_INT("YV4_SD_ABLATE", 0);
   a.ablate = ablate;
   a.fd_tx = make_fastdiv((unsigned)a.tiles_x);
   a.fd_ty = make_fastdiv((unsigned)(a.tiles_x * a.tiles_y));

@@ -542,8 +542,8 @@ constexpr int kBnUnroll = YV4_BN_UNROLL;    // independent row loads in flight p
 constexpr int kBnRedUnroll = YV4_BN_RED_UNROLL;   // (4 and 8 measured 0.8 % / 3 % slower on the whole step: registers -> occupancy)
 
 // rows per workgroup: enough workgroups to fill the chip (>= ~1024) but at most kBnRows rows each
-static const int g_bn_rows_cap = [] { const char* e = getenv("YV4_BN_ROWS"); return e ? atoi(e) : kBnRows; }();
-static const int g_bn_min_wg = [] { const char* e = getenv("YV4_BN_MINWG"); return e ? atoi(e) : 1024; }();
+static const int g_bn_rows_cap = YV4_ENV_INT("YV4_BN_ROWS", kBnRows);
+static const int g_bn_min_wg = YV4_ENV_INT("YV4_BN_MINWG", 1024);
 static inline int bn_rows_per_block(int64_t M) {
   int64_t r = (M + g_bn_min_wg - 1) / g_bn_min_wg;
   if (r < 32) r = 32;
@@ -1074,11 +1074,11 @@ using namespace yv4;
 // (ablation switch, off by default: 8 channels per thread -- 16-byte accesses on 16-bit rows -- measured no faster on the
 // forward pass and 20 % SLOWER on the backward apply pass over YOLOv4-L's shapes, tools/bn_bench.py --kernels: the
 // passes are bound by bytes in flight per CU, which the extra registers reduce)
-static const bool g_bn_vec8 = [] { const char* e = getenv("YV4_BN_VEC8"); return e && e[0] == '1'; }();
+static const bool g_bn_vec8 = YV4_ENV_INT("YV4_BN_VEC8", 0) == 1;
 
 // test / ablation switch: route 16-bit inputs through the widening fp32-MFMA kernel instead of the
 // 16-bit MFMA one (YV4_WGRAD_WIDEN=1 in the environment)
-static const bool g_wgrad_widen = [] { const char* e = getenv("YV4_WGRAD_WIDEN"); return e && e[0] == '1'; }();
+static const bool g_wgrad_widen = YV4_ENV_INT("YV4_WGRAD_WIDEN", 0) == 1;
 
 // split of the M reduction into chunks (shared by the launch and by yv4_conv_wgrad_workspace)
 static void wgrad_chunks(const yv4_conv_desc* d, int dtype, long long* chunks, long long* rows) {
@@ -1086,8 +1086,8 @@ static void wgrad_chunks(const yv4_conv_desc* d, int dtype, long long* chunks, l
   const int K = d->KH * d->KW * d->Cin;
   if (dtype != YV4_F32 && !g_wgrad_widen) {
     const long long tl = (long long)((K + kWhTile - 1) / kWhTile) * ((d->Cout + kWhTile - 1) / kWhTile);
-    static const int wg_target = [] { const char* e = getenv("YV4_WGRAD_WGS"); return e ? atoi(e) : 1024; }();
-    static const int min_slices = [] { const char* e = getenv("YV4_WGRAD_MINSL"); return e ? atoi(e) : 16; }();
+    static const int wg_target = YV4_ENV_INT("YV4_WGRAD_WGS", 1024);
+    static const int min_slices = YV4_ENV_INT("YV4_WGRAD_MINSL", 16);
     long long ch = (wg_target + tl - 1) / tl;             // default: ~2 rounds of 2 workgroups per CU
     const long long mx = (M + min_slices * kWhRows - 1) / (min_slices * kWhRows);   // at least min_slices per chunk
     if (ch > mx) ch = mx;

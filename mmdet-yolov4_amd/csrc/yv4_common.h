@@ -9,6 +9,19 @@
 
 #include "yv4.h"
 
+// Measurement switches.  The PRODUCT library (lib/libyv4_hip.so) reads no environment variable: every tuning knob is
+// its measured default and the ablation branches (which compute wrong results on purpose, to time a kernel without one
+// of its parts) do not exist.  `make measure` builds lib_alt/libyv4_hip_measure.so with -DYV4_MEASURE, in which
+// YV4_ENV_INT reads the variable once and YV4_ABLATE tests the flag word; YV4_LIB_PATH points the binding at it.
+#ifdef YV4_MEASURE
+#include <cstdlib>
+#define YV4_ENV_INT(NAME, DEFAULT) ([] { const char* e_ = getenv(NAME); return e_ ? atoi(e_) : (DEFAULT); }())
+#define YV4_ABLATE(FLAGS, BIT) ((FLAGS) & (BIT))
+#else
+#define YV4_ENV_INT(NAME, DEFAULT) (DEFAULT)
+#define YV4_ABLATE(FLAGS, BIT) false
+#endif
+
 namespace yv4 {
 
 // ---- host side ---------------------------------------------------------------

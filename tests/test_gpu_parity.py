@@ -176,36 +176,10 @@ def test_conv1x1_ws_kernel_f32_is_refused_outside_its_domain(gpu_device):
         _conv_case(gpu_device, 1, 8, 8, 64, 64, 1, 1, 0, act=1, tile=L.TILE_WS_1x1, residual=True)
 
 
-PP_SHAPES_F32 = [
-    # N, H, W, Cin, Cout  (3x3, stride 1, pad 1): the domain of conv3x3_pp_f32_kernel, tile 10
-    (2, 19, 19, 64, 128),      # two images in three M tiles: image borders inside a tile, ragged last tile
-    (3, 7, 5, 128, 64),        # map narrower than a fragment row group
-    (1, 38, 38, 32, 192),      # one chunk; three column tiles
-    (2, 16, 16, 96, 72),       # three chunks, Cout tail inside a 64-column tile
-    (1, 1, 300, 64, 64),       # one image row: every kh = 0 / 2 tap is padding
-    (5, 3, 3, 32, 64),         # tiny images
-    (24, 38, 38, 64, 128),     # 136 x 2 = 272 tiles > 256: the persistent form, two tiles for some workgroups
-    (70, 19, 19, 32, 192),     # 99 x 3 = 297 tiles, ragged last row tile, three column tiles
-]
-
-
-@pytest.mark.parametrize('shape', PP_SHAPES_F32)
-def test_conv3x3_pp_kernel_f32(gpu_device, shape):
-    """The ping-pong 3x3 kernel: within 1e-4 of the fp64 convolution and bit-identical to the LDS-DMA tiles (same
-    summation order), with a residual, the two-stage epilogue and channel-offset views."""
-    N, H, W, Cin, Cout = shape
-    _conv_case(gpu_device, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=L.TILE_PP_3x3)
-    outs = []
-    for tile in (L.TILE_PP_3x3, L.TILE_DMA_64x64, L.TILE_DMA_128x128):
-        outs.append(_conv_case(gpu_device, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=tile, residual=True, two_stage=True,
-                               x_off=8, y_off=4, raw=True))
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-
-
-def test_conv3x3_pp_kernel_f32_is_refused_outside_its_domain(gpu_device):
-    for shape in [(1, 8, 8, 64, 64, 1, 1, 0), (1, 8, 8, 64, 64, 3, 2, 1), (1, 8, 8, 16, 64, 3, 1, 1), (1, 8, 8, 64, 32, 3, 1, 1)]:
-        with pytest.raises(L.Yv4Error):
-            _conv_case(gpu_device, *shape, act=1, tile=L.TILE_PP_3x3)
+def test_removed_tile_id_is_refused(gpu_device):
+    """Tile id 10 (the fp32 ping-pong 3x3 form of round 2, removed in round 3: DESIGN 9.12) is refused, not replaced."""
+    with pytest.raises(L.Yv4Error):
+        _conv_case(gpu_device, 1, 8, 8, 64, 64, 3, 1, 1, act=1, tile=10)
 
 
 def test_conv_big_k_accuracy(gpu_device):
