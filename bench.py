@@ -124,29 +124,60 @@ def init_head(det, plan, img, target_per_img, logit_std=2.0):
     return count
 
 
-def pmc_traffic(tile_name):
-    """HBM bytes per launch of the dominant conv kernel from the committed rocprofv3 --pmc summary of
-    this same command (profiles/rNN_pmc_per_kernel.json; counters cannot be read from inside the bench)."""
+def tile_of_kernel(name):
+    """Tile class (the names of ``_lib.TILE_NAMES`` / ``HTILE_NAMES`` + the fused / persistent kernels) of a kernel name as
+    rocprofv3 prints it; None for kernels that are not convolutions."""
+    import re
+    m = re.search(r'conv_mfma_f32_dma_kernel<(\d+), (\d+)', name)
+    if m:
+        return f'dma{m.group(1)}x{m.group(2)}'
+    m = re.search(r'conv_mfma_f32_kernel<(\d+), (\d+)', name)
+    if m:
+        return f'{m.group(1)}x{m.group(2)}'
+    m = re.search(r'conv_mfma_h16_kernel<(?:true|false), (\d+), (\d+)', name)
+    if m:
+        return f'h16_{m.group(1)}x{m.group(2)}'
+    for pat, tile in (('conv1x1_ws_f32_kernel', 'ws_1x1'), ('conv1x1_ws_kernel', 'h16_ws_1x1'), ('conv3x3_small_kernel', 'h16_s3x3'),
+                      ('stem_down', 'stem_down'), ('conv_stem3x3_kernel', 'stem3x3'), ('conv3x3_pp_h16_kernel', 'h16_pp3x3')):
+        if re.search(pat, name):
+            return tile
+    return None
+
+
+def pmc_traffic(tile_name, run_key, alg_bytes_per_launch, launches_per_step):
+    """HBM bytes per launch of the dominant conv tile class from the committed rocprofv3 --pmc summary of THIS command
+    (counters cannot be read from inside the bench): the newest ``profiles/rNN_pmc_per_kernel*.json`` that holds a run
+    named ``run_key``.  The summary carries the ``roofline.tiles`` block of the bench line printed under the profiler; it
+    is REFUSED (traffic null, the reason in ``traffic_source``) unless that block's launch set equals this run's: same
+    launches per step of the tile class and the same algorithmic bytes per launch within 2 % -- a summary of another
+    kernel selection or another layer set says nothing about this run."""
     import glob
-    kern = {'dma64x64': 'yv4::conv_mfma_f32_dma_kernel<64, 64, 2, 2, 2>',
-            'dma128x64': 'yv4::conv_mfma_f32_dma_kernel<128, 64, 2, 2, 2>',
-            'dma128x128': 'yv4::conv_mfma_f32_dma_kernel<128, 128, 2, 2, 2>'}.get(tile_name)
-    if tile_name.startswith('h16_'):       # 16-bit path: per tile class, from the per-layer traffic table (bf16 run)
-        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_tiles_bf16.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel*.json')), reverse=True)
+    for f in files:
         try:
-            d = json.load(open(files[-1]))['tiles'][tile_name]
-            return d['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)
+            d = json.load(open(f))
         except Exception:
-            return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel.json')))
-    if not kern or not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1])).get(kern, {})
-        if 'hbm_bytes_per_launch' in d:
-            return round(d['hbm_bytes_per_launch']), os.path.relpath(files[-1], ROOT)
-    except Exception:
-        pass
+            continue
+        run = d.get(run_key)
+        if not isinstance(run, dict) or '_run' not in run:
+            continue
+        rel = os.path.relpath(f, ROOT) + ':' + run_key
+        t = run['_run'].get('tiles', {}).get(tile_name)
+        if t is None:
+            return None, f'refused: {rel} was taken when no launch used tile {tile_name}'
+        if t['launches_per_step'] != launches_per_step or \
+                abs(t['algorithmic_bytes_per_launch'] - alg_bytes_per_launch) > 0.02 * alg_bytes_per_launch:
+            return None, (f"refused: {rel} profiled {t['launches_per_step']} launches/step of {tile_name} at "
+                          f"{t['algorithmic_bytes_per_launch']} algorithmic B/launch, this run has {launches_per_step} at "
+                          f'{round(alg_bytes_per_launch)}')
+        tot, n = 0.0, 0
+        for k, e in run.items():
+            if k != '_run' and tile_of_kernel(k) == tile_name and 'hbm_bytes_per_launch' in e:
+                tot += e['hbm_bytes_per_launch'] * e['launches_sampled']
+                n += e['launches_sampled']
+        if n == 0:
+            return None, f'refused: {rel} holds no counters for tile {tile_name}'
+        return round(tot / n), rel
     return None, None
 
 
@@ -215,6 +246,45 @@ def cpu_baseline_v3(det, sd, size, budget_s):
     return dict(value=round(n / el, 4), unit='images/sec', cores=threads, kind='port',
                 sample=f'{n} single-image {size}x{size} forward+decode+NMS runs of the CPU oracle (YOLOv3) '
                        f'({el:.1f} s, {threads} torch threads = cgroup CPU quota), same weights as the GPU run')
+
+
+# image 0's pred maps of the timed step vs the CPU oracle, |diff| / (1 + |ref|): fp32 bounds = the ones
+# tests/test_gpu_fullsize.py holds the path to (measured mean 9e-6 / max 4e-4); 16-bit operands: one rounding per fused
+# layer through ~110 layers (measured mean 5e-3 fp16 / 4e-2 bf16) -- bounds that a skipped MFMA, a missing
+# slice or a stale buffer exceed by orders of magnitude
+ORACLE_BOUNDS = {'f32': (5e-5, 2e-3), 'f16': (3e-2, 1.0), 'bf16': (2e-1, 4.0)}
+
+
+def oracle_check(det, img0, pred0, dets0, dtype):
+    """The checker leg of the bench: the oracle (test infrastructure) evaluates image 0 of the timed batch on the CPU in
+    fp32; the timed plan's pred maps must agree within ORACLE_BOUNDS[dtype] and, in fp32, the detection count with the
+    oracle's own post-processing (+-2: near-ties at the max_per_img cut)."""
+    from oracle import yolov4_oracle as O
+    sd = {k: v.detach().cpu().clone() for k, v in det.state_dict().items()}
+    stages, reps = O.ARCH[det_scale(det)]
+    outs = list(det.backbone.out_indices) if hasattr(det.backbone, 'out_indices') else [3, 4, 5]
+    neck = 'v5' if type(det.neck).__name__ == 'YOLOV5Neck' else 'v4'
+    with torch.no_grad():
+        ref, _ = O.forward_pred_maps(img0, sd, stages, reps, outs, neck=neck)
+    mean_b, max_b = ORACLE_BOUNDS[dtype]
+    worst_mean = worst_max = 0.0
+    for got, r in zip(pred0, ref):
+        r = r[0]
+        if tuple(got.shape) != tuple(r.shape):
+            return False, f'pred map shape {tuple(got.shape)} != oracle {tuple(r.shape)}'
+        e = (got - r).abs() / (1 + r.abs())
+        if not bool(torch.isfinite(e).all()):
+            return False, 'non-finite pred map'
+        worst_mean, worst_max = max(worst_mean, float(e.mean())), max(worst_max, float(e.max()))
+    msg = (f'image 0 pred maps of the timed step vs the CPU oracle: mean {worst_mean:.2e} / max {worst_max:.2e} of 1 + |logit| '
+           f'(bounds {mean_b:g} / {max_b:g})')
+    ok = worst_mean <= mean_b and worst_max <= max_b
+    if dtype == 'f32' and ok:
+        res = O.get_bboxes(ref, [[1.0, 1.0, 1.0, 1.0]], 80, rescale=True)[0]
+        k = int(res[0].shape[0])
+        msg += f'; detections {dets0[0]} vs oracle {k}'
+        ok = abs(k - dets0[0]) <= 2
+    return ok, msg
 
 
 def vs_published(args, value):
@@ -421,12 +491,18 @@ def main():
     conv_time = sum(v[1] for v in per_tile.values())
     dom = max(per_tile, key=lambda k: per_tile[k][1])
     dflops, dtime, dn = per_tile[dom]
-    headline = (args.model, args.size, args.batch, args.dtype) == ('yolov4l', 608, 32, 'f32')
-    # the committed PMC summaries are of the headline run and of the same workload on bf16 operands
-    v4l = (args.model, args.size, args.batch) == ('yolov4l', 608, 32)
-    traffic, traffic_src = pmc_traffic(dom) if headline or (v4l and args.dtype == 'bf16') else (None, None)
     peak = PEAK_H16_MFMA_TFLOPS if h16 else PEAK_FP32_MFMA_TFLOPS
     dbytes = sum(o.bytes for o, _, _ in events if tile_of(o) == dom)
+    n_instr_steps = max(len(events) // len(conv_ops), 1)
+    tiles_block = {}
+    for tname, (tf, tt, tn) in per_tile.items():
+        tb = sum(o.bytes for o, _, _ in events if tile_of(o) == tname)
+        tiles_block[tname] = dict(launches_per_step=tn // n_instr_steps, avg_launch_us=round(tt / tn * 1e6, 2),
+                                  gflop_per_launch=round(tf / tn / 1e9, 3), algorithmic_bytes_per_launch=round(tb / tn),
+                                  tflops=round(tf / tt / 1e12, 1), gbps=round(tb / tt / 1e9, 1),
+                                  share_of_conv_time=round(tt / conv_time, 4))
+    run_key = f'{args.model}_{args.size}_b{args.batch}_{args.dtype}'
+    traffic, traffic_src = pmc_traffic(dom, run_key, dbytes / dn, dn // n_instr_steps)
     roofline = dict(bound='mfma', kernel=f'conv_mfma_{"h16" if h16 else "f32"}_kernel<{dom}>',
                     achieved=round(dflops / dtime / 1e12, 2), peak=peak, unit='TFLOP/s',
                     frac=round(dflops / dtime / 1e12 / peak, 4), traffic=traffic,
@@ -438,7 +514,7 @@ def main():
                     all_convs_frac=round(conv_flops / conv_time / 1e12 / peak, 4),
                     conv_share_of_step=round(conv_time / max(len(events) // len(conv_ops), 1) /
                                              (elapsed / args.steps), 4),
-                    instrumented_steps=len(events) // len(conv_ops))
+                    instrumented_steps=len(events) // len(conv_ops), run_key=run_key, tiles=tiles_block)
     # which roof bounds the dominant kernel: the higher of its two floors (FLOPs / matrix peak, algorithmic bytes /
     # HBM peak).  fp32: the matrix core by 14x; the 16-bit operands move the small-model / batch-256 configurations
     # (BASELINE.json configs[3]) and most tile classes of YOLOv4-L under the HBM roof
@@ -461,6 +537,7 @@ def main():
     # batch-2 plan computes for the same two images (per-image NMS, eval-mode BN, every conv tile walks K in the same
     # order) -- a wrong fast path (cached outputs, skipped images) cannot pass this
     torch.cuda.synchronize()
+    check_failed = None
     if args.batch >= 2:
         small = det.compile(2, args.size, args.size, device=dev, rescale=True,
                             dtype={'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.dtype])
@@ -468,16 +545,24 @@ def main():
         torch.cuda.synchronize()
         for n in range(2):
             k = int(host_count[n])
-            assert int(small.post['count'][n]) == k, f'image {n}: batch-{args.batch} step kept {k} detections, batch-2 plan ' \
-                                                     f'{int(small.post["count"][n])}'
-            assert torch.equal(small.post['dets'][n, :k].cpu(), host_dets[n, :k]) and \
-                torch.equal(small.post['labels'][n, :k].cpu().to(torch.int32), host_labels[n, :k]), \
-                f'image {n} of the batch-{args.batch} step differs from the batch-2 plan'
+            if int(small.post['count'][n]) != k:
+                check_failed = f'image {n}: batch-{args.batch} step kept {k} detections, batch-2 plan {int(small.post["count"][n])}'
+            elif not (torch.equal(small.post['dets'][n, :k].cpu(), host_dets[n, :k]) and
+                      torch.equal(small.post['labels'][n, :k].cpu().to(torch.int32), host_labels[n, :k])):
+                check_failed = f'image {n} of the batch-{args.batch} step differs from the batch-2 plan'
         del small
         output_check = f'images 0-1 of the timed batch-{args.batch} step == a batch-2 plan on the same images (bit-exact; ' \
                        f'{int(host_count[0])} + {int(host_count[1])} detections)'
+        if check_failed:
+            output_check = 'FAILED: ' + check_failed
     else:
         output_check = None
+    # image 0's pred maps of the TIMED plan, kept for the oracle leg below (the CPU oracle runs on this box anyway for
+    # cpu_baseline): the batch-2 comparison above goes through the same library, so a library that is wrong in a
+    # self-consistent way would pass it; the oracle is independent of the library
+    pred0 = [v.buf.tensor.view(v.N, v.H, v.W, v.C)[0].permute(2, 0, 1).float().cpu() for v in plan.pred_views] \
+        if getattr(plan, 'pred_views', None) and rank == 0 else None
+    dets0 = (int(host_count[0]), host_dets[0].clone(), host_labels[0].clone())
 
     # the inference numbers are final here: leave the group, free the plan, then let a child measure the train step
     D.finalize()
@@ -511,9 +596,15 @@ def main():
             roofline=roofline, output_check=output_check, train_step=train)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(det, args.size)
+            if pred0 is not None and not MODELS[args.model].get('v3'):
+                ok, msg = oracle_check(det, img[:1].cpu(), pred0, dets0, args.dtype)
+                out['output_check_oracle'] = ('' if ok else 'FAILED: ') + msg
+                check_failed = check_failed or (None if ok else msg)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
+        if check_failed:            # the metric line is out; a wrong result still fails the run
+            sys.exit(3)
 
 
 if __name__ == '__main__':

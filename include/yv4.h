@@ -323,10 +323,12 @@ int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, i
 #define YV4_HTILE_128x128 1
 #define YV4_HTILE_128x64 2
 #define YV4_HTILE_64x64 3
-/* 3x3 / stride 1 / pad 1, Cin % 64 == 0 only (conv3x3_h16.hip): 256 pixels x 128 (64) channels on 8 waves, the three kw
- * taps of a (chunk, kh) share one LDS image of the activations */
-#define YV4_HTILE_C3_256x128 4
-#define YV4_HTILE_C3_256x64 5
+/* 3x3 / stride 1 / pad 1, Cin % 64 == 0, even Cout >= 64, 16-bit output, even channel strides / offsets
+ * (conv3x3_pp_h16.hip): one PERSISTENT 8-wave workgroup per CU in ping-pong, 256 pixels x 128 channels per tile, the
+ * three kw taps of a (chunk, kh) share one LDS image of the activations, the LDS-DMA ring runs on across tiles, the
+ * epilogue stores channel pairs straight from the accumulators.  Same K order and epilogue expressions as the generic
+ * tiles.  (Id 5, the 256 x 64 form of round 2's non-persistent kernel, is gone and refused.) */
+#define YV4_HTILE_PP3x3 4
 /* 1x1 / stride 1, Cin <= 256, even Cout >= 16, 16-bit output, no residual (conv1x1_ws_h16.hip): one persistent
  * 8-wave workgroup per CU, the weight slab resident in LDS, wave-private rings of 32-pixel strips */
 #define YV4_HTILE_WS_1x1 6

@@ -1,0 +1,424 @@
+// 3x3 / stride-1 / pad-1 fused convolution for gfx950 with 16-bit operands: the MFMA-bound layers of CSPDarknet53 / PAN
+// (darknetcsp.py:38-64 bottleneck 3x3, yolo_neck_csp.py out convs) and their data gradients -- PERSISTENT ping-pong form.
+//
+// Geometry (unchanged from round 2's conv3x3_h16.hip, which this file replaces): one 8-wave workgroup per CU owns
+// 256 pixels x 128 channels; a stage is one (64-channel chunk, kh, kw) tap = 16 MFMAs (32x32x16) per wave; the three kw
+// taps of a (chunk, kh) read ONE LDS image of the 258 source pixels (fragment row = output row + kw; what a shifted row
+// must not see -- image borders, the neighbouring image -- is masked by redirecting the lane's read to a zero row), so
+// the activations are fetched 3 instead of 9 times per chunk: 28 KB of LDS fill per 4.2 MFLOP stage, under what the
+// L2 -> LDS path delivers (the generic tiles of conv_mfma_h16.hip move 24 KB per 1.05 MFLOP and sit at that limit).
+// Waves 4-7 run one phase behind waves 0-3: on every SIMD one wave is in its MFMA phase while its partner reads LDS,
+// issues DMA and waits (MI355X_MICROARCH.md "Two waves per SIMD").
+//
+// What round 2 measured on that kernel: 25 of a layer's 71 us were outside the K loop -- per tile 3 us of prologue
+// (address set-up, first-slice latency) and 6 us of epilogue, on one workgroup per CU with nothing to overlap them.
+// What changed here:
+//   * the workgroup is persistent (grid = min(tiles, CUs)) and the LDS-DMA ring runs ON ACROSS TILES: the issue side
+//     walks (tile, chunk, kh, kw) three stages ahead of the compute side with its own per-tile lane constants, so the
+//     first stages of tile t + 1 land while tile t is in its last stages and its epilogue -- no per-tile prologue;
+//   * the epilogue needs no LDS and no barrier: affine + activation in the MFMA's C layout (a lane owns ONE output
+//     channel of 16 rows), then lanes (r even, r odd) trade halves through one DPP swap per value, after which a lane
+//     owns channel PAIRS of 8 rows: residual add, second affine + activation, and dword stores of two 16-bit values
+//     (64 contiguous bytes per 16 lanes; these layers move 0.4 bytes per kFLOP, store shape is not their bound).  The
+//     round-2 form staged every accumulator tile through LDS patches carved from the K-loop buffers, which forced a
+//     drain + barrier before and after, and kept 64 VGPRs of per-lane affine alive across the K loop (68 spilled);
+//   * same K order as the generic tiles (chunk-major, taps inside, four 16-deep MFMA steps per tap) and the same
+//     epilogue expressions on the same fp32 accumulators, so a layer gives the same bits whichever kernel a batch size
+//     selects (tests/test_gpu_h16.py::test_pp3x3_matches_generic_bitwise).
+//
+// vmcnt bookkeeping: DMA(s) = PB weight pieces (+ PA activation pieces when stage s opens a (chunk, kh) group).  In
+// the LOAD phase of stage t a wave issues DMA(t + 3), reads the 16 fragments of stage t, then waits until its own
+// DMA(t + 1) has landed: everything newer -- DMA(t + 2), DMA(t + 3) -- may stay in flight (2 PB + PA for kw = 0, 1;
+// 2 PB for kw = 2).  The epilogue's loads and stores enter the same in-order counter BETWEEN DMAs: they make a counted
+// wait more conservative (it then also covers an older DMA), never less.  Reads of a staged buffer come one barrier
+// after the wait that retires it; a buffer is re-filled one barrier after the lgkmcnt(0) that retired its last reads.
+#include "conv_h16_common.h"
+
+namespace yv4 {
+
+constexpr int kP3Threads = 512;
+constexpr int kP3BM = 256;
+constexpr int kP3BN = 128;
+constexpr int kP3ARows = 320;       // BM + 2 source pixels, padded to 5 DMA passes of 64 rows; rows >= 258 stay zero
+constexpr int kP3PA = kP3ARows / 64;
+constexpr int kP3PB = kP3BN / 64;
+constexpr int kP3ZeroRow = 304;     // any row in [258, 320): only ever zero-filled
+constexpr int kP3NB = 4;            // weight ring slots
+constexpr int kP3Lds = (2 * kP3ARows + kP3NB * kP3BN) * 128;
+
+// Epilogue of one 32x32 accumulator tile straight from the MFMA's C layout (lane (r, h): channel co_base + r of the
+// rows (e & 3) + 8 (e >> 2) + 4 h).  Expressions and their order are epilogue_tile_h's (conv_h16_common.h).
+template <bool BF16>
+__device__ __forceinline__ void epilogue_pairs_h(const ConvArgsH& p, const f32x16& acc, int lane, int m_base, int co_base,
+                                                 bool has2) {
+  typedef typename Elem<BF16>::T T;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  const int r = lane & 31, h = lane >> 5;
+  const bool odd = r & 1;
+  const int c = co_base + r;
+  const int cp = c - (odd ? 1 : 0);                  // even channel of this lane's pair
+  const bool c_ok = cp + 1 < p.Cout;                 // Cout is even in this kernel's domain
+  const int cc = c_ok ? c : 0;
+  const float s1 = p.s1[cc], t1 = p.t1[cc];
+  // rows this lane stores after the exchange: (j & 3) + 8 (j >> 2) + 4 h (+ 16 on odd lanes)
+  const int row0 = m_base + 4 * h + (odd ? 16 : 0);
+  unsigned resw[8];
+  if (p.res) {
+    const T* rp = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = row0 + (j & 3) + 8 * (j >> 2);
+      resw[j] = (c_ok && m < p.M) ? *reinterpret_cast<const unsigned*>(rp + (int64_t)m * p.r_cs + p.r_co + cp) : 0u;
+    }
+  }
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] = __builtin_fmaf(acc[e], s1, t1);
+  {
+    float lo[8], hi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[e + 8]; }
+    act_row8(lo, p.act1, p.slope1);
+    act_row8(hi, p.act1, p.slope1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = lo[e]; v[e + 8] = hi[e]; }
+  }
+  // exchange: the even lane keeps its rows e < 8 and receives the odd lane's, the odd lane keeps e >= 8
+  float a[8], b[8];                                  // channel cp, channel cp + 1 of row j
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float send = odd ? v[j] : v[j + 8];
+    const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));
+    a[j] = odd ? recv : v[j];
+    b[j] = odd ? v[j + 8] : recv;
+  }
+  if (p.res) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const T2 rr = __builtin_bit_cast(T2, resw[j]);
+      a[j] += (float)rr[0];
+      b[j] += (float)rr[1];
+    }
+  }
+  if (has2) {
+    const int c2 = c_ok ? cp : 0;
+    const float s2a = p.s2[c2], t2a = p.t2[c2], s2b = p.s2[c2 + 1], t2b = p.t2[c2 + 1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] = __builtin_fmaf(a[j], s2a, t2a);
+      b[j] = __builtin_fmaf(b[j], s2b, t2b);
+    }
+    act_row8(a, p.act2, p.slope2);
+    act_row8(b, p.act2, p.slope2);
+  }
+  T* yp = reinterpret_cast<T*>(p.y);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int m = row0 + (j & 3) + 8 * (j >> 2);
+    T2 pk;
+    pk[0] = (T)a[j];
+    pk[1] = (T)b[j];
+    if (c_ok && m < p.M)
+      *reinterpret_cast<unsigned*>(yp + (int64_t)m * p.y_cs + p.y_co + cp) = __builtin_bit_cast(unsigned, pk);
+  }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
+  typedef typename Elem<BF16>::V8 V8;
+  constexpr int TM = 2, TN = 2;            // wave tile 64 x 64
+  constexpr int PA = kP3PA, PB = kP3PB;
+  constexpr int kRowB = 128;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_p3[];
+  char* As = smem_p3;                                  // [2][kP3ARows][128 B]
+  char* Bs = smem_p3 + 2 * kP3ARows * kRowB;           // [kP3NB][BN][128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1;                // 0..3: 64-row slab
+  const int wn = wave & 1;                 // 64-column slab
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  const u32x4_t rsA = make_rsrc_h(p.x, x_bytes);
+  const u32x4_t rsB = make_rsrc_h(p.w, w_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_p3;
+  const int NHW = p.N * p.H * p.W;
+  const int nwg = (int)gridDim.x;
+
+  // virtual tile index -> tile: each XCD (workgroups with equal id mod 8) walks a contiguous run of tiles, tile_n fastest
+  const unsigned q8 = (unsigned)ntiles >> 3, rem8 = (unsigned)ntiles & 7u;
+  auto tile_of = [&](int vt) -> unsigned {
+    const unsigned x = (unsigned)vt & 7u;
+    return (x < rem8 ? x * (q8 + 1) : rem8 * (q8 + 1) + (x - rem8) * q8) + ((unsigned)vt >> 3);
+  };
+
+  // ---- staging lanes: a DMA instruction of a wave fills 8 LDS rows (lane / 8) x 8 chunks (lane % 8) ----
+  const int srow = 8 * wave + (lane >> 3);               // 0..63, + 64 per pass
+  const int pc = lane & 7;
+  const int lc = pc ^ ((srow >> 1) & 7);                 // (row >> 1) & 7 is the same for row + 64 q
+  int a_s[PA];                                           // source pixel of LDS row (srow + 64 q) for kh = 1
+  unsigned a_off[PA];                                    // its byte offset (wrapping arithmetic; used only when valid)
+  unsigned b_off[PB];
+  int i_vt = (int)blockIdx.x;                            // issue side: virtual tile, walk inside it, global counters
+  auto issue_tile_setup = [&]() {
+    const bool live = i_vt < ntiles;
+    const unsigned tile = live ? tile_of(i_vt) : 0u;
+    const int tn = (int)(tile % (unsigned)p.tiles_n);
+    const int m0i = (int)(tile / (unsigned)p.tiles_n) * kP3BM;
+    const int n0i = tn * kP3BN;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int row = srow + 64 * q;
+      a_s[q] = (live && row < kP3BM + 2) ? m0i - 1 + row : (int)0x40000000;     // beyond the image for every kh: zero
+      a_off[q] = (unsigned)((((int64_t)(m0i - 1 + row)) * p.x_cs + p.x_co + lc * 8) * 2);
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int co = n0i + srow + 64 * q;
+      b_off[q] = (live && co < p.Cout) ? (unsigned)(((int64_t)co * p.Kw + lc * 8) * 2) : kOOB;
+    }
+  };
+  issue_tile_setup();
+
+  // ---- fragment read addresses (tile-independent) ----
+  unsigned a_rd[TM][3];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rr = wm * 64 + i * 32 + r;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int row = rr + kw;
+      a_rd[i][kw] = (unsigned)(row * kRowB + ((((row >> 1) & 7) ^ h) << 4));
+    }
+  }
+  const unsigned zero_rd = (unsigned)(kP3ZeroRow * kRowB);     // all chunks of that row are zero: no swizzle needed
+  unsigned b_rd[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int row = wn * 64 + i * 32 + r;
+    b_rd[i] = (unsigned)(row * kRowB + ((((row >> 1) & 7) ^ h) << 4));
+  }
+
+  const int nchunks = p.Cin >> 6;
+  const int G = 3 * nchunks;               // (chunk, kh) groups per tile; stage = 3 g + kw
+  int i_c0 = 0, i_kh = 0, i_kw = 0, i_g = 0;
+  unsigned i_t = 0u, i_gg = 0u;            // global stage / group counters: ring slot i_t & 3, activation buffer i_gg & 1
+
+  // ISSUE: weights of the next stage into ring slot i_t & 3 and, when the stage opens a group, the group's activation
+  // rows into activation buffer i_gg & 1.  Beyond the last tile the same number of (out-of-range, zero-filling) DMAs is
+  // issued so that the vmcnt bookkeeping stays uniform.
+#define YV4_P3_ISSUE()                                                                              \
+  {                                                                                                 \
+    const unsigned lb_ = lds_base + (unsigned)((2 * kP3ARows + (int)(i_t & 3u) * kP3BN + 8 * wave) * kRowB); \
+    const unsigned kb = (unsigned)((((i_kh * 3 + i_kw) * p.Cin) + i_c0) * 2);                        \
+    _Pragma("unroll") for (int q = 0; q < PB; ++q)                                                  \
+        lds_dma16_h(rsB, lb_ + 64 * q * kRowB, b_off[q], kb);   /* (the range check sees voffset only) */                \
+    if (i_kw == 0) {                                                                                \
+      const unsigned la_ = lds_base + (unsigned)(((int)(i_gg & 1u) * kP3ARows + 8 * wave) * kRowB);  \
+      const int ds = (i_kh - 1) * p.W;                                                              \
+      const unsigned step = (unsigned)(((int64_t)ds * p.x_cs + i_c0) * 2);                          \
+      _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                              \
+        const bool ok = (unsigned)(a_s[q] + ds) < (unsigned)NHW;                                    \
+        lds_dma16_h(rsA, la_ + 64 * q * kRowB, ok ? a_off[q] + step : kOOB, 0u);                     \
+      }                                                                                             \
+    }                                                                                               \
+    i_t += 1u;                                                                                      \
+    i_kw += 1;                                                                                      \
+    if (i_kw == 3) {                                                                                \
+      i_kw = 0;                                                                                     \
+      i_gg += 1u;                                                                                   \
+      i_g += 1;                                                                                     \
+      i_kh += 1;                                                                                    \
+      if (i_kh == 3) { i_kh = 0; i_c0 += kHBK; }                                                    \
+      if (i_g == G) {                                                                               \
+        i_g = 0; i_c0 = 0;                                                                          \
+        i_vt += nwg;                                                                                \
+        issue_tile_setup();                                                                         \
+      }                                                                                             \
+    }                                                                                               \
+  }
+
+#define YV4_P3_WAIT(NEWER) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEWER) : "memory")
+
+  V8 fa4[4][TM], fb4[4][TN];
+  f32x16 acc[TM][TN];
+#define YV4_P3_LOAD(KW, ABUF, BSLOT, MK)                                                            \
+  {                                                                                                 \
+    const char* as_ = As + (ABUF) * (kP3ARows * kRowB);                                             \
+    const char* bs_ = Bs + (BSLOT) * (kP3BN * kRowB);                                               \
+    unsigned ar[TM];                                                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+        ar[i] = ((MK[i] >> (KW)) & 1u) ? a_rd[i][KW] : zero_rd;                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
+          fa4[j][i] = *reinterpret_cast<const V8*>(as_ + (ar[i] ^ (unsigned)(j << 5)));             \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                \
+          fb4[j][i] = *reinterpret_cast<const V8*>(bs_ + (b_rd[i] ^ (unsigned)(j << 5)));           \
+    }                                                                                               \
+  }
+#define YV4_P3_MFMA()                                                                               \
+  {                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
+        _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                           \
+            acc[i][jn] = Elem<BF16>::mfma(fa4[j][i], fb4[j][jn], acc[i][jn]);                       \
+  }
+#define YV4_P3_STAGE(KW, NEWER)                                                                     \
+  {                                                                                                 \
+    YV4_P3_ISSUE();                                                                                 \
+    YV4_P3_LOAD(KW, ab, (t0 + (KW)) & 3u, mk3);                                                     \
+    YV4_P3_WAIT(NEWER);                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                  \
+    YV4_P3_MFMA();                                                                                  \
+    __builtin_amdgcn_s_setprio(0);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    __builtin_amdgcn_s_barrier();                                                                   \
+  }
+
+  // prologue: stages 0, 1, 2 of the first tile in flight, then wait for stage 0 (newer: weights 1, 2)
+  YV4_P3_ISSUE();
+  YV4_P3_ISSUE();
+  YV4_P3_ISSUE();
+  YV4_P3_WAIT(2 * PB);
+  __builtin_amdgcn_s_barrier();
+  if (wm >= 2) __builtin_amdgcn_s_barrier();           // waves 4-7 run one phase behind waves 0-3
+
+  const bool has2 = p.s2 != nullptr;
+  unsigned gg = 0u;                                    // compute side: global group counter
+  for (int vt = (int)blockIdx.x; vt < ntiles; vt += nwg) {
+    const unsigned tile = tile_of(vt);
+    const int tile_n = (int)(tile % (unsigned)p.tiles_n);
+    const int tile_m = (int)(tile / (unsigned)p.tiles_n);
+    const int m0 = tile_m * kP3BM;
+    const int n0 = tile_n * kP3BN;
+    unsigned mask9[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * 64 + i * 32 + r;
+      unsigned mk = 0u;
+      if (m < p.M) {
+        const int hw = p.H * p.W;
+        const int n = fd_div(m, p.fd_hw);
+        const int rm = m - n * hw;
+        const int ho = fd_div(rm, p.fd_wo);
+        const int wo = rm - ho * p.W;
+        mk = (unsigned)tap_mask(ho - 1, wo - 1, 3, 3, p.H, p.W);
+      }
+      mask9[i] = mk;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int kh = 0;
+    for (int g = 0; g < G; ++g) {
+      unsigned mk3[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) mk3[i] = mask9[i] >> (3 * kh);
+      kh = kh == 2 ? 0 : kh + 1;
+      const unsigned ab = gg & 1u;
+      const unsigned t0 = 3u * gg;
+      gg += 1u;
+      YV4_P3_STAGE(0, 2 * PB + PA);
+      YV4_P3_STAGE(1, 2 * PB + PA);
+      YV4_P3_STAGE(2, 2 * PB);
+    }
+
+    // ---- BatchNorm statistics of the tile (training forward, identity epilogue), as conv_mfma_h16.hip ----
+    if (p.stats) {
+      typedef typename Elem<BF16>::T TS;
+      double* rep = p.stats + (size_t)(tile_m & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        float su = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mb = m0 + wm * 64 + i * 32 + 4 * h;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = mb + (e & 3) + 8 * (e >> 2);
+            const float v = (float)(TS)acc[i][jn][e];
+            if (m < p.M) { su += v; sq += v * v; }
+          }
+        }
+        su += __shfl_xor(su, 32);
+        sq += __shfl_xor(sq, 32);
+        const int col = n0 + wn * 64 + jn * 32 + r;
+        if (h == 0 && col < p.Cout) {
+          atomicAdd(&rep[col], (double)su);
+          atomicAdd(&rep[p.Cout + col], (double)sq);
+        }
+      }
+    }
+    // ---- epilogue: no LDS, no barrier; the next tile's first three stages are already in flight ----
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        epilogue_pairs_h<BF16>(p, acc[i][jn], lane, m0 + wm * 64 + i * 32, n0 + wn * 64 + jn * 32, has2);
+  }
+  if (wm < 2) __builtin_amdgcn_s_barrier();            // same number of barriers for both halves
+#undef YV4_P3_STAGE
+#undef YV4_P3_MFMA
+#undef YV4_P3_LOAD
+#undef YV4_P3_ISSUE
+  YV4_P3_WAIT(0);                                      // the zero-filling tail DMAs must land before the LDS is released
+#undef YV4_P3_WAIT
+}
+
+// Is this layer in the kernel's domain?  3x3, stride 1, pad 1 (so Ho = H, Wo = W), 64-channel chunks of input, even
+// Cout (channel pairs are stored as dwords) and dword-aligned output / residual views, 16-bit output.
+bool conv3x3_pp_h16_applies(const ConvArgsH& a) {
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && (a.Cin & 63) == 0 &&
+         !a.ys_on && !a.out_f32 && a.Cout >= 64 && (a.Cout & 1) == 0 && ((a.y_cs | a.y_co) & 1) == 0 &&
+         (a.res == nullptr || ((a.r_cs | a.r_co) & 1) == 0);
+}
+
+static int g_p3_cus = 0;
+
+template <bool BF16>
+static int launch_p3(const ConvArgsH& a, hipStream_t stream) {
+  ConvArgsH p = a;
+  const int tiles_m = (p.M + kP3BM - 1) / kP3BM;
+  p.tiles_n = (p.Cout + kP3BN - 1) / kP3BN;
+  p.fd_hw = make_fastdiv((unsigned)(p.H * p.W));
+  p.fd_wo = make_fastdiv((unsigned)p.W);
+  const long long tiles = (long long)tiles_m * p.tiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffLL) {
+    set_error("conv3x3 pp h16: grid of %lld tiles out of range", tiles);
+    return YV4_E_INVALID;
+  }
+  if (g_p3_cus == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    g_p3_cus = cus;
+  }
+  const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 2, wb = (long long)p.Cout * p.Kw * 2;
+  auto kern = conv3x3_pp_h16_kernel<BF16>;
+  static LdsAttrOnce once;
+  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), (size_t)kP3Lds, "conv3x3_pp_h16")) return rc;
+  const unsigned grid = (unsigned)(tiles < g_p3_cus ? tiles : g_p3_cus);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kP3Threads), (size_t)kP3Lds, stream, p, (unsigned)xb, (unsigned)wb, (int)tiles);
+  YV4_CHECK_LAUNCH("conv3x3_pp_h16");
+  return YV4_OK;
+}
+
+int conv3x3_pp_h16_launch(const ConvArgsH& a, bool bf16, hipStream_t s) {
+  return bf16 ? launch_p3<true>(a, s) : launch_p3<false>(a, s);
+}
+
+}  // namespace yv4

@@ -345,20 +345,21 @@ static int dispatch_h16(const ConvArgsH& a, int tile, bool general, hipStream_t 
   return dispatch_h16_n<BF16, 2>(a, tile, general, s);
 }
 
-// conv3x3_h16.hip
-bool conv3x3_h16_applies(const ConvArgsH& a);
-int conv3x3_h16_launch(const ConvArgsH& a, bool bf16, int tile, hipStream_t s);
+// conv3x3_pp_h16.hip
+bool conv3x3_pp_h16_applies(const ConvArgsH& a);
+int conv3x3_pp_h16_launch(const ConvArgsH& a, bool bf16, hipStream_t s);
 
-// YV4_C3=1: the 3x3 / stride-1 kernel takes every layer in its domain that fills at least ~40 % of the chip with its
-// one-workgroup-per-CU tiles.  Off by default: measured on MI355X (profiles/r02_c3_ablation.md) it is within +-2 % of
-// the generic tiles on YOLOv4-L (inference 3531 vs 3585 images/s bf16, train step 768 vs 759) -- it removes the
-// L2 -> LDS fill cost it was built to remove (10 us of a 77 us layer instead of 23) but runs one workgroup per CU, so
-// its prologue / epilogue (25 us per two-round launch) no longer overlap another workgroup's K loop.
-static bool prefer_c3(const ConvArgsH& a) {
-  static const int mode = YV4_ENV_INT("YV4_C3", 0);
-  if (!mode || !conv3x3_h16_applies(a)) return false;
-  const long long tiles = ((long long)a.M + 255) / 256 * ((a.Cout + (a.Cout > 64 ? 127 : 63)) / (a.Cout > 64 ? 128 : 64));
-  return tiles >= 100;
+// The persistent ping-pong 3x3 kernel takes the stride-1 3x3 layers with >= 128 input channels whose 256 x 128 tiles
+// fill the one-workgroup-per-CU rounds: at least 150 tiles and at least 60 % of the last round's CUs busy (362 tiles =
+// 2 rounds at 71 %, 184 tiles = 1 round at 72 %; a batch-2 plan's 24 tiles stay on the generic tiles, which sum K in
+// the same order and apply the same epilogue expressions -- same bits).  YV4_PP3=0 (measurement build) switches it off.
+static bool prefer_pp3(const ConvArgsH& a) {
+  static const int mode = YV4_ENV_INT("YV4_PP3", 1);
+  static const int cus = YV4_ENV_INT("YV4_PP3_CUS", 256);
+  if (!mode || !conv3x3_pp_h16_applies(a) || a.Cin < 128) return false;
+  const long long tiles = ((long long)a.M + 255) / 256 * ((a.Cout + 127) / 128);
+  const long long rounds = (tiles + cus - 1) / cus;
+  return tiles >= 150 && tiles * 100 >= rounds * cus * 60;
 }
 
 // conv1x1_ws_h16.hip
@@ -410,8 +411,9 @@ extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
     ConvArgsH a{};
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
     a.Cin = d->Cin; a.Cout = d->Cout; a.ys_on = 0; a.M = (int)((long long)d->N * d->Ho * d->Wo);
-    if (prefer_c3(a)) return d->Cout > 64 ? YV4_HTILE_C3_256x128 : YV4_HTILE_C3_256x64;
     a.K = a.Kw = d->KH * d->KW * d->Cin; a.res = nullptr; a.out_f32 = (d->Cout & 1) ? 1 : 0;   // (odd Cout: a pred map)
+    a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = d->r_cstride; a.r_co = d->r_coff;
+    if (prefer_pp3(a)) return YV4_HTILE_PP3x3;
     if (prefer_ws(a)) return YV4_HTILE_WS_1x1;
     a.N = d->N; a.stats = nullptr; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = d->r_cstride; a.r_co = d->r_coff;
     if (prefer_s3(a)) return YV4_HTILE_S3x3;
@@ -465,9 +467,10 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   a.stats = stats;
   const bool general = (d->Cin % kHBK) != 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const bool c3_id = d->tile == YV4_HTILE_C3_256x128 || d->tile == YV4_HTILE_C3_256x64;
-  if (c3_id) YV4_REQUIRE(conv3x3_h16_applies(a), "conv h16: the C3 tiles need a 3x3 / stride 1 / pad 1 conv with Cin %% 64 == 0, Cout >= 64");
-  if (c3_id || (d->tile == YV4_TILE_AUTO && prefer_c3(a))) return conv3x3_h16_launch(a, dtype == YV4_BF16, d->tile, s);
+  if (d->tile == YV4_HTILE_PP3x3)
+    YV4_REQUIRE(conv3x3_pp_h16_applies(a), "conv h16: the ping-pong 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with "
+                "Cin %% 64 == 0, even Cout >= 64, 16-bit output and even channel strides / offsets");
+  if (d->tile == YV4_HTILE_PP3x3 || (d->tile == YV4_TILE_AUTO && prefer_pp3(a))) return conv3x3_pp_h16_launch(a, dtype == YV4_BF16, s);
   if (d->tile == YV4_HTILE_WS_1x1)
     YV4_REQUIRE(conv1x1_ws_applies(a), "conv h16: the weight-stationary tile needs a 1x1 / stride 1 conv with Cin <= 256, "
                 "Cout >= 16 (even unless the output is fp32) and no residual");

@@ -24,7 +24,7 @@ HT = dict(t128x128=1, t128x64=2, t64x64=3)
 
 
 def _h16_conv(dev, dtype, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=False, two_stage=False, x_off=0,
-              y_off=0, out_f32=False, seed=0):
+              y_off=0, out_f32=False, seed=0, raw=False):
     g = torch.Generator().manual_seed(seed)
     cp = (Cin + 7) // 8 * 8
     x = torch.randn(N, H, W, Cin, generator=g).to(dtype)
@@ -74,6 +74,8 @@ def _h16_conv(dev, dtype, N, H, W, Cin, Cout, k, stride, pad, act, tile, residua
                                          torch.cuda.current_stream().cuda_stream)
     L.check(rc, 'yv4_conv_bn_act_fwd_h16')
     torch.cuda.synchronize()
+    if raw:
+        return ybuf[..., y_off:y_off + Cout].clone()
     got = ybuf[..., y_off:y_off + Cout].double().cpu()
     assert bool((ybuf[..., :y_off] == 7.0).all()) and bool((ybuf[..., y_off + Cout:] == 7.0).all())
     ulp = 2e-5 if out_f32 else (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11)
@@ -111,69 +113,76 @@ def test_h16_conv_epilogues(gpu_device, dtype, act):
     _h16_conv(gpu_device, dtype, 1, 9, 11, 40, 64, 3, 1, 1, act, 3, out_f32=True, y_off=4)
 
 
-C3_SHAPES = [
-    # N, H, W, Cin, Cout  (3x3, stride 1, pad 1): the domain of conv3x3_h16.hip, tiles 4 (256x128) and 5 (256x64)
+PP3_SHAPES = [
+    # N, H, W, Cin, Cout  (3x3, stride 1, pad 1): the domain of conv3x3_pp_h16.hip, tile 4 (256 pixels x 128 channels)
     (2, 19, 19, 64, 128),      # two images in three M tiles: image borders inside a tile, ragged last tile
-    (3, 7, 5, 128, 64),        # map narrower than a fragment row group: many left / right borders per tile
+    (3, 7, 5, 128, 64),        # map narrower than a fragment row group: many left / right borders per tile; half-empty columns
     (1, 38, 38, 64, 192),      # Cout not a multiple of 128: half-empty last column tile
     (2, 16, 16, 192, 72),      # three channel chunks, Cout tail inside a 32-column group
     (1, 1, 300, 64, 64),       # one image row: every kh = 0 / 2 tap is padding
     (5, 3, 3, 64, 64),         # tiny images: almost every tap is masked somewhere
+    (24, 38, 38, 64, 256),     # 136 x 2 = 272 tiles > 256 CUs: some workgroups walk two tiles, the ring runs on across them
+    (70, 19, 19, 128, 384),    # 99 x 3 = 297 tiles, ragged last row tile, three column tiles, two chunks
 ]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('tile', [4, 5])
-@pytest.mark.parametrize('shape', C3_SHAPES)
-def test_h16_conv3x3_kernel_shapes(gpu_device, dtype, tile, shape):
+@pytest.mark.parametrize('shape', PP3_SHAPES)
+def test_h16_pp3x3_kernel_shapes(gpu_device, dtype, shape):
     N, H, W, Cin, Cout = shape
-    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=tile)
+    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=4)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('act', [0, 1, 2, 3])
-def test_h16_conv3x3_kernel_epilogues(gpu_device, dtype, act):
-    """Residual + two-stage epilogue + channel-offset views on both sides + fp32 output through the 3x3 kernel."""
+def test_h16_pp3x3_kernel_epilogues(gpu_device, dtype, act):
+    """Residual + two-stage epilogue + channel-offset views on both sides through the persistent 3x3 kernel."""
     _h16_conv(gpu_device, dtype, 2, 13, 13, 64, 72, 3, 1, 1, act, 4, residual=True, two_stage=True, x_off=8, y_off=16)
-    _h16_conv(gpu_device, dtype, 1, 20, 9, 128, 128, 3, 1, 1, act, 5, residual=True, x_off=16)
-    _h16_conv(gpu_device, dtype, 1, 9, 11, 64, 64, 3, 1, 1, act, 4, out_f32=True, y_off=4)
+    _h16_conv(gpu_device, dtype, 1, 20, 9, 128, 128, 3, 1, 1, act, 4, residual=True, x_off=16)
+    _h16_conv(gpu_device, dtype, 30, 38, 38, 64, 128, 3, 1, 1, act, 4, residual=True, two_stage=True, y_off=8)   # 170 tiles
 
 
-def test_h16_conv3x3_kernel_is_refused_outside_its_domain(gpu_device):
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_pp3x3_matches_generic_bitwise(gpu_device, dtype):
+    """Same K order (chunk-major, taps inside, four 16-deep MFMA steps per tap) and the same epilogue expressions on the
+    same fp32 accumulators: the persistent 3x3 kernel and the generic tiles return the same BITS, so a plan may pick
+    either by batch size (bench.py's batch-32 vs batch-2 output check, the plans' batch-composition independence)."""
+    for shape, kw in [((2, 19, 19, 128, 128), dict(residual=True, two_stage=True)), ((3, 38, 38, 64, 192), dict()),
+                      ((9, 38, 38, 256, 256), dict(residual=True))]:
+        N, H, W, Cin, Cout = shape
+        outs = [_h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=t, raw=True, **kw) for t in (4, 1, 2, 3)]
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o)
+
+
+def test_h16_pp3x3_kernel_is_refused_outside_its_domain(gpu_device):
     for shape in [(1, 8, 8, 64, 64, 1, 1, 0), (1, 8, 8, 64, 64, 3, 2, 1), (1, 8, 8, 32, 64, 3, 1, 1)]:
         with pytest.raises(L.Yv4Error):
             _h16_conv(gpu_device, torch.bfloat16, *shape, act=1, tile=4)
+    with pytest.raises(L.Yv4Error):                                      # fp32 output (pred maps) stays on the generic tiles
+        _h16_conv(gpu_device, torch.bfloat16, 1, 9, 11, 64, 64, 3, 1, 1, act=1, tile=4, out_f32=True, y_off=4)
+    with pytest.raises(L.Yv4Error):                                      # id 5 (round 2's 256 x 64 form) no longer exists
+        _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 64, 3, 1, 1, act=1, tile=5)
 
 
-def test_h16_conv3x3_kernel_auto_choice_is_opt_in(gpu_device):
-    """YV4_C3=1 lets the auto tile choice take the 3x3 kernel for big layers (a child process: the switch is read once
-    per process); the default keeps the generic tiles (measured parity, profiles/r02_c3_ablation.md)."""
-    import subprocess
+def test_h16_pp3x3_auto_choice(gpu_device):
+    """The auto tile choice takes the persistent 3x3 kernel for the stride-1 3x3 layers with >= 128 input channels whose
+    tiles fill the chip; a batch-2 plan's layers and the few-channel layers keep the generic tiles."""
     d = L.ConvDesc()
     d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 32, 38, 38, 256, 38, 38, 256
     d.KH = d.KW = 3
     d.stride, d.pad = 1, 1
-    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) in (1, 2, 3)
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch; import test_gpu_h16 as T; "
-            "T._c3_auto_checks(torch.device('cuda:0'))") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                            os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, YV4_C3='1'), capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-def _c3_auto_checks(gpu_device):
-    d = L.ConvDesc()
-    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 32, 38, 38, 256, 38, 38, 256
-    d.KH = d.KW = 3
-    d.stride, d.pad = 1, 1
-    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 4
-    d.Cout = 64
-    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 5
-    d.N = 1                                                  # 6 x 2 tiles: the generic tiles' occupancy wins
-    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) in (1, 2, 3)
-    _h16_conv(gpu_device, torch.bfloat16, 8, 38, 38, 128, 128, 3, 1, 1, act=1, tile=0)     # 46 x 1 tiles ... generic
-    _h16_conv(gpu_device, torch.bfloat16, 20, 38, 38, 64, 128, 3, 1, 1, act=1, tile=0)     # 113 tiles: the C3 kernel
+    d.x_cstride, d.y_cstride, d.r_cstride = 256, 256, 256
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 4           # 362 tiles
+    d.N, d.H, d.W, d.Ho, d.Wo, d.Cin, d.Cout = 32, 19, 19, 19, 19, 512, 512
+    d.x_cstride, d.y_cstride = 512, 512
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 4           # 184 tiles: one round at 72 %
+    d.N = 2
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) in (1, 2, 3)   # 12 tiles
+    d.N, d.H, d.W, d.Ho, d.Wo, d.Cin, d.Cout = 32, 152, 152, 152, 152, 64, 64
+    d.x_cstride, d.y_cstride = 64, 64
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) != 4           # 64 input channels: the few-channel kernel's layer
+    _h16_conv(gpu_device, torch.bfloat16, 32, 38, 38, 128, 128, 3, 1, 1, act=1, tile=0)     # auto -> persistent kernel
 
 
 WS_SHAPES = [

@@ -2,7 +2,8 @@
 # Rehearsal of `bench.py --gpus 2` on a ONE-GPU box: both ranks use cuda:0 (LOCAL_RANK=0) and line up over gloo
 # (YV4_DIST_BACKEND; RCCL refuses two ranks on one device).  Exercises the launcher contract, the barrier/max
 # timing, the train-step child processes and their own rendezvous port -- not the xGMI all-reduce rate.
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
+cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/rehearse2; mkdir -p $OUT
 export WORLD_SIZE=2 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 YV4_DIST_BACKEND=gloo
 ARGS="--gpus 2 --steps 5 --warmup 2 --batch 16 --train-batch 16 $@"

@@ -1,7 +1,8 @@
 #!/bin/bash
 # PMC passes over one conv shape (GPU box).  Usage: run_pmc_conv.sh "<filter>" "<tiles>" <tag>
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
+cd "$GRAFT_REPO_ROOT"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$3
 mkdir -p $OUT
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/l2 -- python3 tools/conv_bench.py --filter "$1" --tiles $2 --reps 1 > $OUT/l2.log 2>&1

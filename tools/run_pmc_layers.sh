@@ -2,7 +2,8 @@
 # Per-layer HBM traffic table (run on the GPU box through gpurun) -> gpurun_out/pmc_layers_<dtype>/layer_traffic.md
 # YV4_PROF_DTYPE=bf16 profiles the 16-bit path.
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
+cd "$GRAFT_REPO_ROOT"
 DT=${YV4_PROF_DTYPE:-f32}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_layers_$DT
 if [ "$DT" != f32 ]; then export YV4_ESIZE=2; fi

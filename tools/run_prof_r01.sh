@@ -2,7 +2,8 @@
 # Round-1 profiles (run on the GPU box through gpurun).  Raw output -> gpurun_out/prof_r01/,
 # summaries -> gpurun_out/prof_r01/summary/ (copied into profiles/ by tools/summarize_prof.py).
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
+cd "$GRAFT_REPO_ROOT"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r01
 rm -rf $OUT; mkdir -p $OUT
 BENCH="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train"

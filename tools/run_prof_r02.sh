@@ -2,10 +2,12 @@
 # Round-2 profiles (run on the GPU box through gpurun).  Raw output -> gpurun_out/prof_r02/, summaries ->
 # gpurun_out/prof_r02/summary/ (copied into profiles/ as r02_*).  Counters are collected in their own runs
 # (--pmc without any trace domain), one pass per counter group as the microarchitecture guide prescribes.
+set -eu
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02
-rm -rf $OUT; mkdir -p $OUT
+cd "$GRAFT_REPO_ROOT"
+OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_r02"
+rm -rf "$OUT"; mkdir -p "$OUT"
 BENCH="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train"
 # 1. per-kernel time of the headline command (steady state: every profiled launch is a launch of the timed step)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $BENCH > $OUT/trace.log 2>&1 < /dev/null

@@ -4,7 +4,8 @@
 # compared 1:1 with the `roofline.avg_launch_us` that the same (profiled) process prints.
 # Raw output -> gpurun_out/prof_steady/, summaries -> gpurun_out/prof_steady/summary/ (copy into profiles/).
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
+cd "$GRAFT_REPO_ROOT"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_steady
 rm -rf $OUT; mkdir -p $OUT/summary
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train --no-autotune > $OUT/trace.log 2>&1 < /dev/null
