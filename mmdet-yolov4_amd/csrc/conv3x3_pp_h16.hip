@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
 
 #define YV4_P3_WAIT(NEWER) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEWER) : "memory")
 
-  V8 fa4[4][TM], fb4[4][TN];
+  V8 fa4[4][TM] = {}, fb4[4][TN] = {};
   f32x16 acc[TM][TN];
 #define YV4_P3_LOAD(KW, ABUF, BSLOT, MK)                                                            \
   {                                                                                                 \
@@ -268,15 +268,17 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
         _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                           \
             acc[i][jn] = Elem<BF16>::mfma(fa4[j][i], fb4[j][jn], acc[i][jn]);                       \
   }
+// (measurement build only, YV4_H16_ABLATE: 1 no DMA after the prologue, 2 no MFMA, 4 no fragment reads, 8 no epilogue,
+// 16 no vmcnt wait -- wrong results on purpose, to time the loop without one of its parts)
 #define YV4_P3_STAGE(KW, NEWER)                                                                     \
   {                                                                                                 \
-    YV4_P3_ISSUE();                                                                                 \
-    YV4_P3_LOAD(KW, ab, (t0 + (KW)) & 3u, mk3);                                                     \
-    YV4_P3_WAIT(NEWER);                                                                             \
+    if (!YV4_ABLATE(p.ablate, 1)) YV4_P3_ISSUE();                                                   \
+    if (!YV4_ABLATE(p.ablate, 4)) YV4_P3_LOAD(KW, ab, (t0 + (KW)) & 3u, mk3);                       \
+    if (!YV4_ABLATE(p.ablate, 16)) YV4_P3_WAIT(NEWER); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     __builtin_amdgcn_s_barrier();                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     __builtin_amdgcn_s_setprio(1);                                                                  \
-    YV4_P3_MFMA();                                                                                  \
+    if (!YV4_ABLATE(p.ablate, 2)) YV4_P3_MFMA();                                                    \
     __builtin_amdgcn_s_setprio(0);                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     __builtin_amdgcn_s_barrier();                                                                   \
@@ -361,11 +363,15 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
       }
     }
     // ---- epilogue: no LDS, no barrier; the next tile's first three stages are already in flight ----
+    if (!YV4_ABLATE(p.ablate, 8)) {
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn)
+      for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        epilogue_pairs_h<BF16>(p, acc[i][jn], lane, m0 + wm * 64 + i * 32, n0 + wn * 64 + jn * 32, has2);
+        for (int i = 0; i < TM; ++i)
+          epilogue_pairs_h<BF16>(p, acc[i][jn], lane, m0 + wm * 64 + i * 32, n0 + wn * 64 + jn * 32, has2);
+    } else if (acc[0][0][0] == 12345.678f) {
+      reinterpret_cast<float*>(p.y)[0] = acc[0][1][1] + acc[1][0][2] + acc[1][1][3];      // keep the accumulators live
+    }
   }
   if (wm < 2) __builtin_amdgcn_s_barrier();            // same number of barriers for both halves
 #undef YV4_P3_STAGE

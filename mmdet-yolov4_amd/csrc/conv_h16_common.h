@@ -183,7 +183,7 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
       if (m < p.M) {
         float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = v[u] * s1[u] + t1[u];
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_fmaf(v[u], s1[u], t1[u]);     // (explicit: every 16-bit conv kernel rounds the affine the same way)
         act_row8(v, p.act1, p.slope1);
         if (p.res) {
           const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.r_cs + p.r_co + co);
@@ -192,7 +192,7 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
         }
         if (has2) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = v[u] * s2[u] + t2[u];
+          for (int u = 0; u < 8; ++u) v[u] = __builtin_fmaf(v[u], s2[u], t2[u]);
           act_row8(v, p.act2, p.slope2);
         }
         if (YV4_ABLATE(p.ablate, 16)) {
@@ -222,10 +222,10 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
         const int row = 2 * k + h;
         const int m = m_base + row;
         if (m >= p.M) continue;
-        float v = ep[row * kPitch + r] * sc1 + sh1;
+        float v = __builtin_fmaf(ep[row * kPitch + r], sc1, sh1);
         v = apply_act(v, p.act1, p.slope1);
         if (p.res) v += (float)reinterpret_cast<const T*>(p.res)[(int64_t)m * p.r_cs + p.r_co + c];
-        if (has2) v = apply_act(v * sc2 + sh2, p.act2, p.slope2);
+        if (has2) v = apply_act(__builtin_fmaf(v, sc2, sh2), p.act2, p.slope2);
         reinterpret_cast<float*>(p.y)[out_row_h(p, m) * p.y_cs + p.y_co + c] = v;
       }
     }
@@ -239,10 +239,10 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
       for (int u = 0; u < 8; ++u) {
         const int c = co + u;
         if (c < p.Cout) {
-          float v = ep[row * kPitch + c8 + u] * p.s1[c] + p.t1[c];
+          float v = __builtin_fmaf(ep[row * kPitch + c8 + u], p.s1[c], p.t1[c]);
           v = apply_act(v, p.act1, p.slope1);
           if (p.res) v += (float)reinterpret_cast<const T*>(p.res)[(int64_t)m * p.r_cs + p.r_co + c];
-          if (has2) v = apply_act(v * p.s2[c] + p.t2[c], p.act2, p.slope2);
+          if (has2) v = apply_act(__builtin_fmaf(v, p.s2[c], p.t2[c]), p.act2, p.slope2);
           if (p.out_f32)
             reinterpret_cast<float*>(p.y)[out_row_h(p, m) * p.y_cs + p.y_co + c] = v;
           else

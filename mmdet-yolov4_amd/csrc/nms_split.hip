@@ -274,164 +274,3 @@ extern "C" int yv4_nms_split(const uint64_t* keys, int64_t n, float max_coord, c
   YV4_CHECK_LAUNCH("nms_split");
   return YV4_OK;
 }
-
-// ---------------------------------------------------------------------------------
-// nms_pre: per-image top-k of the objectness (yolocsp_head.py:349-355 `conf_pred.topk(nms_pre)`).
-// One key per anchor box, (order(conf) << 32 | anchor index): ascending key = descending conf,
-// ties by ascending anchor index (torch.topk leaves ties unspecified).  A segmented radix sort
-// over the N images, then the k-th key of every image is the admission threshold the decode
-// kernel compares against -- the top-k index list itself is never materialised.
-// ---------------------------------------------------------------------------------
-namespace yv4 {
-
-struct ConfKeyArgs {
-  const float* pred[8];
-  int boxes[8];        // H*W*A per level
-  int level_base[9];
-  int num_levels, attr, total;
-};
-
-__global__ __launch_bounds__(256) void conf_keys_kernel(ConfKeyArgs p, uint64_t* __restrict__ keys) {
-  const int n = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= p.total) return;
-  int lvl = 0;
-  while (lvl + 1 < p.num_levels && j >= p.level_base[lvl + 1]) ++lvl;
-  const int jl = j - p.level_base[lvl];
-  const float logit = p.pred[lvl][((size_t)n * p.boxes[lvl] + jl) * p.attr + 4];
-  keys[(size_t)n * p.total + j] = ((uint64_t)score_to_key(sigmoid_f32(logit)) << 32) | (uint32_t)j;
-}
-
-__global__ void conf_offsets_kernel(int* __restrict__ off, int N, int total) {
-  for (int i = threadIdx.x; i <= N; i += blockDim.x) off[i] = i * total;
-}
-
-__global__ void conf_kth_kernel(const uint64_t* __restrict__ sorted, int N, int total, int k, uint64_t* __restrict__ out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < N) out[n] = sorted[(size_t)n * total + (k - 1)];
-}
-
-struct TopkLayout {
-  size_t keys_a, keys_b, offsets, cub, cub_bytes, total_bytes;
-};
-static TopkLayout topk_layout(int N, long long total, int nseg = 0) {
-  TopkLayout L;
-  if (nseg <= 0) nseg = N;          // segments: one per image, or one per (image, level)
-  const size_t kb = ((size_t)N * (size_t)total * sizeof(uint64_t) + 255) / 256 * 256;
-  size_t t = 0;
-  hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, t, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)(N * total),
-                                             nseg, (const int*)nullptr, (const int*)nullptr);
-  L.keys_a = 0;
-  L.keys_b = kb;
-  L.offsets = 2 * kb;
-  L.cub = L.offsets + ((size_t)(nseg + 1) * sizeof(int) + 255) / 256 * 256;
-  L.cub_bytes = t;
-  L.total_bytes = L.cub + (t + 255) / 256 * 256;
-  return L;
-}
-
-}  // namespace yv4
-
-// Per-level form (YOLOV3Head: `conf_pred.topk(nms_pre)` inside the level loop, yolo_head.py:281-303,
-// only on levels with more than nms_pre boxes: core/export/onnx_helper.py:45-78): segments are
-// (image, level); a level with <= k boxes gets the all-admitting key.
-namespace yv4 {
-__global__ void conf_level_offsets_kernel(int* __restrict__ off, int N, int L, ConfKeyArgs a) {
-  for (int i = threadIdx.x; i <= N * L; i += blockDim.x) {
-    const int n = i / L, l = i - n * L;
-    off[i] = i == N * L ? N * a.total : n * a.total + a.level_base[l];
-  }
-}
-__global__ void conf_kth_level_kernel(const uint64_t* __restrict__ sorted, int N, int L, ConfKeyArgs a, int k,
-                                      uint64_t* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * L) return;
-  const int n = i / L, l = i - n * L;
-  out[i] = a.boxes[l] > k ? sorted[(size_t)n * a.total + a.level_base[l] + (k - 1)] : ~0ull;
-}
-}  // namespace yv4
-
-extern "C" int yv4_conf_topk_levels(const yv4_level_desc* levels, int num_levels, int N, int A, int num_classes, int k,
-                                    void* work, uint64_t* topk_keys, void* stream) {
-  using namespace yv4;
-  YV4_REQUIRE(levels && work && topk_keys, "conf_topk_levels: null pointer");
-  YV4_REQUIRE(num_levels > 0 && num_levels <= 8 && N > 0 && A > 0 && A <= 8 && num_classes >= 0 && k > 0,
-              "conf_topk_levels: bad sizes");
-  ConfKeyArgs a;
-  long long total = 0;
-  for (int l = 0; l < num_levels; ++l) {
-    YV4_REQUIRE(levels[l].pred && levels[l].H > 0 && levels[l].W > 0, "conf_topk_levels: level %d is malformed", l);
-    a.pred[l] = levels[l].pred;
-    a.boxes[l] = levels[l].H * levels[l].W * A;
-    a.level_base[l] = (int)total;
-    total += a.boxes[l];
-  }
-  a.level_base[num_levels] = (int)total;
-  a.num_levels = num_levels; a.attr = 5 + num_classes; a.total = (int)total;
-  YV4_REQUIRE((long long)N * total < (1LL << 31), "conf_topk_levels: N * anchors overflows int32");
-  const TopkLayout L = topk_layout(N, total, N * num_levels);
-  char* w = static_cast<char*>(work);
-  uint64_t* ka = reinterpret_cast<uint64_t*>(w + L.keys_a);
-  uint64_t* kb = reinterpret_cast<uint64_t*>(w + L.keys_b);
-  int* off = reinterpret_cast<int*>(w + L.offsets);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(conf_keys_kernel, dim3((unsigned)((total + 255) / 256), N), dim3(256), 0, s, a, ka);
-  hipLaunchKernelGGL(conf_level_offsets_kernel, dim3(1), dim3(256), 0, s, off, N, num_levels, a);
-  size_t cub_bytes = L.cub_bytes;
-  if (hipcub::DeviceSegmentedRadixSort::SortKeys(w + L.cub, cub_bytes, ka, kb, (int)(N * total), N * num_levels, off,
-                                                 off + 1, 0, 64, s) != hipSuccess) {
-    set_error("conf_topk_levels: segmented sort failed");
-    return YV4_E_LAUNCH;
-  }
-  hipLaunchKernelGGL(conf_kth_level_kernel, dim3((N * num_levels + 63) / 64), dim3(64), 0, s, kb, N, num_levels, a, k,
-                     topk_keys);
-  YV4_CHECK_LAUNCH("conf_topk_levels");
-  return YV4_OK;
-}
-
-extern "C" size_t yv4_conf_topk_levels_work(int N, int64_t total_anchors, int num_levels) {
-  if (N <= 0 || total_anchors <= 0 || num_levels <= 0 || (long long)N * total_anchors >= (1LL << 31)) return 0;
-  return yv4::topk_layout(N, total_anchors, N * num_levels).total_bytes;
-}
-
-extern "C" size_t yv4_conf_topk_work(int N, int64_t total_anchors) {
-  if (N <= 0 || total_anchors <= 0 || (long long)N * total_anchors >= (1LL << 31)) return 0;
-  return yv4::topk_layout(N, total_anchors).total_bytes;
-}
-
-extern "C" int yv4_conf_topk(const yv4_level_desc* levels, int num_levels, int N, int A, int num_classes, int k, void* work,
-                             uint64_t* topk_keys, void* stream) {
-  using namespace yv4;
-  YV4_REQUIRE(levels && work && topk_keys, "conf_topk: null pointer");
-  YV4_REQUIRE(num_levels > 0 && num_levels <= 8 && N > 0 && A > 0 && A <= 8 && num_classes >= 0, "conf_topk: bad sizes");
-  ConfKeyArgs a;
-  long long total = 0;
-  for (int l = 0; l < num_levels; ++l) {
-    YV4_REQUIRE(levels[l].pred && levels[l].H > 0 && levels[l].W > 0, "conf_topk: level %d is malformed", l);
-    a.pred[l] = levels[l].pred;
-    a.boxes[l] = levels[l].H * levels[l].W * A;
-    a.level_base[l] = (int)total;
-    total += a.boxes[l];
-  }
-  a.level_base[num_levels] = (int)total;
-  a.num_levels = num_levels; a.attr = 5 + num_classes; a.total = (int)total;
-  YV4_REQUIRE(k > 0 && k < total, "conf_topk: need 0 < k < anchors per image (k = %d, anchors = %lld)", k, total);
-  YV4_REQUIRE((long long)N * total < (1LL << 31), "conf_topk: N * anchors overflows int32");
-  const TopkLayout L = topk_layout(N, total);
-  char* w = static_cast<char*>(work);
-  uint64_t* ka = reinterpret_cast<uint64_t*>(w + L.keys_a);
-  uint64_t* kb = reinterpret_cast<uint64_t*>(w + L.keys_b);
-  int* off = reinterpret_cast<int*>(w + L.offsets);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(conf_keys_kernel, dim3((unsigned)((total + 255) / 256), N), dim3(256), 0, s, a, ka);
-  hipLaunchKernelGGL(conf_offsets_kernel, dim3(1), dim3(256), 0, s, off, N, (int)total);
-  size_t cub_bytes = L.cub_bytes;
-  if (hipcub::DeviceSegmentedRadixSort::SortKeys(w + L.cub, cub_bytes, ka, kb, (int)(N * total), N, off, off + 1, 0, 64, s) !=
-      hipSuccess) {
-    set_error("conf_topk: segmented sort failed");
-    return YV4_E_LAUNCH;
-  }
-  hipLaunchKernelGGL(conf_kth_kernel, dim3((N + 63) / 64), dim3(64), 0, s, kb, N, (int)total, k, topk_keys);
-  YV4_CHECK_LAUNCH("conf_topk");
-  return YV4_OK;
-}

@@ -157,8 +157,10 @@ class _PackCache:
         e = self.entries.get(self.key(weight, dtype, mode))
         if e is None:
             return None
-        if e['wref']() is None:             # the first owner died, the same storage lives on under another tensor object
-            e['wref'] = weakref.ref(weight)
+        if e['wref']() is not weight:       # the owner died and the allocator handed its address to another tensor of the
+            del self.entries[self.key(weight, dtype, mode)]     # same shape: a miss (the table is rebuilt on the next add)
+            self.dirty_table = True
+            return None
         if e['version'] != weight._version or e['gen'] != _PACK_GENERATION[0]:
             self.refresh(weight)
         return e

@@ -536,6 +536,59 @@ def test_conf_topk_threshold_keys(gpu_device):
     assert L.yv4_conf_topk(levels, 2, N, A, ncls, 0, work.data_ptr(), out.data_ptr(), None) != 0
 
 
+@pytest.mark.parametrize('per_level', [False, True])
+def test_conf_topk_radix_select_at_full_size(gpu_device, per_level):
+    """The radix select (csrc/conf_topk.hip: one workgroup per segment, eight 256-bin passes) at the real segment sizes:
+    YOLOv4-L 608 (22 743 boxes per image) and YOLOv3's per-level form (1 083 / 4 332 / 17 328 boxes), quantised logits so
+    that thousands of boxes tie exactly and the k-th key is decided by the index half -- against a full sort on the host."""
+    import ctypes as C
+    from mmdet_yolov4_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(11)
+    N, A, ncls = 5, 3, 2
+    sizes = [(76, 76), (38, 38), (19, 19)]
+    preds = [torch.randn(N, h, w, A * (5 + ncls), device=gpu_device) for h, w in sizes]
+    for p in preds:                                                      # 1/8-steps: ~50 distinct conf values
+        c = p.view(N, -1, 5 + ncls)[:, :, 4]
+        c.copy_((c * 8).round() / 8)
+    preds[0].view(N, -1, 5 + ncls)[1, :, 4] = 0.5                      # image 1, level 0: ALL boxes tie
+    levels = (_lib.LevelDesc * 3)()
+    for i, (p, (h, w)) in enumerate(zip(preds, sizes)):
+        levels[i].pred = p.data_ptr()
+        levels[i].H, levels[i].W, levels[i].stride = h, w, 8 << i
+    boxes = [h * w * A for h, w in sizes]
+    total = sum(boxes)
+    base = np.concatenate([[0], np.cumsum(boxes)])
+    conf = torch.cat([p.view(N, -1, 5 + ncls)[:, :, 4] for p in preds], 1).sigmoid().cpu().numpy()
+    s = torch.cuda.current_stream().cuda_stream
+    for k in (1, 1000, 4332, 17000):
+        if per_level:
+            work = torch.empty(L.yv4_conf_topk_levels_work(N, total, 3), dtype=torch.uint8, device=gpu_device)
+            out = torch.zeros(N * 3, dtype=torch.int64, device=gpu_device)
+            _lib.check(L.yv4_conf_topk_levels(levels, 3, N, A, ncls, k, work.data_ptr(), out.data_ptr(), s), 'topk_levels')
+            got = out.cpu().numpy().astype(np.uint64).reshape(N, 3)
+            for n in range(N):
+                for l in range(3):
+                    if boxes[l] <= k:
+                        assert got[n, l] == np.uint64(0xffffffffffffffff), (k, n, l)
+                        continue
+                    idx = np.arange(base[l], base[l + 1])
+                    order = idx[np.lexsort((idx, -conf[n, idx].astype(np.float64)))]
+                    assert int(got[n, l] & np.uint64(0xffffffff)) == order[k - 1], (k, n, l)
+        else:
+            work = torch.empty(L.yv4_conf_topk_work(N, total), dtype=torch.uint8, device=gpu_device)
+            out = torch.zeros(N, dtype=torch.int64, device=gpu_device)
+            _lib.check(L.yv4_conf_topk(levels, 3, N, A, ncls, k, work.data_ptr(), out.data_ptr(), s), 'topk')
+            got = out.cpu().numpy().astype(np.uint64)
+            for n in range(N):
+                order = np.lexsort((np.arange(total), -conf[n].astype(np.float64)))
+                assert int(got[n] & np.uint64(0xffffffff)) == order[k - 1], (k, n)
+                # the key's score half decodes to the k-th conf (the kernel's own sigmoid: 1 ulp of torch's)
+                u = ~np.uint32(int(got[n] >> np.uint64(32)))
+                sc = (np.uint32(u & np.uint32(0x7fffffff)) if u & np.uint32(0x80000000) else ~u).view(np.float32)
+                assert abs(float(sc) - float(conf[n, order[k - 1]])) <= 1e-6, (k, n)
+
+
 @pytest.mark.parametrize('form,tag', [('div', 'div'), ('mul', 'mul')])
 def test_nms_boundary_pairs_bit_exact(golden, gpu_device, form, tag):
     """IoU == threshold (fp32) and one-rounding-off pairs, under both of mmcv's predicates (tests/golden/

@@ -397,8 +397,10 @@ def test_packed_weight_cache_follows_the_weights(gpu_device):
         assert torch.equal(a, b)
     # temporaries are not recorded (the stem weight is re-padded in every step -- a fresh non-leaf tensor
     # whose entry would never be hit again and whose storage the table would pin)
+    pack_all(True)                                                              # (pack_all(False) cleared the table)
     cache = T._PACK_CACHES[gpu_device]
     n0 = len(cache.entries)
+    assert n0 == 6
     for _ in range(3):
         tmp = torch.nn.functional.pad(ws[0], (0, 0, 0, 0, 0, 5))
         got, cp = T.packed_weight(tmp, torch.bfloat16)
@@ -414,4 +416,12 @@ def test_packed_weight_cache_follows_the_weights(gpu_device):
         ws[0].add_(1.0)
     T.packed_weight(ws[0], torch.bfloat16)
     assert len(cache.entries) == 3
+    # an address the allocator hands to a NEW parameter of the same shape is a miss, not a stale hit
+    shape, old_ptr = tuple(ws[0].shape), ws[0].data_ptr()
+    ws.clear()
+    gc.collect()
+    fresh_w = torch.nn.Parameter(torch.randn(shape, device=gpu_device))
+    got, _ = T.packed_weight(fresh_w, torch.bfloat16)
+    T.clear_pack_cache()
+    assert torch.equal(got, T.packed_weight(fresh_w, torch.bfloat16)[0]), (fresh_w.data_ptr() == old_ptr)
     T.clear_pack_cache()
