@@ -26,12 +26,17 @@
 //     epilogue expressions on the same fp32 accumulators, so a layer gives the same bits whichever kernel a batch size
 //     selects (tests/test_gpu_h16.py::test_pp3x3_matches_generic_bitwise).
 //
-// vmcnt bookkeeping: DMA(s) = PB weight pieces (+ PA activation pieces when stage s opens a (chunk, kh) group).  In
-// the LOAD phase of stage t a wave issues DMA(t + 3), reads the 16 fragments of stage t, then waits until its own
-// DMA(t + 1) has landed: everything newer -- DMA(t + 2), DMA(t + 3) -- may stay in flight (2 PB + PA for kw = 0, 1;
-// 2 PB for kw = 2).  The epilogue's loads and stores enter the same in-order counter BETWEEN DMAs: they make a counted
-// wait more conservative (it then also covers an older DMA), never less.  Reads of a staged buffer come one barrier
-// after the wait that retires it; a buffer is re-filled one barrier after the lgkmcnt(0) that retired its last reads.
+// Phases and vmcnt bookkeeping.  A wave alternates LOAD(t) = { the PB weight pieces of stage t + 3; 16 fragment reads of
+// stage t; wait; barrier } and MFMA(t) = { 16 MFMAs, with the PA activation pieces of stage t + 3 issued BETWEEN them when
+// that stage opens a (chunk, kh) group, i.e. at kw = 0; barrier }.  The split is the measured balance
+// (profiles/r03_pp3_ablation.md): every 1 KB piece costs its wave ~100 cycles of issue wherever it is placed, the reads
+// ~500 and the 16 MFMAs ~720 cycles per stage, and an interval lasts as long as the longer of one group's LOAD and the
+// other's MFMA phase.  In program order a wave has issued ... B(t+1) A(t+1) B(t+2) A(t+2) B(t+3) when it waits in LOAD(t);
+// it needs its own B(t+1) and A(t+1) landed, so B(t+2), A(t+2), B(t+3) may stay in flight: 2 PB pieces at kw = 0 and 2,
+// 2 PB + PA at kw = 1 (A(t+2) exists when stage t + 2 opens a group).  The epilogue's loads and stores enter the same
+// in-order counter BETWEEN DMAs: they make a counted wait more conservative (it then also covers an older DMA), never
+// less.  Reads of a staged buffer come one barrier after the wait that retires it; a buffer is re-filled at least one
+// barrier after the lgkmcnt(0) that retired its last reads.
 #include "conv_h16_common.h"
 
 namespace yv4 {
@@ -44,13 +49,33 @@ constexpr int kP3PA = kP3ARows / 64;
 constexpr int kP3PB = kP3BN / 64;
 constexpr int kP3ZeroRow = 304;     // any row in [258, 320): only ever zero-filled
 constexpr int kP3NB = 4;            // weight ring slots
-constexpr int kP3Lds = (2 * kP3ARows + kP3NB * kP3BN) * 128;
+constexpr int kP3RingBytes = (2 * kP3ARows + kP3NB * kP3BN) * 128;
+constexpr int kP3MaxCout = 1024;     // the per-channel affine of the whole layer lives in the last 16 KB of LDS
+constexpr int kP3Lds = kP3RingBytes + 4 * kP3MaxCout * 4;
 
 // Epilogue of one 32x32 accumulator tile straight from the MFMA's C layout (lane (r, h): channel co_base + r of the
-// rows (e & 3) + 8 (e >> 2) + 4 h).  Expressions and their order are epilogue_tile_h's (conv_h16_common.h).
+// rows (e & 3) + 8 (e >> 2) + 4 h).  Expressions and their order are epilogue_tile_h's (conv_h16_common.h).  `aff` is
+// the layer's affine in LDS ([s1 | t1 | s2 | t2] x Cout); `resw` the residual words of this tile, requested by the caller
+// for all of the wave's tiles before the first is finished (one memory round trip per tile of the grid, not per value).
+template <bool BF16>
+__device__ __forceinline__ void residual_prefetch_h(const ConvArgsH& p, int lane, int m_base, int co_base, unsigned (&resw)[8]) {
+  typedef typename Elem<BF16>::T T;
+  const int r = lane & 31, h = lane >> 5;
+  const bool odd = r & 1;
+  const int cp = co_base + r - (odd ? 1 : 0);
+  const bool c_ok = cp + 1 < p.Cout;
+  const int row0 = m_base + 4 * h + (odd ? 16 : 0);
+  const T* rp = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int m = row0 + (j & 3) + 8 * (j >> 2);
+    resw[j] = (c_ok && m < p.M) ? *reinterpret_cast<const unsigned*>(rp + (int64_t)m * p.r_cs + p.r_co + cp) : 0u;
+  }
+}
+
 template <bool BF16>
 __device__ __forceinline__ void epilogue_pairs_h(const ConvArgsH& p, const f32x16& acc, int lane, int m_base, int co_base,
-                                                 bool has2) {
+                                                 bool has2, const float* aff, const unsigned (&resw)[8]) {
   typedef typename Elem<BF16>::T T;
   typedef T T2 __attribute__((ext_vector_type(2)));
   const int r = lane & 31, h = lane >> 5;
@@ -59,18 +84,9 @@ __device__ __forceinline__ void epilogue_pairs_h(const ConvArgsH& p, const f32x1
   const int cp = c - (odd ? 1 : 0);                  // even channel of this lane's pair
   const bool c_ok = cp + 1 < p.Cout;                 // Cout is even in this kernel's domain
   const int cc = c_ok ? c : 0;
-  const float s1 = p.s1[cc], t1 = p.t1[cc];
+  const float s1 = aff[cc], t1 = aff[p.Cout + cc];
   // rows this lane stores after the exchange: (j & 3) + 8 (j >> 2) + 4 h (+ 16 on odd lanes)
   const int row0 = m_base + 4 * h + (odd ? 16 : 0);
-  unsigned resw[8];
-  if (p.res) {
-    const T* rp = reinterpret_cast<const T*>(p.res);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = row0 + (j & 3) + 8 * (j >> 2);
-      resw[j] = (c_ok && m < p.M) ? *reinterpret_cast<const unsigned*>(rp + (int64_t)m * p.r_cs + p.r_co + cp) : 0u;
-    }
-  }
   float v[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) v[e] = __builtin_fmaf(acc[e], s1, t1);
@@ -102,7 +118,7 @@ __device__ __forceinline__ void epilogue_pairs_h(const ConvArgsH& p, const f32x1
   }
   if (has2) {
     const int c2 = c_ok ? cp : 0;
-    const float s2a = p.s2[c2], t2a = p.t2[c2], s2b = p.s2[c2 + 1], t2b = p.t2[c2 + 1];
+    const float s2a = aff[2 * p.Cout + c2], t2a = aff[3 * p.Cout + c2], s2b = aff[2 * p.Cout + c2 + 1], t2b = aff[3 * p.Cout + c2 + 1];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       a[j] = __builtin_fmaf(a[j], s2a, t2a);
@@ -112,14 +128,14 @@ __device__ __forceinline__ void epilogue_pairs_h(const ConvArgsH& p, const f32x1
     act_row8(b, p.act2, p.slope2);
   }
   T* yp = reinterpret_cast<T*>(p.y);
+  T* y0 = yp + (int64_t)row0 * p.y_cs + p.y_co + cp;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int m = row0 + (j & 3) + 8 * (j >> 2);
+    const int dj = (j & 3) + 8 * (j >> 2);
     T2 pk;
     pk[0] = (T)a[j];
     pk[1] = (T)b[j];
-    if (c_ok && m < p.M)
-      *reinterpret_cast<unsigned*>(yp + (int64_t)m * p.y_cs + p.y_co + cp) = __builtin_bit_cast(unsigned, pk);
+    if (c_ok && row0 + dj < p.M) *reinterpret_cast<unsigned*>(y0 + (int64_t)dj * p.y_cs) = __builtin_bit_cast(unsigned, pk);
   }
 }
 
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
     const bool live = i_vt < ntiles;
     const unsigned tile = live ? tile_of(i_vt) : 0u;
     const int tn = (int)(tile % (unsigned)p.tiles_n);
-    const int m0i = (int)(tile / (unsigned)p.tiles_n) * kP3BM;
+    const int m0i = YV4_ABLATE(p.ablate, 32) ? 0 : (int)(tile / (unsigned)p.tiles_n) * kP3BM;   // (bit 32: every tile reads tile 0's pixels)
     const int n0i = tn * kP3BN;
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
@@ -206,31 +222,44 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
 
   const int nchunks = p.Cin >> 6;
   const int G = 3 * nchunks;               // (chunk, kh) groups per tile; stage = 3 g + kw
-  int i_c0 = 0, i_kh = 0, i_kw = 0, i_g = 0;
+  int i_c0 = 0, i_kh = 0, i_g = 0;
   unsigned i_t = 0u, i_gg = 0u;            // global stage / group counters: ring slot i_t & 3, activation buffer i_gg & 1
 
-  // ISSUE: weights of the next stage into ring slot i_t & 3 and, when the stage opens a group, the group's activation
-  // rows into activation buffer i_gg & 1.  Beyond the last tile the same number of (out-of-range, zero-filling) DMAs is
-  // issued so that the vmcnt bookkeeping stays uniform.
-#define YV4_P3_ISSUE()                                                                              \
+  // ---- the layer's affine into LDS, once per workgroup (the epilogue of every tile reads it from there) ----
+  float* aff = reinterpret_cast<float*>(smem_p3 + kP3RingBytes);
+  const bool has2 = p.s2 != nullptr;
+  for (int c = tid; c < p.Cout; c += kP3Threads) {
+    aff[c] = p.s1[c];
+    aff[p.Cout + c] = p.t1[c];
+    aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
+    aff[3 * p.Cout + c] = has2 ? p.t2[c] : 0.f;
+  }
+
+  // ISSUE of the stage three ahead, in three pieces that the MFMA phase interleaves with its MFMAs: the weight pieces
+  // into ring slot i_t & 3; when the stage opens a group (its kw = the current stage's KW = 0) the group's activation
+  // rows into activation buffer i_gg & 1; then the walk.  Beyond the last tile the same number of (out-of-range,
+  // zero-filling) DMAs is issued so that the vmcnt bookkeeping stays uniform.
+#define YV4_P3_ISSUE_B(KW)                                                                          \
   {                                                                                                 \
     const unsigned lb_ = lds_base + (unsigned)((2 * kP3ARows + (int)(i_t & 3u) * kP3BN + 8 * wave) * kRowB); \
-    const unsigned kb = (unsigned)((((i_kh * 3 + i_kw) * p.Cin) + i_c0) * 2);                        \
+    const unsigned kb = (unsigned)((((i_kh * 3 + (KW)) * p.Cin) + i_c0) * 2);                        \
     _Pragma("unroll") for (int q = 0; q < PB; ++q)                                                  \
-        lds_dma16_h(rsB, lb_ + 64 * q * kRowB, b_off[q], kb);   /* (the range check sees voffset only) */                \
-    if (i_kw == 0) {                                                                                \
-      const unsigned la_ = lds_base + (unsigned)(((int)(i_gg & 1u) * kP3ARows + 8 * wave) * kRowB);  \
-      const int ds = (i_kh - 1) * p.W;                                                              \
-      const unsigned step = (unsigned)(((int64_t)ds * p.x_cs + i_c0) * 2);                          \
-      _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                              \
-        const bool ok = (unsigned)(a_s[q] + ds) < (unsigned)NHW;                                    \
-        lds_dma16_h(rsA, la_ + 64 * q * kRowB, ok ? a_off[q] + step : kOOB, 0u);                     \
-      }                                                                                             \
+        lds_dma16_h(rsB, lb_ + 64 * q * kRowB, b_off[q], kb);   /* (the range check sees voffset only) */ \
+  }
+#define YV4_P3_ISSUE_A(Q0, Q1)                                                                      \
+  {                                                                                                 \
+    const unsigned la_ = lds_base + (unsigned)(((int)(i_gg & 1u) * kP3ARows + 8 * wave) * kRowB);    \
+    const int ds = (i_kh - 1) * p.W;                                                                \
+    const unsigned step = (unsigned)(((int64_t)ds * p.x_cs + i_c0) * 2);                            \
+    _Pragma("unroll") for (int q = (Q0); q < (Q1); ++q) {                                           \
+      const bool ok = (unsigned)(a_s[q] + ds) < (unsigned)NHW;                                      \
+      lds_dma16_h(rsA, la_ + 64 * q * kRowB, ok ? a_off[q] + step : kOOB, 0u);                       \
     }                                                                                               \
+  }
+#define YV4_P3_ADVANCE(KW)                                                                          \
+  {                                                                                                 \
     i_t += 1u;                                                                                      \
-    i_kw += 1;                                                                                      \
-    if (i_kw == 3) {                                                                                \
-      i_kw = 0;                                                                                     \
+    if ((KW) == 2) {                                                                                \
       i_gg += 1u;                                                                                   \
       i_g += 1;                                                                                     \
       i_kh += 1;                                                                                    \
@@ -261,39 +290,66 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
           fb4[j][i] = *reinterpret_cast<const V8*>(bs_ + (b_rd[i] ^ (unsigned)(j << 5)));           \
     }                                                                                               \
   }
-#define YV4_P3_MFMA()                                                                               \
+#define YV4_P3_MFMA_J(J)                                                                            \
   {                                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
-        _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                           \
-            acc[i][jn] = Elem<BF16>::mfma(fa4[j][i], fb4[j][jn], acc[i][jn]);                       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+      _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                             \
+          acc[i][jn] = Elem<BF16>::mfma(fa4[J][i], fb4[J][jn], acc[i][jn]);                         \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
   }
 // (measurement build only, YV4_H16_ABLATE: 1 no DMA after the prologue, 2 no MFMA, 4 no fragment reads, 8 no epilogue,
-// 16 no vmcnt wait -- wrong results on purpose, to time the loop without one of its parts)
+// 16 no vmcnt wait, 32 every tile reads tile 0's pixels, 64 print per-phase cycle sums, 128 no activation pieces, 256 no
+// weight pieces -- wrong results on purpose, to time the loop without one of its parts)
+#ifdef YV4_MEASURE
+#define YV4_P3_STAMP(SLOT) if (YV4_ABLATE(p.ablate, 64)) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tsum[SLOT] += n_ - tlast; tlast = n_; }
+#else
+#define YV4_P3_STAMP(SLOT)
+#endif
 #define YV4_P3_STAGE(KW, NEWER)                                                                     \
   {                                                                                                 \
-    if (!YV4_ABLATE(p.ablate, 1)) YV4_P3_ISSUE();                                                   \
+    YV4_P3_STAMP(5);                                                                                \
+    if (!YV4_ABLATE(p.ablate, 1) && !YV4_ABLATE(p.ablate, 256)) YV4_P3_ISSUE_B(KW);                 \
     if (!YV4_ABLATE(p.ablate, 4)) YV4_P3_LOAD(KW, ab, (t0 + (KW)) & 3u, mk3);                       \
+    YV4_P3_STAMP(0);                                                                                \
     if (!YV4_ABLATE(p.ablate, 16)) YV4_P3_WAIT(NEWER); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    YV4_P3_STAMP(1);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                   \
+    YV4_P3_STAMP(2);                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     __builtin_amdgcn_s_setprio(1);                                                                  \
-    if (!YV4_ABLATE(p.ablate, 2)) YV4_P3_MFMA();                                                    \
+    if (!YV4_ABLATE(p.ablate, 2)) YV4_P3_MFMA_J(0);                                                 \
+    if ((KW) == 0 && !YV4_ABLATE(p.ablate, 1) && !YV4_ABLATE(p.ablate, 128)) YV4_P3_ISSUE_A(0, 2);  \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    if (!YV4_ABLATE(p.ablate, 2)) YV4_P3_MFMA_J(1);                                                 \
+    if ((KW) == 0 && !YV4_ABLATE(p.ablate, 1) && !YV4_ABLATE(p.ablate, 128)) YV4_P3_ISSUE_A(2, 4);  \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    if (!YV4_ABLATE(p.ablate, 2)) YV4_P3_MFMA_J(2);                                                 \
+    if ((KW) == 0 && !YV4_ABLATE(p.ablate, 1) && !YV4_ABLATE(p.ablate, 128)) YV4_P3_ISSUE_A(4, PA); \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    if (!YV4_ABLATE(p.ablate, 2)) YV4_P3_MFMA_J(3);                                                 \
+    YV4_P3_ADVANCE(KW);                                                                             \
     __builtin_amdgcn_s_setprio(0);                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                              \
+    YV4_P3_STAMP(3);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                   \
+    YV4_P3_STAMP(4);                                                                                \
   }
 
   // prologue: stages 0, 1, 2 of the first tile in flight, then wait for stage 0 (newer: weights 1, 2)
-  YV4_P3_ISSUE();
-  YV4_P3_ISSUE();
-  YV4_P3_ISSUE();
+  YV4_P3_ISSUE_B(0); YV4_P3_ISSUE_A(0, PA); YV4_P3_ADVANCE(0);
+  YV4_P3_ISSUE_B(1); YV4_P3_ADVANCE(1);
+  YV4_P3_ISSUE_B(2); YV4_P3_ADVANCE(2);
   YV4_P3_WAIT(2 * PB);
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();                        // (also publishes the affine written above)
   if (wm >= 2) __builtin_amdgcn_s_barrier();           // waves 4-7 run one phase behind waves 0-3
 
-  const bool has2 = p.s2 != nullptr;
   unsigned gg = 0u;                                    // compute side: global group counter
+#ifdef YV4_MEASURE
+  // bit 64: cycles per wave spent in [0] fragment-read issue, [1] vmcnt/lgkmcnt wait, [2] barrier after LOAD, [3] MFMA phase
+  // (with the DMA pieces), [4] barrier after MFMA, [5] between stages (tile set-up, epilogue); printed by two workgroups
+  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+  const unsigned long long tbegin = tlast;
+#endif
   for (int vt = (int)blockIdx.x; vt < ntiles; vt += nwg) {
     const unsigned tile = tile_of(vt);
     const int tile_n = (int)(tile % (unsigned)p.tiles_n);
@@ -331,7 +387,7 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
       const unsigned ab = gg & 1u;
       const unsigned t0 = 3u * gg;
       gg += 1u;
-      YV4_P3_STAGE(0, 2 * PB + PA);
+      YV4_P3_STAGE(0, 2 * PB);
       YV4_P3_STAGE(1, 2 * PB + PA);
       YV4_P3_STAGE(2, 2 * PB);
     }
@@ -362,22 +418,37 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
         }
       }
     }
-    // ---- epilogue: no LDS, no barrier; the next tile's first three stages are already in flight ----
+    // ---- epilogue: no ring LDS, no barrier; the next tile's first three stages are already in flight ----
     if (!YV4_ABLATE(p.ablate, 8)) {
+      unsigned resw[TM * TN][8];
+      if (p.res) {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            residual_prefetch_h<BF16>(p, lane, m0 + wm * 64 + i * 32, n0 + wn * 64 + jn * 32, resw[jn * TM + i]);
+      }
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          epilogue_pairs_h<BF16>(p, acc[i][jn], lane, m0 + wm * 64 + i * 32, n0 + wn * 64 + jn * 32, has2);
+          epilogue_pairs_h<BF16>(p, acc[i][jn], lane, m0 + wm * 64 + i * 32, n0 + wn * 64 + jn * 32, has2, aff, resw[jn * TM + i]);
     } else if (acc[0][0][0] == 12345.678f) {
       reinterpret_cast<float*>(p.y)[0] = acc[0][1][1] + acc[1][0][2] + acc[1][1][3];      // keep the accumulators live
     }
   }
   if (wm < 2) __builtin_amdgcn_s_barrier();            // same number of barriers for both halves
+#ifdef YV4_MEASURE
+  if (YV4_ABLATE(p.ablate, 64) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 101))
+    printf("pp3 wg %d wave %d: total %llu | read-issue %llu wait %llu bar1 %llu mfma+dma %llu bar2 %llu between %llu (cycles)\n",
+           (int)blockIdx.x, wave, __builtin_amdgcn_s_memtime() - tbegin, tsum[0], tsum[1], tsum[2], tsum[3], tsum[4], tsum[5]);
+#endif
 #undef YV4_P3_STAGE
-#undef YV4_P3_MFMA
+#undef YV4_P3_MFMA_J
 #undef YV4_P3_LOAD
-#undef YV4_P3_ISSUE
+#undef YV4_P3_ADVANCE
+#undef YV4_P3_ISSUE_A
+#undef YV4_P3_ISSUE_B
   YV4_P3_WAIT(0);                                      // the zero-filling tail DMAs must land before the LDS is released
 #undef YV4_P3_WAIT
 }
@@ -386,7 +457,7 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
 // Cout (channel pairs are stored as dwords) and dword-aligned output / residual views, 16-bit output.
 bool conv3x3_pp_h16_applies(const ConvArgsH& a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && (a.Cin & 63) == 0 &&
-         !a.ys_on && !a.out_f32 && a.Cout >= 64 && (a.Cout & 1) == 0 && ((a.y_cs | a.y_co) & 1) == 0 &&
+         !a.ys_on && !a.out_f32 && a.Cout >= 64 && a.Cout <= kP3MaxCout && (a.Cout & 1) == 0 && ((a.y_cs | a.y_co) & 1) == 0 &&
          (a.res == nullptr || ((a.r_cs | a.r_co) & 1) == 0);
 }
 
