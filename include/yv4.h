@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YV4_ABI_VERSION 4
+#define YV4_ABI_VERSION 5
 
 /* error codes */
 #define YV4_OK 0
@@ -615,6 +615,15 @@ int yv4_conv_bn_act_fwd_splitk(const yv4_conv_desc* d, const float* x, const flo
                                const float* shift1, const float* scale2, const float* shift2,
                                const float* residual, float* y, float* workspace, size_t workspace_bytes,
                                void* stream);
+
+/* The same for 16-bit operands (yv4_conv_bn_act_fwd_h16): 64 x 64 tiles, K slices of 64, fp32 partial slabs, a finishing
+ * kernel with the 16-bit tiles' epilogue expressions (16-bit or fp32 output).  Layers outside the uniform-K tiles
+ * (Cin % 64 != 0) are not split: the call forwards to yv4_conv_bn_act_fwd_h16. */
+size_t yv4_conv_h16_splitk_workspace(const yv4_conv_desc* d, int* ksplit);
+int yv4_conv_bn_act_fwd_h16_splitk(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x, const void* w,
+                                   const float* scale1, const float* shift1, const float* scale2,
+                                   const float* shift2, const void* residual, void* y, float* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* ---- train-side input pipeline (configs/yolov4/yolov4l_coco_mosaic.py:22-69) ----------------------------------
  * Replaces, per batch: Resize(keep_ratio) of 4 source images + MosaicPipeline (mmdet/datasets/pipelines/

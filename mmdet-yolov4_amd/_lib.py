@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('YV4_LIB_PATH') or os.path.join(LIB_DIR, 'libyv4_hip.s
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 # ---- constants mirrored from include/yv4.h -------------------------------------
-ABI_VERSION = 4
+ABI_VERSION = 5
 STATS_REPLICAS = 64        # YV4_STATS_REPLICAS
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_MISH, ACT_LEAKY, ACT_SWISH = 0, 1, 2, 3
@@ -93,6 +93,8 @@ SIGNATURES = {
                                       _vp, _vp, _vp, _vp, _vp]),
     'yv4_conv_splitk_workspace': (_sz, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
     'yv4_conv_bn_act_fwd_splitk': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'yv4_conv_h16_splitk_workspace': (_sz, [C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
+    'yv4_conv_bn_act_fwd_h16_splitk': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'yv4_conv_flops': (C.c_double, [C.POINTER(ConvDesc)]),
     'yv4_conv_pick_tile': (C.c_int, [C.POINTER(ConvDesc)]),
     'yv4_spp_pool_fwd': (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp]),

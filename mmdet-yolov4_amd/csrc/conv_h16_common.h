@@ -34,7 +34,13 @@ struct ConvArgsH {
   int ablate;     // measurement only (YV4_H16_ABLATE): 1 = issue no DMA after the first slice, 2 = no MFMA, 4 = no barrier
   double* stats;  // training: per-channel [sum | sum of squares] of the STORED outputs, YV4_STATS_REPLICAS x 2*Cout
   FastDiv fd_hw, fd_wo;   // m / (Ho*Wo), r / Wo (set by launch_h16)
-  FastDiv fd_cin, fd_kw;  // GENERAL_K: k / Cin, tap / KW, once per lane per slice
+  FastDiv fd_cin, fd_kw;  // GENERAL_K: k / Cin, tap / KW, once per lane per slice; fd_kw also: tap -> (kh, kw) of a split
+  // split-K (single-image plans, uniform-K tiles only): workgroup (tile, split) reduces K slices [split * ks_slices, ...)
+  // and stores its RAW fp32 partial tile into slab `split` of ws ([ksplit][M][ws_cs]); splitk_finish_h16_kernel adds the
+  // slabs in slab order and applies the epilogue.  ksplit <= 1: off.
+  int ksplit, ks_slices, ws_cs;
+  float* ws;
+  FastDiv fd_taps;        // slice -> (chunk, tap) at a split's first slice
 };
 
 __device__ __forceinline__ int64_t out_row_h(const ConvArgsH& p, int m) {
@@ -172,6 +178,21 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
   if (!FINISH) return;
   const int c8 = (lane & 3) * 8;
   const int co = co_base + c8;
+  if (p.ksplit > 1) {                       // split-K partial: raw accumulators into a dense [M][ws_cs] slab (p.y = the slab)
+    if (co < p.ws_cs) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int row = (lane >> 2) + 16 * k;
+        const int m = m_base + row;
+        if (m < p.M) {
+          float* dst = reinterpret_cast<float*>(p.y) + (int64_t)m * p.ws_cs + co;
+          *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(ep + row * kPitch + c8);
+          *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(ep + row * kPitch + c8 + 4);
+        }
+      }
+    }
+    return;
+  }
   if (full) {
     const float (&s1)[8] = af.s1; const float (&t1)[8] = af.t1; const float (&s2)[8] = af.s2; const float (&t2)[8] = af.t2;
 #pragma unroll

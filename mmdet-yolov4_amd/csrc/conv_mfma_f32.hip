@@ -1354,7 +1354,9 @@ extern "C" int yv4_conv_bn_act_fwd_splitk(const yv4_conv_desc* d, const float* x
   a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.Kw = a.K; a.tiles_n = 0; a.ys_on = 0; a.stats = nullptr;
   const int nk = a.K / kBK;
-  a.ksplit = ks; a.ks_slices = (nk + ks - 1) / ks; a.ws_cs = (d->Cout + 3) / 4 * 4; a.ws = workspace;
+  a.ks_slices = (nk + ks - 1) / ks;
+  a.ksplit = (nk + a.ks_slices - 1) / a.ks_slices;      // no empty split
+  a.ws_cs = (d->Cout + 3) / 4 * 4; a.ws = workspace;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (int rc = launch_conv_dma<64, 64, 2, 2, 2>(a, s)) return rc;
   const long long work = M * (a.ws_cs / 4);

@@ -52,11 +52,15 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
   const unsigned nwg = gridDim.x;
   const unsigned bid = blockIdx.x;
   const unsigned xcd = bid & 7u, q8 = nwg >> 3, rem8 = nwg & 7u;
-  const unsigned tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (bid >> 3);
+  const unsigned tile_s = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (bid >> 3);
+  const int ksplit = (!GENERAL_K && p.ksplit > 1) ? p.ksplit : 1;
+  const unsigned tile = tile_s / (unsigned)ksplit;          // the splits of one tile are neighbours (same L2)
+  const int split = (int)(tile_s - tile * (unsigned)ksplit);
   const int tile_n = tile % p.tiles_n;
   const int tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
+  if (ksplit > 1) p.y = p.ws + (size_t)split * p.M * p.ws_cs;
 
   const u32x4_t rsA = make_rsrc_h(p.x, x_bytes);
   const u32x4_t rsB = make_rsrc_h(p.w, w_bytes);
@@ -101,6 +105,15 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
   const int ntaps = p.KH * p.KW;
   int s_tap = 0, s_c0 = 0, s_kh = 0, s_kw = 0;
   unsigned s_kb = 0;
+  const int slice0 = ksplit > 1 ? split * p.ks_slices : 0;      // first K slice of this workgroup
+  if (slice0) {
+    const int chunk = fd_div(slice0, p.fd_taps);
+    s_tap = slice0 - chunk * ntaps;
+    s_c0 = chunk * kHBK;
+    s_kh = fd_div(s_tap, p.fd_kw);
+    s_kw = s_tap - s_kh * p.KW;
+    s_kb = (unsigned)((s_tap * p.Cin + s_c0) * 2);
+  }
   int g_k = lc * 8;     // GENERAL_K: first K index of this lane's chunk in the next slice
 
 #define YV4_H_DMA(BUF)                                                                           \
@@ -210,7 +223,8 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
   }
 
-  const int nk = (p.K + kHBK - 1) / kHBK;
+  const int nk_all = (p.K + kHBK - 1) / kHBK;
+  const int nk = ksplit > 1 ? (nk_all - slice0 < p.ks_slices ? nk_all - slice0 : p.ks_slices) : nk_all;
   int issued = 0;        // slices whose DMA has been issued
   int wbuf = 0;          // ring slot the next DMA goes to
 #pragma unroll
@@ -302,7 +316,8 @@ static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
   p.fd_wo = make_fastdiv((unsigned)p.Wo);
   p.fd_cin = make_fastdiv((unsigned)p.Cin);
   p.fd_kw = make_fastdiv((unsigned)p.KW);
-  const long long tiles = (long long)tiles_m * p.tiles_n;
+  p.fd_taps = make_fastdiv((unsigned)(p.KH * p.KW));
+  const long long tiles = (long long)tiles_m * p.tiles_n * (p.ksplit > 1 ? p.ksplit : 1);
   if (tiles <= 0 || tiles > 0x7fffffffLL) {
     set_error("conv h16: grid of %lld tiles out of range", tiles);
     return YV4_E_INVALID;
@@ -411,6 +426,7 @@ extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
     ConvArgsH a{};
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
     a.Cin = d->Cin; a.Cout = d->Cout; a.ys_on = 0; a.M = (int)((long long)d->N * d->Ho * d->Wo);
+    a.ksplit = 0; a.ws = nullptr;
     a.K = a.Kw = d->KH * d->KW * d->Cin; a.res = nullptr; a.out_f32 = (d->Cout & 1) ? 1 : 0;   // (odd Cout: a pred map)
     a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = d->r_cstride; a.r_co = d->r_coff;
     if (prefer_pp3(a)) return YV4_HTILE_PP3x3;
@@ -462,6 +478,7 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0;
   a.out_f32 = out_dtype == YV4_F32 ? 1 : 0;
   a.ys_on = 0;
+  a.ksplit = 0; a.ks_slices = 0; a.ws_cs = 0; a.ws = nullptr;
   static const int ablate = YV4_ENV_INT("YV4_H16_ABLATE", 0);
   a.ablate = ablate;
   a.stats = stats;
@@ -495,6 +512,161 @@ int conv_stats_h16(const yv4_conv_desc* d, int dtype, const void* x, const void*
   return conv_h16_impl(d, dtype, dtype, x, w, ones, zeros, nullptr, nullptr, nullptr, y, stats, stream);
 }
 
+// ---- split-K: the single-image (latency) form of the 16-bit tiles (the fp32 form: conv_mfma_f32.hip) ----------------
+// At batch 1 (the reference's only published protocol, tools/analysis_tools/benchmark.py:83-109) the deep layers have a
+// handful of output tiles and 36-72 K slices each.  Splitting K over `ksplit` workgroups per 64 x 64 tile fills the CUs;
+// partials go to per-split fp32 slabs (plain stores, no atomics) that one small kernel adds IN SLAB ORDER before the
+// usual epilogue (the expressions of epilogue_tile_h), so the result is deterministic -- but its summation order is not
+// the unsplit tiles': plans use it for N == 1 only, where no cross-batch bit-exactness is claimed.
+namespace yv4 {
+template <bool BF16>
+__global__ __launch_bounds__(256) void splitk_finish_h16_kernel(ConvArgsH p) {
+  typedef typename Elem<BF16>::T T;
+  typedef typename Elem<BF16>::V8 V8;
+  const int c8n = p.ws_cs >> 3;
+  const long long total = (long long)p.M * c8n;
+  const bool has2 = p.s2 != nullptr;
+  const size_t slab = (size_t)p.M * p.ws_cs;
+  const bool vec_y = p.out_f32 ? ((p.y_cs | p.y_co) & 3) == 0 : ((p.y_cs | p.y_co) & 7) == 0;
+  const bool vec_r = p.res == nullptr || ((p.r_cs | p.r_co) & 7) == 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / c8n);
+    const int co = (int)(i - (long long)m * c8n) * 8;
+    const float* src = p.ws + (int64_t)m * p.ws_cs + co;
+    float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+    for (int s = 1; s < p.ksplit; ++s) {
+      const float4 b0 = *reinterpret_cast<const float4*>(src + s * slab), b1 = *reinterpret_cast<const float4*>(src + s * slab + 4);
+      a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+      a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+    }
+    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const bool full = co + 7 < p.Cout;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = full ? co + u : (co + u < p.Cout ? co + u : 0);
+      v[u] = __builtin_fmaf(v[u], p.s1[c], p.t1[c]);
+    }
+    act_row8(v, p.act1, p.slope1);
+    if (p.res) {
+      const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.r_cs + p.r_co + co;
+      if (full && vec_r) {
+        const V8 rr = *reinterpret_cast<const V8*>(rp);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] += (float)rr[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (co + u < p.Cout) v[u] += (float)rp[u];
+      }
+    }
+    if (has2) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = full ? co + u : (co + u < p.Cout ? co + u : 0);
+        v[u] = __builtin_fmaf(v[u], p.s2[c], p.t2[c]);
+      }
+      act_row8(v, p.act2, p.slope2);
+    }
+    if (p.out_f32) {
+      float* dst = reinterpret_cast<float*>(p.y) + (int64_t)m * p.y_cs + p.y_co + co;
+      if (full && vec_y) {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (co + u < p.Cout) dst[u] = v[u];
+      }
+    } else {
+      T* dst = reinterpret_cast<T*>(p.y) + (int64_t)m * p.y_cs + p.y_co + co;
+      if (full && vec_y) {
+        V8 o;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = (T)v[u];
+        *reinterpret_cast<V8*>(dst) = o;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (co + u < p.Cout) dst[u] = (T)v[u];
+      }
+    }
+  }
+}
+
+// how many ways to split K on a 256-CU chip: double while the 64 x 64 tiles x splits stay under ~2 per CU and every split
+// keeps at least 4 slices of 64; 1 = do not split (enough tiles already, or a layer outside the uniform-K tiles)
+static int splitk_choice_h16(const yv4_conv_desc* d) {
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const long long K = (long long)d->KH * d->KW * d->Cin;
+  if (d->Cin % kHBK != 0 || M >= (1LL << 31)) return 1;
+  if ((long long)d->N * d->H * d->W * d->x_cstride * 2 >= 0xFFFFFFF0LL || (long long)d->Cout * K * 2 >= 0xFFFFFFF0LL) return 1;
+  const long long tiles = ((M + 63) / 64) * ((d->Cout + 63) / 64);
+  const int nk = (int)(K / kHBK);
+  static const int target = YV4_ENV_INT("YV4_SPLITK_TARGET_H16", 512);
+  static const int min_slices = YV4_ENV_INT("YV4_SPLITK_MINSL_H16", 4);
+  int ks = 1;
+  while (tiles * ks < target && nk / (ks * 2) >= min_slices && ks < 32) ks *= 2;
+  return ks;
+}
+}  // namespace yv4
+
+extern "C" size_t yv4_conv_h16_splitk_workspace(const yv4_conv_desc* d, int* ksplit) {
+  if (ksplit) *ksplit = 1;
+  if (!d) return 0;
+  const int ks = splitk_choice_h16(d);
+  if (ksplit) *ksplit = ks;
+  if (ks <= 1) return 0;
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  return (size_t)ks * (size_t)M * (size_t)((d->Cout + 7) / 8 * 8) * sizeof(float);
+}
+
+extern "C" int yv4_conv_bn_act_fwd_h16_splitk(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x, const void* w,
+                                              const float* scale1, const float* shift1, const float* scale2,
+                                              const float* shift2, const void* residual, void* y, float* workspace,
+                                              size_t workspace_bytes, void* stream) {
+  YV4_REQUIRE(d, "conv h16 splitk: null descriptor");
+  const int ks = splitk_choice_h16(d);
+  if (ks <= 1) return yv4_conv_bn_act_fwd_h16(d, dtype, out_dtype, x, w, scale1, shift1, scale2, shift2, residual, y, stream);
+  YV4_REQUIRE(x && w && scale1 && shift1 && y && workspace, "conv h16 splitk: null argument");
+  YV4_REQUIRE(dtype == YV4_F16 || dtype == YV4_BF16, "conv h16 splitk: dtype must be YV4_F16 or YV4_BF16");
+  YV4_REQUIRE(out_dtype == dtype || out_dtype == YV4_F32, "conv h16 splitk: out_dtype must be the operand type or YV4_F32");
+  YV4_REQUIRE((scale2 == nullptr) == (shift2 == nullptr), "conv h16 splitk: scale2/shift2 must come together");
+  YV4_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 64 &&
+              d->stride > 0 && d->pad >= 0, "conv h16 splitk: bad shape");
+  YV4_REQUIRE(d->x_cstride % 8 == 0 && d->x_coff % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 &&
+              ((uintptr_t)workspace & 15) == 0, "conv h16 splitk: alignment");
+  YV4_REQUIRE(d->x_coff + d->Cin <= d->x_cstride && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_cstride,
+              "conv h16 splitk: view exceeds its pixel stride");
+  const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  YV4_REQUIRE(Ho == d->Ho && Wo == d->Wo, "conv h16 splitk: Ho/Wo do not match the geometry");
+  if (residual) YV4_REQUIRE(d->r_coff >= 0 && d->r_coff + d->Cout <= d->r_cstride, "conv h16 splitk: residual view");
+  YV4_REQUIRE(d->act1 >= 0 && d->act1 <= YV4_ACT_SWISH && d->act2 >= 0 && d->act2 <= YV4_ACT_SWISH, "conv h16 splitk: activation id");
+  YV4_REQUIRE(workspace_bytes >= yv4_conv_h16_splitk_workspace(d, nullptr), "conv h16 splitk: workspace too small");
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  ConvArgsH a;
+  a.x = x; a.w = w; a.s1 = scale1; a.t1 = shift1; a.s2 = scale2; a.t2 = shift2; a.res = residual; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff;
+  a.r_cs = d->r_cstride; a.r_co = d->r_coff;
+  a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
+  a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.Kw = a.K; a.tiles_n = 0; a.ys_on = 0; a.stats = nullptr; a.ablate = 0;
+  a.out_f32 = out_dtype == YV4_F32 ? 1 : 0;
+  const int nk = a.K / kHBK;
+  a.ks_slices = (nk + ks - 1) / ks;
+  a.ksplit = (nk + a.ks_slices - 1) / a.ks_slices;      // no empty split (72 slices 16 ways = 15 splits of 5, the last of 2)
+  a.ws_cs = (d->Cout + 7) / 8 * 8; a.ws = workspace;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (int rc = dtype == YV4_BF16 ? launch_h16<true, 64, 64, false, 2>(a, s) : launch_h16<false, 64, 64, false, 2>(a, s)) return rc;
+  const long long work = M * (a.ws_cs / 8);
+  unsigned g = (unsigned)((work + 255) / 256);
+  if (g > 2048) g = 2048;
+  if (dtype == YV4_BF16) hipLaunchKernelGGL(splitk_finish_h16_kernel<true>, dim3(g), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(splitk_finish_h16_kernel<false>, dim3(g), dim3(256), 0, s, a);
+  YV4_CHECK_LAUNCH("conv h16 splitk finish");
+  return YV4_OK;
+}
+
 // 16-bit form of yv4_conv_scatter_fwd (conv_mfma_f32.hip): one parity class of a stride-2 data gradient.
 extern "C" int yv4_conv_scatter_fwd_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
                                         const float* scale1, const float* shift1, void* y, int Hy, int Wy, int sh, int sw,
@@ -523,6 +695,7 @@ extern "C" int yv4_conv_scatter_fwd_h16(const yv4_conv_desc* d, int dtype, const
   a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = 0; a.r_co = 0;
   a.act1 = 0; a.act2 = 0; a.slope1 = 0.f; a.slope2 = 0.f; a.stats = nullptr;
   a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0; a.out_f32 = 0; a.ablate = 0;
+  a.ksplit = 0; a.ks_slices = 0; a.ws_cs = 0; a.ws = nullptr;
   a.ys_on = 1; a.ys_H = Hy; a.ys_W = Wy; a.ys_sh = sh; a.ys_sw = sw; a.ys_oh = oh; a.ys_ow = ow;
   const bool general = (d->Cin % kHBK) != 0;
   const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;

@@ -228,13 +228,31 @@ class Plan:
                                                    L['t1'].data_ptr(), L['y'].ptr(), out_code, stream),
                       'yv4_conv_stem_fwd')
         elif self.h16:
-            def fn(stream, L=L, out_code=out_code):
-                check(_lib.lib().yv4_conv_bn_act_fwd_h16(
-                    C.byref(L['d']), self.dcode, out_code, L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(),
-                    L['t1'].data_ptr(), L['s2'].data_ptr() if L['s2'] is not None else None,
-                    L['t2'].data_ptr() if L['t2'] is not None else None,
-                    L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), stream),
-                    'yv4_conv_bn_act_fwd_h16')
+            # single-image plans split the K loop of the layers with too few tiles, as the fp32 plans below do
+            ks = C.c_int(1)
+            ws_bytes = 0
+            if x.N == 1 and d.tile == _lib.TILE_AUTO and os.environ.get('YV4_SPLITK', '1') != '0':
+                ws_bytes = int(_lib.lib().yv4_conv_h16_splitk_workspace(C.byref(d), C.byref(ks)))
+            if ws_bytes:
+                self._splitk_bytes = max(getattr(self, '_splitk_bytes', 0), ws_bytes)
+                L['ksplit'] = ks.value
+
+                def fn(stream, L=L, out_code=out_code):
+                    ws = self._splitk_ws
+                    check(_lib.lib().yv4_conv_bn_act_fwd_h16_splitk(
+                        C.byref(L['d']), self.dcode, out_code, L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(),
+                        L['t1'].data_ptr(), L['s2'].data_ptr() if L['s2'] is not None else None,
+                        L['t2'].data_ptr() if L['t2'] is not None else None,
+                        L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), ws.data_ptr(), ws.numel() * 4,
+                        stream), 'yv4_conv_bn_act_fwd_h16_splitk')
+            else:
+                def fn(stream, L=L, out_code=out_code):
+                    check(_lib.lib().yv4_conv_bn_act_fwd_h16(
+                        C.byref(L['d']), self.dcode, out_code, L['x'].ptr(), L['w'].data_ptr(), L['s1'].data_ptr(),
+                        L['t1'].data_ptr(), L['s2'].data_ptr() if L['s2'] is not None else None,
+                        L['t2'].data_ptr() if L['t2'] is not None else None,
+                        L['res'].ptr() if L['res'] is not None else None, L['y'].ptr(), stream),
+                        'yv4_conv_bn_act_fwd_h16')
         else:
             # single-image plans (the reference's benchmark protocol, tools/analysis_tools/benchmark.py:83-109): the
             # deep layers have too few output tiles for 256 CUs; split their K loop (yv4_conv_bn_act_fwd_splitk).

@@ -258,7 +258,7 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None):
         cache = _PACK_CACHES.get(w.device)
         if cache is None:
             cache = _PACK_CACHES[w.device] = _PackCache(w.device)
-        e = cache.lookup(w, dtype, mode)
+        e = cache.lookup(weight, dtype, mode)
         if e is not None:
             return e['dst'], e['cp']
     if w.dtype != torch.float32:

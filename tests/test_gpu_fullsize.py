@@ -212,3 +212,29 @@ def test_single_image_plan_splits_k_and_matches_the_batched_plan(v4l):
     p1.run(img[:1])
     again = [v.buf.tensor.view(v.N, v.H, v.W, v.C) for v in p1.pred_views]
     assert all(torch.equal(a, b) for a, b in zip(again, got))
+
+
+@pytest.mark.parametrize('dtype,bound', [(torch.float16, 2e-2), (torch.bfloat16, 1.5e-1)])
+def test_single_image_16bit_plan_splits_k(v4l, dtype, bound):
+    """The 16-bit form of the batch-1 protocol (yv4_conv_bn_act_fwd_h16_splitk): the single-image plan splits the deep
+    layers' K loops, is run-to-run bit-identical, and agrees with the batch-2 plan of the same images to the noise ONE
+    16-bit rounding flip per layer grows into over ~110 layers (the split sums fp32 partials in another order, so a few
+    outputs per layer round the other way; mean of |diff| / (1 + |logit|) stated per type)."""
+    det, img = v4l
+    p1 = det.compile(1, SIZE, SIZE, device=img.device, rescale=True, dtype=dtype)
+    nsplit = sum(1 for o in p1.ops if o.kind == 'conv' and 'ksplit' in o.info['launch'])
+    assert nsplit > 40
+    p2 = det.compile(2, SIZE, SIZE, device=img.device, rescale=True, dtype=dtype)
+    assert not any('ksplit' in o.info['launch'] for o in p2.ops if o.kind == 'conv')
+    p2.run(img)
+    ref = [v.buf.tensor.view(v.N, v.H, v.W, v.C)[:1].float().clone() for v in p2.pred_views]
+    p1.run(img[:1])
+    got = [v.buf.tensor.view(v.N, v.H, v.W, v.C).float().clone() for v in p1.pred_views]
+    for a, b in zip(got, ref):
+        e = (a - b).abs() / (1 + b.abs())
+        print(f'{dtype} split-K vs batched plan: max {float(e.max()):.2e} mean {float(e.mean()):.2e}')
+        assert bool(torch.isfinite(a).all()) and float(e.mean()) <= bound
+    p1.run(img[:1])
+    again = [v.buf.tensor.view(v.N, v.H, v.W, v.C).float() for v in p1.pred_views]
+    assert all(torch.equal(a, b) for a, b in zip(again, got))
+    det._engines.clear()

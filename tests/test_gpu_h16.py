@@ -24,7 +24,7 @@ HT = dict(t128x128=1, t128x64=2, t64x64=3)
 
 
 def _h16_conv(dev, dtype, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=False, two_stage=False, x_off=0,
-              y_off=0, out_f32=False, seed=0, raw=False):
+              y_off=0, out_f32=False, seed=0, raw=False, splitk=False):
     g = torch.Generator().manual_seed(seed)
     cp = (Cin + 7) // 8 * 8
     x = torch.randn(N, H, W, Cin, generator=g).to(dtype)
@@ -66,12 +66,24 @@ def _h16_conv(dev, dtype, N, H, W, Cin, Cout, k, stride, pad, act, tile, residua
     d.tile = tile
     dev_f = lambda t: t.to(dev).float().contiguous()
     s1d, t1d, s2d, t2d = dev_f(s1), dev_f(t1), dev_f(s2), dev_f(t2)
-    rc = L.lib().yv4_conv_bn_act_fwd_h16(C.byref(d), 1 if dtype == torch.float16 else 2, 0 if out_f32 else
-                                         (1 if dtype == torch.float16 else 2), xbuf.data_ptr(), wbuf.data_ptr(),
-                                         s1d.data_ptr(), t1d.data_ptr(), s2d.data_ptr() if two_stage else None,
-                                         t2d.data_ptr() if two_stage else None,
-                                         rbuf.data_ptr() if residual else None, ybuf.data_ptr(),
-                                         torch.cuda.current_stream().cuda_stream)
+    dcode, ocode = 1 if dtype == torch.float16 else 2, 0 if out_f32 else (1 if dtype == torch.float16 else 2)
+    if splitk:
+        ks = C.c_int(0)
+        nbytes = int(L.lib().yv4_conv_h16_splitk_workspace(C.byref(d), C.byref(ks)))
+        assert (ks.value > 1) == (nbytes > 0)
+        _h16_conv.last_ksplit = ks.value
+        ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=dev)
+        rc = L.lib().yv4_conv_bn_act_fwd_h16_splitk(C.byref(d), dcode, ocode, xbuf.data_ptr(), wbuf.data_ptr(),
+                                                    s1d.data_ptr(), t1d.data_ptr(), s2d.data_ptr() if two_stage else None,
+                                                    t2d.data_ptr() if two_stage else None,
+                                                    rbuf.data_ptr() if residual else None, ybuf.data_ptr(), ws.data_ptr(),
+                                                    ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+    else:
+        rc = L.lib().yv4_conv_bn_act_fwd_h16(C.byref(d), dcode, ocode, xbuf.data_ptr(), wbuf.data_ptr(),
+                                             s1d.data_ptr(), t1d.data_ptr(), s2d.data_ptr() if two_stage else None,
+                                             t2d.data_ptr() if two_stage else None,
+                                             rbuf.data_ptr() if residual else None, ybuf.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
     L.check(rc, 'yv4_conv_bn_act_fwd_h16')
     torch.cuda.synchronize()
     if raw:
@@ -111,6 +123,40 @@ def test_h16_conv_epilogues(gpu_device, dtype, act):
     _h16_conv(gpu_device, dtype, 2, 13, 13, 64, 72, 3, 1, 1, act, 0, residual=True, two_stage=True, x_off=8, y_off=16)
     _h16_conv(gpu_device, dtype, 1, 9, 11, 64, 255, 1, 1, 0, act, 0, out_f32=True)           # pred maps in fp32
     _h16_conv(gpu_device, dtype, 1, 9, 11, 40, 64, 3, 1, 1, act, 3, out_f32=True, y_off=4)
+
+
+SPLITK_SHAPES = [
+    # N, H, W, Cin, Cout, k, stride, pad : single-image layers of YOLOv4-L 608 (the batch-1 protocol) + awkward ones
+    (1, 19, 19, 512, 512, 3, 1, 1),     # 48 tiles, 72 slices: 16 ways -> 15 splits of 5 slices, the last of 2
+    (1, 19, 19, 1024, 512, 1, 1, 0),    # 1x1, 16 slices
+    (1, 38, 38, 256, 256, 3, 1, 1),     # 92 tiles, 36 slices
+    (1, 38, 38, 128, 256, 3, 2, 1),     # stride 2
+    (1, 19, 19, 1024, 255, 1, 1, 0),    # head: Cout 255 (slab rows padded to 256)
+    (1, 11, 13, 192, 72, 3, 1, 1),      # ragged M, Cout tail inside an 8-channel group
+    (1, 76, 76, 128, 128, 3, 1, 1),     # 182 tiles: two ways
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', SPLITK_SHAPES)
+def test_h16_splitk_conv(gpu_device, dtype, shape):
+    """yv4_conv_bn_act_fwd_h16_splitk (single-image plans, tools/analysis_tools/benchmark.py:83-109): within the same
+    bound of the fp64 convolution as the unsplit tiles (fp32 partial slabs added in slab order, one rounding at the end),
+    run-to-run bit-identical, residual + two-stage epilogue + views; fp32 output for the head shape."""
+    head = shape[4] == 255
+    kw = dict(out_f32=True) if head else dict(residual=True, two_stage=True, x_off=8, y_off=16)
+    _h16_conv(gpu_device, dtype, *shape, act=1, tile=0, splitk=True, **kw)
+    assert _h16_conv.last_ksplit > 1
+    a = _h16_conv(gpu_device, dtype, *shape, act=1, tile=0, splitk=True, raw=True, **kw)
+    b = _h16_conv(gpu_device, dtype, *shape, act=1, tile=0, splitk=True, raw=True, **kw)
+    assert torch.equal(a, b)
+
+
+def test_h16_splitk_forwards_when_not_split(gpu_device):
+    """Enough tiles already, or Cin % 64 != 0: ksplit = 1, no workspace, the call is the plain entry."""
+    for shape in [(8, 38, 38, 256, 256, 3, 1, 1), (1, 19, 19, 96, 64, 3, 1, 1)]:
+        _h16_conv(gpu_device, torch.bfloat16, *shape, act=1, tile=0, splitk=True)
+        assert _h16_conv.last_ksplit == 1
 
 
 PP3_SHAPES = [
