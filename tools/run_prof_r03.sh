@@ -12,7 +12,7 @@ cd "$GRAFT_REPO_ROOT"
 OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_r03"
 mkdir -p "$OUT"
 PARTS="${*:-f32 bf16 cfg3 train}"
-COMMON="--steps 10 --warmup 2 --no-cpu-baseline --no-train"
+COMMON="--steps 10 --warmup 2 --no-cpu-baseline --no-train --no-output-check"
 
 prof_bench () {   # name, bench arguments...
   local name="$1"; shift
