@@ -229,13 +229,16 @@ def clear_pack_cache():
     _PACK_CACHES.clear()
 
 
-def packed_weight(weight, dtype, transpose_flip=False, taps=None):
+def packed_weight(weight, dtype, transpose_flip=False, taps=None, owner=None):
     """The conv kernels' weight operand from an fp32 (Cout, Cin, KH, KW) parameter in one launch (``yv4_pack_weight``):
     rows x (KH'*KW'*Cp), K ordered (kh, kw, channel), channels zero-padded to a 16-byte chunk, cast to ``dtype``.
     ``transpose_flip``: the data gradient's operand (rows = Cin, channels = Cout, taps mirrored).  ``taps``:
     ((kh0, kh_step, KH'), (kw0, kw_step, KW')) selects source taps explicitly (rows = Cin, channels = Cout): the
     operand of one parity class of a stride-2 data gradient.  Returns (w, Cp).  The result is a cached buffer that the
-    next refresh overwrites: use it on the current stream before the weights change again (the conv launches do)."""
+    next refresh overwrites: use it on the current stream before the weights change again (the conv launches do).
+    ``owner``: the parameter ``weight`` is a detached alias of (``conv2d`` hands ``ConvFunction`` the detached weight
+    when dW goes straight into ``weight.grad``): the table records and weakly references the OWNER, so a fresh alias
+    per step still hits its entry."""
     Cout, Cin, KH, KW = weight.shape
     al = 4 if dtype == torch.float32 else 8
     transpose = bool(transpose_flip or taps is not None)
@@ -250,7 +253,9 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None):
     w = weight.detach()
     # temporaries (the stem weight zero-padded to a 16-byte chunk in every step, darknetcsp.Conv.fwd: a fresh non-leaf
     # tensor each time) take the per-call launch below: cached, each step would add an entry that is never hit again
-    persistent = weight.is_leaf and (weight.requires_grad or isinstance(weight, torch.nn.Parameter))
+    ident = owner if owner is not None else weight
+    persistent = ident.is_leaf and (ident.requires_grad or isinstance(ident, torch.nn.Parameter)) and \
+        ident.data_ptr() == weight.data_ptr()
     cacheable = _PACK_CACHE_ON and persistent and w.dtype == torch.float32 and w.is_cuda
     cache = None
     mode = (bool(transpose_flip), taps)
@@ -258,7 +263,7 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None):
         cache = _PACK_CACHES.get(w.device)
         if cache is None:
             cache = _PACK_CACHES[w.device] = _PackCache(w.device)
-        e = cache.lookup(weight, dtype, mode)
+        e = cache.lookup(ident, dtype, mode)
         if e is not None:
             return e['dst'], e['cp']
     if w.dtype != torch.float32:
@@ -269,20 +274,20 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None):
                                      kws, int(transpose), al, out.data_ptr(), _DCODE[dtype], stream_ptr()),
           'yv4_pack_weight')
     if cacheable:
-        cache.add(weight, dtype, mode, dict(w=w.data_ptr(), s_co=st[0], s_ci=st[1], s_kh=st[2], s_kw=st[3], Cout=Cout, Cin=Cin,
+        cache.add(ident, dtype, mode, dict(w=w.data_ptr(), s_co=st[0], s_ci=st[1], s_kh=st[2], s_kw=st[3], Cout=Cout, Cin=Cin,
                                        KHo=KHo, KWo=KWo, kh0=kh0, kh_step=khs, kw0=kw0, kw_step=kws,
                                        transpose=int(transpose), pad_to=al, dtype=_DCODE[dtype]), out, cp)
     return out, cp
 
 
-def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None, residual=None, res_cs=None):
+def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None, residual=None, res_cs=None, owner=None):
     """dX = correlate(dY zero-dilated by `stride`, W flipped in (kh,kw) and transposed in (co,ci)), pad k-1-p."""
     N, Cin, H, W = xshape
     Cout, _, KH, KW = weight.shape
     Ho, Wo = dy.shape[2], dy.shape[3]
     h16 = dtype != torch.float32
     L = _lib.lib()
-    wtp, _ = packed_weight(weight, dtype, transpose_flip=True)     # rows = Cin, taps mirrored, cast: one launch
+    wtp, _ = packed_weight(weight, dtype, transpose_flip=True, owner=owner)     # rows = Cin, taps mirrored, cast: one launch
     src_cs = None
     if stride == 1:
         src, src_cs = dy, dy_cs
@@ -312,7 +317,7 @@ def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None, residual=
     return dxf
 
 
-def _dgrad_s2_parity(dy, weight, xshape, dtype, dy_cs=None):
+def _dgrad_s2_parity(dy, weight, xshape, dtype, dy_cs=None, owner=None):
     """Data gradient of a 3x3 / stride 2 / pad 1 convolution as four parity classes: with
     hi = 2*ho - 1 + kh, the input rows hi = 2i + a receive only the taps kh with (a + 1 - kh) even
     (a = 0: kh = 1 from dY row i;  a = 1: kh = 2 from row i and kh = 0 from row i + 1), likewise in x.
@@ -333,7 +338,7 @@ def _dgrad_s2_parity(dy, weight, xshape, dtype, dy_cs=None):
             Wb = (W - b + 1) // 2
             if Ha == 0 or Wb == 0:
                 continue
-            wp, _ = packed_weight(wd, dtype, taps=(taps[a], taps[b]))          # (Cin, KH'*KW'*Cout), one launch
+            wp, _ = packed_weight(wd, dtype, taps=(taps[a], taps[b]), owner=owner if owner is not None else weight)
             d = ConvDesc()
             d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, Ho, Wo, Cout, Ha, Wb, Cin
             d.KH, d.KW, d.stride, d.pad = taps[a][2], taps[b][2], 1, 0
@@ -433,7 +438,7 @@ class ConvFunction(torch.autograd.Function):
         N, _, H, W = x.shape
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        wp, cp = packed_weight(weight, dtype)
+        wp, cp = packed_weight(weight, dtype, owner=direct.p if direct is not None else None)
         y = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=dtype, memory_format=torch.channels_last)
         _conv_launch(x, wp, cp, Cout, KH, KW, stride, pad, y, stats)
         ctx.save_for_backward(x, weight)
@@ -493,9 +498,10 @@ class ConvFunction(torch.autograd.Function):
                     joined = to_nhwc(joined.to(dtype))
                     jcs = None
             if stride == 2 and (KH, KW, pad) == (3, 3, 1) and Cout % (8 if h16 else 32) == 0:
-                dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype, dy_cs)
+                dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype, dy_cs, owner=ctx.direct.p if ctx.direct is not None else None)
             else:
-                dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype, dy_cs, residual=joined, res_cs=jcs)
+                dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype, dy_cs, residual=joined, res_cs=jcs,
+                                    owner=ctx.direct.p if ctx.direct is not None else None)
                 joined = None
             if joined is not None:
                 dx = dx + joined
