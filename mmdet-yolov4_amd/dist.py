@@ -186,6 +186,7 @@ class GradReducer:
         self._index_of = {}
         self._stage = {}
         self._comm_stream = None
+        self._timing = None          # enable_timing(): device events at arm / every bucket launch / finish
         for si, p in enumerate(flat._params):
             if p.requires_grad:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(si)))
@@ -223,8 +224,46 @@ class GradReducer:
             self._event(si)
         return hook
 
+    # ---- where in backward a bucket becomes exchangeable (measurement; works with one rank too) -------------------
+    def enable_timing(self):
+        """Record a device event when the window is armed, when each bucket is launched (its gradients are final: from
+        here its exchange can run beside the rest of backward) and when ``finish()`` is called (end of backward)."""
+        self._timing = dict(arm=None, finish=None, launch={})
+
+    def timing_report(self):
+        """After a synchronised step: per bucket (in launch order) its bytes and the fraction of the backward pass that
+        was still ahead when it was launched = the share of backward its exchange can overlap; plus the byte-weighted
+        mean.  With one rank nothing is exchanged, but the launch points are the same as on a node."""
+        t = self._timing
+        if not t or t['arm'] is None or t['finish'] is None:
+            return None
+        total = t['arm'].elapsed_time(t['finish'])
+        rows, wsum, bsum = [], 0.0, 0
+        for bi in self.launch_order:
+            lo, hi, _ = self.buckets[bi]
+            ev = t['launch'].get(bi)
+            ahead = max(0.0, ev.elapsed_time(t['finish'])) / total if ev is not None and total > 0 else 0.0
+            rows.append(dict(bucket=bi, mbytes=round((hi - lo) * 4 / 1e6, 1), backward_ahead=round(ahead, 3)))
+            wsum += ahead * (hi - lo)
+            bsum += hi - lo
+        return dict(backward_ms=round(total, 2), buckets=rows, overlappable_fraction=round(wsum / max(bsum, 1), 3),
+                    exchanged_mbytes=round(bsum * 4 / 1e6, 1), mode=self.mode, world=self.world)
+
+    def _stamp(self, what, bi=None):
+        if self._timing is None or not self.flat.grads.is_cuda:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        if bi is None:
+            self._timing[what] = ev
+        else:
+            self._timing['launch'][bi] = ev
+
     def arm(self):
         self._armed = True
+        if self._timing is not None:
+            self._timing['launch'] = {}
+            self._stamp('arm')
         self._pending = [sum(1 for si in b[2] if self.flat._params[si].requires_grad) for b in self.buckets]
         self._done = set()
         self._ready = [n == 0 for n in self._pending]
@@ -271,6 +310,7 @@ class GradReducer:
             return
         self._launched[bi] = True
         self.launch_order.append(bi)
+        self._stamp('launch', bi)
         if self.world <= 1:
             return
         lo, hi, _ = self.buckets[bi]
@@ -293,6 +333,7 @@ class GradReducer:
         """Exchange whatever backward has not triggered (unused parameters), wait, average."""
         if not self._armed:
             raise RuntimeError('GradReducer.finish() without arm()')
+        self._stamp('finish')
         self._ready = [True] * len(self.buckets)
         self._cascade()
         for h in self._handles:

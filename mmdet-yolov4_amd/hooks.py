@@ -22,6 +22,8 @@ The schedule arithmetic is exposed as pure functions (``warmup_factor``, ``ema_m
 """
 import math
 
+import os
+
 import torch
 
 from . import _lib
@@ -174,7 +176,9 @@ class Fp16GradAccumulateOptimizerHook(Hook):
                                             device=flat.device)
             self.ctrl = torch.zeros(4, dtype=torch.float32, device=flat.device)
             self.work = torch.zeros(2, dtype=torch.float64, device=flat.device)
-            if self.distributed and _world_size() > 1:
+            if self.distributed and (_world_size() > 1 or os.environ.get('YV4_REDUCER_AT_WORLD1') == '1'):
+                # (YV4_REDUCER_AT_WORLD1=1: build the reducer with one rank too -- tools/train_bench.py --overlap-report
+                # measures where in backward each bucket becomes exchangeable; nothing is exchanged)
                 from .dist import GradReducer
                 mb = self.bucket_size_mb if self.bucket_size_mb and self.bucket_size_mb > 0 else 64
                 self.reducer = GradReducer(flat, bucket_mb=mb, mode=self.grad_exchange)

@@ -25,9 +25,14 @@ def main():
     ap.add_argument('--torch-optim', action='store_true')
     ap.add_argument('--grad-exchange', default=None, choices=['allreduce', 'direct', 'direct_bf16'],
                     help='dist.GradReducer mode (default: YV4_GRAD_EXCHANGE or allreduce)')
+    ap.add_argument('--overlap-report', action='store_true',
+                    help='record when each gradient bucket becomes exchangeable inside backward (GradReducer timing events) and '
+                         'print the share of backward its exchange can overlap; works with one rank (nothing is exchanged)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'],
                     help='activation / conv operand type (master weights, statistics and losses stay fp32)')
     a = ap.parse_args()
+    if a.overlap_report:
+        os.environ['YV4_REDUCER_AT_WORLD1'] = '1'
     rank, local_rank, world = D.env_world()
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
@@ -91,6 +96,11 @@ def main():
 
     for _ in range(a.warmup):
         l0 = step()
+    red = None
+    if a.overlap_report and not a.torch_optim:
+        red = next((h.reducer for h in runner._hooks if getattr(h, 'reducer', None) is not None), None)
+        if red is not None:
+            red.enable_timing()
     D.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -107,7 +117,8 @@ def main():
                               optimizer='torch SGD + DDP' if a.torch_optim else 'flat arenas + recipe hooks',
                               backend=D.backend_name(), grad_exchange=D.exchange_name(a.grad_exchange, world),
                               approx_conv_tflops=round(fl * a.batch * world * a.steps / el / 1e12, 1),
-                              peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))))
+                              peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                              **({'overlap': red.timing_report()} if red is not None else {}))))
     D.finalize()
 
 
