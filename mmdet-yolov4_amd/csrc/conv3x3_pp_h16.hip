@@ -53,92 +53,6 @@ constexpr int kP3RingBytes = (2 * kP3ARows + kP3NB * kP3BN) * 128;
 constexpr int kP3MaxCout = 1024;     // the per-channel affine of the whole layer lives in the last 16 KB of LDS
 constexpr int kP3Lds = kP3RingBytes + 4 * kP3MaxCout * 4;
 
-// Epilogue of one 32x32 accumulator tile straight from the MFMA's C layout (lane (r, h): channel co_base + r of the
-// rows (e & 3) + 8 (e >> 2) + 4 h).  Expressions and their order are epilogue_tile_h's (conv_h16_common.h).  `aff` is
-// the layer's affine in LDS ([s1 | t1 | s2 | t2] x Cout); `resw` the residual words of this tile, requested by the caller
-// for all of the wave's tiles before the first is finished (one memory round trip per tile of the grid, not per value).
-template <bool BF16>
-__device__ __forceinline__ void residual_prefetch_h(const ConvArgsH& p, int lane, int m_base, int co_base, unsigned (&resw)[8]) {
-  typedef typename Elem<BF16>::T T;
-  const int r = lane & 31, h = lane >> 5;
-  const bool odd = r & 1;
-  const int cp = co_base + r - (odd ? 1 : 0);
-  const bool c_ok = cp + 1 < p.Cout;
-  const int row0 = m_base + 4 * h + (odd ? 16 : 0);
-  const T* rp = reinterpret_cast<const T*>(p.res);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int m = row0 + (j & 3) + 8 * (j >> 2);
-    resw[j] = (c_ok && m < p.M) ? *reinterpret_cast<const unsigned*>(rp + (int64_t)m * p.r_cs + p.r_co + cp) : 0u;
-  }
-}
-
-template <bool BF16>
-__device__ __forceinline__ void epilogue_pairs_h(const ConvArgsH& p, const f32x16& acc, int lane, int m_base, int co_base,
-                                                 bool has2, const float* aff, const unsigned (&resw)[8]) {
-  typedef typename Elem<BF16>::T T;
-  typedef T T2 __attribute__((ext_vector_type(2)));
-  const int r = lane & 31, h = lane >> 5;
-  const bool odd = r & 1;
-  const int c = co_base + r;
-  const int cp = c - (odd ? 1 : 0);                  // even channel of this lane's pair
-  const bool c_ok = cp + 1 < p.Cout;                 // Cout is even in this kernel's domain
-  const int cc = c_ok ? c : 0;
-  const float s1 = aff[cc], t1 = aff[p.Cout + cc];
-  // rows this lane stores after the exchange: (j & 3) + 8 (j >> 2) + 4 h (+ 16 on odd lanes)
-  const int row0 = m_base + 4 * h + (odd ? 16 : 0);
-  float v[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) v[e] = __builtin_fmaf(acc[e], s1, t1);
-  {
-    float lo[8], hi[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[e + 8]; }
-    act_row8(lo, p.act1, p.slope1);
-    act_row8(hi, p.act1, p.slope1);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { v[e] = lo[e]; v[e + 8] = hi[e]; }
-  }
-  // exchange: the even lane keeps its rows e < 8 and receives the odd lane's, the odd lane keeps e >= 8
-  float a[8], b[8];                                  // channel cp, channel cp + 1 of row j
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float send = odd ? v[j] : v[j + 8];
-    const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));
-    a[j] = odd ? recv : v[j];
-    b[j] = odd ? v[j + 8] : recv;
-  }
-  if (p.res) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const T2 rr = __builtin_bit_cast(T2, resw[j]);
-      a[j] += (float)rr[0];
-      b[j] += (float)rr[1];
-    }
-  }
-  if (has2) {
-    const int c2 = c_ok ? cp : 0;
-    const float s2a = aff[2 * p.Cout + c2], t2a = aff[3 * p.Cout + c2], s2b = aff[2 * p.Cout + c2 + 1], t2b = aff[3 * p.Cout + c2 + 1];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      a[j] = __builtin_fmaf(a[j], s2a, t2a);
-      b[j] = __builtin_fmaf(b[j], s2b, t2b);
-    }
-    act_row8(a, p.act2, p.slope2);
-    act_row8(b, p.act2, p.slope2);
-  }
-  T* yp = reinterpret_cast<T*>(p.y);
-  T* y0 = yp + (int64_t)row0 * p.y_cs + p.y_co + cp;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int dj = (j & 3) + 8 * (j >> 2);
-    T2 pk;
-    pk[0] = (T)a[j];
-    pk[1] = (T)b[j];
-    if (c_ok && row0 + dj < p.M) *reinterpret_cast<unsigned*>(y0 + (int64_t)dj * p.y_cs) = __builtin_bit_cast(unsigned, pk);
-  }
-}
-
 template <bool BF16>
 __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
   typedef typename Elem<BF16>::V8 V8;
@@ -314,6 +228,7 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
     if (!YV4_ABLATE(p.ablate, 16)) YV4_P3_WAIT(NEWER); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     YV4_P3_STAMP(1);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                   \
+    asm volatile("" ::: "memory");                                                                  \
     YV4_P3_STAMP(2);                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     __builtin_amdgcn_s_setprio(1);                                                                  \
@@ -332,6 +247,7 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
     __builtin_amdgcn_sched_barrier(0);                                                              \
     YV4_P3_STAMP(3);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                   \
+    asm volatile("" ::: "memory");   /* no LDS read of the next stage may move above the barrier */  \
     YV4_P3_STAMP(4);                                                                                \
   }
 

@@ -364,17 +364,19 @@ static int dispatch_h16(const ConvArgsH& a, int tile, bool general, hipStream_t 
 bool conv3x3_pp_h16_applies(const ConvArgsH& a);
 int conv3x3_pp_h16_launch(const ConvArgsH& a, bool bf16, hipStream_t s);
 
-// The persistent ping-pong 3x3 kernel takes the stride-1 3x3 layers with >= 128 input channels that give every CU at
-// least two of its 256 x 128 tiles (measured per layer, tools/conv_bench.py --dtype bf16 --tiles 4,2, batch 32:
-// 128->128 @76 87 vs 95 us, 128->256 @76 166 vs 171, 256->512 @38 141 vs 156; with 1-1.4 tiles per CU -- 256->256 @38,
-// 512->512 @19 -- the generic tiles' three workgroups per CU are as fast or faster: 85 vs 82, 74 vs 74).  Both sum K in
-// the same order and apply the same epilogue expressions: same bits.  YV4_PP3=0 (measurement build) switches it off.
+// The persistent ping-pong 3x3 kernel takes the stride-1 3x3 layers with >= 128 input channels whose 256 x 128 tiles
+// fill the one-workgroup-per-CU rounds: at least 150 tiles and at least 60 % of the last round's CUs busy.  Measured
+// per layer (tools/conv_bench.py --dtype bf16 --tiles 4,2, batch 32, one box): 128->128 @76 76 vs 87 us, 256->256 @38
+// 74 vs 78, 512->512 @19 67 vs 71, 128->256 @76 143 vs 167, 256->512 @38 117 vs 147, 512->1024 @19 126 vs 145.  A
+// batch-2 plan's 24 tiles stay on the generic tiles, which sum K in the same order and apply the same epilogue
+// expressions -- same bits.  YV4_PP3=0 (measurement build) switches it off.
 static bool prefer_pp3(const ConvArgsH& a) {
   static const int mode = YV4_ENV_INT("YV4_PP3", 1);
-  static const int min_tiles = YV4_ENV_INT("YV4_PP3_MINTILES", 512);
+  static const int cus = YV4_ENV_INT("YV4_PP3_CUS", 256);
   if (!mode || !conv3x3_pp_h16_applies(a) || a.Cin < 128) return false;
   const long long tiles = ((long long)a.M + 255) / 256 * ((a.Cout + 127) / 128);
-  return tiles >= min_tiles;
+  const long long rounds = (tiles + cus - 1) / cus;
+  return tiles >= 150 && tiles * 100 >= rounds * cus * 60;
 }
 
 // conv1x1_ws_h16.hip

@@ -173,19 +173,21 @@ PP3_SHAPES = [
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('tile', [4])
 @pytest.mark.parametrize('shape', PP3_SHAPES)
-def test_h16_pp3x3_kernel_shapes(gpu_device, dtype, shape):
+def test_h16_pp3x3_kernel_shapes(gpu_device, dtype, tile, shape):
     N, H, W, Cin, Cout = shape
-    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=4)
+    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=tile)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('tile', [4])
 @pytest.mark.parametrize('act', [0, 1, 2, 3])
-def test_h16_pp3x3_kernel_epilogues(gpu_device, dtype, act):
-    """Residual + two-stage epilogue + channel-offset views on both sides through the persistent 3x3 kernel."""
-    _h16_conv(gpu_device, dtype, 2, 13, 13, 64, 72, 3, 1, 1, act, 4, residual=True, two_stage=True, x_off=8, y_off=16)
-    _h16_conv(gpu_device, dtype, 1, 20, 9, 128, 128, 3, 1, 1, act, 4, residual=True, x_off=16)
-    _h16_conv(gpu_device, dtype, 30, 38, 38, 64, 128, 3, 1, 1, act, 4, residual=True, two_stage=True, y_off=8)   # 170 tiles
+def test_h16_pp3x3_kernel_epilogues(gpu_device, dtype, tile, act):
+    """Residual + two-stage epilogue + channel-offset views on both sides through the persistent 3x3 kernels."""
+    _h16_conv(gpu_device, dtype, 2, 13, 13, 64, 72, 3, 1, 1, act, tile, residual=True, two_stage=True, x_off=8, y_off=16)
+    _h16_conv(gpu_device, dtype, 1, 20, 9, 128, 128, 3, 1, 1, act, tile, residual=True, x_off=16)
+    _h16_conv(gpu_device, dtype, 30, 38, 38, 64, 128, 3, 1, 1, act, tile, residual=True, two_stage=True, y_off=8)   # 170 tiles
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
@@ -212,27 +214,24 @@ def test_h16_pp3x3_kernel_is_refused_outside_its_domain(gpu_device):
 
 
 def test_h16_pp3x3_auto_choice(gpu_device):
-    """The auto tile choice takes the persistent 3x3 kernel for the stride-1 3x3 layers with >= 128 input channels that
-    give every CU at least two tiles; fewer tiles, a batch-2 plan's layers and the few-channel layers keep the generic
-    tiles (same bits either way: test_pp3x3_matches_generic_bitwise)."""
+    """The auto tile choice takes the persistent 3x3 kernel for the stride-1 3x3 layers with >= 128 input channels whose
+    tiles fill the chip; a batch-2 plan's layers and the few-channel layers keep the generic tiles (same bits either way:
+    test_pp3x3_matches_generic_bitwise)."""
     d = L.ConvDesc()
-    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 32, 76, 76, 128, 76, 76, 128
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 32, 38, 38, 256, 38, 38, 256
     d.KH = d.KW = 3
     d.stride, d.pad = 1, 1
-    d.x_cstride, d.y_cstride, d.r_cstride = 128, 128, 128
-    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 4           # 722 tiles
-    d.N, d.H, d.W, d.Ho, d.Wo, d.Cin, d.Cout = 32, 38, 38, 38, 38, 256, 512
-    d.x_cstride, d.y_cstride = 256, 512
-    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 4           # 724 tiles
-    d.Cout = 256
-    d.y_cstride = 256
-    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) in (1, 2, 3)   # 362 tiles: 1.4 per CU
+    d.x_cstride, d.y_cstride, d.r_cstride = 256, 256, 256
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 4           # 362 tiles
+    d.N, d.H, d.W, d.Ho, d.Wo, d.Cin, d.Cout = 32, 19, 19, 19, 19, 512, 512
+    d.x_cstride, d.y_cstride = 512, 512
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 4           # 184 tiles: one round at 72 %
     d.N = 2
-    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) in (1, 2, 3)   # 24 tiles
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) in (1, 2, 3)   # 12 tiles
     d.N, d.H, d.W, d.Ho, d.Wo, d.Cin, d.Cout = 32, 152, 152, 152, 152, 64, 64
     d.x_cstride, d.y_cstride = 64, 64
     assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) != 4           # 64 input channels: the few-channel kernel's layer
-    _h16_conv(gpu_device, torch.bfloat16, 32, 76, 76, 128, 128, 3, 1, 1, act=1, tile=0)     # auto -> persistent kernel
+    _h16_conv(gpu_device, torch.bfloat16, 32, 38, 38, 128, 128, 3, 1, 1, act=1, tile=0)     # auto -> persistent kernel
 
 
 WS_SHAPES = [
