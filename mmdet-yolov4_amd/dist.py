@@ -124,8 +124,10 @@ class GradReducer:
 
     Here the gradients already ARE one contiguous arena (``FlatState.grads``), so a bucket is a
     slice of it: no copy-in/copy-out, and few large collectives (xGMI is point-to-point, a ring
-    all-reduce is per-link bound, so larger messages amortise the per-step latency better; 64 MB
-    default -> 4 collectives for YOLOv4-L's 212 MB).  Buckets are launched from post-accumulate-grad
+    all-reduce is per-link bound, so larger messages amortise the per-step latency better; 32 MB
+    default -> 7 collectives for YOLOv4-L's 212 MB: the bucket that holds the first-registered parameters is final only
+    when the stem's gradient is, so its exchange is the exposed tail -- measured with ``enable_timing`` at 64 MB: 0 % of
+    backward left when it launches, 96 / 72 / 64 % for the three before it; halving the bucket halves that tail).  Buckets are launched from post-accumulate-grad
     hooks as soon as every gradient inside is final, i.e. overlapped with the rest of backward: arena
     order is registration order, backward produces the tail first, so the last bucket goes out first.
 
@@ -153,7 +155,7 @@ class GradReducer:
 
     MODES = ('allreduce', 'direct', 'direct_bf16')
 
-    def __init__(self, flat, bucket_mb=64, group=None, mode=None, overlap=True):
+    def __init__(self, flat, bucket_mb=32, group=None, mode=None, overlap=True):
         self.flat = flat
         self.group = group
         self.mode = mode or os.environ.get('YV4_GRAD_EXCHANGE', 'allreduce')

@@ -180,7 +180,7 @@ class Fp16GradAccumulateOptimizerHook(Hook):
                 # (YV4_REDUCER_AT_WORLD1=1: build the reducer with one rank too -- tools/train_bench.py --overlap-report
                 # measures where in backward each bucket becomes exchangeable; nothing is exchanged)
                 from .dist import GradReducer
-                mb = self.bucket_size_mb if self.bucket_size_mb and self.bucket_size_mb > 0 else 64
+                mb = self.bucket_size_mb if self.bucket_size_mb and self.bucket_size_mb > 0 else 32
                 self.reducer = GradReducer(flat, bucket_mb=mb, mode=self.grad_exchange)
 
     def before_run(self, runner):
