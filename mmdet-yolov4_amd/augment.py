@@ -181,7 +181,10 @@ class FusedTrainPipeline:
                                       mean.data_ptr(), std.data_ptr(), int(self.to_rgb), self.pad_val, stream_ptr()),
               'yv4_mosaic_augment_u8')
         total = seg[-1]
-        cap = self.max_boxes
+        # a sample never keeps more boxes than its four tiles bring: size the output rows from the largest sample, so that
+        # no ground truth is dropped silently (the reference's MosaicPipeline keeps every box of the four tiles;
+        # `max_boxes` is only the floor of the allocation)
+        cap = max(int(self.max_boxes), max((seg[n + 1] - seg[n] for n in range(N)), default=0), 1)
         ob = torch.empty((N, cap, 4), dtype=torch.float32, device=dev)
         ol = torch.empty((N, cap), dtype=torch.int32, device=dev)
         oc = torch.zeros((N,), dtype=torch.int32, device=dev)

@@ -152,3 +152,25 @@ def test_augment_rejects_bad_inputs(gpu_device):
         pipe([[(img.float(),) + e] * 4])
     with pytest.raises(TypeError):
         pipe([[(img.cpu(),) + e] * 4])
+
+
+def test_crowded_sample_keeps_every_box(gpu_device):
+    """a mosaic sample with more ground-truth boxes than `max_boxes` must not lose labels silently (the
+    reference's MosaicPipeline keeps every box of its four tiles): the output rows are sized from the largest sample."""
+    side = 256
+    pipe = FusedTrainPipeline(img_scale=(side, side), pad_val=0, pad_to=side, crop=side, scale_limit=0.0, out_size=side,
+                              flip_p=0.0, min_area=-1.0, min_visibility=-1.0, hsv=None, min_size=-1, max_aspect_ratio=1e30,
+                              max_boxes=8)
+    blank = torch.zeros((side, side, 3), dtype=torch.uint8, device=gpu_device)
+    rng = np.random.default_rng(0)
+    k = 40                                                              # per tile: 160 boxes in the sample, cap floor 8
+    four = []
+    for i in range(4):
+        xy = rng.uniform(20, 120, (k, 2)).astype(np.float32)
+        wh = rng.uniform(8, 40, (k, 2)).astype(np.float32)
+        four.append((blank, np.concatenate([xy, xy + wh], 1), np.full(k, i, np.int64)))
+    out = pipe([four], params=[dict(h_start=0.0, w_start=0.0, scale=1.0, flip=False)])
+    n = int(out['gt_labels'][0].numel())
+    assert n > 8 and out['gt_bboxes'][0].shape == (n, 4)
+    # tile 0 (top-left quadrant of the mosaic, fully inside the crop at h_start = w_start = 0) keeps all its boxes
+    assert int((out['gt_labels'][0] == 0).sum()) == k
