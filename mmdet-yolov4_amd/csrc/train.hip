@@ -379,6 +379,255 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(WgradArgs p, uns
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / stride-1 / pad-1 layers with Cin % 128 == 0 (71 % of YOLOv4-L's weight-gradient FLOPs):
+// the three kw taps of one (kh, 128-channel chunk) share ONE LDS image of the slice's source pixels.
+//   dW[co][kh][kw][ci] = sum_m dY[m][co] * X[m + (kh - 1) W + (kw - 1)][ci]      (flattened pixel index m; borders masked)
+// The kernel above fetches 32 KB per 64-row slice for a 128 x 128 tile of dW (64 FLOP per byte of LDS fill, the regime
+// in which the forward tiles sit at the L2 -> LDS limit).  Here an 8-wave workgroup owns 128 co x (3 kw x 128 ci) of dW
+// and one chunk of the M reduction: per slice the 64 rows of dY and the 66 source pixels of X (one image for all three
+// kw: operand row = reduction row + kw) are 32.5 KB of fill for 6.3 MFLOP -- 190 FLOP per byte -- and a wave (64 co x 32
+// ci x 3 kw = six accumulators) needs ten transposed reads per six MFMAs instead of eight per four.  What a shifted row
+// must not see (left / right image border, rows above / below, the neighbouring image) is masked per LANE: a lane of a
+// ds_read_b64_tr_b16 supplies the address of ONE reduction row, so redirecting it to a zero row zeroes that row's
+// contribution for every column of the transposed block.  Four slice buffers, three slices of LDS-DMA in flight, one
+// barrier per slice placed in front of the LAST 16-row step so that the next slice's first fragments are read while
+// that step's MFMAs run.  Same chunked, deterministic output as above (slab per chunk + wgrad_reduce_kernel).
+// ---------------------------------------------------------------------------------
+constexpr int kW3Threads = 512;
+constexpr int kW3Rows = 64;                        // reduction rows per slice
+constexpr int kW3XRows = 68;                       // 66 source pixels + one DMA group of 4; rows 66, 67 are only ever zero
+constexpr int kW3ZeroRow = 66;
+constexpr int kW3BufBytes = (kW3Rows + kW3XRows) * 256;
+constexpr int kW3NBuf = 4;
+constexpr int kW3Lds = kW3NBuf * kW3BufBytes;      // 135 168 B: one workgroup per CU
+
+template <bool BF16>
+__global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_w3[];
+  constexpr int kRowB = 256;
+  constexpr int kDBytes = kW3Rows * kRowB;           // dY part of a buffer; the X image follows it
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 2;                          // co half (64 rows of dW)
+  const int wk = wave & 3;                           // ci slab (32 columns per kw)
+
+  // tile: (co tile, kh, ci tile), ci fastest
+  const int tiles_ci = p.Cin >> 7;
+  const int tile = (int)blockIdx.x;
+  const int tci = tile % tiles_ci;
+  const int kh = (tile / tiles_ci) % 3;
+  const int tco = tile / (3 * tiles_ci);
+  const int co0 = tco * 128, ci0 = tci * 128;
+  const int m_lo = (int)blockIdx.y * p.rows_per_chunk;
+  const int m_hi = min(m_lo + p.rows_per_chunk, p.M);
+  if (m_lo >= m_hi) return;
+  const int NHW = p.N * p.H * p.W;
+
+  const u32x4_t rsX = make_rsrc_t(p.x, x_bytes);
+  const u32x4_t rsD = make_rsrc_t(p.dy, dy_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_w3;
+
+  // ---- staging: a DMA instruction covers 4 rows x 16 chunks; wave w fills rows 8w .. 8w+7 of dY and of the X image,
+  // wave 0 also the 17th group of the image (rows 64 .. 67: pixels 64, 65 + two zero rows)
+  const int srow = lane >> 4;
+  const int pc = lane & 15;
+  auto swz_of = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+  int d_col[2], x_col[3], x_row[3];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 8 * wave + 4 * q + srow;
+    const int lc = pc ^ swz_of(row);
+    const int co = co0 + lc * 8;
+    d_col[q] = co < p.Cout ? co : -1;
+    x_col[q] = ci0 + lc * 8;
+    x_row[q] = row;
+  }
+  {
+    const int row = 64 + srow;
+    x_col[2] = ci0 + (pc ^ swz_of(row)) * 8;
+    x_row[2] = row;
+  }
+  const int x_shift = (kh - 1) * p.W - 1;            // image row ir <-> pixel m_slice + ir + x_shift
+  auto issue = [&](int sl, int nsl) {
+    const int buf = sl & (kW3NBuf - 1);
+    const int m_base = m_lo + sl * kW3Rows;
+    const bool live = sl < nsl;
+    const unsigned lb = lds_base + (unsigned)(buf * kW3BufBytes + 8 * wave * kRowB);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int m = m_base + 8 * wave + 4 * q + srow;
+      unsigned doff = kOOB;
+      if (live && m < m_hi && d_col[q] >= 0) doff = (unsigned)((((int64_t)m * p.dy_cs) + p.dy_co + d_col[q]) * 2);
+      lds_dma16_t(rsD, lb + (unsigned)(4 * q * kRowB), doff, 0u);
+      const int pix = m_base + x_row[q] + x_shift;
+      unsigned xoff = kOOB;
+      if (live && (unsigned)pix < (unsigned)NHW) xoff = (unsigned)((((int64_t)pix * p.x_cs) + p.x_co + x_col[q]) * 2);
+      lds_dma16_t(rsX, lb + (unsigned)(kDBytes + 4 * q * kRowB), xoff, 0u);
+    }
+    if (wave == 0) {
+      const int pix = m_base + x_row[2] + x_shift;
+      unsigned xoff = kOOB;
+      if (live && x_row[2] < 66 && (unsigned)pix < (unsigned)NHW) xoff = (unsigned)((((int64_t)pix * p.x_cs) + p.x_co + x_col[2]) * 2);
+      lds_dma16_t(rsX, lds_base + (unsigned)(buf * kW3BufBytes + kDBytes + 64 * kRowB), xoff, 0u);
+    }
+  };
+
+  // ---- transposed fragment reads (see conv_wgrad_h16_kernel): lane = 16 g + 4 qq + pp supplies row (block + qq),
+  // columns 4 pp .. 4 pp + 3 of its 16-column half
+  const int g = lane >> 4, i16 = lane & 15;
+  const int hh = g >> 1, colhalf = g & 1;
+  const int qq = i16 >> 2, pp = i16 & 3;
+  auto row_addr = [&](int row, int col_base) -> unsigned {
+    const int chunk = (col_base + 16 * colhalf) / 8 + (pp >> 1);
+    return (unsigned)(kRowB * row + 16 * (chunk ^ swz_of(row)) + 8 * (pp & 1));
+  };
+  unsigned d_rd[2][4][2];                            // dY: [co tile a][step s][j]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) d_rd[a][s][j] = row_addr(16 * s + 8 * hh + 4 * j + qq, wc * 64 + a * 32);
+  const unsigned zero_rd = (unsigned)(kDBytes + kW3ZeroRow * kRowB);
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int nsl = (m_hi - m_lo + kW3Rows - 1) / kW3Rows;
+  // border masks of this lane's eight reduction rows of a slice: bit (s * 2 + j) * 3 + kw set = row contributes to tap kw
+  auto slice_masks = [&](int sl) -> unsigned {
+    unsigned mk = 0u;
+    const int hw = p.H * p.W;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = m_lo + sl * kW3Rows + 16 * s + 8 * hh + 4 * j + qq;
+        unsigned b3 = 0u;
+        if (m < m_hi) {
+          const int n = fd_div(m, p.fd_hw);
+          const int rm = m - n * hw;
+          const int ho = fd_div(rm, p.fd_wo);
+          const int wo = rm - ho * p.W;
+          if ((unsigned)(ho + kh - 1) < (unsigned)p.H)
+            b3 = (wo > 0 ? 1u : 0u) | 2u | (wo + 1 < p.W ? 4u : 0u);
+        }
+        mk |= b3 << ((s * 2 + j) * 3);
+      }
+    return mk;
+  };
+
+  s16x8_t fa[2][2], fb[2][3];                        // fragment sets: step s computes from set s & 1
+#define YV4_W3_LOAD(SET, BUFP, S, MK)                                                                         \
+  {                                                                                                           \
+    const char* db_ = (BUFP);                                                                                 \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                           \
+      const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(db_ + d_rd[a][S][0]));           \
+      const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(db_ + d_rd[a][S][1]));           \
+      fa[SET][a] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);                                   \
+    }                                                                                                         \
+    _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                        \
+      const unsigned r0_ = (((MK) >> (((S) * 2 + 0) * 3 + kw)) & 1u)                                          \
+          ? (unsigned)kDBytes + row_addr(16 * (S) + 8 * hh + qq + kw, wk * 32) : zero_rd;                     \
+      const unsigned r1_ = (((MK) >> (((S) * 2 + 1) * 3 + kw)) & 1u)                                          \
+          ? (unsigned)kDBytes + row_addr(16 * (S) + 8 * hh + 4 + qq + kw, wk * 32) : zero_rd;                 \
+      const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(db_ + r0_));                      \
+      const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(db_ + r1_));                      \
+      fb[SET][kw] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);                                  \
+    }                                                                                                         \
+  }
+#define YV4_W3_MFMA(SET)                                                                                      \
+  {                                                                                                           \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                             \
+      _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                      \
+        if (BF16)                                                                                             \
+          acc[a][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, fa[SET][a]),      \
+                                                               __builtin_bit_cast(bf16x8_w, fb[SET][kw]), acc[a][kw], 0, 0, 0); \
+        else                                                                                                  \
+          acc[a][kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_w, fa[SET][a]),        \
+                                                              __builtin_bit_cast(f16x8_w, fb[SET][kw]), acc[a][kw], 0, 0, 0); \
+      }                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  }
+  // pieces per slice: 4 (5 on wave 0).  In slice t the wave issues DMA(t + 3) BEFORE the wait in front of the last
+  // step, where it needs its own DMA(t + 1) landed: DMA(t + 2) and DMA(t + 3) may stay in flight.
+#define YV4_W3_WAIT()                                                                                         \
+  {                                                                                                           \
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");                               \
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                          \
+  }
+
+  issue(0, nsl);
+  issue(1, nsl);
+  issue(2, nsl);
+  YV4_W3_WAIT();                                      // DMA(0) landed (newer: 1, 2)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  unsigned mk = slice_masks(0);
+  YV4_W3_LOAD(0, smem_w3, 0, mk);
+  for (int sl = 0; sl < nsl; ++sl) {
+    const char* bufp = smem_w3 + (sl & (kW3NBuf - 1)) * kW3BufBytes;
+    const char* nbufp = smem_w3 + ((sl + 1) & (kW3NBuf - 1)) * kW3BufBytes;
+    const unsigned mkn = slice_masks(sl + 1);
+    YV4_W3_LOAD(1, bufp, 1, mk);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_W3_MFMA(0);
+    issue(sl + 3, nsl);                               // into the buffer slice sl - 1 read (freed by the previous barrier)
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_W3_LOAD(0, bufp, 2, mk);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_W3_MFMA(1);
+    YV4_W3_LOAD(1, bufp, 3, mk);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_W3_MFMA(0);
+    YV4_W3_WAIT();                                    // own DMA(sl + 1) landed; every read of slice sl has returned
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    YV4_W3_LOAD(0, nbufp, 0, mkn);                    // (beyond the last slice: zero-filled buffers, never used)
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_W3_MFMA(1);
+    mk = mkn;
+  }
+#undef YV4_W3_WAIT
+#undef YV4_W3_MFMA
+#undef YV4_W3_LOAD
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the dummy tail DMAs must land before the LDS is released
+
+  // D[row = co][col = ci]: row = (e&3) + 8*(e>>2) + 4*(lane>>5), col = lane&31
+  const int r = lane & 31, h5 = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int kcol = (kh * 3 + kw) * p.Cin + ci0 + wk * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wc * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h5;
+        if (co < p.Cout) {
+          if (p.ws) p.ws[(size_t)blockIdx.y * p.ws_stride + (size_t)co * p.K + kcol] = acc[a][kw][e];
+          else atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[a][kw][e]);
+        }
+      }
+    }
+}
+
+// domain of conv_wgrad3x3_h16_kernel
+static bool wgrad3x3_applies(const yv4_conv_desc* d, int dtype) {
+  static const int mode = YV4_ENV_INT("YV4_WGRAD3", 1);
+  return mode && dtype != YV4_F32 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H &&
+         d->Wo == d->W && (d->Cin & 127) == 0 && (long long)d->N * d->H * d->W < (1LL << 30);
+}
+
 // dw[i] += sum over chunks of slab_c[i], in a FIXED order: the deterministic tail of the weight gradient.
 // A workgroup owns 16 float4 columns; its 16 chunk lanes q each add the slabs c = q, q + 16, q + 32, ... in ascending
 // order (independent loads, 4 in flight), the 16 lane sums are then added in lane order.  (One thread per column
@@ -1084,6 +1333,25 @@ static const bool g_wgrad_widen = YV4_ENV_INT("YV4_WGRAD_WIDEN", 0) == 1;
 static void wgrad_chunks(const yv4_conv_desc* d, int dtype, long long* chunks, long long* rows) {
   const long long M = (long long)d->N * d->Ho * d->Wo;
   const int K = d->KH * d->KW * d->Cin;
+  if (!g_wgrad_widen && wgrad3x3_applies(d, dtype)) {
+    // one 8-wave workgroup per CU.  Measured (tools/wgrad_bench.py --det, batch 64): ONE full round of (co tile, kh, ci
+    // tile, chunk) workgroups beats two (half the slab traffic and epilogues: 160 vs 179 us on 128->128 @76) unless the
+    // tiles leave more than ~10 % of the CUs idle (512->1024 @19: 96 tiles x 2 chunks = 192 workgroups, 403 vs 342 us);
+    // never one workgroup beyond a full round (it costs a whole round).
+    const long long tl = (long long)((d->Cout + 127) / 128) * 3 * (d->Cin / 128);
+    static const int cus = YV4_ENV_INT("YV4_WGRAD3_CUS", 256);
+    long long ch = cus / tl;
+    if (ch < 1 || tl * ch * 10 < (long long)cus * 9) ch = (2 * cus) / tl;
+    const long long mx = (M + 8 * kW3Rows - 1) / (8 * kW3Rows);
+    if (ch > mx) ch = mx;
+    if (ch < 1) ch = 1;
+    if (ch > 65535) ch = 65535;
+    long long rw = (M + ch - 1) / ch;
+    rw = (rw + kW3Rows - 1) / kW3Rows * kW3Rows;
+    *rows = rw;
+    *chunks = (M + rw - 1) / rw;
+    return;
+  }
   if (dtype != YV4_F32 && !g_wgrad_widen) {
     const long long tl = (long long)((K + kWhTile - 1) / kWhTile) * ((d->Cout + kWhTile - 1) / kWhTile);
     static const int wg_target = YV4_ENV_INT("YV4_WGRAD_WGS", 1024);
@@ -1157,6 +1425,20 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     YV4_CHECK_LAUNCH("conv_wgrad reduce");
     return YV4_OK;
   };
+  if (!g_wgrad_widen && wgrad3x3_applies(d, dtype)) {
+    const long long tl = (long long)((a.Cout + 127) / 128) * 3 * (a.Cin / 128);
+    static LdsAttrOnce once3b, once3h;
+    if (int rc = ensure_dyn_lds(once3b, reinterpret_cast<const void*>(conv_wgrad3x3_h16_kernel<true>), (size_t)kW3Lds, "conv_wgrad3x3_h16")) return rc;
+    if (int rc = ensure_dyn_lds(once3h, reinterpret_cast<const void*>(conv_wgrad3x3_h16_kernel<false>), (size_t)kW3Lds, "conv_wgrad3x3_h16")) return rc;
+    if (dtype == YV4_BF16)
+      hipLaunchKernelGGL(conv_wgrad3x3_h16_kernel<true>, dim3((unsigned)tl, (unsigned)ch), dim3(kW3Threads), (size_t)kW3Lds,
+                         reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
+    else
+      hipLaunchKernelGGL(conv_wgrad3x3_h16_kernel<false>, dim3((unsigned)tl, (unsigned)ch), dim3(kW3Threads), (size_t)kW3Lds,
+                         reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
+    YV4_CHECK_LAUNCH("conv_wgrad3x3_h16");
+    return finish();
+  }
   if (dtype != YV4_F32 && !g_wgrad_widen) {
     // 16-bit MFMA form: 128 x 128 tiles of dW, 64-row slices
     a.tiles_k = (a.K + kWhTile - 1) / kWhTile;

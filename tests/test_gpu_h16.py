@@ -487,6 +487,47 @@ def test_h16_conv_autograd(gpu_device, dtype, tol, shape):
     assert wr.grad.dtype == torch.float32 and rel(wr.grad, w64.grad) <= max(tol / 4, 2e-3)   # dW accumulates in fp32
 
 
+W3_SHAPES = [
+    # N, Cin, Cout, H, W (3x3, stride 1, pad 1, Cin % 128 == 0): the domain of conv_wgrad3x3_h16_kernel
+    (2, 128, 128, 19, 19),     # two images, ragged last slice (722 rows), image borders inside every slice
+    (3, 256, 64, 7, 5),        # map narrower than a transposed block: many left / right borders; half-empty co tile
+    (1, 128, 128, 1, 300),     # one image row: the kh = 0 / 2 tiles see only padding
+    (5, 128, 192, 3, 3),       # tiny images; Cout tail inside a co tile
+    (4, 384, 136, 16, 16),     # three ci tiles, two co tiles, 1 024 rows
+    (16, 128, 128, 38, 38),    # 23 104 rows: several chunks per tile (the split reduction + ordered slab sum)
+]
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize('shape', W3_SHAPES)
+def test_h16_wgrad3x3_kernel(gpu_device, dtype, tol, shape):
+    """The kw-shared weight-gradient kernel (train.hip conv_wgrad3x3_h16_kernel; auto-selected for 3x3 / stride 1 with
+    Cin % 128 == 0) through ConvFunction, vs fp64 autograd on the same rounded operands; deterministic run to run."""
+    N, Cin, Cout, H, W = shape
+    torch.manual_seed(1)
+    x = torch.randn(N, Cin, H, W, device=gpu_device).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, device=gpu_device) * (Cin * 9) ** -0.5)
+    gy = None
+    grads = []
+    for _ in range(2):
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        y = T.conv2d(xr, wr, 1, 1, dtype=dtype)
+        if gy is None:
+            gy = torch.randn_like(y.float()).to(dtype)
+        y.backward(gy)
+        grads.append(wr.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    x64 = x.double()
+    w64 = w.to(dtype).double().requires_grad_(True)
+    F.conv2d(x64, w64, None, 1, 1).backward(gy.double())
+    err = float((grads[0].double() - w64.grad).abs().max() / (w64.grad.abs().max() + 1e-12))
+    assert err <= 2e-3, err                                             # dW accumulates in fp32
+    # every tap of every (co, ci) block: a shifted-row or masking mistake shows as one wrong (kh, kw) plane
+    per_tap = (grads[0].double() - w64.grad).abs().amax(dim=(0, 1)) / (w64.grad.abs().amax(dim=(0, 1)) + 1e-12)
+    assert float(per_tap.max()) <= 4e-3, per_tap
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.bfloat16, 3e-2), (torch.float16, 4e-3)])
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_h16_bn_act_autograd(gpu_device, dtype, tol, act):
