@@ -460,7 +460,10 @@ int yv4_pack_weight(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kh, in
  * operand and data-gradient operand -- 750 launches of a few microseconds each on YOLOv4-L; the table is built once and
  * replayed after every optimizer step).  The table lives in DEVICE memory; descriptor i serves workgroups
  * [first_block, first_block + nblocks), rows_per_block output rows each (the caller lays the ranges out back to
- * back, total_blocks = their sum); the other fields are yv4_pack_weight's arguments. */
+ * back, total_blocks = their sum); the other fields are yv4_pack_weight's arguments.  Any rows_per_block >= 1 is
+ * correct; the pass is fastest when a workgroup owns whole rows r with all their KHo*KWo taps (forward operand) or groups
+ * of max(8, 64 / taps) such rows (transpose = 1: the source is contiguous ACROSS r), since a workgroup stages the source
+ * box of its rows in LDS in source order. */
 typedef struct yv4_pack_desc {
   const float* w;
   int64_t s_co, s_ci, s_kh, s_kw;

@@ -1252,24 +1252,89 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 
 // The same pass over a TABLE of weights in one launch (yv4_pack_weights_multi): workgroup b serves the descriptor whose
 // [first_block, first_block + nblocks) range holds b, rows_per_block output rows of it.
+//
+// An output row (r, kh, kw) runs over the channel ic; in the SOURCE (an fp32 (Cout, Cin, KH, KW) parameter, normally
+// contiguous) the element sits at r*s_r + ic*s_ic + tap offset, and whichever of the forward operand (s_ic = KH*KW) and
+// the data-gradient operand (s_ic = Cin*KH*KW) is packed, neighbouring ic are 36 bytes or kilobytes apart: reading row
+// by row (round 2) moved 4 bytes per 64- or 128-byte line touched and took 0.87 ms per YOLOv4-L step (64 M parameters,
+// both operands).  Here a workgroup stages a box of the source -- NR rows r x ICc channels x every tap the descriptor
+// uses -- in LDS, walking the source in ITS order (taps fastest, then whichever of r / ic has the smaller stride), and
+// writes the output rows from LDS with the channel across lanes.
+constexpr int kPackStage = 9216;       // floats staged per pass (36 KB)
+
 template <typename T>
-__device__ __forceinline__ void pack_rows(const yv4_pack_desc& d, int row0, int row1) {
+__device__ __forceinline__ void pack_rows(const yv4_pack_desc& d, int row0, int row1, float* stage) {
   const int tf = d.transpose;
   const int IC = tf ? d.Cout : d.Cin;
   const int ICp = (IC + d.pad_to - 1) / d.pad_to * d.pad_to;
   const int taps = d.KHo * d.KWo;
-  const long long s_ic = tf ? d.s_co : d.s_ci;
+  const long long s_ic = tf ? d.s_co : d.s_ci, s_r = tf ? d.s_ci : d.s_co;
   T* dst = reinterpret_cast<T*>(d.dst);
-  for (int row = row0; row < row1; ++row) {
-    const int r = row / taps;
-    const int tap = row - r * taps;
-    const int kh = tap / d.KWo, kw = tap - kh * d.KWo;
-    const float* src = d.w + (d.kh0 + kh * d.kh_step) * d.s_kh + (d.kw0 + kw * d.kw_step) * d.s_kw + (tf ? r * d.s_ci : r * d.s_co);
-    T* o = dst + (size_t)row * ICp;
-    for (int ic = threadIdx.x; ic < ICp; ic += 256) o[ic] = (T)(ic < IC ? src[ic * s_ic] : 0.f);
+  // bounding box of the source taps the descriptor reads
+  const int khl = d.kh0 + (d.KHo - 1) * d.kh_step, kwl = d.kw0 + (d.KWo - 1) * d.kw_step;
+  const int khmin = min(d.kh0, khl), kwmin = min(d.kw0, kwl);
+  const int nbh = abs(khl - d.kh0) + 1, nbw = abs(kwl - d.kw0) + 1;
+  const int TB = nbh * nbw, TBs = TB | 1;                    // odd LDS pitch per (r, ic): channel-strided reads hit all banks
+  const int rA = row0 / taps, rB = (row1 - 1) / taps;        // rows r touched (inclusive)
+  const bool ic_inner = s_ic <= s_r;
+  int NR, ICc;
+  if (ic_inner) {
+    if (ICp * TBs <= kPackStage) { ICc = ICp; NR = min(rB - rA + 1, kPackStage / (ICp * TBs)); }
+    else { NR = 1; ICc = (kPackStage / TBs) & ~7; }
+  } else {
+    NR = min(rB - rA + 1, max(8, 64 / TB));                  // >= 256 contiguous source bytes per ic
+    ICc = min(ICp, (kPackStage / (NR * TBs)) & ~7);
+  }
+  constexpr int VEC = sizeof(T) == 2 ? 2 : 1;                // 16-bit outputs are stored in pairs
+  const FastDiv fd_tb = make_fastdiv((unsigned)TB), fd_bw = make_fastdiv((unsigned)nbw), fd_kwo = make_fastdiv((unsigned)d.KWo),
+                fd_taps = make_fastdiv((unsigned)taps);
+  const int tid = threadIdx.x;
+  for (int r0 = rA; r0 <= rB; r0 += NR) {
+    const int nr = min(NR, rB - r0 + 1);
+    const FastDiv fd_nr = make_fastdiv((unsigned)nr);
+    const int orow0 = max(row0, r0 * taps), orow1 = min(row1, (r0 + nr) * taps);
+    for (int c0 = 0; c0 < ICp; c0 += ICc) {
+      const int cn = min(ICc, ICp - c0);
+      const FastDiv fd_cn = make_fastdiv((unsigned)cn);
+      __syncthreads();                                       // the previous pass has been written out
+      const int total = nr * cn * TB;
+      for (int e = tid; e < total; e += 256) {
+        const int q = fd_div(e, fd_tb), t = e - q * TB;
+        int rl, cl;
+        if (ic_inner) { rl = fd_div(q, fd_cn); cl = q - rl * cn; }
+        else { cl = fd_div(q, fd_nr); rl = q - cl * nr; }
+        const int bh = fd_div(t, fd_bw), bw = t - bh * nbw;
+        const int ic = c0 + cl;
+        float v = 0.f;
+        if (ic < IC) v = d.w[(long long)(r0 + rl) * s_r + (long long)ic * s_ic + (khmin + bh) * d.s_kh + (kwmin + bw) * d.s_kw];
+        stage[(rl * cn + cl) * TBs + t] = v;
+      }
+      __syncthreads();
+      const int cv = cn / VEC;
+      const FastDiv fd_cv = make_fastdiv((unsigned)cv);
+      const int wtotal = (orow1 - orow0) * cv;
+      for (int i = tid; i < wtotal; i += 256) {
+        const int ro = fd_div(i, fd_cv), pc = i - ro * cv;
+        const int row = orow0 + ro;
+        const int r = fd_div(row, fd_taps), tap = row - r * taps;
+        const int kh = fd_div(tap, fd_kwo), kw = tap - kh * d.KWo;
+        const int tb = (d.kh0 + kh * d.kh_step - khmin) * nbw + (d.kw0 + kw * d.kw_step - kwmin);
+        const float* sp = stage + ((r - r0) * cn + pc * VEC) * TBs + tb;
+        T* o = dst + (size_t)row * ICp + c0 + pc * VEC;
+        if constexpr (VEC == 2) {
+          union { T h[2]; unsigned u; } pk;
+          pk.h[0] = (T)sp[0];
+          pk.h[1] = (T)sp[TBs];
+          *reinterpret_cast<unsigned*>(o) = pk.u;
+        } else {
+          o[0] = (T)sp[0];
+        }
+      }
+    }
   }
 }
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const yv4_pack_desc* __restrict__ table, int n) {
+  __shared__ float stage[kPackStage];
   // binary search of the descriptor (uniform per workgroup)
   int lo = 0, hi = n - 1;
   const int b = (int)blockIdx.x;
@@ -1282,10 +1347,11 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const yv4_pack_
   const int nrows = R * d.KHo * d.KWo;
   const int row0 = (b - d.first_block) * d.rows_per_block;
   const int row1 = row0 + d.rows_per_block < nrows ? row0 + d.rows_per_block : nrows;
+  if (row0 >= row1) return;
   switch (d.dtype) {
-    case YV4_F32: pack_rows<float>(d, row0, row1); break;
-    case YV4_F16: pack_rows<_Float16>(d, row0, row1); break;
-    default: pack_rows<__bf16>(d, row0, row1); break;
+    case YV4_F32: pack_rows<float>(d, row0, row1, stage); break;
+    case YV4_F16: pack_rows<_Float16>(d, row0, row1, stage); break;
+    default: pack_rows<__bf16>(d, row0, row1, stage); break;
   }
 }
 

@@ -48,7 +48,7 @@ void set_error(const char* fmt, ...);
 // (the per-row (n, ho, wo) decomposition in the conv prologues: 8 divides per lane were longer than the whole
 // MFMA phase of the K <= 256 layers).  Exact for 0 <= x < 2^31.
 struct FastDiv { unsigned mul, shr; };
-static inline FastDiv make_fastdiv(unsigned d) {
+__host__ __device__ static inline FastDiv make_fastdiv(unsigned d) {
   FastDiv f = {0u, 0u};
   if (d > 1) {
     unsigned lg = 0;

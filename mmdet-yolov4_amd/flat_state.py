@@ -123,14 +123,20 @@ class FlatState:
     # ---- gradients -------------------------------------------------------------------
     def attach_grads(self):
         """Point every trainable parameter's ``.grad`` at its slice of the gradient arena, so
-        autograd accumulates in place (``zero_grad(set_to_none=True)`` detaches them again)."""
-        for seg, p in zip(self.param_segments, self._params):
+        autograd accumulates in place (``zero_grad(set_to_none=True)`` detaches them again).  Runs between the forward
+        and the backward pass of every step (the optimizer hook zeroes there), i.e. on the host's critical path: the
+        slice addresses are computed once, a parameter that already points at its slice costs one comparison."""
+        ptrs = getattr(self, '_grad_ptrs', None)
+        base = self.grads.data_ptr()
+        if ptrs is None or self._grad_ptr_base != base:
+            ptrs = self._grad_ptrs = [base + 4 * seg.offset for seg in self.param_segments]
+            self._grad_ptr_base = base
+        for seg, p, ptr in zip(self.param_segments, self._params, ptrs):
             if p.requires_grad:
                 g = p.grad
-                want = _view_as_param(self.grads, seg)
-                if g is None or g.data_ptr() != want.data_ptr():
-                    p.grad = want
-                p._yv4_grad_in_arena = True      # conv weights: dW may be accumulated here directly (train_ops)
+                if g is None or g.data_ptr() != ptr:
+                    p.grad = _view_as_param(self.grads, seg)
+                    p._yv4_grad_in_arena = True      # conv weights: dW may be accumulated here directly (train_ops)
 
     def zero_grad(self):
         self.grads.zero_()

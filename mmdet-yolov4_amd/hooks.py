@@ -208,8 +208,14 @@ class Fp16GradAccumulateOptimizerHook(Hook):
         first = runner.iter % self.accumulation == 0
         last = (runner.iter + 1) % self.accumulation == 0
         if first:
-            model.zero_grad()
-            runner.optimizer.zero_grad()
+            # the reference zeroes through the model and through the optimizer; with both on the same gradient arena
+            # one memset (and one walk over the parameters) does it
+            fs = getattr(model, '_flat_state', None)
+            if fs is not None and fs is getattr(runner.optimizer, 'flat', None):
+                fs.zero_grad()
+            else:
+                model.zero_grad()
+                runner.optimizer.zero_grad()
         if self.reducer is not None and last:
             self.reducer.arm()
         (runner.outputs['loss'] * self.scale_state[0]).backward()
@@ -224,8 +230,11 @@ class Fp16GradAccumulateOptimizerHook(Hook):
                                  self.work.data_ptr(), self.ctrl.data_ptr(), stream_ptr()), 'yv4_grad_prepare')
         log = getattr(runner, 'log_buffer', None)
         if self.grad_clip is not None and log is not None:
-            c = self.ctrl.tolist()     # the reference's float(grad_norm) synchronises here too
-            log.update({'grad_norm': c[1], 'grad_scale': 1.0 / c[3]}, runner.outputs.get('num_samples', 1))
+            # the reference's float(grad_norm) drains the device here, between the backward pass and the update; the
+            # copy is queued instead and waited for when the log buffer is read
+            from .deferred import read_back_later
+            log.update(read_back_later(self.ctrl, ['grad_norm', 'grad_scale'], lambda c: [c[1], 1.0 / c[3]]),
+                       runner.outputs.get('num_samples', 1))
         runner.optimizer.step(ctrl=self.ctrl)
         if self.dynamic:
             check(L.yv4_loss_scale_update(self.scale_state.data_ptr(), self.ctrl.data_ptr(),
@@ -502,7 +511,8 @@ class LogBuffer:
         self.history = []
 
     def update(self, values, count=1):
-        self.history.append((dict(values), count))
+        # a DeferredLogVars stays as it is (copying it would wait for the device)
+        self.history.append((values if getattr(values, 'pending', False) else dict(values), count))
 
 
 class Runner:

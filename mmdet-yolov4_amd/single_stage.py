@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from .bricks import HipModule, plan_cache_get, plan_cache_put
+from .deferred import DeferredLogVars, read_back_later  # noqa: F401
 from .plan import Plan
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 from .yolocsp_head import collect_results, set_scale_factors
@@ -145,7 +146,8 @@ class SingleStageDetector(HipModule):
         """detectors/base.py:171-204: total = sum of the entries whose key contains 'loss'; every log variable is the
         mean over ranks, returned as a python float.  The reference issues one all-reduce and one ``.item()`` (a host
         sync) PER log variable (base.py:197-202); here the variables are stacked on the device, exchanged by ONE
-        all-reduce and read back by ONE device-to-host copy -- same values, one sync per step."""
+        all-reduce and read back by ONE device-to-host copy -- same values, one sync per step, taken when a value is
+        first read (``DeferredLogVars``)."""
         log_vars = OrderedDict()
         for name, value in losses.items():
             if isinstance(value, torch.Tensor):
@@ -159,6 +161,10 @@ class SingleStageDetector(HipModule):
         stacked = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(stacked.div_(dist.get_world_size()))
+        if stacked.is_cuda:
+            # stream-ordered copy into pinned memory; the host waits for it when a value is first read (see
+            # DeferredLogVars) -- normally after the backward pass has been queued
+            return loss, read_back_later(stacked, list(log_vars))
         for name, value in zip(list(log_vars), stacked.tolist()):
             log_vars[name] = value
         return loss, log_vars

@@ -140,7 +140,7 @@ _PACK_CACHE_ON = os.environ.get('YV4_PACK_CACHE', '1') != '0'
 
 
 class _PackCache:
-    ROWS_TARGET = 4096          # output elements per workgroup
+    ROWS_TARGET = 16384         # output elements per workgroup
 
     def __init__(self, device):
         self.device = device
@@ -184,7 +184,11 @@ class _PackCache:
             d.dst = e['dst'].data_ptr()
             rows = (d.Cin if d.transpose else d.Cout) * d.KHo * d.KWo
             icp = ((d.Cout if d.transpose else d.Cin) + d.pad_to - 1) // d.pad_to * d.pad_to
-            d.rows_per_block = max(1, self.ROWS_TARGET // icp)
+            # whole rows r (all their taps) per workgroup; the data-gradient operand is read ACROSS r (the source is
+            # contiguous along it), so its workgroups take groups of rows (pack_rows in csrc/train.hip)
+            taps = d.KHo * d.KWo
+            group = taps * (max(8, 64 // taps) if d.transpose else 1)
+            d.rows_per_block = group * max(1, self.ROWS_TARGET // (icp * group))
             d.nblocks = (rows + d.rows_per_block - 1) // d.rows_per_block
             d.first_block = blk
             blk += d.nblocks

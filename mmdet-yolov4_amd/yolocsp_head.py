@@ -132,7 +132,7 @@ class YoloLossFunction(torch.autograd.Function):
         n = npos.double()
         has = n > 0
         per_pos = torch.where(has, 1. / n.clamp(min=1), torch.zeros_like(n))
-        boxes = sums.new_tensor([float(N * r.shape[2] * r.shape[3] * A) for r in raws])
+        boxes = _upload(torch.tensor([float(N * r.shape[2] * r.shape[3] * A) for r in raws], dtype=sums.dtype), dev)
         out = torch.stack([sums[:, 0] * per_pos / max(C_, 1) * d.w_cls, sums[:, 1] / boxes * d.w_conf,
                            sums[:, 2] * per_pos * d.w_bbox], dim=1)
         return out.float()
@@ -152,6 +152,16 @@ class YoloLossFunction(torch.autograd.Function):
         d.gpos = gpos.data_ptr()
         check(_lib.lib().yv4_yolo_loss_bwd(C.byref(d), gout.data_ptr(), ops.stream_ptr()), 'yv4_yolo_loss_bwd')
         return (None, None, None, None) + tuple(draws) + tuple(b.float() for b in dbias)
+
+
+def _upload(host, device):
+    """Host tensor -> device through pinned memory, stream-ordered: a pageable source makes the copy wait for
+    everything queued before it (the whole forward pass, when the loss is where it is issued), and with the host
+    parked there the backward pass cannot be queued ahead.  torch's caching host allocator keeps the pinned block
+    until the copy has executed."""
+    if device.type != 'cuda':
+        return host.to(device)
+    return host.pin_memory().to(device, non_blocking=True)
 
 
 class RawPredMap:
@@ -343,7 +353,7 @@ class YOLOCSPHead(HipModule):
     # ---- training (yolocsp_head.py:384-575) -------------------------------------------------------
     def loss(self, pred_maps, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
         device = pred_maps[0].device
-        num_gts = torch.tensor([g.size(0) for g in gt_bboxes], dtype=torch.float32, device=device).mean()
+        num_gts = _upload(torch.tensor([g.size(0) for g in gt_bboxes], dtype=torch.float32).mean(), device)
         pred_maps = [p if isinstance(p, RawPredMap) else p.float() for p in pred_maps]
         featmap_sizes = [pred_maps[i].shape[-2:] for i in range(self.num_levels)]
         if self.assigner is not None:
@@ -386,7 +396,7 @@ class YOLOCSPHead(HipModule):
         sizes = [int(g.shape[0]) for g in gt_bboxes]
         gt = torch.cat(list(gt_bboxes), dim=0).reshape(-1, 4)
         labels = torch.cat(list(gt_labels), dim=0).reshape(-1)
-        img = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(device, non_blocking=True)
+        img = _upload(torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)), device)
         out = YoloLossFunction.apply(self, gt, labels, img, *[p.raw for p in pred_maps], *[p.bias for p in pred_maps])
         l_cls = [out[l, 0].reshape(1) for l in range(self.num_levels)]
         l_conf = [out[l, 1] * self.conf_level_balance_weight[l] for l in range(self.num_levels)]

@@ -354,6 +354,41 @@ def test_wgrad_deterministic_form(gpu_device, dtype):
     assert float((dwn - dwa).abs().max()) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+def test_pack_table_launch_matches_the_per_call_pack(gpu_device, dtype):
+    """``yv4_pack_weights_multi`` (LDS-staged boxes of the source, one launch for the whole table) writes bit for bit
+    what ``yv4_pack_weight`` writes per call: forward operand, data-gradient operand, the four parity classes of a
+    stride-2 layer; 1x1 and 3x3; channel counts that are not multiples of the staging chunk; a channels_last source."""
+    from mmdet_yolov4_amd import train_ops as T
+    torch.manual_seed(3)
+    shapes = [(255, 512, 1), (512, 256, 3), (64, 32, 3), (1024, 512, 3), (96, 1000, 1), (40, 24, 3), (8, 1032, 3)]
+    ws = [torch.nn.Parameter(torch.randn(co, ci, k, k, device=gpu_device)) for co, ci, k in shapes]
+    ws.append(torch.nn.Parameter(torch.randn(48, 72, 3, 3, device=gpu_device).contiguous(memory_format=torch.channels_last)))
+    parity = [((1, 1, 1), (1, 1, 1)), ((1, 1, 1), (2, -2, 2)), ((2, -2, 2), (1, 1, 1)), ((2, -2, 2), (2, -2, 2))]
+
+    def modes(w):
+        m = [dict(), dict(transpose_flip=True)]
+        if w.shape[2] == 3:
+            m += [dict(taps=t) for t in parity]
+        return m
+
+    T.clear_pack_cache()
+    for w in ws:                                    # record every request (each packed per call the first time)
+        for m in modes(w):
+            T.packed_weight(w, dtype, **m)
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5).add_(0.125)                 # version counters move: the next request replays the table
+    table = [[T.packed_weight(w, dtype, **m)[0].clone() for m in modes(w)] for w in ws]
+    assert len(T._PACK_CACHES[gpu_device].entries) == sum(len(modes(w)) for w in ws)
+    for w, got in zip(ws, table):
+        for m, g in zip(modes(w), got):
+            T.clear_pack_cache()
+            want = T.packed_weight(w, dtype, **m)[0]
+            assert torch.equal(g, want), (tuple(w.shape), m)
+    T.clear_pack_cache()
+
+
 def test_packed_weight_cache_follows_the_weights(gpu_device):
     """The recorded operands are re-packed in one launch when the weight's version counter moves (an in-place update,
     an optimizer step), and an operand asked for after that is the fresh one -- for the forward, the data-gradient and

@@ -28,6 +28,9 @@ def main():
     ap.add_argument('--overlap-report', action='store_true',
                     help='record when each gradient bucket becomes exchangeable inside backward (GradReducer timing events) and '
                          'print the share of backward its exchange can overlap; works with one rank (nothing is exchanged)')
+    ap.add_argument('--phase-report', action='store_true',
+                    help='device time (events) and host enqueue time of forward+loss / log-variable readback / backward+update '
+                         'per step: where the device waits for the host')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'],
                     help='activation / conv operand type (master weights, statistics and losses stay fp32)')
     a = ap.parse_args()
@@ -83,6 +86,30 @@ def main():
         runner.call_hook('before_train_epoch')
         last = {}
 
+        phases = []
+
+        def step_phases():
+            # the same calls as step() below with train_step opened up (single_stage.train_step = forward_train +
+            # _parse_losses; forward_train = extract_feat + bbox_head.forward_train)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+            h = [time.perf_counter()]
+            ev[0].record()
+            runner.call_hook('before_train_iter')
+            x = det.extract_feat(data['img'])
+            ev[1].record(); h.append(time.perf_counter())
+            losses = det.bbox_head.forward_train(x, data['img_metas'], data['gt_bboxes'], data['gt_labels'], None)
+            ev[2].record(); h.append(time.perf_counter())
+            loss, log_vars = det._parse_losses(losses)
+            ev[3].record(); h.append(time.perf_counter())
+            loss.register_hook(lambda g: (ev[4].record(), h.append(time.perf_counter()), None)[2])
+            runner.outputs = dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+            runner.call_hook('after_train_iter')
+            ev[5].record(); h.append(time.perf_counter())
+            runner.iter += 1
+            phases.append((ev, h))
+            last['loss'] = log_vars['loss']
+            return last['loss']
+
         def step():
             # exactly what the runner does per iteration (mmcv epoch_based_runner.run_iter): hooks around
             # ``model.train_step`` -- including its log-variable exchange (one all-reduce, one D2H copy = one host
@@ -94,6 +121,8 @@ def main():
             last['loss'] = runner.outputs['log_vars']['loss']
             return last['loss']
 
+    if a.phase_report and not a.torch_optim:
+        step = step_phases
     for _ in range(a.warmup):
         l0 = step()
     red = None
@@ -107,6 +136,18 @@ def main():
         l1 = step()
     D.barrier()
     el = D.max_over_ranks(time.perf_counter() - t0, dev)
+    phase_rep = None
+    if a.phase_report and not a.torch_optim:
+        torch.cuda.synchronize()
+        names = ['backbone+neck+head forward', 'loss forward', 'log_vars (sync)', 'hooks before backward', 'backward+update']
+        dev_ms = [0.0] * 5
+        host_ms = [0.0] * 5
+        tail = phases[-a.steps:]
+        for ev, h in tail:
+            for i in range(5):
+                dev_ms[i] += ev[i].elapsed_time(ev[i + 1]) / len(tail)
+                host_ms[i] += (h[i + 1] - h[i]) * 1e3 / len(tail)
+        phase_rep = {n: dict(device_ms=round(d, 2), host_ms=round(hh, 2)) for n, d, hh in zip(names, dev_ms, host_ms)}
     if rank == 0:
         per_img = {'yolov4l': 108.516e9 / 608.0 ** 2, 'yolov5l': 108.574e9 / 640.0 ** 2, 'yolov4s': 8.942e9 / 416.0 ** 2,
                    'yolov3': 140.692e9 / 608.0 ** 2}    # 75 convs, Plan.total_flops() (= darknet's 140.69 BFLOPs)
@@ -118,7 +159,8 @@ def main():
                               backend=D.backend_name(), grad_exchange=D.exchange_name(a.grad_exchange, world),
                               approx_conv_tflops=round(fl * a.batch * world * a.steps / el / 1e12, 1),
                               peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                              **({'overlap': red.timing_report()} if red is not None else {}))))
+                              **({'overlap': red.timing_report()} if red is not None else {}),
+                              **({'phases': phase_rep} if phase_rep is not None else {}))))
     D.finalize()
 
 
