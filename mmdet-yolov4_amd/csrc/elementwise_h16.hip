@@ -35,19 +35,20 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_h16_kernel(const float* __re
   }
 }
 
-// Small-C form (the 3-channel image padded to one 16-byte chunk, C + pad == 8): one thread per pixel reads its C
-// planar fp32 values (coalesced per plane) and writes 8 sixteen-bit values in one store; grid (pixel blocks, image).
-template <typename T, typename V8>
+// Small-C form (the 3-channel image padded to NV 16-byte chunks, C + pad == 8 NV): one thread per pixel reads its C
+// planar fp32 values (coalesced per plane) and writes 8 NV sixteen-bit values in NV stores; grid (pixel blocks, image).
+template <typename T, typename V8, int NV>
 __global__ __launch_bounds__(256) void nchw_to_nhwc8_h16_kernel(const float* __restrict__ src, T* __restrict__ dst, int C,
                                                                 int HW, int dst_cs, int dst_co) {
   const int n = blockIdx.y;
   const float* s0 = src + (size_t)n * C * HW;
   T* d0 = dst + (size_t)n * HW * dst_cs + dst_co;
   for (int px = blockIdx.x * 256 + threadIdx.x; px < HW; px += gridDim.x * 256) {
-    V8 o;
+    V8 o[NV];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] = (T)(c < C ? s0[(size_t)c * HW + px] : 0.f);
-    *reinterpret_cast<V8*>(d0 + (size_t)px * dst_cs) = o;
+    for (int c = 0; c < 8 * NV; ++c) o[c >> 3][c & 7] = (T)(c < C ? s0[(size_t)c * HW + px] : 0.f);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<V8*>(d0 + (size_t)px * dst_cs + 8 * v) = o[v];
   }
 }
 
@@ -179,15 +180,18 @@ extern "C" int yv4_nchw_to_nhwc_h16(const float* src, void* dst, int N, int C, i
   YV4_REQUIRE(N <= 65535, "nchw_to_nhwc_h16: N > 65535");
   const int HW = H * W;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (C + zero_pad == 8 && dst_cstride % 8 == 0 && dst_coff % 8 == 0 && ((uintptr_t)dst & 15) == 0) {
+  if ((C + zero_pad == 8 || C + zero_pad == 16) && dst_cstride % 8 == 0 && dst_coff % 8 == 0 && ((uintptr_t)dst & 15) == 0) {
     unsigned gx = (unsigned)((HW + 255) / 256);
     if (gx > 4096) gx = 4096;
-    if (dtype == YV4_BF16)
-      hipLaunchKernelGGL((nchw_to_nhwc8_h16_kernel<__bf16, bf16x8_e>), dim3(gx, (unsigned)N), dim3(256), 0, s, src, (__bf16*)dst,
-                         C, HW, dst_cstride, dst_coff);
-    else
-      hipLaunchKernelGGL((nchw_to_nhwc8_h16_kernel<_Float16, f16x8_e>), dim3(gx, (unsigned)N), dim3(256), 0, s, src,
-                         (_Float16*)dst, C, HW, dst_cstride, dst_coff);
+    const bool two = C + zero_pad == 16;
+    const dim3 grid(gx, (unsigned)N);
+    if (dtype == YV4_BF16) {
+      if (two) hipLaunchKernelGGL((nchw_to_nhwc8_h16_kernel<__bf16, bf16x8_e, 2>), grid, dim3(256), 0, s, src, (__bf16*)dst, C, HW, dst_cstride, dst_coff);
+      else hipLaunchKernelGGL((nchw_to_nhwc8_h16_kernel<__bf16, bf16x8_e, 1>), grid, dim3(256), 0, s, src, (__bf16*)dst, C, HW, dst_cstride, dst_coff);
+    } else {
+      if (two) hipLaunchKernelGGL((nchw_to_nhwc8_h16_kernel<_Float16, f16x8_e, 2>), grid, dim3(256), 0, s, src, (_Float16*)dst, C, HW, dst_cstride, dst_coff);
+      else hipLaunchKernelGGL((nchw_to_nhwc8_h16_kernel<_Float16, f16x8_e, 1>), grid, dim3(256), 0, s, src, (_Float16*)dst, C, HW, dst_cstride, dst_coff);
+    }
     YV4_CHECK_LAUNCH("nchw_to_nhwc_h16");
     return YV4_OK;
   }

@@ -1151,76 +1151,135 @@ __global__ __launch_bounds__(256) void spp_pool_bwd_kernel(const T* __restrict__
   }
 }
 
-// The same scatter with the accumulator of one (image, 32-channel group) in LDS: the maps an SPP block sees are
-// small (19x19 at 608 px), so the whole H*W x 32 fp32 slice fits a workgroup's LDS, the 16 adds per element become
-// LDS atomics and dx is written once with plain stores -- the global-atomic form above spends most of its 2 ms
-// (batch 64, 512 channels) on 47 M float atomics into a 47 MB tensor.
-constexpr int kSppCG = 32;     // channels per workgroup
+// The same scatter for the maps an SPP block actually sees (19x19 at 608 px): everything in LDS, and the window
+// argmax found by CASCADED 5x5 pools instead of a 13x13 scan per pixel.
+//   * Every element becomes a KEY: (order-preserving bits of the value) : (all-ones - position).  The maximum key of a
+//     window is its largest value and, among equal values, the smallest position -- the first hit of the row-major scan
+//     `v > best` that torch's pooling (and the kernel above) performs.  Keys make the argmax a plain associative,
+//     idempotent max, so pool9 = pool5 o pool5 and pool13 = pool5 o pool9 exactly (windows clipped at the border), and
+//     each 5x5 pool separates into a row pass and a column pass: 30 LDS reads per element for the three pools instead
+//     of 169 global loads and 507 compare/select pairs (the round-2 form: 0.99 ms at batch 64 x 512 channels).
+//   * one workgroup = one image x CG channels (8 for 16-bit keys, 4 for 64-bit keys of fp32 values): three key planes (in, row-pass, out -- rotated through the cascade)
+//     and the fp32 accumulator plane, H*W x CG each; the three pool gradients go to the accumulator by LDS atomics,
+//     the identity branch by a plain add, and dx is written once.
+template <typename T> struct SppKey;
+template <> struct SppKey<float> {
+  typedef unsigned long long K;
+  static constexpr int CG = 4;
+  static __device__ __forceinline__ K make(float v, int pos) {
+    unsigned b = __float_as_uint(v);
+    if (b == 0x80000000u) b = 0u;                                     // -0 == +0 for `>`
+    b ^= (b & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;
+    return ((K)b << 32) | (K)(0xFFFFFFFFu - (unsigned)pos);
+  }
+  static __device__ __forceinline__ int pos(K k) { return (int)(0xFFFFFFFFu - (unsigned)k); }
+};
+template <typename T> struct SppKey {                                 // _Float16 / __bf16
+  typedef unsigned K;
+  static constexpr int CG = 8;
+  static __device__ __forceinline__ K make(T v, int pos) {
+    unsigned b = (unsigned)__builtin_bit_cast(unsigned short, v);
+    if (b == 0x8000u) b = 0u;
+    b ^= (b & 0x8000u) ? 0xFFFFu : 0x8000u;
+    return (b << 16) | (0xFFFFu - (unsigned)pos);
+  }
+  static __device__ __forceinline__ int pos(K k) { return (int)(0xFFFFu - (k & 0xFFFFu)); }
+};
+
+constexpr int kSppItems = 16;      // (position, channel) items per thread: H*W*CG <= 4096 (the 64 KB LDS bound of the launch)
 template <typename T>
 __global__ __launch_bounds__(256) void spp_pool_bwd_lds_kernel(const T* __restrict__ xcat, int x_cs, int x_co,
                                                                const T* __restrict__ dcat, int d_cs, int d_co,
                                                                float* __restrict__ dx, int H, int W, int C) {
-  extern __shared__ float sacc[];          // [H*W][kSppCG]
+  typedef SppKey<T> SK;
+  typedef typename SK::K K;
+  constexpr int CG = SK::CG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char spp_raw[];
   const int HW = H * W;
+  K* ka = reinterpret_cast<K*>(spp_raw);             // [HW][CG]
+  K* kb = ka + (size_t)HW * CG;
+  K* kc = kb + (size_t)HW * CG;
+  float* acc = reinterpret_cast<float*>(kc + (size_t)HW * CG);
   const int n = blockIdx.y;
-  const int cg0 = blockIdx.x * kSppCG;
-  const int nq = min(kSppCG, C - cg0) >> 2;                 // channel quads of this group
-  for (int i = threadIdx.x; i < HW * kSppCG; i += 256) sacc[i] = 0.f;
-  __syncthreads();
-  const float ninf = -__builtin_huge_valf();
+  const int cg0 = blockIdx.x * CG;
+  const int nc = min(CG, C - cg0);
+  const int items = HW * CG;
   const T* xb = xcat + (size_t)n * HW * x_cs + x_co + cg0;
   const T* gb = dcat + (size_t)n * HW * d_cs + d_co + cg0;
-  for (int item = threadIdx.x; item < HW * 8; item += 256) {
-    const int q = item & 7;
-    if (q >= nq) continue;
-    const int pos0 = item >> 3;
-    const int y = pos0 / W, x = pos0 - y * W;
-    const T* base = xb + q * 4;
-    float m[3][4];
-    int am[3][4];
+  const FastDiv fd_w = make_fastdiv((unsigned)W);
+  // a thread keeps the same items (i = tid + 256 j) through every pass: their coordinates and their three pool gradients
+  // are fetched once, all loads in flight together
+  float g[3][kSppItems];
+  short iy[kSppItems], ix[kSppItems];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+  for (int j = 0; j < kSppItems; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int pos = i / CG, c = i - pos * CG;
+    const int y = fd_div(pos, fd_w);
+    iy[j] = (short)y;
+    ix[j] = (short)(pos - y * W);
+    const bool ok = i < items && c < nc;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { m[k][u] = ninf; am[k][u] = pos0; }
-    for (int dy = -6; dy <= 6; ++dy) {
-      const int yy = y + dy;
-      if ((unsigned)yy >= (unsigned)H) continue;
-      const int ady = dy < 0 ? -dy : dy;
-      for (int dxx = -6; dxx <= 6; ++dxx) {
-        const int xx = x + dxx;
-        if ((unsigned)xx >= (unsigned)W) continue;
-        const int adx = dxx < 0 ? -dxx : dxx;
-        const int rad = ady > adx ? ady : adx;
-        const int pos = yy * W + xx;
-        const float4 v4 = El<T>::ld4(base + (size_t)pos * x_cs);
-        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (v[u] > m[2][u]) { m[2][u] = v[u]; am[2][u] = pos; }
-          if (rad <= 4 && v[u] > m[1][u]) { m[1][u] = v[u]; am[1][u] = pos; }
-          if (rad <= 2 && v[u] > m[0][u]) { m[0][u] = v[u]; am[0][u] = pos; }
-        }
-      }
-    }
-    const T* g = gb + (size_t)pos0 * d_cs + q * 4;
-    const float4 g0 = El<T>::ld4(g);
-    const float gi[4] = {g0.x, g0.y, g0.z, g0.w};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) atomicAdd(&sacc[pos0 * kSppCG + q * 4 + u], gi[u]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float4 gk = El<T>::ld4(g + (k + 1) * C);
-      const float gv[4] = {gk.x, gk.y, gk.z, gk.w};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) atomicAdd(&sacc[am[k][u] * kSppCG + q * 4 + u], gv[u]);
+    for (int k = 0; k < 3; ++k) g[k][j] = ok ? (float)gb[(size_t)pos * d_cs + (size_t)(k + 1) * C + c] : 0.f;
+    if (i < items) {
+      ka[i] = ok ? SK::make(xb[(size_t)pos * x_cs + c], pos) : (K)0;
+      acc[i] = ok ? (float)gb[(size_t)pos * d_cs + c] : 0.f;     // the identity branch's gradient
     }
   }
   __syncthreads();
-  float* out = dx + (size_t)n * HW * C + cg0;
-  for (int i = threadIdx.x; i < HW * 8; i += 256) {
-    const int q = i & 7, pos = i >> 3;
-    if (q < nq)
-      *reinterpret_cast<float4*>(out + (size_t)pos * C + q * 4) = *reinterpret_cast<const float4*>(&sacc[pos * kSppCG + q * 4]);
+  K* src = ka; K* tmp = kb; K* out = kc;
+#pragma unroll 1
+  for (int k = 0; k < 3; ++k) {
+    // row pass: tmp(y, x) = max src(y, x-2 .. x+2)
+#pragma unroll
+    for (int j = 0; j < kSppItems; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < items) {
+        const int c = i & (CG - 1), y = iy[j], x = ix[j];
+        const K* row = src + (size_t)y * W * CG + c;
+        K m = row[x * CG];
+#pragma unroll
+        for (int d = -2; d <= 2; ++d) {
+          if (d == 0) continue;
+          const int xx = min(max(x + d, 0), W - 1);              // a clamped neighbour repeats an element of the window
+          const K v = row[xx * CG];
+          m = v > m ? v : m;
+        }
+        tmp[i] = m;
+      }
+    }
+    __syncthreads();
+    // column pass + scatter of this pool's gradient to its argmax
+#pragma unroll
+    for (int j = 0; j < kSppItems; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < items) {
+        const int c = i & (CG - 1), y = iy[j], x = ix[j];
+        const K* col = tmp + (size_t)x * CG + c;
+        K m = col[(size_t)y * W * CG];
+#pragma unroll
+        for (int d = -2; d <= 2; ++d) {
+          if (d == 0) continue;
+          const int yy = min(max(y + d, 0), H - 1);
+          const K v = col[(size_t)yy * W * CG];
+          m = v > m ? v : m;
+        }
+        out[i] = m;
+        const float gv = k == 0 ? g[0][j] : (k == 1 ? g[1][j] : g[2][j]);
+        if (c < nc) atomicAdd(&acc[SK::pos(m) * CG + c], gv);
+      }
+    }
+    __syncthreads();
+    K* t = src; src = out; out = t;                  // the pooled keys feed the next 5x5 pool
+  }
+  float* o = dx + (size_t)n * HW * C + cg0;
+#pragma unroll
+  for (int j = 0; j < kSppItems; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    if (i < items) {
+      const int pos = i / CG, c = i - pos * CG;
+      if (c < nc) o[(size_t)pos * C + c] = acc[i];
+    }
   }
 }
 
@@ -1298,16 +1357,29 @@ __device__ __forceinline__ void pack_rows(const yv4_pack_desc& d, int row0, int 
       const FastDiv fd_cn = make_fastdiv((unsigned)cn);
       __syncthreads();                                       // the previous pass has been written out
       const int total = nr * cn * TB;
-      for (int e = tid; e < total; e += 256) {
-        const int q = fd_div(e, fd_tb), t = e - q * TB;
-        int rl, cl;
-        if (ic_inner) { rl = fd_div(q, fd_cn); cl = q - rl * cn; }
-        else { cl = fd_div(q, fd_nr); rl = q - cl * nr; }
-        const int bh = fd_div(t, fd_bw), bw = t - bh * nbw;
-        const int ic = c0 + cl;
-        float v = 0.f;
-        if (ic < IC) v = d.w[(long long)(r0 + rl) * s_r + (long long)ic * s_ic + (khmin + bh) * d.s_kh + (kwmin + bw) * d.s_kw];
-        stage[(rl * cn + cl) * TBs + t] = v;
+      // eight independent loads in flight per thread (the staging is latency-bound otherwise)
+      for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+        float v[8];
+        int li[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + 256 * u;
+          v[u] = 0.f;
+          li[u] = -1;
+          if (e < total) {
+            const int q = fd_div(e, fd_tb), t = e - q * TB;
+            int rl, cl;
+            if (ic_inner) { rl = fd_div(q, fd_cn); cl = q - rl * cn; }
+            else { cl = fd_div(q, fd_nr); rl = q - cl * nr; }
+            const int bh = fd_div(t, fd_bw), bw = t - bh * nbw;
+            const int ic = c0 + cl;
+            li[u] = (rl * cn + cl) * TBs + t;
+            if (ic < IC) v[u] = d.w[(long long)(r0 + rl) * s_r + (long long)ic * s_ic + (khmin + bh) * d.s_kh + (kwmin + bw) * d.s_kw];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (li[u] >= 0) stage[li[u]] = v[u];
       }
       __syncthreads();
       const int cv = cn / VEC;
@@ -1788,9 +1860,11 @@ extern "C" int yv4_spp_pool_bwd(const void* xcat, int x_cstride, int x_coff, con
   YV4_REQUIRE(((C | x_cstride | x_coff | d_cstride | d_coff) & 3) == 0, "spp_pool_bwd: channels must be multiples of 4");
   YV4_REQUIRE(x_coff + C <= x_cstride && d_coff + 4 * C <= d_cstride, "spp_pool_bwd: view exceeds its pixel stride");
   YV4_REQUIRE((long long)H * W < (1LL << 31), "spp_pool_bwd: H*W does not fit 31 bits");
-  const size_t lds = (size_t)H * W * kSppCG * sizeof(float);
-  if (lds <= 64 * 1024 && N <= 65535) {        // small maps: LDS-resident accumulator, dx written once
-    dim3 grid((unsigned)((C + kSppCG - 1) / kSppCG), (unsigned)N);
+  const bool f32 = dtype == YV4_F32;
+  const int cg = f32 ? SppKey<float>::CG : SppKey<__bf16>::CG;
+  const size_t lds = (size_t)H * W * cg * (3 * (f32 ? 8 : 4) + 4);
+  if (lds <= 64 * 1024 && N <= 65535 && (long long)H * W * cg <= 256 * kSppItems) {   // small maps: keys and accumulator LDS-resident
+    dim3 grid((unsigned)((C + cg - 1) / cg), (unsigned)N);
     YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(spp_pool_bwd_lds_kernel<T>, grid, dim3(256), lds,
                                              reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(xcat),
                                              x_cstride, x_coff, reinterpret_cast<const T*>(dcat), d_cstride, d_coff, dx, H,

@@ -27,6 +27,7 @@ from . import train_ops as T
 from .plan import act_id, bn_affine
 
 _CONV_STATS = os.environ.get('YV4_CONV_STATS', '1') != '0'    # BN statistics in the conv epilogue (A/B switch)
+_CAT_SLOTS = os.environ.get('YV4_CAT_SLOTS', '1') != '0'      # CSP halves written straight into the concat buffer (A/B switch)
 from .registry import BACKBONES
 
 
@@ -92,16 +93,26 @@ class Conv(HipModule):
                          name=name or f'conv{self.kernel_size}x{self.kernel_size}',
                          bn1=(self.norm, 0, self.out_channels) if self.with_norm else None, bn2=bn2)
 
-    def fwd(self, x, residual=None, sink=None, res_sink=None):
+    def fwd(self, x, residual=None, sink=None, res_sink=None, cat=None):
         """``sink`` / ``res_sink``: a ``train_ops.GradSink`` this conv's data gradient consumes / the residual's
-        gradient is parked in (both ends of a Bottleneck's shortcut, see ``Bottleneck.fwd``)."""
+        gradient is parked in (both ends of a Bottleneck's shortcut, see ``Bottleneck.fwd``).  ``cat``: a
+        ``train_ops.CatSlot`` -- the activation is written into its concat buffer, which is returned."""
         w = self.conv.weight
         dt = T.train_dtype(self, x)
         al = 4 if dt == torch.float32 else 8
         if x.shape[1] % al:          # the 3-channel image: zero-pad x and the weight to one 16-byte chunk
-            padc = al - x.shape[1] % al
-            x = F.pad(x, (0, 0, 0, 0, 0, padc))
-            w = F.pad(w, (0, 0, 0, 0, 0, padc))
+            if (dt != torch.float32 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+                    and not x.requires_grad and x.shape[1] < 16 and self.kernel_size == 3 and self.stride == 1
+                    and self.padding == 1):
+                # 16-bit stem: 16 channels per pixel, the narrowest input of the few-channel 3x3 kernel
+                # (conv3x3_small_h16.hip; the generic tile's per-lane (tap, channel) decode of a 72-wide K takes
+                # 1.6 ms for this HBM-bound layer at 64 x 608 x 608), converted from the fp32 NCHW batch in one pass
+                # (the weight keeps its 3 channels: ConvFunction packs it to x's width and takes dW over 8)
+                x = T.image_to_nhwc16(x, dt, 16)
+            else:
+                padc = al - x.shape[1] % al
+                x = F.pad(x, (0, 0, 0, 0, 0, padc))
+                w = F.pad(w, (0, 0, 0, 0, 0, padc))
         if self.with_norm:      # batch statistics in training mode, running statistics under norm_eval / frozen stages
             bn = self.norm
             stats = None
@@ -113,10 +124,11 @@ class Conv(HipModule):
                     stats = self._yv4_stats = T.conv_stats_buffer(w.shape[0], x.device, persistent=True)
             try:
                 y = T.conv2d(x, w, self.stride, self.padding, dtype=dt, stats=stats, sink=sink)
-                return T.bn_act(y, bn, act_id(self.activate), residual, sums=stats, res_sink=res_sink)
+                return T.bn_act(y, bn, act_id(self.activate), residual, sums=stats, res_sink=res_sink, cat=cat)
             except Exception:
                 self._yv4_stats = None       # a half-used statistics buffer is not clean: drop it
                 raise
+        assert cat is None, 'a concat slot needs the fused BN path'
         y = T.conv2d(x, w, self.stride, self.padding, dtype=dt)
         if self.conv.bias is not None:
             y = y + self.conv.bias.view(1, -1, 1, 1)
@@ -136,8 +148,15 @@ def _spp_cat(mod, x):
     return torch.cat([x] + [mp(x) for mp in mod.maxpools], 1)
 
 
-def bare_conv_fwd(conv, x):
-    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0])      # follows x's dtype
+def bare_conv_fwd(conv, x, cat=None):
+    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0], cat=cat)      # follows x's dtype
+
+
+def _cat_ok(mod, *xs):
+    """The producers of a CSP concat write straight into the concat buffer (``train_ops.CatSlot``) when every half has
+    a channel count the kernels can address (a whole number of 16-byte chunks) and the fused BN path is on."""
+    al = 4 if T.train_dtype(mod, xs[0]) == torch.float32 else 8
+    return _CAT_SLOTS and mod.hidden % al == 0 and all(x.is_cuda for x in xs)
 
 
 def emit_bare_conv(plan, conv, x, stage, out=None, name='conv1x1_bare'):
@@ -170,14 +189,14 @@ class Bottleneck(HipModule):
         y = self.conv1.emit(plan, x)
         return self.conv2.emit(plan, y, out=out, residual=x if self.shortcut else None, post=post)
 
-    def fwd(self, x):
+    def fwd(self, x, cat=None):
         if not self.shortcut:
-            return self.conv2.fwd(self.conv1.fwd(x))
+            return self.conv2.fwd(self.conv1.fwd(x), cat=cat)
         # out = x + f(x): d_out reaches x twice; the second path is added inside conv1's data-gradient launch
         # (train_ops.GradSink) instead of by autograd's add kernel -- when both convs run the fused BN path
         sink = T.grad_sink_for(x) if (self.conv1.with_norm and self.conv2.with_norm and self.conv1.stride == 1
                                       and T.train_dtype(self, x) == x.dtype) else None
-        return self.conv2.fwd(self.conv1.fwd(x, sink=sink), residual=x, res_sink=sink)
+        return self.conv2.fwd(self.conv1.fwd(x, sink=sink), residual=x, res_sink=sink, cat=cat)
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')
@@ -229,7 +248,12 @@ class BottleneckCSP(HipModule):
         y = self.conv1.fwd(x)
         for b in self.bottlenecks:
             y = b.fwd(y)
-        z = torch.cat((bare_conv_fwd(self.conv3, y), bare_conv_fwd(self.conv2, x)), dim=1)
+        h = self.hidden
+        if _cat_ok(self, x, y):      # both bare convs write their half of the concat buffer
+            z = bare_conv_fwd(self.conv3, y, cat=T.CatSlot(2 * h, 0))
+            z = bare_conv_fwd(self.conv2, x, cat=T.CatSlot(2 * h, h, z))
+        else:
+            z = torch.cat((bare_conv_fwd(self.conv3, y), bare_conv_fwd(self.conv2, x)), dim=1)
         return self.conv4.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
 
     def forward(self, x):
@@ -270,9 +294,15 @@ class BottleneckCSP2(HipModule):
     def fwd(self, x):
         x1 = self.conv1.fwd(x)
         y1 = x1
-        for b in self.bottlenecks:
-            y1 = b.fwd(y1)
-        z = torch.cat((y1, bare_conv_fwd(self.conv2, x1)), dim=1)
+        h = self.hidden
+        n = len(self.bottlenecks)
+        slot = n > 0 and _cat_ok(self, x1) and all(b.conv2.with_norm for b in self.bottlenecks)
+        for i, b in enumerate(self.bottlenecks):     # the last bottleneck's activation lands in the concat buffer
+            y1 = b.fwd(y1, cat=T.CatSlot(2 * h, 0) if slot and i == n - 1 else None)
+        if slot:
+            z = bare_conv_fwd(self.conv2, x1, cat=T.CatSlot(2 * h, h, y1))
+        else:
+            z = torch.cat((y1, bare_conv_fwd(self.conv2, x1)), dim=1)
         return self.conv3.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
 
     def forward(self, x):
@@ -347,8 +377,13 @@ class SPPV4(HipModule):
 
     def fwd(self, x):
         x1 = self.conv4.fwd(self.conv3.fwd(self.conv1.fwd(x)))
-        y1 = self.conv6.fwd(self.conv5.fwd(_spp_cat(self, x1)))
-        z = torch.cat((y1, bare_conv_fwd(self.conv2, x)), dim=1)
+        h = self.hidden
+        if _cat_ok(self, x, x1) and self.conv6.with_norm:
+            z = self.conv6.fwd(self.conv5.fwd(_spp_cat(self, x1)), cat=T.CatSlot(2 * h, 0))
+            z = bare_conv_fwd(self.conv2, x, cat=T.CatSlot(2 * h, h, z))
+        else:
+            y1 = self.conv6.fwd(self.conv5.fwd(_spp_cat(self, x1)))
+            z = torch.cat((y1, bare_conv_fwd(self.conv2, x)), dim=1)
         return self.conv7.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
 
     def forward(self, x):

@@ -33,6 +33,17 @@ def to_nhwc(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
+def image_to_nhwc16(x, dtype, channels):
+    """fp32 NCHW image batch -> dense 16-bit NHWC with ``channels`` per pixel (the real ones, then zeros) in ONE pass
+    (``yv4_nchw_to_nhwc_h16``); returned as the logical (N, channels, H, W) channels_last tensor the conv ops take.
+    ATen needs a zero fill, a padded copy, a cast and a layout copy for the same result (0.66 ms at 64 x 3 x 608 x 608)."""
+    N, C_, H, W = x.shape
+    out = torch.empty((N, channels, H, W), device=x.device, dtype=dtype, memory_format=torch.channels_last)
+    check(_lib.lib().yv4_nchw_to_nhwc_h16(x.data_ptr(), out.data_ptr(), N, C_, H, W, channels, 0, channels - C_,
+                                          _DCODE[dtype], stream_ptr()), 'yv4_nchw_to_nhwc_h16')
+    return out
+
+
 import os as _os0
 
 _SLICE_GRADS = _os0.environ.get('YV4_SLICE_GRADS', '1') != '0'     # A/B switch
@@ -71,7 +82,8 @@ def _identity_affine(device, C_):
 _DCODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
-def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None, x_cs=None, residual=None, res_cs=None):
+def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None, x_cs=None, residual=None, res_cs=None,
+                 y_cs=None, y_co=0):
     """Identity-epilogue conv of a channels_last tensor; fp32, or fp16 / bf16 operands (fp32 accumulate).
     ``stats``: a float64 buffer of ``STATS_REPLICAS * 2 * Cout`` entries that receives the BatchNorm sums of the
     output (``yv4_conv_fwd_stats``: accumulated in the conv kernel's epilogue)."""
@@ -80,7 +92,8 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None,
     d = ConvDesc()
     d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin_p, Ho, Wo, Cout
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-    d.x_cstride, d.y_cstride = (x_cs if x_cs is not None else Cin_p), Cout
+    d.x_cstride, d.y_cstride = (x_cs if x_cs is not None else Cin_p), (y_cs if y_cs is not None else Cout)
+    d.y_coff = y_co
     if residual is not None:        # out = conv + residual (a gradient that joins this one: see GradSink)
         assert stats is None and residual.dtype == x.dtype
         d.r_cstride, d.r_coff = (res_cs if res_cs is not None else Cout), 0
@@ -233,7 +246,7 @@ def clear_pack_cache():
     _PACK_CACHES.clear()
 
 
-def packed_weight(weight, dtype, transpose_flip=False, taps=None, owner=None):
+def packed_weight(weight, dtype, transpose_flip=False, taps=None, owner=None, pad_to=None):
     """The conv kernels' weight operand from an fp32 (Cout, Cin, KH, KW) parameter in one launch (``yv4_pack_weight``):
     rows x (KH'*KW'*Cp), K ordered (kh, kw, channel), channels zero-padded to a 16-byte chunk, cast to ``dtype``.
     ``transpose_flip``: the data gradient's operand (rows = Cin, channels = Cout, taps mirrored).  ``taps``:
@@ -242,9 +255,13 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None, owner=None):
     next refresh overwrites: use it on the current stream before the weights change again (the conv launches do).
     ``owner``: the parameter ``weight`` is a detached alias of (``conv2d`` hands ``ConvFunction`` the detached weight
     when dW goes straight into ``weight.grad``): the table records and weakly references the OWNER, so a fresh alias
-    per step still hits its entry."""
+    per step still hits its entry.  ``pad_to``: pad the channels to a multiple of this instead of one 16-byte chunk (the
+    stem: 3 input channels against an activation stored with 16)."""
     Cout, Cin, KH, KW = weight.shape
     al = 4 if dtype == torch.float32 else 8
+    if pad_to is not None:
+        assert pad_to % al == 0
+        al = pad_to
     transpose = bool(transpose_flip or taps is not None)
     rows, ic = (Cin, Cout) if transpose else (Cout, Cin)
     cp = (ic + al - 1) // al * al
@@ -262,7 +279,7 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None, owner=None):
         ident.data_ptr() == weight.data_ptr()
     cacheable = _PACK_CACHE_ON and persistent and w.dtype == torch.float32 and w.is_cuda
     cache = None
-    mode = (bool(transpose_flip), taps)
+    mode = (bool(transpose_flip), taps, al)
     if cacheable:
         cache = _PACK_CACHES.get(w.device)
         if cache is None:
@@ -427,26 +444,48 @@ class ConvFunction(torch.autograd.Function):
     master copy the optimizer steps; autocast semantics of the reference's Fp16 hook)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, dtype, stats=None, direct=None, sink=None):
+    def forward(ctx, x, weight, stride, pad, dtype, stats=None, direct=None, sink=None, cat_buf=None, cat_total=0,
+                cat_off=0):
         """``direct``: a ``_ParamRef`` to the parameter whose ``.grad`` receives dW in place (then ``weight`` is the
-        detached parameter: autograd does not track it through this Function, see ``conv2d``)."""
+        detached parameter: autograd does not track it through this Function, see ``conv2d``).
+        ``cat_total`` > 0: the output is channels [cat_off, cat_off + Cout) of a (N, cat_total, Ho, Wo) concat buffer --
+        ``cat_buf`` if given (written in place and returned), else a fresh one whose other channels a later producer
+        fills (see ``CatSlot``)."""
         _need_cuda(x, 'x')
         ctx.direct = direct
         ctx.sink = sink if stride == 1 else None     # (the stride-2 parity form has no residual input)
         Cout, Cin, KH, KW = weight.shape
         al = 4 if dtype == torch.float32 else 8
-        assert x.shape[1] == Cin and Cout % al == 0 and Cin % al == 0, \
-            f'training conv needs channel counts that are multiples of {al} (got {Cin}->{Cout})'
+        xc = x.shape[1]
+        # ``x`` may carry MORE channels than the weight (zeros: the image stored with a whole number of 16-byte chunks
+        # per pixel, ``image_to_nhwc16``): the forward operand is packed to x's width, the weight gradient is taken
+        # over the weight's own (padded) channels with x's pixel stride; such an x has no gradient
+        assert xc >= Cin and Cout % al == 0 and xc % al == 0 and (xc == Cin or not ctx.needs_input_grad[0]), \
+            f'training conv needs channel counts that are multiples of {al} (got {xc}/{Cin}->{Cout})'
         ctx.x_dtype = x.dtype
         x = to_nhwc(x.to(dtype))
         N, _, H, W = x.shape
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        wp, cp = packed_weight(weight, dtype, owner=direct.p if direct is not None else None)
-        y = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=dtype, memory_format=torch.channels_last)
-        _conv_launch(x, wp, cp, Cout, KH, KW, stride, pad, y, stats)
+        wp, cp = packed_weight(weight, dtype, owner=direct.p if direct is not None else None,
+                               pad_to=xc if xc != Cin else None)
+        assert cp == xc
+        ctx.cat = None
+        if cat_total:
+            assert stats is None and cat_off % al == 0 and cat_off + Cout <= cat_total
+            if cat_buf is None:
+                y = torch.empty((N, cat_total, Ho, Wo), device=x.device, dtype=dtype, memory_format=torch.channels_last)
+            else:
+                assert tuple(cat_buf.shape) == (N, cat_total, Ho, Wo) and cat_buf.dtype == dtype and _is_nhwc(cat_buf)
+                y = cat_buf
+                ctx.mark_dirty(cat_buf)
+            ctx.cat = (cat_off, cat_buf is not None)
+            _conv_launch(x, wp, cp, Cout, KH, KW, stride, pad, y, None, y_cs=cat_total, y_co=cat_off)
+        else:
+            y = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=dtype, memory_format=torch.channels_last)
+            _conv_launch(x, wp, cp, Cout, KH, KW, stride, pad, y, stats)
         ctx.save_for_backward(x, weight)
-        ctx.geom = (stride, pad, dtype, cp)
+        ctx.geom = (stride, pad, dtype, (Cin + al - 1) // al * al)
         return y
 
     @staticmethod
@@ -455,6 +494,11 @@ class ConvFunction(torch.autograd.Function):
         stride, pad, dtype, cp = ctx.geom
         Cout, Cin, KH, KW = weight.shape
         N, _, H, W = x.shape
+        dcat = None
+        if ctx.cat is not None:          # dy is the gradient of the whole concat buffer: this conv's slice of it,
+            off, passed = ctx.cat        # and the buffer's gradient handed on to the producer of the other channels
+            dcat = dy if passed else None
+            dy = dy[:, off:off + Cout]
         dy, dy_cs = nhwc_or_slice(dy, dtype)
         Ho, Wo = dy.shape[2], dy.shape[3]
         L = _lib.lib()
@@ -468,7 +512,7 @@ class ConvFunction(torch.autograd.Function):
             d = ConvDesc()
             d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, cp, Ho, Wo, Cout
             d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-            d.x_cstride, d.y_cstride = cp, dy_cs
+            d.x_cstride, d.y_cstride = x.shape[1], dy_cs
             if _WGRAD_ATOMIC:
                 if h16:
                     check(L.yv4_conv_wgrad_h16(C.byref(d), code, x.data_ptr(), dy.data_ptr(), dwp.data_ptr(),
@@ -512,7 +556,7 @@ class ConvFunction(torch.autograd.Function):
             dx = dx.to(ctx.x_dtype)
         elif ctx.sink is not None and ctx.sink.value is not None:
             dx, ctx.sink.value = ctx.sink.value, None       # nobody wants this conv's share: hand the parked one on
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, dcat, None, None
 
 
 def train_dtype(module, x):
@@ -524,17 +568,34 @@ def train_dtype(module, x):
     return x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
 
 
-def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None, sink=None):
+class CatSlot:
+    """Where a producer writes inside a channel-concat buffer instead of returning a tensor of its own that
+    ``torch.cat`` would copy: ``CatSlot(total, offset)`` for the FIRST producer (it allocates the (N, total, H, W)
+    buffer and returns it), ``CatSlot(total, offset, buf)`` for every further one (``buf`` = what the previous producer
+    returned; it is written in place and returned again).  The gradient of the buffer reaches every producer's
+    backward whole; each takes its own channel slice (a strided view, no copy)."""
+    __slots__ = ('total', 'off', 'buf')
+
+    def __init__(self, total, off, buf=None):
+        self.total, self.off, self.buf = int(total), int(off), buf
+
+    def args(self):
+        return self.buf, self.total, self.off
+
+
+def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None, sink=None, cat=None):
     """``dtype`` None: follow ``x`` (a 16-bit activation keeps the path 16-bit, anything else is fp32).
-    ``stats``: see ``_conv_launch`` / ``conv_stats_buffer``; pass the same buffer to ``bn_act(..., sums=)``."""
+    ``stats``: see ``_conv_launch`` / ``conv_stats_buffer``; pass the same buffer to ``bn_act(..., sums=)``.
+    ``cat``: a ``CatSlot`` -- the result is the concat buffer with this conv's channels written."""
     if dtype is None:
         dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
+    cargs = cat.args() if cat is not None else (None, 0, 0)
     if (_DIRECT_WGRAD and weight.requires_grad and weight.is_leaf and x.requires_grad and torch.is_grad_enabled()
             and _direct_grad_target(weight, weight.shape[1]) is not None
             and weight.shape[1] % (4 if dtype == torch.float32 else 8) == 0):
         # dW goes straight into weight.grad (see the note above ConvFunction): the Function sees the detached weight
-        return ConvFunction.apply(x, weight.detach(), stride, pad, dtype, stats, _ParamRef(weight), sink)
-    return ConvFunction.apply(x, weight, stride, pad, dtype, stats, None, sink)
+        return ConvFunction.apply(x, weight.detach(), stride, pad, dtype, stats, _ParamRef(weight), sink, *cargs)
+    return ConvFunction.apply(x, weight, stride, pad, dtype, stats, None, sink, *cargs)
 
 
 def stats_numel(cout):
@@ -558,7 +619,7 @@ class BNActFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual, training=True,
-                sync_group=None, sums=None, direct=None, res_sink=None):
+                sync_group=None, sums=None, direct=None, res_sink=None, cat_buf=None, cat_total=0, cat_off=0):
         """``sync_group``: None, or a (process group or 'world') to synchronise the batch statistics over
         (torch.nn.SyncBatchNorm semantics: statistics over all ranks' rows, local dgamma / dbeta).
         ``sums``: the replicated [sum | sum of squares] buffer the producing conv filled (``conv2d(stats=)``):
@@ -618,12 +679,25 @@ class BNActFunction(torch.autograd.Function):
             mean.copy_(running_mean.detach().float())
             torch.rsqrt(running_var.detach().float() + eps, out=invstd)
         res = to_nhwc(residual.to(x.dtype)) if residual is not None else None
-        y = torch.empty_like(x, memory_format=torch.channels_last)
+        ctx.cat = None
+        y_cs, y_co = Cc, 0
+        if cat_total:                # the output is a channel slice of a concat buffer (``CatSlot``)
+            assert cat_off % (4 if x.dtype == torch.float32 else 8) == 0 and cat_off + Cc <= cat_total
+            if cat_buf is None:
+                y = torch.empty((N, cat_total, H, W), device=dev, dtype=x.dtype, memory_format=torch.channels_last)
+            else:
+                assert tuple(cat_buf.shape) == (N, cat_total, H, W) and cat_buf.dtype == x.dtype and _is_nhwc(cat_buf)
+                y = cat_buf
+                ctx.mark_dirty(cat_buf)
+            ctx.cat = (cat_off, cat_buf is not None)
+            y_cs, y_co = cat_total, cat_off
+        else:
+            y = torch.empty_like(x, memory_format=torch.channels_last)
         g = gamma.detach().float().contiguous()
         b = beta.detach().float().contiguous()
         check(L.yv4_bn_act_fwd_h16(x.data_ptr(), code, Cc, 0, mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),
-                                   b.data_ptr(), res.data_ptr() if res is not None else None, Cc, 0, y.data_ptr(), Cc,
-                                   0, M, Cc, int(act), float(slope), stream_ptr()), 'yv4_bn_act_fwd')
+                                   b.data_ptr(), res.data_ptr() if res is not None else None, Cc, 0, y.data_ptr(), y_cs,
+                                   y_co, M, Cc, int(act), float(slope), stream_ptr()), 'yv4_bn_act_fwd')
         ctx.save_for_backward(x, mean, invstd, g, b)
         ctx.direct = direct      # (_ParamRef(weight), _ParamRef(bias)): dgamma / dbeta are added to their .grad in place
         ctx.bwd_work = bwd_work  # 2*C doubles already cleared by the finalize kernel, or None
@@ -638,9 +712,14 @@ class BNActFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x, mean, invstd, g, b = ctx.saved_tensors
         act, slope = ctx.act
+        N, Cc, H, W = x.shape
+        dcat = None
+        if ctx.cat is not None:
+            off, passed = ctx.cat
+            dcat = dy if passed else None
+            dy = dy[:, off:off + Cc]
         dy, dcs = nhwc_or_slice(dy, x.dtype)
         code = _DCODE[x.dtype]
-        N, Cc, H, W = x.shape
         M = N * H * W
         dev = x.device
         dx = torch.empty_like(x, memory_format=torch.channels_last)
@@ -693,7 +772,7 @@ class BNActFunction(torch.autograd.Function):
                 for cb in _direct_grad_listeners:
                     cb(ref.p)
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None, None, None, dcat, None, None
 
 
 def _sync_group(bn):
@@ -711,7 +790,7 @@ def _sync_group(bn):
     return group if group is not None else 'world'
 
 
-def bn_act(x, bn, act=(0, 0.0), residual=None, sums=None, res_sink=None):
+def bn_act(x, bn, act=(0, 0.0), residual=None, sums=None, res_sink=None, cat=None):
     """``bn``: a torch BatchNorm2d; in training mode it normalises with batch statistics and updates
     the running ones, in eval mode (``norm_eval`` / frozen stages inside a training graph) with the
     running statistics as constants.  act = (YV4_ACT_*, slope)."""
@@ -727,7 +806,8 @@ def bn_act(x, bn, act=(0, 0.0), residual=None, sums=None, res_sink=None):
     out = BNActFunction.apply(x, gamma, beta, bn.running_mean if bn.track_running_stats else None,
                               bn.running_var if bn.track_running_stats else None, bn.eps, mom, act[0], act[1],
                               residual, use_batch, _sync_group(bn) if use_batch else None,
-                              sums if use_batch else None, direct, res_sink)
+                              sums if use_batch else None, direct, res_sink,
+                              *(cat.args() if cat is not None else (None, 0, 0)))
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         if _fwd_depth[0] > 0:        # inside a registered module's training forward: one multi-tensor add at its end
             _nbt_pending.append(bn.num_batches_tracked)

@@ -244,6 +244,55 @@ def test_spp_backward_lds_and_atomic_forms(gpu_device, shape):
     torch.testing.assert_close(xr.grad, x2.grad, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('block', ['csp', 'csp2', 'csp2_shortcut', 'sppv4'])
+def test_csp_halves_written_into_the_concat_buffer(gpu_device, monkeypatch, block, dtype):
+    """``train_ops.CatSlot``: the producers of a CSP concat (two bare convs; a bottleneck's BN + act + shortcut and a bare
+    conv; SPPV4's conv6 and conv2) write their channel halves of the concat buffer and the buffer's gradient reaches each
+    of them whole -- against the same module run through ``torch.cat`` (YV4_CAT_SLOTS off): identical outputs,
+    gradients of the input and of every parameter equal up to the BN reductions' atomic order."""
+    from mmdet_yolov4_amd import darknetcsp as D
+    from mmdet_yolov4_amd import train_ops as T
+    torch.manual_seed(5)
+    kw = dict(norm_cfg=dict(type='BN'), act_cfg=dict(type='Mish'))
+    if block == 'csp':
+        mod = D.BottleneckCSP(32, 64, repetition=2, **kw)
+    elif block == 'csp2':
+        mod = D.BottleneckCSP2(32, 32, repetition=2, shortcut=False, **kw)
+    elif block == 'csp2_shortcut':
+        mod = D.BottleneckCSP2(48, 24, repetition=1, shortcut=True, **kw)
+    else:
+        mod = D.SPPV4(64, 32, **kw)
+    mod = mod.to(gpu_device).train()
+    if dtype != torch.float32:
+        pkg.wrap_fp16_model(mod, dtype)
+    cin = 48 if block == 'csp2_shortcut' else (64 if block == 'sppv4' else 32)
+    x0 = torch.randn(3, cin, 19, 21, device=gpu_device).to(dtype).contiguous(memory_format=torch.channels_last)
+
+    def run(slots):
+        monkeypatch.setattr(D, '_CAT_SLOTS', slots)
+        mod.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        out = mod(x)
+        T.flush_batch_counters()
+        gout = torch.linspace(-1, 1, out.numel(), device=gpu_device).view_as(out).to(out.dtype)
+        out.backward(gout)
+        return out.detach().float(), x.grad.float(), [p.grad.detach().float().clone() for p in mod.parameters()]
+
+    launches = []
+    real_cat = torch.cat
+    monkeypatch.setattr(torch, 'cat', lambda *a, **k: (launches.append(1), real_cat(*a, **k))[1])
+    out_a, dx_a, gp_a = run(True)
+    n_slots = len(launches)
+    out_b, dx_b, gp_b = run(False)
+    assert len(launches) - n_slots == n_slots + 1          # the CSP concat itself is the one torch.cat that went away
+    assert torch.equal(out_a, out_b)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((dx_a - dx_b).abs().max()) <= tol * float(dx_b.abs().max())
+    for a, b in zip(gp_a, gp_b):
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6)
+
+
 def test_direct_gradient_accumulation_matches_autograd(gpu_device):
     """Conv dW and BatchNorm dgamma / dbeta written straight into the flat gradient arena (train_ops' direct path:
     detached weights, kernels that accumulate) over two micro-batches == autograd's own accumulation on a copy of
