@@ -148,8 +148,18 @@ def _spp_cat(mod, x):
     return torch.cat([x] + [mp(x) for mp in mod.maxpools], 1)
 
 
-def bare_conv_fwd(conv, x, cat=None):
-    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0], cat=cat)      # follows x's dtype
+def bare_conv_fwd(conv, x, cat=None, park=None):
+    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0], cat=cat, park=park)      # follows x's dtype
+
+
+def _fanout_sink(first, x):
+    """``x`` feeds ``first`` (a ``Conv`` with the fused BN path, stride 1) and a bare conv that writes the SECOND half of
+    the concat buffer: the bare conv's backward necessarily runs before ``first``'s (the buffer's gradient passes
+    through it on the way to the producer of the first half), so it parks its data gradient in this sink and
+    ``first``'s data-gradient launch adds it -- autograd's add kernel over the whole activation goes away."""
+    if first.with_norm and first.stride == 1 and T.train_dtype(first, x) == x.dtype:
+        return T.grad_sink_for(x)
+    return None
 
 
 def _cat_ok(mod, *xs):
@@ -189,9 +199,12 @@ class Bottleneck(HipModule):
         y = self.conv1.emit(plan, x)
         return self.conv2.emit(plan, y, out=out, residual=x if self.shortcut else None, post=post)
 
-    def fwd(self, x, cat=None):
+    def fwd(self, x, cat=None, sink=None):
+        """``sink``: a ``GradSink`` another consumer of ``x`` parks its data gradient in (``_fanout_sink``); only
+        without a shortcut -- with one, conv1's single joining input is the shortcut's gradient."""
         if not self.shortcut:
-            return self.conv2.fwd(self.conv1.fwd(x), cat=cat)
+            return self.conv2.fwd(self.conv1.fwd(x, sink=sink), cat=cat)
+        assert sink is None
         # out = x + f(x): d_out reaches x twice; the second path is added inside conv1's data-gradient launch
         # (train_ops.GradSink) instead of by autograd's add kernel -- when both convs run the fused BN path
         sink = T.grad_sink_for(x) if (self.conv1.with_norm and self.conv2.with_norm and self.conv1.stride == 1
@@ -245,13 +258,15 @@ class BottleneckCSP(HipModule):
         return self.conv4.emit(plan, cat, out=out)
 
     def fwd(self, x):
-        y = self.conv1.fwd(x)
+        h = self.hidden
+        slot = _cat_ok(self, x)
+        sink = _fanout_sink(self.conv1, x) if slot else None
+        y = self.conv1.fwd(x, sink=sink)
         for b in self.bottlenecks:
             y = b.fwd(y)
-        h = self.hidden
-        if _cat_ok(self, x, y):      # both bare convs write their half of the concat buffer
+        if slot:                     # both bare convs write their half of the concat buffer
             z = bare_conv_fwd(self.conv3, y, cat=T.CatSlot(2 * h, 0))
-            z = bare_conv_fwd(self.conv2, x, cat=T.CatSlot(2 * h, h, z))
+            z = bare_conv_fwd(self.conv2, x, cat=T.CatSlot(2 * h, h, z), park=sink)
         else:
             z = torch.cat((bare_conv_fwd(self.conv3, y), bare_conv_fwd(self.conv2, x)), dim=1)
         return self.conv4.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
@@ -297,10 +312,11 @@ class BottleneckCSP2(HipModule):
         h = self.hidden
         n = len(self.bottlenecks)
         slot = n > 0 and _cat_ok(self, x1) and all(b.conv2.with_norm for b in self.bottlenecks)
+        sink = _fanout_sink(self.bottlenecks[0].conv1, x1) if slot and not self.bottlenecks[0].shortcut else None
         for i, b in enumerate(self.bottlenecks):     # the last bottleneck's activation lands in the concat buffer
-            y1 = b.fwd(y1, cat=T.CatSlot(2 * h, 0) if slot and i == n - 1 else None)
+            y1 = b.fwd(y1, cat=T.CatSlot(2 * h, 0) if slot and i == n - 1 else None, sink=sink if i == 0 else None)
         if slot:
-            z = bare_conv_fwd(self.conv2, x1, cat=T.CatSlot(2 * h, h, y1))
+            z = bare_conv_fwd(self.conv2, x1, cat=T.CatSlot(2 * h, h, y1), park=sink)
         else:
             z = torch.cat((y1, bare_conv_fwd(self.conv2, x1)), dim=1)
         return self.conv3.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
@@ -376,11 +392,13 @@ class SPPV4(HipModule):
         return self.conv7.emit(plan, cat, out=out)
 
     def fwd(self, x):
-        x1 = self.conv4.fwd(self.conv3.fwd(self.conv1.fwd(x)))
+        slot = _cat_ok(self, x) and self.conv6.with_norm
+        sink = _fanout_sink(self.conv1, x) if slot else None
+        x1 = self.conv4.fwd(self.conv3.fwd(self.conv1.fwd(x, sink=sink)))
         h = self.hidden
-        if _cat_ok(self, x, x1) and self.conv6.with_norm:
+        if slot:
             z = self.conv6.fwd(self.conv5.fwd(_spp_cat(self, x1)), cat=T.CatSlot(2 * h, 0))
-            z = bare_conv_fwd(self.conv2, x, cat=T.CatSlot(2 * h, h, z))
+            z = bare_conv_fwd(self.conv2, x, cat=T.CatSlot(2 * h, h, z), park=sink)
         else:
             y1 = self.conv6.fwd(self.conv5.fwd(_spp_cat(self, x1)))
             z = torch.cat((y1, bare_conv_fwd(self.conv2, x)), dim=1)

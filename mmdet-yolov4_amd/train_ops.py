@@ -445,14 +445,16 @@ class ConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride, pad, dtype, stats=None, direct=None, sink=None, cat_buf=None, cat_total=0,
-                cat_off=0):
+                cat_off=0, park=None):
         """``direct``: a ``_ParamRef`` to the parameter whose ``.grad`` receives dW in place (then ``weight`` is the
         detached parameter: autograd does not track it through this Function, see ``conv2d``).
         ``cat_total`` > 0: the output is channels [cat_off, cat_off + Cout) of a (N, cat_total, Ho, Wo) concat buffer --
         ``cat_buf`` if given (written in place and returned), else a fresh one whose other channels a later producer
-        fills (see ``CatSlot``)."""
+        fills (see ``CatSlot``).  ``park``: a ``GradSink`` that receives this conv's data gradient instead of autograd
+        (x also feeds a conv whose backward runs LATER and adds the parked gradient in its own launch)."""
         _need_cuda(x, 'x')
         ctx.direct = direct
+        ctx.park = park
         ctx.sink = sink if stride == 1 else None     # (the stride-2 parity form has no residual input)
         Cout, Cin, KH, KW = weight.shape
         al = 4 if dtype == torch.float32 else 8
@@ -556,7 +558,10 @@ class ConvFunction(torch.autograd.Function):
             dx = dx.to(ctx.x_dtype)
         elif ctx.sink is not None and ctx.sink.value is not None:
             dx, ctx.sink.value = ctx.sink.value, None       # nobody wants this conv's share: hand the parked one on
-        return dx, dw, None, None, None, None, None, None, dcat, None, None
+        if ctx.park is not None and dx is not None:
+            ctx.park.value, ctx.park.cs = dx, None          # joins the other consumer's data gradient (GradSink)
+            dx = None
+        return dx, dw, None, None, None, None, None, None, dcat, None, None, None
 
 
 def train_dtype(module, x):
@@ -583,7 +588,7 @@ class CatSlot:
         return self.buf, self.total, self.off
 
 
-def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None, sink=None, cat=None):
+def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None, sink=None, cat=None, park=None):
     """``dtype`` None: follow ``x`` (a 16-bit activation keeps the path 16-bit, anything else is fp32).
     ``stats``: see ``_conv_launch`` / ``conv_stats_buffer``; pass the same buffer to ``bn_act(..., sums=)``.
     ``cat``: a ``CatSlot`` -- the result is the concat buffer with this conv's channels written."""
@@ -594,8 +599,8 @@ def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None, sink=None, cat=No
             and _direct_grad_target(weight, weight.shape[1]) is not None
             and weight.shape[1] % (4 if dtype == torch.float32 else 8) == 0):
         # dW goes straight into weight.grad (see the note above ConvFunction): the Function sees the detached weight
-        return ConvFunction.apply(x, weight.detach(), stride, pad, dtype, stats, _ParamRef(weight), sink, *cargs)
-    return ConvFunction.apply(x, weight, stride, pad, dtype, stats, None, sink, *cargs)
+        return ConvFunction.apply(x, weight.detach(), stride, pad, dtype, stats, _ParamRef(weight), sink, *cargs, park)
+    return ConvFunction.apply(x, weight, stride, pad, dtype, stats, None, sink, *cargs, park)
 
 
 def stats_numel(cout):
