@@ -77,6 +77,7 @@ struct WgradArgs {
   int x_cs, x_co, dy_cs, dy_co;
   int M, K;
   int tiles_k, rows_per_chunk;
+  int tiles = 0, chunks = 0, xcd_map = 0;   // see wgrad_tile_chunk
   FastDiv fd_hw, fd_wo;     // m / (Ho*Wo), r / Wo: the per-slice row decode sits inside the pipelined loop
   // deterministic form: chunk c of the M reduction stores its partial dW to slab c of ws ([chunks][Cout][K], plain
   // stores); wgrad_reduce_kernel then adds the slabs to dw in chunk order.  ws == nullptr: float atomics into dw.
@@ -85,6 +86,36 @@ struct WgradArgs {
 };
 
 constexpr int kWgRows = 32;   // reduction rows per slice
+
+// Which (dW tile, reduction chunk) a workgroup serves.  All tiles of ONE chunk read the same rows of dY and of the
+// activation (each its own columns, but whole 128-byte lines), and a layer whose dW has several tiles re-reads its
+// operands once per tile column / row -- from HBM, when the tiles of a chunk sit on different XCDs: workgroups go to
+// the 8 XCDs round-robin by linear id and every XCD has its own L2.  With xcd_map the grid is one-dimensional and
+// workgroup L serves chunk 8 g + (L mod 8), tile j of it, with L / 8 = g * tiles + j: a chunk's tiles are neighbours in
+// the launch order of ONE XCD, so the re-reads hit that XCD's L2, while the eight XCDs still sweep the reduction range
+// side by side.  (Dealing each XCD one contiguous eighth of the (chunk, tile) pairs instead was measured too: the same
+// gain on the 1x1 layers, but 20-30 % SLOWER on the HBM-bound few-channel layers at 304 / 608 pixels, whose XCDs then
+// stream from eight distant regions.)  Batch 64, same box: 64->128 s2 @304 623 -> 461 us, 128->256 s2 @152 487 -> 379,
+// 256->256 1x1 @38 41 -> 32; network 449 -> 478 TFLOP/s.  The chunk count is rounded to a multiple of 8 for it
+// (wgrad_chunks).  Slabs and their summation order are indexed by the chunk, not by the workgroup: the result does
+// not depend on the mapping.
+__device__ __forceinline__ bool wgrad_tile_chunk(const int tiles, const int chunks, const int xcd_map, int& tile, int& chunk) {
+  if (!xcd_map) {
+    tile = (int)blockIdx.x;
+    chunk = (int)blockIdx.y;
+    return true;
+  }
+  const unsigned L = blockIdx.x;
+  const unsigned j = L >> 3;
+  const unsigned g = j / (unsigned)tiles;
+  tile = (int)(j - g * (unsigned)tiles);
+  chunk = (int)(g * 8u + (L & 7u));
+  return chunk < chunks;
+}
+static inline dim3 wgrad_grid(long long tiles, long long chunks, int xcd_map) {
+  if (!xcd_map) return dim3((unsigned)tiles, (unsigned)chunks);
+  return dim3((unsigned)((chunks + 7) / 8 * 8 * tiles), 1u);
+}
 
 // T = float: rows of 64 floats (256 B), one LDS-DMA instruction of a wave covers 4 rows.
 // T = _Float16 / __bf16: rows of 64 elements (128 B), one instruction covers 8 rows; the operands are
@@ -232,11 +263,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(WgradArgs p, uns
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int tile_k = blockIdx.x % p.tiles_k;
-  const int tile_c = blockIdx.x / p.tiles_k;
+  int tile_id, chunk;
+  if (!wgrad_tile_chunk(p.tiles, p.chunks, p.xcd_map, tile_id, chunk)) return;
+  const int tile_k = tile_id % p.tiles_k;
+  const int tile_c = tile_id / p.tiles_k;
   const int co0 = tile_c * kWhTile;
   const int k0 = tile_k * kWhTile;
-  const int m_lo = blockIdx.y * p.rows_per_chunk;
+  const int m_lo = chunk * p.rows_per_chunk;
   const int m_hi = min(m_lo + p.rows_per_chunk, p.M);
   if (m_lo >= m_hi) return;
 
@@ -372,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(WgradArgs p, uns
       for (int e = 0; e < 16; ++e) {
         const int co = co0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h5;
         if (co < p.Cout) {
-          if (p.ws) p.ws[(size_t)blockIdx.y * p.ws_stride + (size_t)co * p.K + kcol] = acc[a][b][e];
+          if (p.ws) p.ws[(size_t)chunk * p.ws_stride + (size_t)co * p.K + kcol] = acc[a][b][e];
           else atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[a][b][e]);
         }
       }
@@ -417,12 +450,13 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
 
   // tile: (co tile, kh, ci tile), ci fastest
   const int tiles_ci = p.Cin >> 7;
-  const int tile = (int)blockIdx.x;
+  int tile, chunk;
+  if (!wgrad_tile_chunk(p.tiles, p.chunks, p.xcd_map, tile, chunk)) return;
   const int tci = tile % tiles_ci;
   const int kh = (tile / tiles_ci) % 3;
   const int tco = tile / (3 * tiles_ci);
   const int co0 = tco * 128, ci0 = tci * 128;
-  const int m_lo = (int)blockIdx.y * p.rows_per_chunk;
+  const int m_lo = chunk * p.rows_per_chunk;
   const int m_hi = min(m_lo + p.rows_per_chunk, p.M);
   if (m_lo >= m_hi) return;
   const int NHW = p.N * p.H * p.W;
@@ -614,7 +648,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
       for (int e = 0; e < 16; ++e) {
         const int co = co0 + wc * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h5;
         if (co < p.Cout) {
-          if (p.ws) p.ws[(size_t)blockIdx.y * p.ws_stride + (size_t)co * p.K + kcol] = acc[a][kw][e];
+          if (p.ws) p.ws[(size_t)chunk * p.ws_stride + (size_t)co * p.K + kcol] = acc[a][kw][e];
           else atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[a][kw][e]);
         }
       }
@@ -1466,6 +1500,8 @@ static const bool g_bn_vec8 = YV4_ENV_INT("YV4_BN_VEC8", 0) == 1;
 // test / ablation switch: route 16-bit inputs through the widening fp32-MFMA kernel instead of the
 // 16-bit MFMA one (YV4_WGRAD_WIDEN=1 in the environment)
 static const bool g_wgrad_widen = YV4_ENV_INT("YV4_WGRAD_WIDEN", 0) == 1;
+// measurement switch: the XCD-aware (tile, chunk) mapping of the 16-bit weight-gradient kernels (wgrad_tile_chunk)
+static const bool g_wgrad_xcd = YV4_ENV_INT("YV4_WGRAD_XCD", 1) != 0;
 
 // split of the M reduction into chunks (shared by the launch and by yv4_conv_wgrad_workspace)
 static void wgrad_chunks(const yv4_conv_desc* d, int dtype, long long* chunks, long long* rows) {
@@ -1498,7 +1534,8 @@ static void wgrad_chunks(const yv4_conv_desc* d, int dtype, long long* chunks, l
     const long long mx = (M + min_slices * kWhRows - 1) / (min_slices * kWhRows);   // at least min_slices per chunk
     if (ch > mx) ch = mx;
     if (ch < 1) ch = 1;
-    if (ch > 65535) ch = 65535;
+    if (tl >= 2 && ch >= 16) ch = (ch + 7) / 8 * 8;       // whole groups of 8 chunks, one per XCD (wgrad_tile_chunk)
+    if (ch > 65528) ch = 65528;
     long long rw = (M + ch - 1) / ch;
     rw = (rw + kWhRows - 1) / kWhRows * kWhRows;
     *rows = rw;
@@ -1568,11 +1605,15 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     static LdsAttrOnce once3b, once3h;
     if (int rc = ensure_dyn_lds(once3b, reinterpret_cast<const void*>(conv_wgrad3x3_h16_kernel<true>), (size_t)kW3Lds, "conv_wgrad3x3_h16")) return rc;
     if (int rc = ensure_dyn_lds(once3h, reinterpret_cast<const void*>(conv_wgrad3x3_h16_kernel<false>), (size_t)kW3Lds, "conv_wgrad3x3_h16")) return rc;
+    a.tiles = (int)tl;
+    a.chunks = (int)ch;
+    a.xcd_map = 0;         // (one round of workgroups, compute-bound: the mapping gains nothing here)
+    const dim3 grid3 = wgrad_grid(tl, ch, a.xcd_map);
     if (dtype == YV4_BF16)
-      hipLaunchKernelGGL(conv_wgrad3x3_h16_kernel<true>, dim3((unsigned)tl, (unsigned)ch), dim3(kW3Threads), (size_t)kW3Lds,
+      hipLaunchKernelGGL(conv_wgrad3x3_h16_kernel<true>, grid3, dim3(kW3Threads), (size_t)kW3Lds,
                          reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
     else
-      hipLaunchKernelGGL(conv_wgrad3x3_h16_kernel<false>, dim3((unsigned)tl, (unsigned)ch), dim3(kW3Threads), (size_t)kW3Lds,
+      hipLaunchKernelGGL(conv_wgrad3x3_h16_kernel<false>, grid3, dim3(kW3Threads), (size_t)kW3Lds,
                          reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
     YV4_CHECK_LAUNCH("conv_wgrad3x3_h16");
     return finish();
@@ -1586,11 +1627,15 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     static LdsAttrOnce once_b, once_h;
     if (int rc = ensure_dyn_lds(once_b, reinterpret_cast<const void*>(conv_wgrad_h16_kernel<true>), ldsh, "conv_wgrad_h16")) return rc;
     if (int rc = ensure_dyn_lds(once_h, reinterpret_cast<const void*>(conv_wgrad_h16_kernel<false>), ldsh, "conv_wgrad_h16")) return rc;
+    a.tiles = (int)tl;
+    a.chunks = (int)ch;
+    a.xcd_map = g_wgrad_xcd && tl >= 2 && ch >= 16 && tl * (ch + 8) < (1LL << 31) ? 1 : 0;
+    const dim3 grid = wgrad_grid(tl, ch, a.xcd_map);
     if (dtype == YV4_BF16)
-      hipLaunchKernelGGL(conv_wgrad_h16_kernel<true>, dim3((unsigned)tl, (unsigned)ch), dim3(256), ldsh,
+      hipLaunchKernelGGL(conv_wgrad_h16_kernel<true>, grid, dim3(256), ldsh,
                          reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
     else
-      hipLaunchKernelGGL(conv_wgrad_h16_kernel<false>, dim3((unsigned)tl, (unsigned)ch), dim3(256), ldsh,
+      hipLaunchKernelGGL(conv_wgrad_h16_kernel<false>, grid, dim3(256), ldsh,
                          reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
     YV4_CHECK_LAUNCH("conv_wgrad_h16");
     return finish();
