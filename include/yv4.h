@@ -421,7 +421,7 @@ int yv4_bn_act_bwd_accum(const void* x, int dtype, int x_cstride, int x_coff, co
 int yv4_bn_partial_sums(const void* x, int dtype, int64_t M, int C, int x_cstride, int x_coff,
                         double* work, void* stream);
 /* The statistics pass fused into the producing convolution: y = conv(x, w) with the identity epilogue
- * (`ones` / `zeros`: Cout unit scales / zero shifts, dense output: y_cstride == Cout, y_coff == 0) and
+ * (`ones` / `zeros`: Cout unit scales / zero shifts; y may be a channel slice of a wider buffer) and
  * stats = YV4_STATS_REPLICAS x [sum y (Cout) | sum y^2 (Cout)] doubles whose column sums are the
  * per-channel totals (the kernel spreads its atomics over the replicas; the buffer is cleared here).
  * dtype YV4_F32 / YV4_F16 / YV4_BF16 = type of x, w and y.  Feed it to yv4_bn_finalize with

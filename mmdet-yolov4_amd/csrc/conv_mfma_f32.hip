@@ -1378,8 +1378,8 @@ extern "C" int yv4_conv_fwd_stats(const yv4_conv_desc* d, int dtype, const void*
                                   const float* zeros, void* y, double* stats, int stats_is_zero, void* stream) {
   YV4_REQUIRE(d && stats, "conv_fwd_stats: null argument");
   YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "conv_fwd_stats: dtype must be f32, f16 or bf16");
-  YV4_REQUIRE(d->y_coff == 0 && d->y_cstride == d->Cout && d->act1 == YV4_ACT_NONE,
-              "conv_fwd_stats: dense output and identity epilogue only");
+  YV4_REQUIRE(d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_cstride && d->act1 == YV4_ACT_NONE,
+              "conv_fwd_stats: the output view exceeds its pixel stride, or the epilogue is not the identity");
   if (!stats_is_zero &&
       hipMemsetAsync(stats, 0, sizeof(double) * YV4_STATS_REPLICAS * 2 * d->Cout, reinterpret_cast<hipStream_t>(stream)) !=
           hipSuccess) {
@@ -1391,7 +1391,7 @@ extern "C" int yv4_conv_fwd_stats(const yv4_conv_desc* d, int dtype, const void*
   const int rc = conv_f32_impl(d, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(w), ones, zeros, nullptr,
                                nullptr, nullptr, reinterpret_cast<float*>(y), stats, &done, stream);
   if (rc != YV4_OK || done) return rc;
-  return yv4_bn_partial_sums(y, YV4_F32, (int64_t)d->N * d->Ho * d->Wo, d->Cout, d->Cout, 0, stats, stream);
+  return yv4_bn_partial_sums(y, YV4_F32, (int64_t)d->N * d->Ho * d->Wo, d->Cout, d->y_cstride, d->y_coff, stats, stream);
 }
 
 // The stem of the 16-bit path: fp32 image (NHWC, C padded to 4) and fp32 weights in, fp32 MFMA,

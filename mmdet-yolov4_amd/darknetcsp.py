@@ -148,8 +148,21 @@ def _spp_cat(mod, x):
     return torch.cat([x] + [mp(x) for mp in mod.maxpools], 1)
 
 
-def bare_conv_fwd(conv, x, cat=None, park=None):
-    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0], cat=cat, park=park)      # follows x's dtype
+def bare_conv_fwd(conv, x, cat=None, park=None, stats=None):
+    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0], cat=cat, park=park, stats=stats)   # follows x's dtype
+
+
+def _cat_stats(mod, channels, device):
+    """Persistent, kept-clean statistics buffers (``train_ops.conv_stats_buffer``) for the convs that fill the channel
+    ranges of ``mod``'s concat buffer, or None when the joint BatchNorm does not take batch statistics from one rank
+    (eval-mode BN inside a training graph, SyncBN: those keep the statistics pass over the buffer)."""
+    bn = mod.bn
+    if not _CONV_STATS or not (bn.training or not bn.track_running_stats) or T._sync_group(bn) is not None:
+        return None
+    st = getattr(mod, '_yv4_cat_stats', None)
+    if st is None or st[0].device != device or [b.numel() for b in st] != [T.stats_numel(c) for c in channels]:
+        st = mod._yv4_cat_stats = [T.conv_stats_buffer(c, device, persistent=True) for c in channels]
+    return st
 
 
 def _fanout_sink(first, x):
@@ -264,11 +277,16 @@ class BottleneckCSP(HipModule):
         y = self.conv1.fwd(x, sink=sink)
         for b in self.bottlenecks:
             y = b.fwd(y)
-        if slot:                     # both bare convs write their half of the concat buffer
-            z = bare_conv_fwd(self.conv3, y, cat=T.CatSlot(2 * h, 0))
-            z = bare_conv_fwd(self.conv2, x, cat=T.CatSlot(2 * h, h, z), park=sink)
-        else:
-            z = torch.cat((bare_conv_fwd(self.conv3, y), bare_conv_fwd(self.conv2, x)), dim=1)
+        if slot:                     # both bare convs write their half of the concat buffer ...
+            st = _cat_stats(self, (h, h), x.device)      # ... and leave the joint BatchNorm's sums of their channels
+            z = bare_conv_fwd(self.conv3, y, cat=T.CatSlot(2 * h, 0), stats=st[0] if st else None)
+            z = bare_conv_fwd(self.conv2, x, cat=T.CatSlot(2 * h, h, z), park=sink, stats=st[1] if st else None)
+            try:
+                return self.conv4.fwd(T.bn_act(z, self.bn, act_id(self.csp_act), sums=st))
+            except Exception:
+                self._yv4_cat_stats = None       # half-used statistics buffers are not clean: drop them
+                raise
+        z = torch.cat((bare_conv_fwd(self.conv3, y), bare_conv_fwd(self.conv2, x)), dim=1)
         return self.conv4.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
 
     def forward(self, x):

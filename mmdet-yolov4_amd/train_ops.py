@@ -474,7 +474,7 @@ class ConvFunction(torch.autograd.Function):
         assert cp == xc
         ctx.cat = None
         if cat_total:
-            assert stats is None and cat_off % al == 0 and cat_off + Cout <= cat_total
+            assert cat_off % al == 0 and cat_off + Cout <= cat_total
             if cat_buf is None:
                 y = torch.empty((N, cat_total, Ho, Wo), device=x.device, dtype=dtype, memory_format=torch.channels_last)
             else:
@@ -482,7 +482,7 @@ class ConvFunction(torch.autograd.Function):
                 y = cat_buf
                 ctx.mark_dirty(cat_buf)
             ctx.cat = (cat_off, cat_buf is not None)
-            _conv_launch(x, wp, cp, Cout, KH, KW, stride, pad, y, None, y_cs=cat_total, y_co=cat_off)
+            _conv_launch(x, wp, cp, Cout, KH, KW, stride, pad, y, stats, y_cs=cat_total, y_co=cat_off)
         else:
             y = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=dtype, memory_format=torch.channels_last)
             _conv_launch(x, wp, cp, Cout, KH, KW, stride, pad, y, stats)
@@ -665,6 +665,21 @@ class BNActFunction(torch.autograd.Function):
                                     running_var.data_ptr() if running_var is not None else None, 0, None, stream_ptr()),
                   'yv4_bn_finalize')
             ctx.sync_group = group
+        elif training and isinstance(sums, (list, tuple)):
+            # x is a concat buffer whose channel ranges were produced by several convs, each leaving its own sums
+            # (``CatSlot`` + ``conv2d(stats=)``): one finalize per range, on the ranges of mean / invstd / running stats
+            bwd_work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+            off = 0
+            for buf in sums:
+                c = buf.numel() // (2 * _lib.STATS_REPLICAS)
+                check(L.yv4_bn_finalize(buf.data_ptr(), _lib.STATS_REPLICAS, M, None, c, float(eps), float(momentum),
+                                        mean.data_ptr() + 4 * off, invstd.data_ptr() + 4 * off,
+                                        running_mean.data_ptr() + 4 * off if running_mean is not None else None,
+                                        running_var.data_ptr() + 4 * off if running_var is not None else None,
+                                        1 if getattr(buf, '_yv4_kept_clean', False) else 0,
+                                        bwd_work.data_ptr() + 16 * off, stream_ptr()), 'yv4_bn_finalize')
+                off += c
+            assert off == Cc, 'the statistics buffers do not cover the concat buffer'
         elif training and sums is not None:
             # the finalize kernel also clears the backward's reduction buffer (and a persistent statistics buffer)
             bwd_work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)

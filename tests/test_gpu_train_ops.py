@@ -286,8 +286,11 @@ def test_csp_halves_written_into_the_concat_buffer(gpu_device, monkeypatch, bloc
     n_slots = len(launches)
     out_b, dx_b, gp_b = run(False)
     assert len(launches) - n_slots == n_slots + 1          # the CSP concat itself is the one torch.cat that went away
-    assert torch.equal(out_a, out_b)
     tol = 1e-5 if dtype == torch.float32 else 2e-2
+    if block == 'csp':       # the joint BN's sums come from the two conv epilogues: same values, another summation order
+        assert float((out_a - out_b).abs().max()) <= tol * float(out_b.abs().max())
+    else:
+        assert torch.equal(out_a, out_b)
     assert float((dx_a - dx_b).abs().max()) <= tol * float(dx_b.abs().max())
     for a, b in zip(gp_a, gp_b):
         assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6)
