@@ -195,11 +195,13 @@ def test_two_rank_step_equals_one_process_big_batch(tmp_path, backend, mode):
     """backend 'nccl' is RCCL: one rank per GPU, needs two visible GPUs (skipped on the 1-GPU test boxes -- the
     driver's multi-GPU node runs it); 'gloo' runs both ranks on cuda:0.  'direct_bf16' rounds every rank's gradients
     to bf16 once and the reduced chunk once more (fp32 accumulation in between): 2^-8 of each tensor's largest LOCAL
-    entry over the ranks (per-rank gradients may cancel in the mean) instead of 1e-5 of the result's."""
+    entry over the ranks (per-rank gradients may cancel in the mean) instead of 2e-5 of the result's (fp32 round-off of
+    two summation orders: the ranks' BatchNorm sums come from the statistics pass + all-reduce, the one-process run's from
+    the conv epilogues)."""
     if backend == 'nccl' and _gpus() < 2:
         pytest.skip('RCCL with 2 ranks needs 2 GPUs (torch.cuda.device_count() < 2)')
     outs = _run_two_ranks(tmp_path, backend, mode)
-    tol = 2.0 ** -8 if mode == 'direct_bf16' else 1e-5
+    tol = 2.0 ** -8 if mode == 'direct_bf16' else 2e-5
     for o in outs:
         assert o['worst'] < tol, o                            # exchanged gradients == one-process gradients
         assert o['stats'] < 1e-5, o                           # running statistics == big-batch BatchNorm's
