@@ -250,8 +250,8 @@ typedef short s16x8_t __attribute__((ext_vector_type(8)));
 constexpr int kWhRows = 64;    // reduction rows per slice
 constexpr int kWhTile = 128;   // dW tile edge (co and k)
 
-template <bool BF16>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
+template <bool BF16, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void conv_wgrad_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef __attribute__((address_space(3))) s16x4_t* lds_v4_t;
   extern __shared__ __attribute__((aligned(16))) char smem_wh[];
@@ -300,6 +300,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(WgradArgs p, uns
     }
   }
 
+  // (a slice past the end of the chunk is issued all the same, every lane out of range: the count of outstanding
+  // instructions the waits below rely on stays fixed)
   auto issue = [&](int m_base, int buf) {
     // first row of this lane in the slice, decoded once; rows of q = 1..3 follow by +4 pixels
     int m = m_base + 16 * wave + srow;
@@ -355,13 +357,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(WgradArgs p, uns
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+  // NBUF slice buffers, NBUF - 1 slices of LDS-DMA in flight.  A 128 x 128 tile spends ~500 cycles of MFMA on a slice
+  // whose 32 KB take the memory system several times that to deliver: the kernel runs at (bytes in flight) / latency.
+  // NBUF = 2 (two workgroups per CU, each waiting out its one outstanding slice) keeps 2 x 32 KB in flight per CU,
+  // NBUF = 4 (one workgroup, 128 KB of LDS) three slices -- and never drains the queue: the wait in front of slice s
+  // leaves the (NBUF - 2) younger slices outstanding (8 DMA instructions per wave and slice).
   const int nslices = (m_hi - m_lo + kWhRows - 1) / kWhRows;
-  issue(m_lo, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int s0 = 0; s0 < NBUF - 1; ++s0) issue(m_lo + s0 * kWhRows, s0);
   for (int sl = 0; sl < nslices; ++sl) {
-    const int buf = sl & 1;
-    if (sl + 1 < nslices) issue(m_lo + (sl + 1) * kWhRows, buf ^ 1);
+    const int buf = sl % NBUF;
+    if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (NBUF == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (NBUF == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // slice sl is in LDS; every wave is done with slice sl - 1
+    asm volatile("" ::: "memory");
+    issue(m_lo + (sl + NBUF - 1) * kWhRows, (sl + NBUF - 1) % NBUF);        // into the buffer slice sl - 1 left
     char* dbuf = smem_wh + buf * 2 * kOpBytes;
     char* abuf = dbuf + kOpBytes;
     __builtin_amdgcn_s_setprio(1);
@@ -390,9 +402,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(WgradArgs p, uns
         }
     }
     __builtin_amdgcn_s_setprio(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range slices issued past the end
   // D[row = co][col = k]: row = (e&3) + 8*(e>>2) + 4*(lane>>5), col = lane&31
   const int r = lane & 31, h5 = lane >> 5;
 #pragma unroll
@@ -1528,13 +1540,28 @@ static void wgrad_chunks(const yv4_conv_desc* d, int dtype, long long* chunks, l
   }
   if (dtype != YV4_F32 && !g_wgrad_widen) {
     const long long tl = (long long)((K + kWhTile - 1) / kWhTile) * ((d->Cout + kWhTile - 1) / kWhTile);
-    static const int wg_target = YV4_ENV_INT("YV4_WGRAD_WGS", 1024);
+    // Chunks of the reduction: ONE round of two workgroups per CU and never a workgroup more (513 workgroups take two
+    // rounds).  Measured over YOLOv4-L at batch 64 (tools/wgrad_bench.py --det, measure build, YV4_WGRAD_WGS): 512 beats
+    // 1024 on every 1x1 layer (half the partial-sum slabs: 512->256 @38 56 -> 47 us) and on the stride-2 layers, network
+    // 505 -> 525 TFLOP/s.  A dW of more than half a round of tiles cannot fill one round: then the chunk count with the
+    // least (rounds / chunks), the smallest within 20 % of it (512->1024 s2 @38: 288 tiles x 3 chunks, 383 -> 312 us).
+    static const int wg_target = YV4_ENV_INT("YV4_WGRAD_WGS", 512);
     static const int min_slices = YV4_ENV_INT("YV4_WGRAD_MINSL", 16);
-    long long ch = (wg_target + tl - 1) / tl;             // default: ~2 rounds of 2 workgroups per CU
     const long long mx = (M + min_slices * kWhRows - 1) / (min_slices * kWhRows);   // at least min_slices per chunk
+    long long ch = wg_target / tl;
+    if (2 * tl > wg_target) {
+      const long long chmax = 4 * wg_target / tl > 1 ? 4 * wg_target / tl : 1;
+      double best = 1e30;
+      for (long long c = 1; c <= chmax; ++c) {
+        const double sc = (double)((tl * c + wg_target - 1) / wg_target) / (double)c;
+        if (sc < best) best = sc;
+      }
+      for (long long c = 1; c <= chmax; ++c)
+        if ((double)((tl * c + wg_target - 1) / wg_target) / (double)c <= 1.2 * best) { ch = c; break; }
+    }
     if (ch > mx) ch = mx;
     if (ch < 1) ch = 1;
-    if (tl >= 2 && ch >= 16) ch = (ch + 7) / 8 * 8;       // whole groups of 8 chunks, one per XCD (wgrad_tile_chunk)
+    if (tl >= 2 && ch >= 16 && d->Cout >= 128) ch = ch / 8 * 8;   // whole groups of 8 chunks, one per XCD (wgrad_tile_chunk)
     if (ch > 65528) ch = 65528;
     long long rw = (M + ch - 1) / ch;
     rw = (rw + kWhRows - 1) / kWhRows * kWhRows;
@@ -1623,20 +1650,34 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     a.tiles_k = (a.K + kWhTile - 1) / kWhTile;
     const int tc = (a.Cout + kWhTile - 1) / kWhTile;
     const long long tl = (long long)a.tiles_k * tc;
-    const size_t ldsh = (size_t)2 * 2 * kWhRows * 256;
-    static LdsAttrOnce once_b, once_h;
-    if (int rc = ensure_dyn_lds(once_b, reinterpret_cast<const void*>(conv_wgrad_h16_kernel<true>), ldsh, "conv_wgrad_h16")) return rc;
-    if (int rc = ensure_dyn_lds(once_h, reinterpret_cast<const void*>(conv_wgrad_h16_kernel<false>), ldsh, "conv_wgrad_h16")) return rc;
+    // slice buffers: 2 x two workgroups per CU.  (3 to 5 buffers for ONE workgroup per CU -- more bytes in flight, no
+    // queue drain -- are 20-60 % slower on every layer, network 505 -> 408 TFLOP/s: with one wave per SIMD nothing
+    // covers a wave's transposed-read -> MFMA chain.  Those instantiations exist in the measure build only.)
+    static const int nbuf = YV4_ENV_INT("YV4_WGRAD_NBUF", 2);
+    const size_t ldsh = (size_t)nbuf * 2 * kWhRows * 256;
     a.tiles = (int)tl;
     a.chunks = (int)ch;
-    a.xcd_map = g_wgrad_xcd && tl >= 2 && ch >= 16 && tl * (ch + 8) < (1LL << 31) ? 1 : 0;
+    // (not for the few-channel layers at 304 / 608 pixels -- Cout < 128, half-empty dY tiles, pure streaming: inside the
+    // training step they ran 25 % slower with it, tools/train_timeline.py)
+    a.xcd_map = g_wgrad_xcd && tl >= 2 && ch >= 16 && a.Cout >= 128 && tl * (ch + 8) < (1LL << 31) ? 1 : 0;
     const dim3 grid = wgrad_grid(tl, ch, a.xcd_map);
-    if (dtype == YV4_BF16)
-      hipLaunchKernelGGL(conv_wgrad_h16_kernel<true>, grid, dim3(256), ldsh,
-                         reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+#define YV4_WH_LAUNCH(NB)                                                                                              \
+  {                                                                                                                    \
+    static LdsAttrOnce once_b, once_h;                                                                                 \
+    if (int rc = ensure_dyn_lds(once_b, reinterpret_cast<const void*>(conv_wgrad_h16_kernel<true, NB>), ldsh, "conv_wgrad_h16")) return rc;  \
+    if (int rc = ensure_dyn_lds(once_h, reinterpret_cast<const void*>(conv_wgrad_h16_kernel<false, NB>), ldsh, "conv_wgrad_h16")) return rc; \
+    if (dtype == YV4_BF16) hipLaunchKernelGGL((conv_wgrad_h16_kernel<true, NB>), grid, dim3(256), ldsh, hs, a, (unsigned)xb, (unsigned)db);  \
+    else hipLaunchKernelGGL((conv_wgrad_h16_kernel<false, NB>), grid, dim3(256), ldsh, hs, a, (unsigned)xb, (unsigned)db);                  \
+  }
+#ifdef YV4_MEASURE
+    if (nbuf == 3) YV4_WH_LAUNCH(3)
+    else if (nbuf == 4) YV4_WH_LAUNCH(4)
+    else if (nbuf == 5) YV4_WH_LAUNCH(5)
     else
-      hipLaunchKernelGGL(conv_wgrad_h16_kernel<false>, grid, dim3(256), ldsh,
-                         reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
+#endif
+    YV4_WH_LAUNCH(2)
+#undef YV4_WH_LAUNCH
     YV4_CHECK_LAUNCH("conv_wgrad_h16");
     return finish();
   }
