@@ -329,8 +329,9 @@ int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, i
  * epilogue stores channel pairs straight from the accumulators.  Same K order and epilogue expressions as the generic
  * tiles.  (Id 5, the 256 x 64 form of round 2's non-persistent kernel, is gone and refused.) */
 #define YV4_HTILE_PP3x3 4
-/* 1x1 / stride 1, Cin <= 256, even Cout >= 16, 16-bit output, no residual (conv1x1_ws_h16.hip): one persistent
- * 8-wave workgroup per CU, the weight slab resident in LDS, wave-private rings of 32-pixel strips */
+/* 1x1 / stride 1, Cin <= 256, even Cout >= 16 with a 16-bit output (residual allowed) or any Cout >= 16 with an fp32
+ * output (no residual) (conv1x1_ws_h16.hip): one persistent 8-wave workgroup per CU, the weight slab resident in LDS,
+ * wave-private rings of 32-pixel strips */
 #define YV4_HTILE_WS_1x1 6
 /* 3x3 / stride 1 / pad 1 with few channels -- Cin 16, 32 or 64, even Cout in [16, 64], 16-bit output
  * (conv3x3_small_h16.hip): one persistent 8-wave workgroup per CU on 16 x 16 output tiles, the weights resident in LDS,

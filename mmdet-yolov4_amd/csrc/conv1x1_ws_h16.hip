@@ -22,9 +22,10 @@
 //     first version's bottleneck), 64-byte segments per pixel.
 //
 // Any Cin % 8 == 0 up to 256 (laid out as 64 / 128 / 256 channels, zero-padded) and Cout >= 16.
-// Epilogue = the common one minus the residual: affine1 -> act1 -> (affine2 -> act2) -> store at a channel offset
-// (16-bit, or fp32 for the pred maps), or (stats != nullptr) identity + statistics of the rounded outputs.  Residual
-// and scattered output stay with the generic tiles.
+// Epilogue = the common one: affine1 -> act1 -> (+ residual, 16-bit outputs) -> (affine2 -> act2) -> store at a channel
+// offset (16-bit, or fp32 for the pred maps), or (stats != nullptr) identity + statistics of the rounded outputs.
+// Scattered output stays with the generic tiles.  (The residual form serves the training step: the data gradient of a
+// Bottleneck's first conv adds the shortcut's gradient, train_ops.GradSink.)
 #include "conv_h16_common.h"
 
 namespace yv4 {
@@ -224,6 +225,28 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = acc[t][e] * s1[t] + t1[t];
         act_row16_h(v, p.act1, p.slope1);
+        if (p.res) {
+          // residual (16-bit outputs only): the lane reads the dwords (two channels) of the rows it will STORE below,
+          // its pair partner's dwords supply the rows the partner stores (the exchange of conv3x3_small_h16.hip)
+          const bool oddr = r & 1;
+          const int rbr = 4 * h + (oddr ? 16 : 0);
+          const T* rp = reinterpret_cast<const T*>(p.res) + ((int64_t)(m0 + rbr) * p.r_cs + p.r_co + (c & ~1));
+          unsigned mine[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int row = (j & 3) + 8 * (j >> 2);
+            mine[j] = (full || m0 + rbr + row < p.M) ? *reinterpret_cast<const unsigned*>(rp + (int64_t)row * p.r_cs) : 0u;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned theirs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[j], 0xB1, 0xF, 0xF, false);
+            const unsigned a = oddr ? (theirs >> 16) : (mine[j] & 0xffffu);
+            const unsigned b = oddr ? (mine[j] >> 16) : (theirs & 0xffffu);
+            const unsigned short ua = (unsigned short)a, ub = (unsigned short)b;
+            v[j] += (float)__builtin_bit_cast(T, ua);
+            v[j + 8] += (float)__builtin_bit_cast(T, ub);
+          }
+        }
         if (has2) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] = v[e] * s2[t] + t2[t];
@@ -297,7 +320,8 @@ static int ws_slab_cols(const ConvArgsH& a) {
 // Is this layer in the kernel's domain?
 bool conv1x1_ws_applies(const ConvArgsH& a) {
   const bool store_ok = a.out_f32 ? a.stats == nullptr : ((a.Cout & 1) == 0 && ((a.y_cs | a.y_co) & 1) == 0);
-  return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.ys_on && a.res == nullptr && a.Cin >= 16 &&
+  const bool res_ok = a.res == nullptr || (!a.out_f32 && a.stats == nullptr && ((a.r_cs | a.r_co) & 1) == 0);
+  return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.ys_on && res_ok && a.Cin >= 16 &&
          a.Cin <= 256 && (a.Cin & 7) == 0 && a.Kw == a.Cin && a.Cout >= 16 && store_ok && ws_slab_cols(a) > 0;
 }
 

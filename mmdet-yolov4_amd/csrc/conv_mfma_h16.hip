@@ -492,7 +492,7 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   if (d->tile == YV4_HTILE_PP3x3 || (d->tile == YV4_TILE_AUTO && prefer_pp3(a))) return conv3x3_pp_h16_launch(a, dtype == YV4_BF16, s);
   if (d->tile == YV4_HTILE_WS_1x1)
     YV4_REQUIRE(conv1x1_ws_applies(a), "conv h16: the weight-stationary tile needs a 1x1 / stride 1 conv with Cin <= 256, "
-                "Cout >= 16 (even unless the output is fp32) and no residual");
+                "Cout >= 16 (even unless the output is fp32); a residual needs a 16-bit output");
   if (d->tile == YV4_HTILE_WS_1x1 || (d->tile == YV4_TILE_AUTO && prefer_ws(a))) return conv1x1_ws_launch(a, dtype == YV4_BF16, s);
   if (d->tile == YV4_HTILE_S3x3)
     YV4_REQUIRE(conv3x3_small_applies(a), "conv h16: the few-channel 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with Cin 16, 32 "

@@ -270,9 +270,22 @@ def test_h16_conv1x1_ws_kernel_is_refused_outside_its_domain(gpu_device):
         with pytest.raises(L.Yv4Error):
             _h16_conv(gpu_device, torch.bfloat16, *shape, act=1, tile=6)
     with pytest.raises(L.Yv4Error):
-        _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 64, 1, 1, 0, act=1, tile=6, residual=True)
+        _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 64, 1, 1, 0, act=0, tile=6, residual=True, out_f32=True)   # residual: 16-bit outputs
     with pytest.raises(L.Yv4Error):
         _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 63, 1, 1, 0, act=1, tile=6)          # odd Cout needs fp32 output
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(2, 19, 19, 128, 128), (1, 76, 76, 64, 64), (3, 40, 33, 256, 128), (2, 64, 64, 32, 64),
+                                   (1, 5, 5, 128, 96), (2, 52, 52, 32, 16)])
+def test_h16_conv1x1_ws_kernel_residual(gpu_device, dtype, shape):
+    """The residual of the weight-stationary kernel (the data gradient of a Bottleneck's first conv adds the shortcut's
+    gradient): read as channel-pair dwords in the store layout, exchanged between the lanes of a pair, added in fp32
+    before the one rounding -- plain, behind an activation, and in front of a second epilogue stage."""
+    N, H, W, Cin, Cout = shape
+    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 1, 1, 0, act=0, tile=6, residual=True)
+    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 1, 1, 0, act=1, tile=6, residual=True)
+    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 1, 1, 0, act=2, tile=6, residual=True, two_stage=True)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
