@@ -308,3 +308,36 @@ def test_reference_configs_build_unchanged(name):
     assert H.accumulation_steps(64, spg, world) == -(-64 // (spg * world))
     tc = det.bbox_head.test_cfg
     assert tc.score_thr == 0.001 and tc.nms['iou_threshold'] == 0.65 and tc.max_per_img == 300
+
+
+def test_deferred_log_vars_wait_at_the_first_value_access():
+    """``deferred.DeferredLogVars``: keys / length / membership need no synchronisation; the first value access (and
+    everything built on one: dict(), {**}, json, pickle, ==, repr) waits for the copy once and then behaves like the
+    OrderedDict of python floats the reference returns (detectors/base.py:171-204)."""
+    import json
+    import pickle
+    from collections import OrderedDict
+    import torch
+    from mmdet_yolov4_amd.deferred import DeferredLogVars
+
+    class Event:
+        waits = 0
+
+        def synchronize(self):
+            Event.waits += 1
+
+    def make(finish=None):
+        return DeferredLogVars(['loss_cls', 'loss'], torch.tensor([1.5, 4.0]), Event(), finish)
+
+    lv = make()
+    assert lv.pending and len(lv) == 2 and 'loss' in lv and list(lv.keys()) == ['loss_cls', 'loss'] and Event.waits == 0
+    assert lv['loss'] == 4.0 and not lv.pending and Event.waits == 1
+    assert lv['loss_cls'] == 1.5 and Event.waits == 1                       # resolved once
+    want = OrderedDict(loss_cls=1.5, loss=4.0)
+    for build in (dict, OrderedDict, lambda d: {**d}, lambda d: json.loads(json.dumps(d)), lambda d: pickle.loads(pickle.dumps(d)),
+                  lambda d: dict(d.items()), lambda d: {k: d.get(k) for k in d}, lambda d: d.copy()):
+        fresh = make()
+        assert build(fresh) == want and not fresh.pending
+    assert make() == want and make() == make() and 'loss_cls' in repr(make())
+    assert [v for v in make().values()] == [1.5, 4.0]
+    assert make(lambda c: [c[1], 1.0 / c[0]])['loss'] == 1.0 / 1.5          # a map from the copied floats to the values
