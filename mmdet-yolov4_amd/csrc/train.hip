@@ -750,13 +750,17 @@ __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ 
 __device__ __forceinline__ float act_grad(float z, int act, float slope) {
   switch (act) {
     case YV4_ACT_MISH: {
-      // mish.h:21-29 with sp = log1p(e^z):  tanh(sp) = n/(n+2), n = e(e+2);  1 - exp(-sp) = e/(1+e)
-      // hardware exp2 / rcp (1 ulp each): |error| < 1e-6 against the libm form, well inside the
-      // 1e-4 gradient budget, and it keeps the two BN-backward kernels HBM-bound instead of VALU-bound
+      // mish.h:21-29 with sp = log1p(e^z), a = 1 + e^z, w = a^2 + 1:  tanh(sp) = (a^2 - 1) / (a^2 + 1) = 1 - 2 / w  and
+      // (1 - tanh^2(sp)) * (1 - exp(-sp)) = (4 a^2 / w^2) * (e / a), so
+      //     mish'(z) = 1 - 2 / w + 4 z a e / w^2
+      // -- ONE reciprocal and one exp2 (hardware, 1 ulp each; quarter-rate instructions): |error| < 1e-6 against the libm
+      // form, well inside the 1e-4 gradient budget.  The two BN-backward kernels are bound by exactly this arithmetic
+      // (~35 issue slots per element at 16 lanes per SIMD and clock = their 0.6 ms on the 757 M-element layer); the
+      // earlier form spent two reciprocals and ~6 more slots here.
       const float e = __builtin_amdgcn_exp2f(fminf(z, 20.f) * 1.44269504088896340736f);
-      const float n = e * (e + 2.f);
-      const float tsp = n * __builtin_amdgcn_rcpf(n + 2.f);
-      const float g = z * (1.f - tsp * tsp) * (e * __builtin_amdgcn_rcpf(1.f + e)) + tsp;
+      const float a = e + 1.f;
+      const float iw = __builtin_amdgcn_rcpf(__builtin_fmaf(a, a, 1.f));
+      const float g = __builtin_fmaf(4.f * (z * (a * e)), iw * iw, __builtin_fmaf(-2.f, iw, 1.f));
       return z >= 20.f ? 1.f : g;
     }
     case YV4_ACT_LEAKY: return z >= 0.f ? 1.f : slope;
@@ -952,6 +956,7 @@ struct BnArgs {
   int64_t M_total;   // rows behind the statistics (= M, or the sum over ranks for SyncBN)
   const double* rows; // optional device-resident M_total
   int publish;       // the apply pass writes dgamma / dbeta from `sums` (not when `sums` were all-reduced)
+  int red_cg;        // bn_act_bwd_reduce_kernel: channels per workgroup (grid.y groups)
 };
 
 // Elementwise passes use the reductions' thread map too: a thread keeps ONE channel group of V channels (its
@@ -1014,14 +1019,21 @@ __global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_fwd_kernel(BnA
   }
 }
 
+// Grid: (row blocks, channel groups of p.red_cg channels).  Every workgroup ends with one double atomic per channel it
+// covers; with ~1000 row blocks over ALL channels a small map (38 x 38 x 256 at batch 64: 47 MB) spent 12-14 us of its
+// 43 us queueing ~1000 adds on each of its 512 addresses.  Splitting the channels over grid.y keeps the workgroup count
+// (and the bytes in flight) and divides the adds per address by the number of groups; a group is >= 64 channels, so a
+// workgroup still reads whole 128-byte lines of every row.
 template <typename T, int V>
 __global__ __launch_bounds__(256, YV4_BN_RED_WAVES) void bn_act_bwd_reduce_kernel(BnArgs p) {
   typedef RowVec<T, V> RV;
-  extern __shared__ double part[];   // [2][C]: dbeta | dgamma
-  const T* px = reinterpret_cast<const T*>(p.x);
-  const T* pdy = reinterpret_cast<const T*>(p.dy);
-  const int CV = p.C / V;
-  for (int i = threadIdx.x; i < 2 * p.C; i += 256) part[i] = 0.0;
+  extern __shared__ double part[];   // [2][Cl]: dbeta | dgamma of this workgroup's channels
+  const int cb = (int)blockIdx.y * p.red_cg;
+  const int Cl = min(p.red_cg, p.C - cb);
+  const T* px = reinterpret_cast<const T*>(p.x) + p.x_co + cb;
+  const T* pdy = reinterpret_cast<const T*>(p.dy) + p.dy_co + cb;
+  const int CV = Cl / V;
+  for (int i = threadIdx.x; i < 2 * Cl; i += 256) part[i] = 0.0;
   __syncthreads();
   const RedMap mp = red_map(CV);
   const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
@@ -1035,7 +1047,7 @@ __global__ __launch_bounds__(256, YV4_BN_RED_WAVES) void bn_act_bwd_reduce_kerne
       float db[V], dg[V];
 #pragma unroll
       for (int k = 0; k < V; ++k) {
-        mu[k] = p.mean[c + k]; is[k] = p.invstd[c + k]; ga[k] = p.gamma[c + k]; be[k] = p.beta[c + k];
+        mu[k] = p.mean[cb + c + k]; is[k] = p.invstd[cb + c + k]; ga[k] = p.gamma[cb + c + k]; be[k] = p.beta[cb + c + k];
         db[k] = 0.f; dg[k] = 0.f;
       }
       for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnRedUnroll) {
@@ -1044,8 +1056,8 @@ __global__ __launch_bounds__(256, YV4_BN_RED_WAVES) void bn_act_bwd_reduce_kerne
         for (int u = 0; u < kBnRedUnroll; ++u) {
           const int64_t row = rr + (int64_t)u * mp.rstep;
           const bool ok = row < r1;
-          xv[u] = ok ? RV::ld(px + row * p.x_cs + p.x_co + c) : RV::zero();
-          gv[u] = ok ? RV::ld(pdy + row * p.dy_cs + p.dy_co + c) : RV::zero();   // zero beyond r1 -> contributes nothing
+          xv[u] = ok ? RV::ld(px + row * p.x_cs + c) : RV::zero();
+          gv[u] = ok ? RV::ld(pdy + row * p.dy_cs + c) : RV::zero();   // zero beyond r1 -> contributes nothing
         }
 #pragma unroll
         for (int u = 0; u < kBnRedUnroll; ++u) {
@@ -1061,12 +1073,15 @@ __global__ __launch_bounds__(256, YV4_BN_RED_WAVES) void bn_act_bwd_reduce_kerne
 #pragma unroll
       for (int h = 0; h < V; h += 4) {
         const double ddb[4] = {db[h], db[h + 1], db[h + 2], db[h + 3]}, ddg[4] = {dg[h], dg[h + 1], dg[h + 2], dg[h + 3]};
-        red_flush(part, p.C, c + h, ddb, ddg, true);
+        red_flush(part, Cl, c + h, ddb, ddg, true);
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * p.C; i += 256) atomicAdd(&p.sums[i], part[i]);
+  for (int i = threadIdx.x; i < Cl; i += 256) {
+    atomicAdd(&p.sums[cb + i], part[i]);
+    atomicAdd(&p.sums[p.C + cb + i], part[Cl + i]);
+  }
 }
 
 template <typename T, int V>
@@ -1767,8 +1782,21 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   a.rows_per_block = bn_rows_per_block(M);
   dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
   const bool v8 = dtype != YV4_F32 && g_bn_vec8 && ((C | x_cstride | x_coff | dy_cstride | dy_coff | dx_cstride | dx_coff) & 7) == 0;
-  if (phase != 2)
-    YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, V>), grid, dim3(256), sizeof(double) * 2 * C, s, a));
+  if (phase != 2) {
+    // channel groups of >= 64 channels (whole 128-byte lines of 16-bit rows), the row blocks shrunk so that the
+    // workgroup count stays what bn_rows_per_block aims at
+    static const int cg_min = YV4_ENV_INT("YV4_BN_RED_CG", 64);
+    int groups = 1;
+    if (cg_min > 0 && C % cg_min == 0 && C / cg_min >= 2) groups = C / cg_min < 16 ? C / cg_min : 16;
+    while (groups > 1 && (C % groups != 0 || (C / groups) % 8 != 0)) --groups;
+    BnArgs r = a;
+    r.red_cg = C / groups;
+    int64_t rpb = (int64_t)a.rows_per_block * groups;
+    if (rpb > g_bn_rows_cap) rpb = g_bn_rows_cap;
+    r.rows_per_block = (int)rpb;
+    const dim3 rgrid((unsigned)((M + rpb - 1) / rpb), (unsigned)groups);
+    YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, V>), rgrid, dim3(256), sizeof(double) * 2 * r.red_cg, s, r));
+  }
   if (phase == 1) {
     hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
     hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
