@@ -374,6 +374,68 @@ def _dgrad_s2_parity(dy, weight, xshape, dtype, dy_cs=None, owner=None):
     return dx
 
 
+_ROWPAIR_W = {}     # id(owner) -> (weakref(owner), version, generation, dtype, (W2 for a = 0, W2 for a = 1))
+
+
+def _rowpair_weights(weight, dtype, owner):
+    """Operands of ``_dgrad_s2_rowpair``: for row parity a, rows = (b, c) -- column parity and input channel --, K ordered
+    (di, dj, co) over the dY taps (i + di, j + dj); zero where the (parity, tap) pair has no source tap.  Cached per
+    parameter until its version (or the packed-weight generation) moves."""
+    ident = owner if owner is not None else weight
+    key = id(ident)
+    hit = _ROWPAIR_W.get(key)
+    if hit is not None and hit[0]() is ident and hit[1] == ident._version and hit[2] == _PACK_GENERATION[0] \
+            and hit[3] == dtype:
+        return hit[4]
+    w = weight.detach().float()
+    Co, Cx = w.shape[0], w.shape[1]
+    out = []
+    for khs in ((1,), (2, 0)):                       # a = 0: dY row i through kh = 1;  a = 1: row i (kh = 2), row i + 1 (kh = 0)
+        t = w.new_zeros((2, Cx, len(khs), 2, Co))    # (b, c, di, dj, co)
+        for di, kh in enumerate(khs):
+            t[0, :, di, 0] = w[:, :, kh, 1].t()      # b = 0: column j through kw = 1
+            t[1, :, di, 0] = w[:, :, kh, 2].t()      # b = 1: column j (kw = 2) ...
+            t[1, :, di, 1] = w[:, :, kh, 0].t()      # ... and column j + 1 (kw = 0)
+        out.append(t.reshape(2 * Cx, len(khs) * 2 * Co).to(dtype).contiguous())
+    if len(_ROWPAIR_W) > 64:
+        _ROWPAIR_W.clear()
+    _ROWPAIR_W[key] = (weakref.ref(ident), ident._version, _PACK_GENERATION[0], dtype, tuple(out))
+    return tuple(out)
+
+
+def _dgrad_s2_rowpair(dy, weight, xshape, dtype, dy_cs=None, owner=None):
+    """The same data gradient for FEW input channels (2 * Cin <= 64), even H and W: the two column parities of an input
+    row pair are ONE output pixel of 2 * Cin channels -- dX viewed as (N, H, W / 2, 2 Cin) -- so each row parity a is a
+    single stride-1 correlation of dY with a (1 + a) x 2 kernel into 2 Cin channels, scattered to the rows 2 i + a
+    (``yv4_conv_scatter_fwd``, sh = 2, sw = 1).  Two launches instead of four, each with a full 64-column tile and whole
+    128-byte lines per output pixel; a third more FLOPs (the zero blocks) on a layer that is bound by its bytes:
+    conv1 of CSPDarknet (32 -> 64 at 608 -> 304, batch 64): 1.61 -> 0.8 ms."""
+    N, Cin, H, W = xshape
+    Cout = weight.shape[0]
+    Ho, Wo = dy.shape[2], dy.shape[3]
+    h16 = dtype != torch.float32
+    L = _lib.lib()
+    dx = torch.empty((N, Cin, H, W), device=dy.device, dtype=dtype, memory_format=torch.channels_last)
+    ones, zeros = _identity_affine(dy.device, 2 * Cin)
+    w2 = _rowpair_weights(weight, dtype, owner)
+    for a in (0, 1):
+        d = ConvDesc()
+        d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, Ho, Wo, Cout, H // 2, W // 2, 2 * Cin
+        d.KH, d.KW, d.stride, d.pad = 1 + a, 2, 1, 0
+        d.x_cstride, d.y_cstride = (dy_cs if dy_cs is not None else Cout), 2 * Cin
+        if h16:
+            check(L.yv4_conv_scatter_fwd_h16(C.byref(d), _DCODE[dtype], dy.data_ptr(), w2[a].data_ptr(), ones.data_ptr(),
+                                             zeros.data_ptr(), dx.data_ptr(), H, W // 2, 2, 1, a, 0, stream_ptr()),
+                  'yv4_conv_scatter_fwd_h16')
+        else:
+            check(L.yv4_conv_scatter_fwd(C.byref(d), dy.data_ptr(), w2[a].data_ptr(), ones.data_ptr(), zeros.data_ptr(),
+                                         dx.data_ptr(), H, W // 2, 2, 1, a, 0, stream_ptr()), 'yv4_conv_scatter_fwd')
+    return dx
+
+
+_ROWPAIR_ON = os.environ.get('YV4_DGRAD_ROWPAIR', '1') != '0'     # A/B switch
+
+
 # ---- weight gradients straight into the gradient arena -----------------------------------------------------
 # When a conv weight's ``.grad`` is a channels_last fp32 tensor that already exists at backward time (the flat
 # gradient arena of ``flat_state.FlatState``, zeroed once per step), ``yv4_conv_wgrad*`` accumulates INTO it -- its
@@ -548,7 +610,11 @@ class ConvFunction(torch.autograd.Function):
                     joined = to_nhwc(joined.to(dtype))
                     jcs = None
             if stride == 2 and (KH, KW, pad) == (3, 3, 1) and Cout % (8 if h16 else 32) == 0:
-                dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype, dy_cs, owner=ctx.direct.p if ctx.direct is not None else None)
+                own = ctx.direct.p if ctx.direct is not None else None
+                if _ROWPAIR_ON and 2 * Cin <= 64 and H % 2 == 0 and W % 2 == 0 and Cin % (4 if h16 else 2) == 0:
+                    dx = _dgrad_s2_rowpair(dy, weight, (N, Cin, H, W), dtype, dy_cs, owner=own)
+                else:
+                    dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype, dy_cs, owner=own)
             else:
                 dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype, dy_cs, residual=joined, res_cs=jcs,
                                     owner=ctx.direct.p if ctx.direct is not None else None)

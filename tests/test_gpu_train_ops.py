@@ -23,7 +23,10 @@ def rel(got, ref):
     # N, Cin, H, W, Cout, k, stride, pad
     (2, 32, 13, 17, 64, 3, 1, 1),
     (2, 64, 9, 9, 32, 1, 1, 0),
-    (2, 32, 16, 20, 64, 3, 2, 1),      # stride 2, even size
+    (2, 32, 16, 20, 64, 3, 2, 1),      # stride 2, even size (Cin <= 32: the row-pair data gradient, two launches)
+    (2, 16, 12, 8, 32, 3, 2, 1),       # ... 32 output columns per launch
+    (1, 8, 10, 14, 64, 3, 2, 1),       # ... 16
+    (2, 64, 12, 12, 64, 3, 2, 1),      # stride 2, Cin > 32: four parity classes
     (1, 32, 15, 19, 32, 3, 2, 1),      # stride 2, odd size (dilated grid cropped)
     (2, 24, 10, 10, 40, 3, 1, 1),      # Cin, Cout not multiples of 32/64
     (2, 4, 12, 12, 16, 3, 1, 1),       # stem-like (padded image), weight gradient only
@@ -50,6 +53,37 @@ def test_conv_forward_backward(gpu_device, shape):
     assert rel(wd.grad, wr.grad) < 5e-5, 'dW'
     if need_dx:
         assert rel(xd.grad, xr.grad) < 5e-5, 'dX'
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(2, 32, 64, 40, 24), (3, 16, 32, 16, 36), (1, 8, 64, 22, 22)])
+def test_stride2_data_gradient_row_pair_form(gpu_device, monkeypatch, dtype, shape):
+    """``_dgrad_s2_rowpair`` (few input channels: the column parities of a row pair as ONE output pixel of 2 Cin channels,
+    two scattered stride-1 correlations) against the four parity classes and against float64 autograd, with the
+    weight operands rebuilt after an in-place weight update."""
+    N, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    gy = torch.randn(N, Cout, H // 2, W // 2, generator=g)
+    wd = torch.nn.Parameter(w.to(gpu_device))
+
+    def run(rowpair):
+        monkeypatch.setattr(T, '_ROWPAIR_ON', rowpair)
+        xd = x.to(gpu_device).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = T.conv2d(xd, wd, 2, 1, dtype=dtype)
+        y.backward(gy.to(gpu_device).to(dtype))
+        return xd.grad.float()
+
+    tol = 5e-5 if dtype == torch.float32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
+    for step in range(2):
+        xr = x.double().requires_grad_(True)
+        F.conv2d(xr, wd.detach().cpu().double(), None, 2, 1).backward(gy.double())
+        a, b = run(True), run(False)
+        assert rel(a, xr.grad) < tol and rel(b, xr.grad) < tol
+        assert rel(a, b) < tol
+        with torch.no_grad():
+            wd.mul_(-0.7).add_(0.05)        # version counter moves: the cached operands must follow
 
 
 @pytest.mark.parametrize('act', [0, 1, 2, 3])
