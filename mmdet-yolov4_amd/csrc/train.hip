@@ -78,6 +78,7 @@ struct WgradArgs {
   int M, K;
   int tiles_k, rows_per_chunk;
   int tiles = 0, chunks = 0, xcd_map = 0;   // see wgrad_tile_chunk
+  int ablate = 0;                           // measurement build only (YV4_WFC_ABLATE)
   FastDiv fd_hw, fd_wo;     // m / (Ho*Wo), r / Wo: the per-slice row decode sits inside the pipelined loop
   // deterministic form: chunk c of the M reduction stores its partial dW to slab c of ws ([chunks][Cout][K], plain
   // stores); wgrad_reduce_kernel then adds the slabs to dw in chunk order.  ws == nullptr: float atomics into dw.
@@ -665,6 +666,331 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
         }
       }
     }
+}
+
+// ---------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / stride-1 / pad-1 layers with FEW channels (Cin 16, 32 or 64 per pixel, Cout 32 or 64):
+// the stem, the first Bottleneck and the first CSP stage of CSPDarknet at 608 / 304 / 152 pixels.  These layers are bound
+// by their bytes (dY + X once = 0.23-0.45 ms at batch 64) and the 128 x 128 tiles above serve them badly: dW is 32-64
+// rows by 72-576 columns, so a tile is mostly padding, every column tile re-reads dY, and the im2col operand fetches
+// every source pixel nine times -- 960 bytes of LDS fill per output pixel for the 32 -> 64 layer, three times what the
+// memory system delivers per unit time to 64 KB of slice buffers per CU (0.65-0.9 ms per layer).
+//
+// Here an 8-wave workgroup (two per CU) owns ALL of dW and a chunk of the M reduction (flattened pixel index m, as in the
+// kernel above).  A 64-row slice is the rows of dY plus THREE images of the source pixels, one per kh (image row ir <->
+// pixel m + ir + (kh - 1) W - 1, 66 rows; the three kw taps of a kh read one image, operand row = reduction row + kw):
+// 64 Cout * 2 + 3 * 66 * Cin * 2 bytes -- 323 per output pixel for 32 -> 64.  Rows keep their natural pitch (32 / 64 /
+// 128 bytes); 128-byte rows swap their 64-byte halves on rows 2, 3 (mod 4) so that the four rows of a transposed block
+// fall into different banks.  Wave w < 3 * (Cout / 32) computes the (kh = w % 3, 32-row co block w / 3) part of dW: its
+// dY fragment is shared by its 2-6 column blocks (kw x channel halves); all eight waves fill the buffers.  Borders are
+// masked per lane of the transposed reads (a lane supplies ONE reduction row: redirected to the image's zero row it
+// contributes nothing).  Two to four slice buffers per workgroup (two workgroups per CU), one barrier per slice, every wave issues
+// the same number of DMA instructions per slice (dummies into a scratch KB) so that one counted wait serves all.
+// Same chunked, deterministic output as the kernels above.
+// ---------------------------------------------------------------------------------
+constexpr int kFcThreads = 512;
+constexpr int kFcRows = 64;
+constexpr int kFcZeroRow = 66;
+
+template <int CIN, int COUT> struct FcGeom {
+  static constexpr int PX = CIN * 2;                                   // bytes per pixel of an X image row
+  static constexpr int CPP = PX / 16;                                  // 16-byte chunks per pixel
+  static constexpr int XRows = CIN == 16 ? 96 : (CIN == 32 ? 80 : 72); // >= 68 and XRows * CPP % 64 == 0
+  static constexpr int XPieces = XRows * CPP / 64;                     // DMA instructions per image
+  static constexpr int XBytes = XRows * PX;
+  static constexpr int DP = COUT * 2;                                  // bytes per dY row
+  static constexpr int CPD = DP / 16;
+  static constexpr int DPieces = kFcRows * CPD / 64;
+  static constexpr int DBytes = kFcRows * DP;
+  static constexpr int NBK = CIN == 16 ? 2 : CIN / 32 * 3;             // 32-column blocks of dW per kh
+  static constexpr int CB = COUT / 32;
+  static constexpr int BufBytes = DBytes + 3 * XBytes;
+  // slice buffers of ONE workgroup.  Cin 16 / 32: two workgroups share a CU (12 computing waves = three per SIMD: with
+  // one workgroup the six computing waves sit two-two-one-one on the SIMDs and the pair sets the pace).  Cin 64: six
+  // accumulators and two fragment sets are 234 VGPRs -- one workgroup per CU, four buffers.
+  static constexpr int WGs = CIN == 64 ? 1 : 2;
+  static constexpr int NBuf = WGs == 1 ? 4 : (BufBytes * 4 + 1024 <= 80 * 1024 ? 4 : (BufBytes * 3 + 1024 <= 80 * 1024 ? 3 : 2));
+  static constexpr int Pieces = DPieces + 3 * XPieces;
+  static constexpr int PW = (Pieces + 7) / 8;                          // DMA instructions per wave and slice
+  static constexpr int Lds = NBuf * BufBytes + 1024;                   // + the dummies' scratch
+};
+
+template <bool BF16, int CIN, int COUT>
+__global__ __launch_bounds__(kFcThreads, (FcGeom<CIN, COUT>::WGs)) void conv_wgrad_fc_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
+  typedef FcGeom<CIN, COUT> G;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_fc[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = (int)blockIdx.x;
+  const int m_lo = chunk * p.rows_per_chunk;
+  const int m_hi = min(m_lo + p.rows_per_chunk, p.M);
+  if (m_lo >= m_hi) return;
+  const int NHW = p.N * p.H * p.W;
+  const u32x4_t rsX = make_rsrc_t(p.x, x_bytes);
+  const u32x4_t rsD = make_rsrc_t(p.dy, dy_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_fc;
+  auto swz128 = [](int row) { return ((row >> 1) & 1) << 2; };         // 128-byte rows only
+
+  // ---- staging: piece t = wave + 8 i of a slice.  Per lane and piece, fixed for the kernel: the row inside the slice
+  // (a huge one where the lane never fetches: padding rows of an image, dY columns past Cout) and the byte offset of its
+  // 16 bytes at slice 0; per slice the offset advances by 64 rows -- the VALU work of an issue is an add, a range
+  // check and a select per piece (the first version decoded rows and columns per slice and the kernel was bound by its
+  // 132 M VALU instructions, not by LDS or HBM).
+  constexpr int kNever = 1 << 28;
+  int pc_kind[G::PW], pc_row[G::PW];                 // kind: 0 dY, 1..3 image kh = kind - 1, -1 dummy (wave-uniform)
+  unsigned pc_off0[G::PW], pc_lds[G::PW];
+#pragma unroll
+  for (int i = 0; i < G::PW; ++i) {
+    const int t = wave + 8 * i;
+    pc_kind[i] = -1; pc_row[i] = kNever; pc_off0[i] = 0u; pc_lds[i] = 0u;
+    if (t < G::DPieces) {
+      const int L = 64 * t + lane;
+      const int row = L / G::CPD, pc = L % G::CPD;
+      const int lc = G::CPD == 8 ? (pc ^ swz128(row)) : pc;
+      pc_kind[i] = 0;
+      pc_row[i] = lc * 8 < p.Cout ? row : kNever;
+      pc_off0[i] = (unsigned)((((int64_t)(m_lo + row) * p.dy_cs) + p.dy_co + lc * 8) * 2);
+      pc_lds[i] = (unsigned)(t * 1024);
+    } else if (t < G::Pieces) {
+      const int u = t - G::DPieces;
+      const int khp = u / G::XPieces, q = u - khp * G::XPieces;
+      const int L = 64 * q + lane;
+      const int row = L / G::CPP, pc = L % G::CPP;
+      const int lc = G::CPP == 8 ? (pc ^ swz128(row)) : pc;
+      pc_kind[i] = 1 + khp;
+      pc_row[i] = row < kFcZeroRow ? row + (khp - 1) * p.W - 1 : kNever;      // pixel = m_base + pc_row
+      pc_off0[i] = (unsigned)((((int64_t)(m_lo + row + (khp - 1) * p.W - 1) * p.x_cs) + p.x_co + lc * 8) * 2);
+      pc_lds[i] = (unsigned)(G::DBytes + khp * G::XBytes + q * 1024);
+    }
+  }
+  const unsigned d_step = (unsigned)(kFcRows * p.dy_cs * 2), x_step = (unsigned)(kFcRows * p.x_cs * 2);
+  const int HW = p.H * p.W;
+  auto issue = [&](int sl, int nsl) {
+    const int buf = sl % G::NBuf;
+    const int m_base = m_lo + sl * kFcRows;
+    const bool live = sl < nsl;
+    // Vertical borders (uniform per slice): a source pixel of an image's LAST row can only be "the row above" of the next
+    // image's first row, one of its FIRST row only "the row below" of the previous image's last -- such pixels must
+    // arrive as zeros (the horizontal border is the readers' per-row mask).  Whether the 66 pixels of the kh = 0 / 2
+    // images touch such a row is a property of the slice; only then do the lanes look at their own pixel's row.
+    bool edge[3] = {false, false, false};
+#pragma unroll
+    for (int k = 0; k < 3; k += 2) {
+      int a0 = m_base + (k - 1) * p.W - 1, a1 = a0 + kFcZeroRow - 1;
+      a0 = a0 < 0 ? 0 : a0;
+      a1 = a1 >= NHW ? NHW - 1 : a1;
+      if (a0 <= a1) {
+        const int r0 = fd_div(a0, p.fd_wo), r1 = fd_div(a1, p.fd_wo);
+        const int n0 = fd_div(a0, p.fd_hw);
+        const int h0 = r0 - n0 * p.H;                                // row of the first pixel inside its image
+        edge[k] = k == 0 ? (h0 + (r1 - r0) >= p.H - 1) : (h0 == 0 || h0 + (r1 - r0) >= p.H);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G::PW; ++i) {
+      unsigned off = kOOB;
+      unsigned dst = lds_base + (unsigned)(G::NBuf * G::BufBytes);       // dummy: the scratch KB
+      if (pc_kind[i] == 0) {
+        if (live && m_base + pc_row[i] < m_hi) off = pc_off0[i] + (unsigned)sl * d_step;
+        dst = lds_base + (unsigned)(buf * G::BufBytes) + pc_lds[i];
+        lds_dma16_t(rsD, dst, off, 0u);
+      } else {
+        if (pc_kind[i] > 0) {
+          const int pix = m_base + pc_row[i];
+          bool ok = live && (unsigned)pix < (unsigned)NHW;
+          if (pc_kind[i] != 2 && edge[pc_kind[i] - 1]) {
+            const int n = fd_div(pix, p.fd_hw);
+            const int hs = fd_div(pix - n * HW, p.fd_wo);
+            ok = ok && hs != (pc_kind[i] == 1 ? p.H - 1 : 0);
+          }
+          if (ok) off = pc_off0[i] + (unsigned)sl * x_step;
+          dst = lds_base + (unsigned)(buf * G::BufBytes) + pc_lds[i];
+        }
+        lds_dma16_t(rsX, dst, off, 0u);
+      }
+    }
+  };
+
+  // ---- compute roles
+  // measurement-only bits (YV4_WFC_ABLATE): 1 no fragment reads / MFMAs, 2 no DMA, 4 no border masks, 8 no MFMAs
+  // Which waves compute.  A wave sits on SIMD (wave mod 4) and a computing wave keeps its SIMD busy for most of a slice
+  // (its VALU instructions take four cycles each and its MFMAs queue behind one another), so six roles on waves 0..5
+  // load the SIMDs 2-2-1-1 and the pair sets the pace of every slice.  The two workgroups that share a CU (b and b + 256
+  // of a one-round grid) therefore start their roles two waves apart: together 3-3-3-3.
+  const int role = (wave + 8 - 2 * (((int)blockIdx.x >> 8) & 1)) & 7;
+  const bool computes = role < 3 * G::CB && !YV4_ABLATE(p.ablate, 1);
+  const int kh = role % 3, cb = role / 3;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int hh = g >> 1, colhalf = g & 1;
+  const int qq = i16 >> 2, pp = i16 & 3;
+  // dY fragment addresses (inside a buffer): [step s][j]
+  unsigned d_rd[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 16 * s + 8 * hh + 4 * j + qq;
+      const int chunk16 = (cb * 32 + 16 * colhalf) / 8 + (pp >> 1);
+      d_rd[s][j] = (unsigned)(row * G::DP + ((G::CPD == 8 ? (chunk16 ^ swz128(row)) : chunk16) << 4) + 8 * (pp & 1));
+    }
+  // X fragment addresses (inside a buffer) of (step s, j, column block nb), fixed for the kernel: the lane's 16-column
+  // half decides tap and channel base; x_zr[nb] = the same columns of the image's zero row
+  const unsigned ximg = (unsigned)(G::DBytes + kh * G::XBytes);
+  auto kw_of = [&](int nb) -> int { return CIN == 16 ? 2 * nb + colhalf : (CIN == 32 ? nb : nb >> 1); };
+  auto x_addr = [&](int row, int nb) -> unsigned {
+    const int kw = kw_of(nb);
+    const int cib = CIN == 16 ? 0 : (CIN == 32 ? 16 * colhalf : 32 * (nb & 1) + 16 * colhalf);
+    const int r = kw < 3 ? row + kw : kFcZeroRow;
+    const int chunk16 = cib / 8 + (pp >> 1);
+    return ximg + (unsigned)(r * G::PX + ((G::CPP == 8 ? (chunk16 ^ swz128(r)) : chunk16) << 4) + 8 * (pp & 1));
+  };
+  unsigned x_rd[4][2][G::NBK], x_zr[G::NBK];
+#pragma unroll
+  for (int nb = 0; nb < G::NBK; ++nb) {
+    x_zr[nb] = x_addr(kFcZeroRow - kw_of(nb) < 0 ? 0 : kFcZeroRow - (kw_of(nb) < 3 ? kw_of(nb) : 0), nb);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) x_rd[s][j][nb] = x_addr(16 * s + 8 * hh + 4 * j + qq, nb);
+  }
+
+  f32x16 acc[G::NBK];
+#pragma unroll
+  for (int b = 0; b < G::NBK; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+
+  const int nsl = (m_hi - m_lo + kFcRows - 1) / kFcRows;
+  // horizontal border masks of this lane's eight reduction rows of a slice: bit (s * 2 + j) * 3 + kw set = the row's
+  // column wo + kw - 1 exists.  (Rows past the end of the chunk need no mask: their dY rows arrive as zeros.)  No
+  // branches: the eight rows of every lane are computed alike.
+  auto slice_masks = [&](int sl) -> unsigned {
+    unsigned mk = 0u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = m_lo + sl * kFcRows + 16 * s + 8 * hh + 4 * j + qq;
+        const int wo = m - fd_div(m, p.fd_wo) * p.W;
+        const unsigned b3 = (wo > 0 ? 1u : 0u) | 2u | (wo + 1 < p.W ? 4u : 0u);
+        mk |= b3 << ((s * 2 + j) * 3);
+      }
+    return mk;
+  };
+
+#pragma unroll
+  for (int s0 = 0; s0 < G::NBuf - 1; ++s0) issue(s0, nsl);
+  for (int sl = 0; sl < nsl; ++sl) {
+    // own DMA(sl) landed: the NBuf - 2 younger slices (PW instructions each) may stay in flight
+    constexpr int kLeft = (G::NBuf - 2) * G::PW;
+    if (kLeft == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (kLeft == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else if (kLeft == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if (kLeft == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else if (kLeft == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if (kLeft == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (kLeft == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // slice sl complete in LDS; every wave is done with slice sl - 1
+    asm volatile("" ::: "memory");
+    if (!YV4_ABLATE(p.ablate, 2)) issue(sl + G::NBuf - 1, nsl);       // into the buffer slice sl - 1 left
+    if (computes) {
+      const char* bufp = smem_fc + (sl % G::NBuf) * G::BufBytes;
+      // horizontal borders: a slice whose 64 pixels lie inside one image row, away from its ends, needs no mask (uniform)
+      unsigned mk = 0xFFFFFFu;
+      {
+        const int mb = m_lo + sl * kFcRows;
+        const int rb = fd_div(mb, p.fd_wo);
+        const int wb = mb - rb * p.W;
+        if (!(wb > 0 && wb + kFcRows < p.W) && !YV4_ABLATE(p.ablate, 4)) mk = slice_masks(sl);
+      }
+      // two fragment sets: the reads of step s + 1 are issued in front of the MFMAs of step s (left to itself the
+      // compiler reuses one register set and every MFMA waits out a fresh LDS round trip: 2 400 cycles per slice)
+      s16x8_t fa[2], fb[2][G::NBK];
+#define YV4_FC_LOAD(SET, S)                                                                                   \
+      {                                                                                                       \
+        const s16x4_t a0_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(bufp + d_rd[S][0]));          \
+        const s16x4_t a1_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(bufp + d_rd[S][1]));          \
+        fa[SET] = __builtin_shufflevector(a0_, a1_, 0, 1, 2, 3, 4, 5, 6, 7);                                  \
+        _Pragma("unroll") for (int nb = 0; nb < G::NBK; ++nb) {                                               \
+          const int kw_ = kw_of(nb);                                                                          \
+          const int kb_ = kw_ < 3 ? kw_ : 0;                                                                  \
+          const bool ok0_ = kw_ < 3 && ((mk >> (((S) * 2 + 0) * 3 + kb_)) & 1u);                              \
+          const bool ok1_ = kw_ < 3 && ((mk >> (((S) * 2 + 1) * 3 + kb_)) & 1u);                              \
+          const s16x4_t b0_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(bufp + (ok0_ ? x_rd[S][0][nb] : x_zr[nb]))); \
+          const s16x4_t b1_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(bufp + (ok1_ ? x_rd[S][1][nb] : x_zr[nb]))); \
+          fb[SET][nb] = __builtin_shufflevector(b0_, b1_, 0, 1, 2, 3, 4, 5, 6, 7);                            \
+        }                                                                                                     \
+      }
+#define YV4_FC_MFMA(SET)                                                                                      \
+      {                                                                                                       \
+        _Pragma("unroll") for (int nb = 0; nb < G::NBK; ++nb) {                                               \
+          if (YV4_ABLATE(p.ablate, 8)) { acc[nb][0] += __builtin_bit_cast(float, (int)(fa[SET][0] + fb[SET][nb][0])); continue; } \
+          if (BF16)                                                                                           \
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, fa[SET]),          \
+                                                              __builtin_bit_cast(bf16x8_w, fb[SET][nb]), acc[nb], 0, 0, 0); \
+          else                                                                                                \
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_w, fa[SET]),            \
+                                                             __builtin_bit_cast(f16x8_w, fb[SET][nb]), acc[nb], 0, 0, 0);   \
+        }                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+      }
+      YV4_FC_LOAD(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      YV4_FC_LOAD(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      YV4_FC_MFMA(0);
+      YV4_FC_LOAD(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      YV4_FC_MFMA(1);
+      YV4_FC_LOAD(1, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      YV4_FC_MFMA(0);
+      YV4_FC_MFMA(1);
+#undef YV4_FC_MFMA
+#undef YV4_FC_LOAD
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the tail's out-of-range DMAs must land before the LDS goes
+
+  if (!computes) return;
+  // D[row = co][col]: row = (e&3) + 8*(e>>2) + 4*(lane>>5), col = lane&31 -> (kw, ci) of the block
+  const int ncol = lane & 31, h5 = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < G::NBK; ++nb) {
+    int kw, ci;
+    if (CIN == 16) { kw = 2 * nb + (ncol >> 4); ci = ncol & 15; }
+    else if (CIN == 32) { kw = nb; ci = ncol; }
+    else { kw = nb >> 1; ci = 32 * (nb & 1) + ncol; }
+    if (kw >= 3 || ci >= p.Cin) continue;
+    const int kcol = (kh * 3 + kw) * p.Cin + ci;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h5;
+      if (co < p.Cout) {
+        if (p.ws) p.ws[(size_t)chunk * p.ws_stride + (size_t)co * p.K + kcol] = acc[nb][e];
+        else atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[nb][e]);
+      }
+    }
+  }
+}
+
+// domain of conv_wgrad_fc_h16_kernel, and the channels per pixel it loads (0: not applicable)
+static int wgrad_fc_cin(const yv4_conv_desc* d, int dtype) {
+  static const int mode = YV4_ENV_INT("YV4_WGRAD_FC", 1);
+  if (!mode || dtype == YV4_F32 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W)
+    return 0;
+  if (d->Cout != 32 && d->Cout != 64) return 0;
+  const long long M = (long long)d->N * d->H * d->W;
+  if (M >= (1LL << 30) || M < 256LL * kFcRows * 8) return 0;           // at least eight slices for every CU
+  if (d->Cin == 16 || d->Cin == 32 || d->Cin == 64) return d->Cin;
+  // the stem: 8 weight channels against an image stored with 16 per pixel (the other 8 are read and dropped)
+  if (d->Cin == 8 && d->x_coff + 16 <= d->x_cstride) return 16;
+  return 0;
 }
 
 // domain of conv_wgrad3x3_h16_kernel
@@ -1534,6 +1860,15 @@ static const bool g_wgrad_xcd = YV4_ENV_INT("YV4_WGRAD_XCD", 1) != 0;
 static void wgrad_chunks(const yv4_conv_desc* d, int dtype, long long* chunks, long long* rows) {
   const long long M = (long long)d->N * d->Ho * d->Wo;
   const int K = d->KH * d->KW * d->Cin;
+  if (!g_wgrad_widen && wgrad_fc_cin(d, dtype)) {
+    // one round of workgroups (two per CU; one for Cin 64), every one with at least four slices (wgrad_fc_cin)
+    long long ch = wgrad_fc_cin(d, dtype) == 64 ? 256 : 512;
+    long long rw = (M + ch - 1) / ch;
+    rw = (rw + kFcRows - 1) / kFcRows * kFcRows;
+    *rows = rw;
+    *chunks = (M + rw - 1) / rw;
+    return;
+  }
   if (!g_wgrad_widen && wgrad3x3_applies(d, dtype)) {
     // one 8-wave workgroup per CU.  Measured (tools/wgrad_bench.py --det, batch 64): ONE full round of (co tile, kh, ci
     // tile, chunk) workgroups beats two (half the slab traffic and epilogues: 160 vs 179 us on 128->128 @76) unless the
@@ -1642,6 +1977,28 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     YV4_CHECK_LAUNCH("conv_wgrad reduce");
     return YV4_OK;
   };
+  if (const int fc = g_wgrad_widen ? 0 : wgrad_fc_cin(d, dtype)) {
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    static const int fc_ablate = YV4_ENV_INT("YV4_WFC_ABLATE", 0);
+    a.ablate = fc_ablate;
+#define YV4_FC_LAUNCH(CI, CO)                                                                                        \
+  {                                                                                                                  \
+    static LdsAttrOnce once_b, once_h;                                                                               \
+    constexpr size_t lds = FcGeom<CI, CO>::Lds;                                                                      \
+    if (int rc = ensure_dyn_lds(once_b, reinterpret_cast<const void*>(conv_wgrad_fc_h16_kernel<true, CI, CO>), lds, "conv_wgrad_fc_h16")) return rc;  \
+    if (int rc = ensure_dyn_lds(once_h, reinterpret_cast<const void*>(conv_wgrad_fc_h16_kernel<false, CI, CO>), lds, "conv_wgrad_fc_h16")) return rc; \
+    if (dtype == YV4_BF16) hipLaunchKernelGGL((conv_wgrad_fc_h16_kernel<true, CI, CO>), dim3((unsigned)ch), dim3(kFcThreads), lds, hs, a, (unsigned)xb, (unsigned)db); \
+    else hipLaunchKernelGGL((conv_wgrad_fc_h16_kernel<false, CI, CO>), dim3((unsigned)ch), dim3(kFcThreads), lds, hs, a, (unsigned)xb, (unsigned)db);                  \
+  }
+    if (a.Cout == 32) {
+      if (fc == 16) YV4_FC_LAUNCH(16, 32) else if (fc == 32) YV4_FC_LAUNCH(32, 32) else YV4_FC_LAUNCH(64, 32)
+    } else {
+      if (fc == 16) YV4_FC_LAUNCH(16, 64) else if (fc == 32) YV4_FC_LAUNCH(32, 64) else YV4_FC_LAUNCH(64, 64)
+    }
+#undef YV4_FC_LAUNCH
+    YV4_CHECK_LAUNCH("conv_wgrad_fc_h16");
+    return finish();
+  }
   if (!g_wgrad_widen && wgrad3x3_applies(d, dtype)) {
     const long long tl = (long long)((a.Cout + 127) / 128) * 3 * (a.Cin / 128);
     static LdsAttrOnce once3b, once3h;

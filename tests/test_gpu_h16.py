@@ -541,6 +541,64 @@ def test_h16_wgrad3x3_kernel(gpu_device, dtype, tol, shape):
     assert float(per_tap.max()) <= 4e-3, per_tap
 
 
+FC_SHAPES = [
+    # N, Cin, Cout, H, W (3x3, stride 1, pad 1; Cin 16 / 32 / 64 per pixel, Cout 32 / 64; at least 131 072 rows):
+    # the domain of conv_wgrad_fc_h16_kernel
+    (4, 32, 64, 192, 192),     # the first Bottleneck's widths
+    (3, 16, 32, 224, 208),     # 32-byte pixel rows, two taps per 32-column block
+    (2, 64, 64, 260, 256),     # 128-byte rows on both sides (swapped halves), six column blocks per kh
+    (9, 32, 32, 121, 123),     # odd sizes: image and row borders anywhere in a slice, ragged last slice
+    (2, 64, 32, 300, 230),
+    (5, 16, 64, 170, 160),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', FC_SHAPES)
+def test_h16_wgrad_few_channel_kernel(gpu_device, dtype, shape):
+    """The few-channel 3x3 weight-gradient kernel (train.hip conv_wgrad_fc_h16_kernel: all of dW per workgroup, one
+    source image per kh shared by its three kw taps) through ConvFunction, vs fp64 autograd on the same rounded
+    operands; deterministic run to run; per-tap error (a shifted-row or masking mistake is one wrong (kh, kw) plane)."""
+    N, Cin, Cout, H, W = shape
+    torch.manual_seed(2)
+    x = torch.randn(N, Cin, H, W, device=gpu_device).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, device=gpu_device) * (Cin * 9) ** -0.5)
+    gy = None
+    grads = []
+    for _ in range(2):
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        y = T.conv2d(xr, wr, 1, 1, dtype=dtype)
+        if gy is None:
+            gy = torch.randn_like(y.float()).to(dtype)
+        y.backward(gy)
+        grads.append(wr.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    w64 = w.to(dtype).double().requires_grad_(True)
+    F.conv2d(x.double(), w64, None, 1, 1).backward(gy.double())
+    err = float((grads[0].double() - w64.grad).abs().max() / (w64.grad.abs().max() + 1e-12))
+    assert err <= 2e-3, err
+    per_tap = (grads[0].double() - w64.grad).abs().amax(dim=(0, 1)) / (w64.grad.abs().amax(dim=(0, 1)) + 1e-12)
+    assert float(per_tap.max()) <= 4e-3, per_tap
+
+
+def test_h16_wgrad_few_channel_kernel_stem(gpu_device):
+    """The 16-bit stem: 3 weight channels against an image stored with 16 channels per pixel (``image_to_nhwc16``): the
+    kernel loads 16, keeps the weight's (padded) 8."""
+    torch.manual_seed(3)
+    N, H, W = 4, 200, 180
+    img = torch.randn(N, 3, H, W, device=gpu_device)
+    w = (torch.randn(32, 3, 3, 3, device=gpu_device) * 27 ** -0.5).requires_grad_(True)
+    x16 = T.image_to_nhwc16(img, torch.bfloat16, 16)
+    y = T.conv2d(x16, w, 1, 1, dtype=torch.bfloat16)
+    gy = torch.randn_like(y.float()).bfloat16()
+    y.backward(gy)
+    w64 = w.detach().bfloat16().double().requires_grad_(True)
+    F.conv2d(img.bfloat16().double(), w64, None, 1, 1).backward(gy.double())
+    err = float((w.grad.double() - w64.grad).abs().max() / (w64.grad.abs().max() + 1e-12))
+    assert err <= 2e-3, err
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.bfloat16, 3e-2), (torch.float16, 4e-3)])
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_h16_bn_act_autograd(gpu_device, dtype, tol, act):
