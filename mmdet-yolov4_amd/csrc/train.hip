@@ -1097,6 +1097,41 @@ __device__ __forceinline__ float act_grad(float z, int act, float slope) {
     default: return 1.f;
   }
 }
+// Two channels at a time for the Mish passes of the BatchNorm kernels: the compiler does not pair the per-channel fp32
+// arithmetic by itself (no v_pk_* in the scalar loops), and these kernels are bound by their VALU issue slots (a wave
+// instruction takes four cycles on a 16-lane SIMD: ~30 slots per element = 0.6 ms on the 757 M-element layer, which is
+// also its HBM time).  Every operation below is the scalar path's, done on a pair -- v_pk_mul / v_pk_add / v_pk_fma --
+// so the results are bit for bit the scalar ones; the transcendentals stay one per element.
+__device__ __forceinline__ f32x2_t splat2(float v) { f32x2_t r; r.x = v; r.y = v; return r; }
+__device__ __forceinline__ f32x2_t mish_grad2(f32x2_t z) {
+  f32x2_t zc;
+  zc.x = fminf(z.x, 20.f); zc.y = fminf(z.y, 20.f);
+  const f32x2_t t = zc * 1.44269504088896340736f;
+  f32x2_t e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2_t a = e + 1.f;
+  const f32x2_t w = __builtin_elementwise_fma(a, a, splat2(1.f));
+  f32x2_t iw;
+  iw.x = __builtin_amdgcn_rcpf(w.x); iw.y = __builtin_amdgcn_rcpf(w.y);
+  f32x2_t g = __builtin_elementwise_fma(4.f * (z * (a * e)), iw * iw, __builtin_elementwise_fma(splat2(-2.f), iw, splat2(1.f)));
+  g.x = z.x >= 20.f ? 1.f : g.x;
+  g.y = z.y >= 20.f ? 1.f : g.y;
+  return g;
+}
+// mish_fast_f32 on a pair, expression for expression: e = exp2(x log2 e), n = e (e + 2), (x n) / (n + 2), x itself from 20 on
+__device__ __forceinline__ f32x2_t mish_fwd2(f32x2_t x) {
+  const f32x2_t t = x * 1.44269504088896340736f;
+  f32x2_t e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2_t n = e * (e + 2.f);
+  const f32x2_t d = n + 2.f;
+  f32x2_t r;
+  r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+  f32x2_t y = (x * n) * r;
+  y.x = x.x >= 20.f ? x.x : y.x;
+  y.y = x.y >= 20.f ? x.y : y.y;
+  return y;
+}
 // (the forward of the fused BN + activation uses apply_act -- hardware exp2 / rcp Mish, < 2e-6 absolute from the
 // libm form: with the libm form the kernel was VALU-bound, ~45 instructions per element at 2 bytes in, 2 out)
 __device__ __forceinline__ float act_fwd_exact(float z, int act, float slope) {
@@ -1337,8 +1372,20 @@ __global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_fwd_kernel(BnA
         const int64_t row = rr + (int64_t)u * mp.rstep;
         if (row >= r1) continue;
         float o[V];
+        if (p.act == YV4_ACT_MISH) {      // (uniform) pairs of channels: see mish_grad2
 #pragma unroll
-        for (int k = 0; k < V; ++k) o[k] = apply_act(((float)v[u][k] - mu[k]) * sa[k] + be[k], p.act, p.slope) + (float)rs[u][k];
+          for (int k = 0; k < V; k += 2) {
+            f32x2_t x2, m2, s2, b2, r2;
+            x2.x = (float)v[u][k]; x2.y = (float)v[u][k + 1];
+            m2.x = mu[k]; m2.y = mu[k + 1]; s2.x = sa[k]; s2.y = sa[k + 1]; b2.x = be[k]; b2.y = be[k + 1];
+            r2.x = (float)rs[u][k]; r2.y = (float)rs[u][k + 1];
+            const f32x2_t y2 = mish_fwd2((x2 - m2) * s2 + b2) + r2;
+            o[k] = y2.x; o[k + 1] = y2.y;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < V; ++k) o[k] = apply_act(((float)v[u][k] - mu[k]) * sa[k] + be[k], p.act, p.slope) + (float)rs[u][k];
+        }
         RV::st(py + row * p.y_cs + p.y_co + c, o);
       }
     }
@@ -1385,14 +1432,34 @@ __global__ __launch_bounds__(256, YV4_BN_RED_WAVES) void bn_act_bwd_reduce_kerne
           xv[u] = ok ? RV::ld(px + row * p.x_cs + c) : RV::zero();
           gv[u] = ok ? RV::ld(pdy + row * p.dy_cs + c) : RV::zero();   // zero beyond r1 -> contributes nothing
         }
+        if (p.act == YV4_ACT_MISH) {      // (uniform) pairs of channels: see mish_grad2
 #pragma unroll
-        for (int u = 0; u < kBnRedUnroll; ++u) {
+          for (int u = 0; u < kBnRedUnroll; ++u) {
 #pragma unroll
-          for (int k = 0; k < V; ++k) {
-            const float xhat = ((float)xv[u][k] - mu[k]) * is[k];
-            const float g = (float)gv[u][k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
-            db[k] += g;
-            dg[k] += g * xhat;
+            for (int k = 0; k < V; k += 2) {
+              f32x2_t x2, g2, m2, i2, a2, b2, db2, dg2;
+              x2.x = (float)xv[u][k]; x2.y = (float)xv[u][k + 1];
+              g2.x = (float)gv[u][k]; g2.y = (float)gv[u][k + 1];
+              m2.x = mu[k]; m2.y = mu[k + 1]; i2.x = is[k]; i2.y = is[k + 1];
+              a2.x = ga[k]; a2.y = ga[k + 1]; b2.x = be[k]; b2.y = be[k + 1];
+              db2.x = db[k]; db2.y = db[k + 1]; dg2.x = dg[k]; dg2.y = dg[k + 1];
+              const f32x2_t xh2 = (x2 - m2) * i2;
+              const f32x2_t gg = g2 * mish_grad2(xh2 * a2 + b2);
+              db2 = db2 + gg;
+              dg2 = dg2 + gg * xh2;
+              db[k] = db2.x; db[k + 1] = db2.y; dg[k] = dg2.x; dg[k + 1] = dg2.y;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kBnRedUnroll; ++u) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+              const float xhat = ((float)xv[u][k] - mu[k]) * is[k];
+              const float g = (float)gv[u][k] * act_grad(xhat * ga[k] + be[k], p.act, p.slope);
+              db[k] += g;
+              dg[k] += g * xhat;
+            }
           }
         }
       }
@@ -1458,6 +1525,8 @@ __global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_bwd_apply_kern
         const int64_t row = rr + (int64_t)u * mp.rstep;
         if (row >= r1) continue;
         float o[V];
+        // (scalar on purpose: the paired form of the other two passes costs this one 15 registers and, bound by its
+        // 6 bytes per element as it is, 4 % of its speed -- tools/bn_bench.py --kernels, same box)
 #pragma unroll
         for (int k = 0; k < V; ++k) {
           const float xhat = ((float)xv[u][k] - mu[k]) * is[k];
