@@ -303,35 +303,31 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void conv_wgrad_h16_kernel(
 
   // (a slice past the end of the chunk is issued all the same, every lane out of range: the count of outstanding
   // instructions the waits below rely on stays fixed)
+  // No branches in here: every lane decodes its four rows the same way and SELECTS between its offset and the
+  // out-of-range one (the nested ifs and the wrap loop of the first form compiled to a dozen divergent branches per
+  // slice in front of the fragment reads).
   auto issue = [&](int m_base, int buf) {
-    // first row of this lane in the slice, decoded once; rows of q = 1..3 follow by +4 pixels
-    int m = m_base + 16 * wave + srow;
     const int hw = p.Ho * p.Wo;
-    int n = fd_div(m, p.fd_hw);
-    int rm = m - n * hw;
-    int ho = fd_div(rm, p.fd_wo);
-    int wo = rm - ho * p.Wo;
     const unsigned lrow0 = (unsigned)(buf * 2 * kOpBytes + (16 * wave) * kRowB);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      unsigned doff = kOOB, aoff = kOOB;
-      if (m < m_hi) {
-        if (d_col[q] >= 0) doff = (unsigned)((((int64_t)m * p.dy_cs) + p.dy_co + d_col[q]) * 2);
-        if (a_tap[q] >= 0) {
-          const int hi = ho * p.stride - p.pad + a_kh[q];
-          const int wi = wo * p.stride - p.pad + a_kw[q];
-          if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-            aoff = (unsigned)(((((int64_t)n * p.H + hi) * p.W + wi) * p.x_cs + p.x_co + a_ci[q]) * 2);
-        }
-      }
+      const int m = m_base + 16 * wave + srow + 4 * q;
+      const int n = fd_div(m, p.fd_hw);
+      const int rm = m - n * hw;
+      const int ho = fd_div(rm, p.fd_wo);
+      const int wo = rm - ho * p.Wo;
+      const bool rowok = m < m_hi;
+      const int hi = ho * p.stride - p.pad + a_kh[q];
+      const int wi = wo * p.stride - p.pad + a_kw[q];
+      const bool dok = rowok && d_col[q] >= 0;
+      const bool aok = rowok && a_tap[q] >= 0 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const unsigned dval = (unsigned)m * (unsigned)(p.dy_cs * 2) + (unsigned)((p.dy_co + d_col[q]) * 2);
+      const unsigned aval = (unsigned)((n * p.H + hi) * p.W + wi) * (unsigned)(p.x_cs * 2) + (unsigned)((p.x_co + a_ci[q]) * 2);
+      const unsigned doff = dok ? dval : kOOB;
+      const unsigned aoff = aok ? aval : kOOB;
       const unsigned lrow = lrow0 + (unsigned)(4 * q * kRowB);
       lds_dma16_t(rsD, lds_base + lrow, doff, 0u);
       lds_dma16_t(rsX, lds_base + (unsigned)kOpBytes + lrow, aoff, 0u);
-      // next instruction: 4 pixels further
-      m += 4;
-      wo += 4;
-      while (wo >= p.Wo) { wo -= p.Wo; ++ho; }
-      if (ho >= p.Ho) { ho -= p.Ho; ++n; }
     }
   };
 
@@ -378,30 +374,44 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void conv_wgrad_h16_kernel(
     char* dbuf = smem_wh + buf * 2 * kOpBytes;
     char* abuf = dbuf + kOpBytes;
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < kWhRows / 16; ++s) {
-      s16x8_t fa[2], fb[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(dbuf + frag_addr(wm * 64 + t * 32, s, 0)));
-        const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(dbuf + frag_addr(wm * 64 + t * 32, s, 1)));
-        const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(abuf + frag_addr(wn * 64 + t * 32, s, 0)));
-        const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(abuf + frag_addr(wn * 64 + t * 32, s, 1)));
-        fa[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-        fb[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if (BF16)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, fa[a]),
-                                                                __builtin_bit_cast(bf16x8_w, fb[b]), acc[a][b], 0, 0, 0);
-          else
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_w, fa[a]),
-                                                               __builtin_bit_cast(f16x8_w, fb[b]), acc[a][b], 0, 0, 0);
-        }
+    // two fragment sets: the eight reads of step s + 1 are issued in front of the four MFMAs of step s (one set, as the
+    // compiler schedules the plain loop, makes every step wait out a fresh LDS round trip)
+    s16x8_t fa[2][2], fb[2][2];
+#define YV4_WH_LOAD(SET, S)                                                                                           \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                   \
+      const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(dbuf + frag_addr(wm * 64 + t * 32, S, 0))); \
+      const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(dbuf + frag_addr(wm * 64 + t * 32, S, 1))); \
+      const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(abuf + frag_addr(wn * 64 + t * 32, S, 0))); \
+      const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(abuf + frag_addr(wn * 64 + t * 32, S, 1))); \
+      fa[SET][t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);                                          \
+      fb[SET][t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);                                          \
     }
+#define YV4_WH_MFMA(SET)                                                                                              \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                     \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                 \
+        if (BF16)                                                                                                     \
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, fa[SET][a]),               \
+                                                              __builtin_bit_cast(bf16x8_w, fb[SET][b]), acc[a][b], 0, 0, 0); \
+        else                                                                                                          \
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_w, fa[SET][a]),                 \
+                                                             __builtin_bit_cast(f16x8_w, fb[SET][b]), acc[a][b], 0, 0, 0);   \
+      }                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+    static_assert(kWhRows / 16 == 4, "the step schedule below is written for four 16-row steps");
+    YV4_WH_LOAD(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_WH_LOAD(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_WH_MFMA(0);
+    YV4_WH_LOAD(0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_WH_MFMA(1);
+    YV4_WH_LOAD(1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_WH_MFMA(0);
+    YV4_WH_MFMA(1);
+#undef YV4_WH_MFMA
+#undef YV4_WH_LOAD
     __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
