@@ -474,6 +474,13 @@ typedef struct yv4_pack_desc {
 } yv4_pack_desc;
 int yv4_pack_weights_multi(const yv4_pack_desc* table_dev, int n, int total_blocks, void* stream);
 
+/* Backward of yv4_resample_nearest_fwd for INTEGER scale factors (the neck's 2x upsample into its concat buffer,
+ * necks/yolo_neck_csp.py:213-219 / torch's upsample_nearest2d_backward): dx (N, Hs, Ws, C) dense = the sum of the
+ * (Hd / Hs) x (Wd / Ws) pixels of dy that read it; dy is a channel slice (dy_cstride, dy_coff) of an (N, Hd, Wd, .) tensor
+ * of `dtype`; fp32 sum, one rounding. */
+int yv4_resample_nearest_bwd(const void* dy, void* dx, int N, int Hs, int Ws, int Hd, int Wd, int C,
+                             int dy_cstride, int dy_coff, int dtype, void* stream);
+
 /* One parity class of the data gradient of a stride-2 convolution: a stride-1 convolution of dY whose
  * output pixel (n, ho, wo) is stored at y[n, ho*sh + oh, wo*sw + ow, y_coff + c] of an
  * (N, Hy, Wy, y_cstride) tensor.  d->Ho / d->Wo are taken as given (rows past the input's edge read

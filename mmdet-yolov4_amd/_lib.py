@@ -100,6 +100,7 @@ SIGNATURES = {
     'yv4_spp_pool_fwd': (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_resample_nearest_fwd': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i,
                                            _i, _i, _i, _i, _vp]),
+    'yv4_resample_nearest_bwd': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_decode_reset': (C.c_int, [_vp, _vp, _i, _vp]),
     'yv4_decode_filter': (C.c_int, [C.POINTER(LevelDesc), _i, _i, _i, _i, _f,
                                     _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,

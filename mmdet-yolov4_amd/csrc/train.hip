@@ -1902,6 +1902,32 @@ static inline unsigned ew_grid_t(size_t work_items) {
   return (unsigned)g;
 }
 
+// Backward of the nearest resample by an INTEGER factor (yolo_neck_csp.py:213-219: F.interpolate(scale 2) into the concat
+// buffer): dx[n, sy, sx, c] = the sum of the fy x fx gradient pixels that read it, fp32 sum, one rounding.  The gradient is a
+// channel slice of the concat buffer's gradient (dy_cs / dy_co).
+template <typename T>
+__global__ __launch_bounds__(256) void resample_nearest_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int Hs,
+                                                                   int Ws, int fy, int fx, int C4, int dy_cs, int dy_co) {
+  const size_t total = (size_t)N * Hs * Ws * C4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int Wd = Ws * fx, Hd = Hs * fy;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    const int sx = (int)(t % Ws);
+    t /= Ws;
+    const int sy = (int)(t % Hs);
+    const int n = (int)(t / Hs);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < fy; ++j)
+      for (int k = 0; k < fx; ++k) {
+        const float4 v = El<T>::ld4(dy + ((size_t)(n * Hd + sy * fy + j) * Wd + sx * fx + k) * dy_cs + dy_co + c4 * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    El<T>::st4(dx + i * 4, a);
+  }
+}
+
 }  // namespace yv4
 
 using namespace yv4;
@@ -2425,5 +2451,21 @@ extern "C" int yv4_spp_pool_bwd(const void* xcat, int x_cstride, int x_coff, con
                                            x_cstride, x_coff, reinterpret_cast<const T*>(dcat), d_cstride, d_coff, dx, N,
                                            H, W, C));
   YV4_CHECK_LAUNCH("spp_pool_bwd");
+  return YV4_OK;
+}
+
+
+extern "C" int yv4_resample_nearest_bwd(const void* dy, void* dx, int N, int Hs, int Ws, int Hd, int Wd, int C, int dy_cstride,
+                                        int dy_coff, int dtype, void* stream) {
+  YV4_REQUIRE(dy && dx && N > 0 && Hs > 0 && Ws > 0 && C > 0, "resample_bwd: bad argument");
+  YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "resample_bwd: dtype must be f32, f16 or bf16");
+  YV4_REQUIRE(Hd % Hs == 0 && Wd % Ws == 0 && Hd / Hs <= 8 && Wd / Ws <= 8, "resample_bwd: integer scale factors up to 8 only");
+  YV4_REQUIRE(((C | dy_cstride | dy_coff) & 3) == 0 && dy_coff >= 0 && dy_coff + C <= dy_cstride,
+              "resample_bwd: channels must be multiples of 4 and the view inside its pixel stride");
+  const size_t total = (size_t)N * Hs * Ws * (C / 4);
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(resample_nearest_bwd_kernel<T>, dim3(ew_grid_t(total)), dim3(256), 0,
+                                           reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(dy),
+                                           reinterpret_cast<T*>(dx), N, Hs, Ws, Hd / Hs, Wd / Ws, C / 4, dy_cstride, dy_coff));
+  YV4_CHECK_LAUNCH("resample_nearest_bwd");
   return YV4_OK;
 }

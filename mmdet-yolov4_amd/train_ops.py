@@ -915,6 +915,59 @@ def flush_batch_counters():
         _nbt_pending.clear()
 
 
+class ResampleIntoFunction(torch.autograd.Function):
+    """Nearest resample of ``x`` to (Hd, Wd) written into a channel range of a concat buffer (``CatSlot``) -- the
+    ``F.interpolate(...)`` + ``torch.cat`` of necks/yolo_neck_csp.py:213-219,229 without the intermediate tensor; with
+    Hd == Hs it is the plain copy of a saved tensor into its concat half.  Backward: the buffer's gradient slice, summed
+    over the pixels that read each source pixel (``yv4_resample_nearest_bwd``; the slice itself for the copy)."""
+
+    @staticmethod
+    def forward(ctx, x, Hd, Wd, cat_buf, cat_total, cat_off):
+        _need_cuda(x, 'x')
+        if x.dtype not in _DCODE:
+            x = x.float()
+        x = to_nhwc(x)
+        N, Cc, Hs, Ws = x.shape
+        al = 4 if x.dtype == torch.float32 else 8
+        assert Cc % al == 0 and cat_off % al == 0 and cat_total % al == 0 and cat_off + Cc <= cat_total
+        if cat_buf is None:
+            out = torch.empty((N, cat_total, Hd, Wd), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        else:
+            assert tuple(cat_buf.shape) == (N, cat_total, Hd, Wd) and cat_buf.dtype == x.dtype and _is_nhwc(cat_buf)
+            out = cat_buf
+            ctx.mark_dirty(cat_buf)
+        k = 1 if x.dtype == torch.float32 else 2      # a 16-bit map with C % 8 == 0 is an fp32 map with C / 2 channels
+        check(_lib.lib().yv4_resample_nearest_fwd(x.data_ptr(), out.data_ptr(), N, Hs, Ws, Hd, Wd, Cc // k, Cc // k, 0,
+                                                  cat_total // k, cat_off // k, stream_ptr()), 'yv4_resample_nearest_fwd')
+        ctx.geom = (N, Cc, Hs, Ws, Hd, Wd, cat_off, cat_buf is not None, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        N, Cc, Hs, Ws, Hd, Wd, off, passed, dtype = ctx.geom
+        dy, dcs = nhwc_or_slice(dz[:, off:off + Cc], dtype)
+        if (Hs, Ws) == (Hd, Wd):
+            dx = dy                                   # the copy's gradient is the slice itself (a strided view)
+        else:
+            dx = torch.empty((N, Cc, Hs, Ws), device=dz.device, dtype=dtype, memory_format=torch.channels_last)
+            check(_lib.lib().yv4_resample_nearest_bwd(dy.data_ptr(), dx.data_ptr(), N, Hs, Ws, Hd, Wd, Cc, dcs, 0,
+                                                      _DCODE[dtype], stream_ptr()), 'yv4_resample_nearest_bwd')
+        return dx, None, None, (dz if passed else None), None, None
+
+
+def resample_into(x, size, cat):
+    """``x`` nearest-resampled to ``size`` (an integer multiple of its own, or the same) into ``cat`` (a ``CatSlot``)."""
+    return ResampleIntoFunction.apply(x, int(size[0]), int(size[1]), *cat.args())
+
+
+def resample_into_ok(x, size):
+    """Integer scale factors (what the backward kernel sums over), 16-byte channel chunks."""
+    Hs, Ws = x.shape[2], x.shape[3]
+    al = 4 if x.dtype == torch.float32 else 8
+    return x.is_cuda and x.dtype in _DCODE and x.shape[1] % al == 0 and size[0] % Hs == 0 and size[1] % Ws == 0 \
+        and size[0] // Hs <= 8 and size[1] // Ws <= 8
+
+
 class SPPCatFunction(torch.autograd.Function):
     """``torch.cat([x, mp5(x), mp9(x), mp13(x)], 1)`` (darknetcsp.py:176-181,203-206,222-226) as one
     forward (slice copy + ``yv4_spp_pool_fwd``) and one backward launch (``yv4_spp_pool_bwd``); the

@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import darknetcsp as _D
+from . import train_ops as T
 from .bricks import HipModule
 from .darknetcsp import BottleneckCSP, BottleneckCSP2, Conv
 from .registry import NECKS
@@ -52,6 +54,15 @@ class _PANBase(HipModule):
         if 'scale_factor' in self.upsample_cfg:
             return F.interpolate(x, **self.upsample_cfg)
         return F.interpolate(x, size=bottom.shape[2:], **self.upsample_cfg)
+
+    def _up_target(self, x, bottom):
+        """(H, W) ``_up`` produces -- and whether it is the plain nearest mode the resample kernels implement."""
+        if self.upsample_cfg.get('mode', 'nearest') != 'nearest':
+            return (-1, -1)
+        if 'scale_factor' in self.upsample_cfg:
+            sf = self.upsample_cfg['scale_factor']
+            return int(x.shape[2] * sf), int(x.shape[3] * sf)
+        return int(bottom.shape[2]), int(bottom.shape[3])
 
     def forward(self, inputs):
         return self._dispatch((tuple(inputs),), 'tuple')
@@ -151,14 +162,36 @@ class YOLOV4Neck(_PANBase):
         x = inputs[self.backbone_end_level - 1]
         merge = []
         for i in range(used - 1, 0, -1):
-            bottom = self.backbone_pre_concat_convs[i - 1].fwd(inputs[self.start_level + i - 1])
+            lateral = self.backbone_pre_concat_convs[i - 1]
+            src = inputs[self.start_level + i - 1]
             merge.append(x)
-            x = self._up(self.pre_upsample_convs[i - 1].fwd(x), bottom)
-            x = self.post_upsample_concat_csp[i - 1].fwd(torch.cat((bottom, x), dim=1))
+            up = self.pre_upsample_convs[i - 1].fwd(x)
+            size = self._up_target(up, src)
+            t = lateral.out_channels
+            if _D._CAT_SLOTS and lateral.with_norm and lateral.stride == 1 and up.shape[1] == t and T.resample_into_ok(up, size) \
+                    and tuple(size) == tuple(src.shape[2:]):
+                # both halves of cat((bottom, up)) are written where they belong: the lateral conv's activation by its
+                # BN + act pass, the upsampled map by the resample launch (train_ops.CatSlot)
+                z = lateral.fwd(src, cat=T.CatSlot(2 * t, 0))
+                z = T.resample_into(up, size, T.CatSlot(2 * t, t, z))
+            else:
+                bottom = lateral.fwd(src)
+                z = torch.cat((bottom, self._up(up, bottom)), dim=1)
+            x = self.post_upsample_concat_csp[i - 1].fwd(z)
         outs = [x]
         for i in range(used - 1):
-            x = torch.cat((self.downsample_convs[i].fwd(x), merge.pop(-1)), dim=1)
-            x = self.post_downsample_concat_csp[i].fwd(x)
+            down = self.downsample_convs[i]
+            saved = merge.pop(-1)
+            c = down.out_channels
+            if _D._CAT_SLOTS and down.with_norm and saved.shape[1] == c and T.resample_into_ok(saved, saved.shape[2:]):
+                z = down.fwd(x, cat=T.CatSlot(2 * c, 0))
+                if tuple(z.shape[2:]) == tuple(saved.shape[2:]) and z.dtype == saved.dtype:
+                    z = T.resample_into(saved, saved.shape[2:], T.CatSlot(2 * c, c, z))     # copy into its half
+                else:
+                    z = torch.cat((z[:, :c], saved), dim=1)
+            else:
+                z = torch.cat((down.fwd(x), saved), dim=1)
+            x = self.post_downsample_concat_csp[i].fwd(z)
             outs.append(x)
         return tuple(self.out_convs[i].fwd(outs[i]) for i in range(len(outs)))
 
@@ -250,10 +283,29 @@ class YOLOV5Neck(_PANBase):
             bottom = inputs[self.start_level + i - 1]
             x = self.pre_upsample_convs[i - 1].fwd(x)
             merge.append(x)
-            x = self.post_upsample_concat_csp[i - 1].fwd(torch.cat((bottom, self._up(x, bottom)), dim=1))
+            size = self._up_target(x, bottom)
+            t = x.shape[1]
+            if _D._CAT_SLOTS and bottom.shape[1] == t and bottom.dtype == x.dtype and T.resample_into_ok(x, size) \
+                    and T.resample_into_ok(bottom, bottom.shape[2:]) and tuple(size) == tuple(bottom.shape[2:]):
+                z = T.resample_into(bottom, bottom.shape[2:], T.CatSlot(2 * t, 0))      # copy + upsample, no third tensor
+                z = T.resample_into(x, size, T.CatSlot(2 * t, t, z))
+            else:
+                z = torch.cat((bottom, self._up(x, bottom)), dim=1)
+            x = self.post_upsample_concat_csp[i - 1].fwd(z)
         outs = [x]
         for i in range(used - 1):
-            x = torch.cat((self.downsample_convs[i].fwd(x), merge.pop(-1)), dim=1)
-            x = self.post_downsample_concat_csp[i].fwd(x)
+            down = self.downsample_convs[i]
+            saved = merge.pop(-1)
+            c = down.out_channels
+            z = None
+            if _D._CAT_SLOTS and down.with_norm and saved.shape[1] == c and T.resample_into_ok(saved, saved.shape[2:]):
+                z = down.fwd(x, cat=T.CatSlot(2 * c, 0))
+                if tuple(z.shape[2:]) == tuple(saved.shape[2:]) and z.dtype == saved.dtype:
+                    z = T.resample_into(saved, saved.shape[2:], T.CatSlot(2 * c, c, z))
+                else:
+                    z = torch.cat((z[:, :c], saved), dim=1)
+            if z is None:
+                z = torch.cat((down.fwd(x), saved), dim=1)
+            x = self.post_downsample_concat_csp[i].fwd(z)
             outs.append(x)
         return tuple(outs)

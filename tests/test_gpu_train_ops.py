@@ -330,6 +330,80 @@ def test_csp_halves_written_into_the_concat_buffer(gpu_device, monkeypatch, bloc
         assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 16, 7, 9, 2), (3, 24, 5, 5, 1), (1, 8, 6, 4, 4)])
+def test_resample_into_concat_slot(gpu_device, dtype, shape):
+    """``train_ops.resample_into``: nearest upsample by an integer factor (or the plain copy) straight into a channel
+    range of a concat buffer, and the backward that sums the buffer's gradient slice over the pixels that read each
+    source pixel -- against F.interpolate + torch.cat autograd (the forward bit for bit; fp32 sums on both sides)."""
+    N, C_, H, W, f = shape
+    torch.manual_seed(7)
+    a = torch.randn(N, C_, H * f, W * f, device=gpu_device).to(dtype)
+    b = torch.randn(N, C_, H, W, device=gpu_device).to(dtype)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    z = T.resample_into(ar, (H * f, W * f), T.CatSlot(2 * C_, 0))                 # copy into the first half
+    z = T.resample_into(br, (H * f, W * f), T.CatSlot(2 * C_, C_, z))             # upsample into the second
+    g = torch.randn(N, 2 * C_, H * f, W * f, device=gpu_device).to(dtype).contiguous(memory_format=torch.channels_last)
+    z.backward(g)
+    a2, b2 = a.float().requires_grad_(True), b.float().requires_grad_(True)
+    ref = torch.cat((a2, F.interpolate(b2, size=(H * f, W * f), mode='nearest')), 1)
+    ref.backward(g.float())
+    assert torch.equal(z.detach().float(), ref.detach())
+    assert torch.equal(ar.grad.float(), a2.grad)
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert rel(br.grad.float(), b2.grad) <= tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('neck', ['v4', 'v5'])
+def test_neck_halves_written_into_the_concat_buffers(gpu_device, monkeypatch, neck, dtype):
+    """The necks' concatenations (lateral conv / backbone map with the upsampled map; stride-2 conv with the saved
+    top-down map) through ``CatSlot`` producers against the same neck through ``torch.cat`` (YV4_CAT_SLOTS off)."""
+    from mmdet_yolov4_amd import darknetcsp as D
+    from mmdet_yolov4_amd import yolo_neck_csp as NK
+    torch.manual_seed(11)
+    if neck == 'v4':
+        mod = NK.YOLOV4Neck(in_channels=[32, 64, 64], out_channels=[32, 64, 128], csp_repetition=1)
+        chans = [32, 64, 64]
+    else:
+        mod = NK.YOLOV5Neck(in_channels=[32, 64, 128], out_channels=[32, 64, 128], csp_repetition=1)
+        chans = [32, 64, 128]
+    mod = mod.to(gpu_device).train()
+    if dtype != torch.float32:
+        pkg.wrap_fp16_model(mod, dtype)
+    xs0 = [torch.randn(2, c, 24 >> i, 16 >> i, device=gpu_device).to(dtype).contiguous(memory_format=torch.channels_last)
+           for i, c in enumerate(chans)]
+
+    def run(slots):
+        monkeypatch.setattr(D, '_CAT_SLOTS', slots)
+        mod.zero_grad(set_to_none=True)
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        outs = mod(xs)
+        T.flush_batch_counters()
+        loss = sum((o.float() * torch.linspace(-1, 1, o.numel(), device=gpu_device).view_as(o)).sum() for o in outs)
+        loss.backward()
+        return [o.detach().float() for o in outs], [x.grad.float() for x in xs], \
+            [p.grad.detach().float().clone() for p in mod.parameters()]
+
+    cats = []
+    real_cat = torch.cat
+    monkeypatch.setattr(torch, 'cat', lambda *a, **k: (cats.append(1), real_cat(*a, **k))[1])
+    out_a, dx_a, gp_a = run(True)
+    with_slots = len(cats)
+    out_b, dx_b, gp_b = run(False)
+    assert with_slots == 0 and len(cats) >= 4          # two top-down and two bottom-up concatenations (+ the CSP ones)
+    # fp32 is the check of the plumbing.  In bf16 the forward is bit for bit the same, but the slot path also joins the
+    # CSP blocks' fan-out gradients inside a data-gradient launch (one rounding) where autograd adds two rounded
+    # tensors: rounding noise that a BatchNorm weight gradient three blocks upstream (a sum with cancellation) shows
+    # as a few per cent of its largest entry
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a, b in zip(out_a, out_b):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())
+    gtol = 1e-5 if dtype == torch.float32 else 1e-1
+    for a, b in zip(dx_a + gp_a, dx_b + gp_b):
+        assert float((a - b).abs().max()) <= gtol * max(float(b.abs().max()), 1e-6)
+
+
 def test_direct_gradient_accumulation_matches_autograd(gpu_device):
     """Conv dW and BatchNorm dgamma / dbeta written straight into the flat gradient arena (train_ops' direct path:
     detached weights, kernels that accumulate) over two micro-batches == autograd's own accumulation on a copy of
