@@ -336,6 +336,62 @@ def det_scale(det):
     return det._bench_scale
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, script=None, python=None, timeout=None):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as CHILD processes (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment -- the contract of
+    ``torch.distributed.run``, tools/dist_train.sh:8-10), relay rank 0's output (the one JSON line) and return the worst
+    exit code.  The parent never initialises the GPU and never exec()s: it only waits.  A rank that dies takes the
+    others with it after a grace period (they would otherwise sit in a collective until its timeout)."""
+    import subprocess
+    import threading
+    script = script or os.path.abspath(__file__)
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs on this driver
+        env.setdefault('OMP_NUM_THREADS', str(max(1, host_cpu_budget() // n)))
+        procs.append(subprocess.Popen([python or sys.executable, script] + list(argv), env=env, stdin=subprocess.DEVNULL,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    t0 = time.time()
+    rcs = [None] * n
+    failed_at = None
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        bad = [rc for rc in rcs if rc not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at = time.time()
+        if (failed_at is not None and time.time() - failed_at > 30) or (timeout and time.time() - t0 > timeout):
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.kill()                                   # exactly the PIDs started here
+                    rcs[i] = p.wait()
+            break
+        time.sleep(0.2)
+    t.join(timeout=5)
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst:
+        print(f'bench.py launcher: rank exit codes {rcs}', file=sys.stderr)
+    return min(worst, 255)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -368,10 +424,17 @@ def main():
                     help='bracket the conv launches with HIP events in every n-th timed step (events cost ~2 %%)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches the GPU) and the N
+        # ranks are its children -- what tools/dist_train.sh:8-10 does with torch.distributed.launch
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import mmdet_yolov4_amd as pkg
     from mmdet_yolov4_amd import dist as D
     rank, local_rank, world = D.env_world()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; start it as `python bench.py --gpus N` '
+                 '(self-launching) or under torch.distributed.run with --nproc-per-node N')
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     D.init(backend='nccl', device=dev)              # RCCL; a no-op for a single process

@@ -155,7 +155,7 @@ class GradReducer:
 
     MODES = ('allreduce', 'direct', 'direct_bf16')
 
-    def __init__(self, flat, bucket_mb=32, group=None, mode=None, overlap=True):
+    def __init__(self, flat, bucket_mb=32, group=None, mode=None, overlap=True, head_mb=8, exchange_at_world1=None):
         self.flat = flat
         self.group = group
         self.mode = mode or os.environ.get('YV4_GRAD_EXCHANGE', 'allreduce')
@@ -163,16 +163,12 @@ class GradReducer:
             raise ValueError(f'GradReducer mode {self.mode!r} not in {self.MODES}')
         self.overlap = overlap
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        cap = max(4, int(bucket_mb * (1 << 20) // 4))
-        self.buckets = []          # [lo, hi, [segment indices]]
-        cur = None
-        for si, seg in enumerate(flat.param_segments):
-            end = flat.param_segments[si + 1].offset if si + 1 < len(flat.param_segments) else flat.n_param
-            if cur is None or (end - cur[0]) > cap and cur[2]:
-                cur = [seg.offset, end, []]
-                self.buckets.append(cur)
-            cur[1] = end
-            cur[2].append(si)
+        # a one-rank group still runs every collective (identity): the RCCL init, all_to_all_single /
+        # all_gather_into_tensor and the side-stream ordering execute on a 1-GPU box (tests/test_gpu_ddp.py)
+        if exchange_at_world1 is None:
+            exchange_at_world1 = os.environ.get('YV4_EXCHANGE_AT_WORLD1') == '1'
+        self.exchange = self.world > 1 or (bool(exchange_at_world1) and dist.is_available() and dist.is_initialized())
+        self.buckets = self._make_buckets(flat, bucket_mb, head_mb)          # [lo, hi, [segment indices]]
         self._bucket_of = {}
         for bi, b in enumerate(self.buckets):
             for si in b[2]:
@@ -197,6 +193,33 @@ class GradReducer:
         # hooks): train_ops tells us when such a gradient is final
         from . import train_ops as _T
         self._direct_cb = _T.add_direct_grad_listener(self._on_direct_grad)
+
+    @staticmethod
+    def _make_buckets(flat, bucket_mb, head_mb):
+        """Bucket boundaries by REVERSE cumulative size.  Backward finishes the arena from its end (arena order =
+        registration order), so buckets are cut walking from the last segment towards the first, and the bucket of
+        the FIRST-registered parameters -- final only when the stem's gradient is, i.e. the one exchange that cannot
+        overlap backward -- is cut first and holds at most ``head_mb`` (8 MB for 32 MB buckets; it held whatever the
+        forward walk left, 33 MB on YOLOv4-L, profiles/r03_train_overlap_bf16.json).  A single segment larger than a
+        cap is a bucket by itself."""
+        segs = flat.param_segments
+        n = len(segs)
+        ends = [segs[i + 1].offset if i + 1 < n else flat.n_param for i in range(n)]
+        cap = max(4, int(bucket_mb * (1 << 20) // 4))
+        head_cap = min(cap, max(4, int(head_mb * (1 << 20) // 4))) if head_mb else cap
+        k = 0                                     # head bucket = segments [0, k)
+        while k < n and (k == 0 or ends[k] - segs[0].offset <= head_cap):
+            k += 1
+        if k >= n:
+            return [[segs[0].offset, ends[-1], list(range(n))]] if n else []
+        rev, cur = [], None                       # the rest, cut from the end
+        for si in range(n - 1, k - 1, -1):
+            if cur is None or (cur[1] - segs[si].offset) > cap:
+                cur = [segs[si].offset, ends[si], []]
+                rev.append(cur)
+            cur[0] = segs[si].offset
+            cur[2].insert(0, si)
+        return [[segs[0].offset, ends[k - 1], list(range(k))]] + rev[::-1]
 
     # ---- gradient-final events -------------------------------------------------------------------
     def _event(self, si):
@@ -240,15 +263,22 @@ class GradReducer:
         if not t or t['arm'] is None or t['finish'] is None:
             return None
         total = t['arm'].elapsed_time(t['finish'])
-        rows, wsum, bsum = [], 0.0, 0
+        rows, wsum, bsum, exposed = [], 0.0, 0, 0
         for bi in self.launch_order:
             lo, hi, _ = self.buckets[bi]
             ev = t['launch'].get(bi)
             ahead = max(0.0, ev.elapsed_time(t['finish'])) / total if ev is not None and total > 0 else 0.0
-            rows.append(dict(bucket=bi, mbytes=round((hi - lo) * 4 / 1e6, 1), backward_ahead=round(ahead, 3)))
+            rows.append(dict(bucket=bi, mbytes=round((hi - lo) * 4 / 1e6, 1), backward_ahead=round(ahead, 3),
+                             ahead_ms=round(ahead * total, 2)))
             wsum += ahead * (hi - lo)
             bsum += hi - lo
+            # a bucket's exchange is EXPOSED when backward ends before it can: at a (pessimistic) 100 GB/s of ring
+            # bus bandwidth plus 0.1 ms of launch latency per collective
+            need_ms = 0.1 + (hi - lo) * 4 * 2 / 100e9 * 1e3
+            if ahead * total < need_ms:
+                exposed += hi - lo
         return dict(backward_ms=round(total, 2), buckets=rows, overlappable_fraction=round(wsum / max(bsum, 1), 3),
+                    exposed_mbytes=round(exposed * 4 / 1e6, 1),
                     exchanged_mbytes=round(bsum * 4 / 1e6, 1), mode=self.mode, world=self.world)
 
     def _stamp(self, what, bi=None):
@@ -313,7 +343,7 @@ class GradReducer:
         self._launched[bi] = True
         self.launch_order.append(bi)
         self._stamp('launch', bi)
-        if self.world <= 1:
+        if not self.exchange:
             return
         lo, hi, _ = self.buckets[bi]
         if self.mode == 'allreduce':
@@ -342,7 +372,7 @@ class GradReducer:
             h.wait()
         self._handles = []
         self._armed = False
-        if self.world > 1:
+        if self.exchange:
             if self.mode == 'allreduce':
                 self.flat.grads.mul_(1.0 / self.world)
             elif self._comm_stream is not None:

@@ -120,7 +120,8 @@ class SingleStageDetector(HipModule):
 
     def _check_eval(self):
         if self.training:
-            raise NotImplementedError('inference entry points need .eval() (train-mode BN is not built yet)')
+            raise NotImplementedError('inference entry points need .eval(): they replay launch plans with folded BatchNorm; '
+                                      'a module in .train() mode runs the autograd path (forward_train / train_step)')
 
     def forward_test(self, imgs, img_metas, **kwargs):
         for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:

@@ -227,3 +227,100 @@ def test_two_rank_syncbn_step_at_yolov5l_width(tmp_path):
         assert o['worst_rest'] < TOL_FULL and o['worst'] < TOL_POOL, o
         assert o['stats'] < 1e-4, o
     _check_common(outs)
+
+
+ONE_RANK = textwrap.dedent('''
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import torch
+    import torch.distributed as dist
+    import mmdet_yolov4_amd as pkg
+    from mmdet_yolov4_amd import dist as D
+    from mmdet_yolov4_amd.flat_state import FlatState
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    rank, local_rank, world = D.init(backend='nccl', device=dev)       # YV4_DIST_FORCE_INIT=1: a ONE-rank RCCL group
+    assert dist.is_initialized() and D.backend_name() == 'nccl' and dist.get_world_size() == 1
+    D.barrier()                                                       # the timed region's bracket of bench.py, on RCCL
+    worst = D.max_over_ranks(1.25, device=dev)
+    torch.manual_seed(0)
+    det = pkg.build_detector(dict(
+        type='SingleStageDetector',
+        backbone=dict(type='DarknetCSP', scale=[['conv', 'bottleneck', 'csp', 'csp', 'csp'], [None, 1, 1, 1, 1],
+                                                [8, 16, 16, 32, 32]], out_indices=[2, 3, 4]),
+        neck=dict(type='YOLOV4Neck', in_channels=[16, 32, 32], out_channels=[16, 32, 32], csp_repetition=1),
+        bbox_head=dict(type='YOLOCSPHead', num_classes=4, in_channels=[16, 32, 32], featmap_strides=[4, 8, 16],
+                       anchor_generator=dict(type='YOLOV4AnchorGenerator', strides=[4, 8, 16],
+                                             base_sizes=[[(6, 8), (10, 6), (12, 12)], [(16, 20), (24, 16), (28, 30)],
+                                                         [(40, 36), (50, 60), (64, 64)]]))))
+    det.init_weights()
+    det.train().to(dev)
+    start = {k: v.clone() for k, v in det.state_dict().items()}
+    fs = FlatState(det)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(3, 3, 64, 64, generator=g).to(dev)
+    boxes = [torch.tensor([[8., 10., 40., 44.]], device=dev)] * 3
+    labels = [torch.tensor([1], device=dev)] * 3
+
+    def total(losses):
+        return sum(sum(x.mean() for x in v) if isinstance(v, (list, tuple)) else v.mean()
+                   for k, v in losses.items() if 'loss' in k)
+
+    def step(red):
+        det.load_state_dict(start)
+        fs.zero_grad()
+        if red is not None:
+            red.arm()
+        total(det(img=img, img_metas=[dict()] * 3, gt_bboxes=boxes, gt_labels=labels)).backward()
+        launched = red is not None and all(red._launched)
+        if red is not None:
+            red.finish()
+        torch.cuda.synchronize()
+        return fs.grads.clone(), launched
+
+    ref, _ = step(None)
+    out = dict(worst=worst, modes={})
+    for mode in D.GradReducer.MODES:
+        red = D.GradReducer(fs, bucket_mb=0.05, head_mb=0.01, mode=mode, exchange_at_world1=True)
+        assert red.exchange and red.world == 1
+        got, launched = step(red)
+        scale = float(ref.abs().max())
+        out['modes'][mode] = dict(err=float((got - ref).abs().max()) / scale, equal=bool(torch.equal(got, ref)),
+                                  launched=launched, nb=len(red.buckets), order=red.launch_order,
+                                  side_stream=red._comm_stream is not None,
+                                  head_floats=red.buckets[0][1] - red.buckets[0][0])
+        red.remove()
+    print('RESULT ' + json.dumps(out), flush=True)
+    D.finalize()
+''')
+
+
+def test_one_rank_rccl_group_carries_every_exchange_mode(tmp_path):
+    """RCCL on the box's one GPU: a one-rank `nccl` group (YV4_DIST_FORCE_INIT=1) runs the barrier / MAX all-reduce of
+    bench.py's timed region and, with ``exchange_at_world1``, every collective of ``GradReducer`` -- async
+    ``all_reduce`` per bucket, ``all_to_all_single`` + local fp32 sum + ``all_gather_into_tensor`` on the side stream --
+    launched from the backward hooks in descending bucket order.  With one rank every exchange is the identity: the fp32
+    wire formats must return the local gradients bit for bit, the bf16 wire within its two roundings (2^-8).  What this
+    does NOT show is a second rank (mmdet/apis/train.py:74-82 on a node): no N > 1 RCCL run exists in this build."""
+    script = tmp_path / 'one_rank.py'
+    script.write_text(ONE_RANK % ROOT)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               YV4_DIST_FORCE_INIT='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('YV4_DIST_BACKEND', None)
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith('RESULT ')][0][7:])
+    assert out['worst'] == 1.25
+    for mode, o in out['modes'].items():
+        assert o['nb'] > 2 and o['launched'] and o['order'] == sorted(o['order'], reverse=True), (mode, o)
+        assert o['head_floats'] * 4 <= 0.01 * (1 << 20) or o['nb'] == 1, (mode, o)
+        if mode == 'direct_bf16':
+            assert o['err'] <= 2.0 ** -8, (mode, o)
+        else:
+            assert o['equal'], (mode, o)
+        assert o['side_stream'] == (mode != 'allreduce')

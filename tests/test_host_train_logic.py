@@ -357,3 +357,26 @@ def test_soft_focal_loss_matches_reference(golden):
         y.sum().backward()
         np.testing.assert_allclose(y.detach().numpy(), z[f'{tag}/out'], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(x.grad.numpy(), z[f'{tag}/grad'], rtol=2e-6, atol=1e-7)
+
+
+def test_grad_reducer_cuts_buckets_from_the_end_with_a_small_head():
+    """Bucket boundaries by reverse cumulative size: the bucket of the first-registered parameters (final only when the
+    stem's gradient is: the exchange that cannot overlap backward) holds at most ``head_mb``; the others are filled from
+    the END of the arena, so the leftover is next to the head, not at the tail that backward finishes first."""
+    from mmdet_yolov4_amd.dist import GradReducer
+    model = Toy()
+    fs = FlatState(model)
+    offs = [s.offset for s in fs.param_segments] + [fs.n_param]
+    red = GradReducer(fs, bucket_mb=60 * 4 / (1 << 20), head_mb=20 * 4 / (1 << 20))
+    spans = [(b[0], b[1]) for b in red.buckets]
+    assert spans[0] == (0, offs[1])                       # one segment even when it exceeds the head cap
+    assert spans[-1][1] == fs.n_param and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert all(hi - lo <= 60 for lo, hi in spans[1:])
+    # cut from the end: the LAST bucket is as full as the cap allows
+    last_lo = spans[-1][0]
+    prev = max(o for o in offs if o < last_lo)
+    assert fs.n_param - prev > 60
+    red.remove()
+    whole = GradReducer(fs, bucket_mb=1, head_mb=1)
+    assert len(whole.buckets) == 1 and whole.buckets[0][:2] == [0, fs.n_param]
+    whole.remove()

@@ -187,7 +187,7 @@ def test_grad_reducer_eight_ranks_gloo_ragged_buckets(tmp_path, mode):
     whose buckets are multiples of neither 8 floats nor the world size: every bucket's per-rank chunk is padded
     (dist.py _staging: ceil(n / 8) rounded up to 8 elements) and the pad must neither leak into the gradients nor
     desynchronise the ranks."""
-    outs = _run_reduce(tmp_path, mode, 8, YV4_TEST_ODD='1', YV4_TEST_BUCKET_FLOATS='100')
+    outs = _run_reduce(tmp_path, mode, 8, YV4_TEST_ODD='1', YV4_TEST_BUCKET_FLOATS='80')
     assert len(outs) == 8
     sizes = outs[0]['sizes']
     assert len(sizes) >= 3 and any(n % 8 for n in sizes), sizes
@@ -304,3 +304,61 @@ def test_train_leg_failure_costs_only_the_train_object(monkeypatch):
         raise subprocess.TimeoutExpired(cmd, timeout)
     monkeypatch.setattr(subprocess, 'run', hangs)
     assert 'killed' in bench.train_step_leg(_leg_args(), 0, 0, 1)['error']
+
+
+LAUNCHED = textwrap.dedent('''
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import torch
+    from mmdet_yolov4_amd import dist as D
+    assert '--gpus' in sys.argv and sys.argv[sys.argv.index('--gpus') + 1] == os.environ['WORLD_SIZE']
+    rank, local_rank, world = D.init(backend='gloo')          # the rendezvous the launcher's environment describes
+    if '--die' in sys.argv and rank == 1:
+        sys.exit(7)
+    worst = D.max_over_ranks(0.5 * (rank + 1))
+    D.barrier(sync_device=False)
+    print('noise from rank %%d' %% rank, flush=True)
+    if rank == 0:
+        print(json.dumps(dict(metric='images/sec', n_gpus=world, worst=worst, local_rank=local_rank)), flush=True)
+    D.finalize()
+''')
+
+
+def test_bench_launches_its_own_ranks(tmp_path, capfd):
+    """`python bench.py --gpus N` with no launcher: the parent starts N children with the torch.distributed.run
+    environment (tools/dist_train.sh:8-10), only rank 0's output is relayed, the worst exit code is returned."""
+    import bench
+    script = tmp_path / 'ranks.py'
+    script.write_text(LAUNCHED % ROOT)
+    rc = bench.launch_ranks(3, ['--gpus', '3', '--steps', '2'], script=str(script), timeout=120)
+    out = capfd.readouterr().out
+    assert rc == 0
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and 'noise from rank 1' not in out and 'noise from rank 0' in out
+    rec = json.loads(lines[0])
+    assert rec == dict(metric='images/sec', n_gpus=3, worst=1.5, local_rank=0)
+
+
+def test_bench_launcher_reports_the_worst_rank(tmp_path, capfd):
+    import bench
+    script = tmp_path / 'ranks.py'
+    script.write_text(LAUNCHED % ROOT)
+    rc = bench.launch_ranks(2, ['--gpus', '2', '--die'], script=str(script), timeout=60)
+    assert rc == 7
+    assert 'rank exit codes' in capfd.readouterr().err
+
+
+def test_bench_main_self_launches_only_without_a_launcher(monkeypatch):
+    import bench
+    called = {}
+    monkeypatch.setattr(bench, 'launch_ranks', lambda n, argv, **kw: called.update(n=n, argv=list(argv)) or 0)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and called == dict(n=4, argv=['--gpus', '4', '--steps', '3'])
+    # under a launcher whose world disagrees with --gpus: a message, not an AssertionError, and no GPU touched
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert 'WORLD_SIZE=2' in str(e.value.code)

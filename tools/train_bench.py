@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Train-step throughput of the fp32 training path (fwd + loss + bwd + SGD step) on synthetic
-COCO-shaped data; one process per GPU, torch DDP over RCCL when WORLD_SIZE > 1.
+"""Train-step throughput of the training path (fwd + fused loss + bwd + gradient exchange + SGD-Nesterov + EMA through
+the recipe hooks) on synthetic COCO-shaped data; one process per GPU, ``dist.GradReducer`` over RCCL when WORLD_SIZE > 1
+(``--torch-optim`` switches to torch.optim.SGD + torch DDP for comparison).
     python tools/train_bench.py --batch 16 --size 608 --steps 5
 Not the headline metric (bench.py is); documents where the training row stands."""
 import argparse, json, os, sys, time
