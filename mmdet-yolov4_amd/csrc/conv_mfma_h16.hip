@@ -299,17 +299,15 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
     const bool full = vec_ok && co + 7 < p.Cout;
     AffH af;
     if (full) load_affine_h(p, co, has2, af);        // once per column group, shared by the TM row tiles
-    if (BR) {
+    if (BR && full) {
       // data-gradient launch that also reduces the BatchNorm backward sums of its output (BnRedH): a lane's 8 columns
-      // are the same for the TM row tiles, their partial sums meet in registers before the butterfly + atomics.
-      // (`full` differs between the lane groups of a ragged column tile: every lane still goes through the SAME
-      // epilogue_tile_h call -- its LDS transposition needs the whole wave -- and only the sums are per lane group)
+      // are the same for the TM row tiles, their partial sums meet in registers before the butterfly + atomics
       BnVecAcc ba;
-      if (full) bnvec_load(p, co, ba);
+      bnvec_load(p, co, ba);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        epilogue_tile_h<BF16>(p, acc[i][jn], ep, lane, m0 + wm * TM * 32 + i * 32, cb, full, has2, af, full ? &ba : nullptr);
-      if (full) bnvec_flush(p, lane, co, tile_m * WAVES_M + wm, ba);
+        epilogue_tile_h<BF16>(p, acc[i][jn], ep, lane, m0 + wm * TM * 32 + i * 32, cb, full, has2, af, &ba);
+      bnvec_flush(p, lane, co, tile_m * WAVES_M + wm, ba);
       continue;
     }
 #pragma unroll

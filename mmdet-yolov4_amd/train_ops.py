@@ -161,7 +161,6 @@ def grad_sink_for(x):
 # reduction pass and compares (tests: a wrong ``grad_final`` shows as a mismatch).
 _BN_BWD_FUSE = os.environ.get('YV4_BN_BWD_FUSE', '1') != '0'
 _BN_BWD_CHECK = os.environ.get('YV4_BN_BWD_CHECK', '0') == '1'
-_FUSE_MASK = int(os.environ.get('YV4_BN_BWD_FUSE_MASK', '31'))
 bn_bwd_fuse_stats = dict(fused=0, unfused=0)        # per process: how many BatchNorm backwards took which path
 
 
@@ -705,13 +704,6 @@ class ConvFunction(torch.autograd.Function):
                     joined = to_nhwc(joined.to(dtype))
                     jcs = None
             link = _link_for_dgrad(ctx.bnlink, dtype, (N, Cin, H, W), ctx.x_dtype)
-            if link is not None and _FUSE_MASK != 31:
-                # measurement: fuse only selected launch classes (1: stride-2 classes, 2: 3x3 with >= 128 channels [the
-                # persistent kernel], 4: 1x1 with <= 256 channels [weight-stationary], 8: few-channel 3x3, 16: the rest)
-                cls = 1 if stride == 2 else (2 if (KH == 3 and Cout >= 128 and Cout % 64 == 0) else
-                                             (4 if (KH == 1 and Cout <= 256) else (8 if (KH == 3 and Cout <= 64) else 16)))
-                if not (_FUSE_MASK & cls):
-                    link = None
             if stride == 2 and (KH, KW, pad) == (3, 3, 1) and Cout % (8 if h16 else 32) == 0:
                 own = ctx.direct.p if ctx.direct is not None else None
                 if joined is not None:

@@ -228,12 +228,9 @@ def test_toy_detector_step_fused_equals_unfused(dt, arena):
     labels = [torch.tensor([1, 5], device=DEV)] * 3
     data = dict(img=img, img_metas=[dict()] * 3, gt_bboxes=boxes, gt_labels=labels)
     worst, st = _ab(det, data, min_fused=25, flat=flat)
-    # The fused sums are fp32 partials of the same stored values in another order (every link is verified against the
-    # reduction pass inside the step, 2e-3 of the largest sum).  dbeta / dgamma are sums with heavy cancellation, so the
-    # last bits of dy move, every later rounding to 16 bits can flip, and the flips travel down ~60 layers of 8-64
-    # channels: worst per-tensor relative L2 distance of the gradients measured 4.2e-2 in bf16 and 5.3e-3 in fp16 --
-    # exactly the 8x of their three mantissa bits, i.e. rounding noise, not a missing term (which is O(1)).  Bounds 2.4x.
-    assert worst <= (0.1 if dt == 'bf16' else 0.0125), (worst, st)
+    # the fused sums are fp32 partials of the same stored values in another order; every downstream rounding to 16
+    # bits can flip a last bit: per-tensor relative L2 distance of the gradients (measured 1e-3 bf16 / 2e-4 fp16)
+    assert worst <= (2e-2 if dt == 'bf16' else 4e-3), (worst, st)
 
 
 @pytest.mark.parametrize('model,size', [('yolov4l', 608), ('yolov5l', 640)])
