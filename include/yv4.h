@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YV4_ABI_VERSION 6
+#define YV4_ABI_VERSION 5
 
 /* error codes */
 #define YV4_OK 0
@@ -493,48 +493,6 @@ int yv4_conv_scatter_fwd(const yv4_conv_desc* d, const float* x, const float* w,
 int yv4_conv_scatter_fwd_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
                              const float* scale1, const float* shift1, void* y, int Hy, int Wy,
                              int sh, int sw, int oh, int ow, void* stream);
-
-/* The reduction pass of the train-mode BatchNorm backward fused into the data-gradient launch that PRODUCES the
- * BatchNorm's output gradient (round 4).  In the reference the gradient dz of a Conv's output z = act(BN(y))
- * (darknetcsp.py:15-35, mish_cuda/mish.py:18-36) is written by the consumer's cuDNN backward-data, then read twice
- * by ATen's batch_norm_backward (reduce: dbeta = sum dz act'(z^), dgamma = sum dz act'(z^) x^; apply).  Here the
- * launch that computes dz (the forward conv kernel on the consumer's dY, see yv4_conv_bn_act_fwd_h16) has every
- * value in registers in its epilogue: it reads y at the same positions and leaves the two per-channel sums in
- * `sums` -- YV4_STATS_REPLICAS x [dbeta (C) | dgamma (C)] doubles whose column sums are the totals (kept zero by
- * yv4_bn_act_bwd_prereduced, which folds and clears them).  The stored dz is unchanged (the sums are those of the
- * STORED, rounded values, as yv4_bn_act_bwd_h16 would read them), so only the order of the summation differs.
- * x: the BatchNorm's saved input y, same dtype / geometry as the launch's output (pixel stride x_cstride, channel
- * offset x_coff); output channel c belongs to BatchNorm channel c % C (C = Cout, or Cout / 2 for the row-pair view
- * of a stride-2 data gradient). */
-typedef struct yv4_bnred {
-  const void* x;
-  int32_t x_cstride, x_coff, C;
-  const float* mean;
-  const float* invstd;
-  const float* gamma;
-  const float* beta;
-  int32_t act;
-  float slope;
-  double* sums;
-} yv4_bnred;
-/* yv4_conv_bn_act_fwd_h16 with the identity epilogue (+ residual = a gradient that joins this one) and the fused
- * reduction above; every 16-bit tile kernel supports it.  Needs Cout % 8 == 0 and 8-aligned y / residual views. */
-int yv4_conv_dgrad_bnred_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w, const float* ones,
-                             const float* zeros, const void* residual, void* y, const yv4_bnred* br,
-                             void* stream);
-/* yv4_conv_scatter_fwd_h16 (one parity class of a stride-2 data gradient) with the same fused reduction: br->x is
- * addressed through the same scattered row map as y. */
-int yv4_conv_scatter_bnred_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
-                               const float* scale1, const float* shift1, void* y, int Hy, int Wy, int sh,
-                               int sw, int oh, int ow, const yv4_bnred* br, void* stream);
-/* The rest of that BatchNorm backward: fold the YV4_STATS_REPLICAS blocks of `replicas` into totals
- * ([dbeta | dgamma], 2*C doubles) and clear them, then the apply pass of yv4_bn_act_bwd_h16 with those totals;
- * flags bit 0: ADD dgamma / dbeta to the given arrays (yv4_bn_act_bwd_accum) instead of overwriting them. */
-int yv4_bn_act_bwd_prereduced(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
-                              int dy_cstride, int dy_coff, const float* mean, const float* invstd,
-                              const float* gamma, const float* beta, void* dx, int dx_cstride, int dx_coff,
-                              float* dgamma, float* dbeta, double* replicas, double* totals, int64_t M,
-                              int C, int act, float slope, int flags, void* stream);
 
 /* Backward of an EVAL-mode BatchNorm (+ activation) inside a training graph (frozen stages /
  * norm_eval, darknetcsp.py:466-480): mean / invstd are the running statistics (constants), so

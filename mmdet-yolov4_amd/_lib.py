@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('YV4_LIB_PATH') or os.path.join(LIB_DIR, 'libyv4_hip.s
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 # ---- constants mirrored from include/yv4.h -------------------------------------
-ABI_VERSION = 6
+ABI_VERSION = 5
 STATS_REPLICAS = 64        # YV4_STATS_REPLICAS
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_MISH, ACT_LEAKY, ACT_SWISH = 0, 1, 2, 3
@@ -67,13 +67,6 @@ class AugImage(C.Structure):
                 ('rh', C.c_int32 * 4), ('rw', C.c_int32 * 4)] + \
                [(n, C.c_int32) for n in ('cxy', 'left', 'top', 'x1', 'y1', 'C', 'S', 'o', 'flip', 'hsv_on')] + \
                [('lut', (C.c_uint8 * 256) * 3)]
-
-
-class BnRed(C.Structure):
-    """``yv4_bnred``."""
-    _fields_ = [('x', C.c_void_p), ('x_cstride', C.c_int32), ('x_coff', C.c_int32), ('C', C.c_int32),
-                ('mean', C.c_void_p), ('invstd', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
-                ('act', C.c_int32), ('slope', C.c_float), ('sums', C.c_void_p)]
 
 
 class PackDesc(C.Structure):
@@ -150,11 +143,6 @@ SIGNATURES = {
                                      _i, _i, _f, _vp]),
     'yv4_conv_scatter_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_conv_scatter_fwd_h16': (C.c_int, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    'yv4_conv_dgrad_bnred_h16': (C.c_int, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(BnRed), _vp]),
-    'yv4_conv_scatter_bnred_h16': (C.c_int, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
-                                             C.POINTER(BnRed), _vp]),
-    'yv4_bn_act_bwd_prereduced': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp,
-                                            _i64, _i, _i, _f, _i, _vp]),
     'yv4_bn_eval_act_bwd': (C.c_int, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i64,
                                       _i, _i, _f, _vp]),
     'yv4_spp_pool_bwd': (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),

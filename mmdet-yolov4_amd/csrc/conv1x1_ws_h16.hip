@@ -55,7 +55,7 @@ __device__ __forceinline__ void act_row16_h(float (&v)[16], int act, float slope
 }
 
 // NT: 32-column tiles of the weight slab (BN = 32 * NT output channels per workgroup)
-template <bool BF16, int NT, bool BR>
+template <bool BF16, int NT>
 __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes, int ncol,
                                                                    int nstrips, int cpr_shift) {
   typedef typename Elem<BF16>::T T;
@@ -172,20 +172,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
   float st_su[NT], st_sq[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { st_su[t] = 0.f; st_sq[t] = 0.f; }
-  // data-gradient launch that reduces the BatchNorm backward sums of its output (BnRedH): per-lane constants of this
-  // lane's NT channels, sums kept in registers over all of the wave's strips (as the forward statistics above)
-  constexpr bool brd = BR;
-  float br_mu[NT], br_is[NT], br_ga[NT], br_be[NT], br_db[NT], br_dg[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int c = n0 + t * 32 + r;
-    const bool ok = brd && c < p.Cout;
-    br_mu[t] = ok ? p.br.mean[c] : 0.f;
-    br_is[t] = ok ? p.br.invstd[c] : 0.f;
-    br_ga[t] = ok ? p.br.gamma[c] : 0.f;
-    br_be[t] = ok ? p.br.beta[c] : 0.f;
-    br_db[t] = 0.f; br_dg[t] = 0.f;
-  }
 
   int rslot = 0;
   for (int i = 0; i < my_n; ++i) {
@@ -267,26 +253,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
           act_row16_h(v, p.act2, p.slope2);
         }
       }
-      if (brd) {
-        // the sums are those of the STORED values: round first (pair_pack16 below rounds the same values again: exact)
-        const bool oddr = r & 1;
-        const int rbr = 4 * h + (oddr ? 16 : 0);
-        const T* bp = reinterpret_cast<const T*>(p.br.x) + ((int64_t)(m0 + rbr) * p.br.cs + p.br.co + (c & ~1));
-        unsigned mine[8];
-        unsigned okmask = 0u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int row = (j & 3) + 8 * (j >> 2);
-          mine[j] = (full || m0 + rbr + row < p.M) ? *reinterpret_cast<const unsigned*>(bp + (int64_t)row * p.br.cs) : 0u;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          v[e] = (float)(T)v[e];
-          okmask |= (full || (m0 + (e & 3) + 8 * (e >> 2) + 4 * h < p.M)) ? (1u << e) : 0u;
-        }
-        bnred_c_layout<T>(v, mine, oddr, okmask, br_mu[t], br_is[t], br_ga[t], br_be[t], p.br.act, p.br.slope, br_db[t],
-                          br_dg[t]);
-      }
       if (p.out_f32) {
         // fp32 output (the pred maps feeding decode): a lane owns one channel, a store instruction writes two runs of
         // 32 consecutive floats -- coalesced whatever the row pitch (255 channels) is
@@ -320,16 +286,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
   // the tail's out-of-range stage DMAs still write (zeros) into this wave's ring: drain before the LDS goes away
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  if (brd && my_n > 0) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float db = br_db[t], dg = br_dg[t];
-      db += __shfl_xor(db, 32);
-      dg += __shfl_xor(dg, 32);
-      const int c = n0 + t * 32 + r;
-      if (h == 0 && c < p.Cout) bnred_flush(p.br, gw, c, db, dg);
-    }
-  }
   if (p.stats && my_n > 0) {
     double* rep = p.stats + (size_t)(gw & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
 #pragma unroll
@@ -369,7 +325,7 @@ bool conv1x1_ws_applies(const ConvArgsH& a) {
          a.Cin <= 256 && (a.Cin & 7) == 0 && a.Kw == a.Cin && a.Cout >= 16 && store_ok && ws_slab_cols(a) > 0;
 }
 
-template <bool BF16, int NT, bool BR>
+template <bool BF16, int NT>
 static int launch_ws(const ConvArgsH& a, hipStream_t stream) {
   constexpr int BN = NT * 32;
   const int ncol = (a.Cout + BN - 1) / BN;
@@ -379,7 +335,7 @@ static int launch_ws(const ConvArgsH& a, hipStream_t stream) {
   int cpr_shift = 0;
   while ((8 << cpr_shift) < cin_lds) ++cpr_shift;
   const long long xb = (long long)a.N * a.H * a.W * a.x_cs * 2, wb = (long long)a.Cout * a.Kw * 2;
-  auto kern = conv1x1_ws_kernel<BF16, NT, BR>;
+  auto kern = conv1x1_ws_kernel<BF16, NT>;
   static LdsAttrOnce once;
   if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024, "conv1x1_ws_h16")) return rc;
   hipLaunchKernelGGL(kern, dim3(kWsGrid), dim3(kWsThreads), lds, stream, a, (unsigned)xb, (unsigned)wb, ncol, nstrips,
@@ -388,20 +344,15 @@ static int launch_ws(const ConvArgsH& a, hipStream_t stream) {
   return YV4_OK;
 }
 
-template <bool BR>
-static int conv1x1_ws_launch_br(const ConvArgsH& a, bool bf16, hipStream_t s) {
+int conv1x1_ws_launch(const ConvArgsH& a, bool bf16, hipStream_t s) {
   switch (ws_slab_cols(a)) {
-    case 128: return bf16 ? launch_ws<true, 4, BR>(a, s) : launch_ws<false, 4, BR>(a, s);
-    case 64: return bf16 ? launch_ws<true, 2, BR>(a, s) : launch_ws<false, 2, BR>(a, s);
-    case 32: return bf16 ? launch_ws<true, 1, BR>(a, s) : launch_ws<false, 1, BR>(a, s);
+    case 128: return bf16 ? launch_ws<true, 4>(a, s) : launch_ws<false, 4>(a, s);
+    case 64: return bf16 ? launch_ws<true, 2>(a, s) : launch_ws<false, 2>(a, s);
+    case 32: return bf16 ? launch_ws<true, 1>(a, s) : launch_ws<false, 1>(a, s);
     default: break;
   }
   set_error("conv1x1 ws: no weight slab of this layer fits the LDS");
   return YV4_E_UNSUPPORTED;
-}
-
-int conv1x1_ws_launch(const ConvArgsH& a, bool bf16, hipStream_t s) {
-  return a.br.sums ? conv1x1_ws_launch_br<true>(a, bf16, s) : conv1x1_ws_launch_br<false>(a, bf16, s);
 }
 
 }  // namespace yv4

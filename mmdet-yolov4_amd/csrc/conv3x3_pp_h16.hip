@@ -53,7 +53,7 @@ constexpr int kP3RingBytes = (2 * kP3ARows + kP3NB * kP3BN) * 128;
 constexpr int kP3MaxCout = 1024;     // the per-channel affine of the whole layer lives in the last 16 KB of LDS
 constexpr int kP3Lds = kP3RingBytes + 4 * kP3MaxCout * 4;
 
-template <bool BF16, bool BR>
+template <bool BF16>
 __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
   typedef typename Elem<BF16>::V8 V8;
   constexpr int TM = 2, TN = 2;            // wave tile 64 x 64
@@ -344,29 +344,11 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
           for (int i = 0; i < TM; ++i)
             residual_prefetch_h<BF16>(p, lane, m0 + wm * 64 + i * 32, n0 + wn * 64 + jn * 32, resw[jn * TM + i]);
       }
-      if (BR) {
-        // data-gradient launch that also reduces the BatchNorm backward sums of its output (BnRedH): the BatchNorm
-        // input is read in the store layout (channel-pair dwords), the sums of a wave's TM row tiles meet in registers
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-          BnPairAcc ba;
-          bnpair_load(p, lane, n0 + wn * 64 + jn * 32, ba);
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            unsigned brw[8];
-            bnred_prefetch_h<BF16>(p, lane, m0 + wm * 64 + i * 32, n0 + wn * 64 + jn * 32, brw);
-            epilogue_pairs_h<BF16, true>(p, acc[i][jn], lane, m0 + wm * 64 + i * 32, n0 + wn * 64 + jn * 32, has2, aff,
-                                         resw[jn * TM + i], brw, &ba);
-          }
-          bnpair_flush(p, lane, n0 + wn * 64 + jn * 32, tile_m * 4 + wm, ba);
-        }
-      } else {
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
           epilogue_pairs_h<BF16>(p, acc[i][jn], lane, m0 + wm * 64 + i * 32, n0 + wn * 64 + jn * 32, has2, aff, resw[jn * TM + i]);
-      }
     } else if (acc[0][0][0] == 12345.678f) {
       reinterpret_cast<float*>(p.y)[0] = acc[0][1][1] + acc[1][0][2] + acc[1][1][3];      // keep the accumulators live
     }
@@ -397,7 +379,7 @@ bool conv3x3_pp_h16_applies(const ConvArgsH& a) {
 
 static int g_p3_cus = 0;
 
-template <bool BF16, bool BR>
+template <bool BF16>
 static int launch_p3(const ConvArgsH& a, hipStream_t stream) {
   ConvArgsH p = a;
   const int tiles_m = (p.M + kP3BM - 1) / kP3BM;
@@ -419,7 +401,7 @@ static int launch_p3(const ConvArgsH& a, hipStream_t stream) {
     g_p3_cus = cus;
   }
   const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 2, wb = (long long)p.Cout * p.Kw * 2;
-  auto kern = conv3x3_pp_h16_kernel<BF16, BR>;
+  auto kern = conv3x3_pp_h16_kernel<BF16>;
   static LdsAttrOnce once;
   if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), (size_t)kP3Lds, "conv3x3_pp_h16")) return rc;
   const unsigned grid = (unsigned)(tiles < g_p3_cus ? tiles : g_p3_cus);
@@ -429,8 +411,7 @@ static int launch_p3(const ConvArgsH& a, hipStream_t stream) {
 }
 
 int conv3x3_pp_h16_launch(const ConvArgsH& a, bool bf16, hipStream_t s) {
-  if (a.br.sums) return bf16 ? launch_p3<true, true>(a, s) : launch_p3<false, true>(a, s);
-  return bf16 ? launch_p3<true, false>(a, s) : launch_p3<false, false>(a, s);
+  return bf16 ? launch_p3<true>(a, s) : launch_p3<false>(a, s);
 }
 
 }  // namespace yv4

@@ -27,7 +27,7 @@ constexpr int kS3Pix = kS3I * kS3I;      // 324
 
 // CINH = Cin / 16 (1, 2, 4), NT = Cout / 32 (1, 2), NW = waves per workgroup (8 or 4: then a wave takes two of the
 // tile's eight row pairs and two to four workgroups share a CU and drift out of phase)
-template <bool BF16, int CINH, int NT, int NW, bool BR>
+template <bool BF16, int CINH, int NT, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_small_kernel(ConvArgsH p, unsigned x_bytes, int tiles_x, int tiles_y,
                                                                       int ntiles, FastDiv fd_tx, FastDiv fd_txy) {
   typedef typename Elem<BF16>::T T;
@@ -113,19 +113,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_small_kernel
   float st_su[NT], st_sq[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { st_su[t] = 0.f; st_sq[t] = 0.f; }
-  // data-gradient launch that reduces the BatchNorm backward sums of its output (BnRedH, conv_h16_common.h)
-  constexpr bool brd = BR;
-  float br_mu[NT], br_is[NT], br_ga[NT], br_be[NT], br_db[NT], br_dg[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int c = t * 32 + r;
-    const bool ok = brd && c < p.Cout;
-    br_mu[t] = ok ? p.br.mean[c] : 0.f;
-    br_is[t] = ok ? p.br.invstd[c] : 0.f;
-    br_ga[t] = ok ? p.br.gamma[c] : 0.f;
-    br_be[t] = ok ? p.br.beta[c] : 0.f;
-    br_db[t] = 0.f; br_dg[t] = 0.f;
-  }
 
   int tile = (int)blockIdx.x;
   if (tile < ntiles) issue_tile(tile, 0);
@@ -255,25 +242,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_small_kernel
           default: break;
         }
       }
-      if (brd) {
-        // sums of the STORED values; the BatchNorm input is read at this lane's store positions (as the residual)
-        const T* bp = reinterpret_cast<const T*>(p.br.x) + (pix0 * p.br.cs + p.br.co + (c & ~1));
-        unsigned mine[8];
-        unsigned okmask = 0u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int col = (j & 3) + 8 * (j >> 2);
-          mine[j] = (row_ok && (full_x || ox0 + col + 4 * h < p.Wo)) ? *reinterpret_cast<const unsigned*>(bp + (size_t)col * p.br.cs) : 0u;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          v[e] = (float)(T)v[e];
-          const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
-          okmask |= (oy0 + 2 * wv + (m >> 4) < p.Ho && ox0 + (m & 15) < p.Wo) ? (1u << e) : 0u;
-        }
-        bnred_c_layout<T>(v, mine, odd, okmask, br_mu[t], br_is[t], br_ga[t], br_be[t], p.br.act, p.br.slope, br_db[t],
-                          br_dg[t]);
-      }
       unsigned pk[8];
       pair_pack16<T>(v, odd, pk);
       // the next tile's DMA has had the whole tile to land: confirm it BEFORE the stores join vmcnt (a wait after
@@ -289,16 +257,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_small_kernel
     }   // wave rows
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (brd) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float db = br_db[t], dg = br_dg[t];
-      db += __shfl_xor(db, 32);
-      dg += __shfl_xor(dg, 32);
-      const int c = t * 32 + r;
-      if (h == 0 && c < p.Cout) bnred_flush(p.br, (int)(blockIdx.x * NW + wave), c, db, dg);
-    }
-  }
   if (p.stats) {
     double* rep = p.stats + (size_t)((blockIdx.x * NW + wave) & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
 #pragma unroll
@@ -328,8 +286,8 @@ bool conv3x3_small_applies(const ConvArgsH& a) {
          (a.res == nullptr || ((a.r_cs | a.r_co) & 1) == 0) && s3_lds_bytes(a.Cin, a.Cout) <= 160 * 1024;
 }
 
-template <bool BF16, int CINH, int NT, int NW, bool BR>
-static int launch_s3_nw_br(const ConvArgsH& a, hipStream_t stream) {
+template <bool BF16, int CINH, int NT, int NW>
+static int launch_s3_nw(const ConvArgsH& a, hipStream_t stream) {
   const int tiles_x = (a.Wo + kS3T - 1) / kS3T, tiles_y = (a.Ho + kS3T - 1) / kS3T;
   const long long nt = (long long)a.N * tiles_x * tiles_y;
   if (nt >= (1LL << 31)) {
@@ -338,7 +296,7 @@ static int launch_s3_nw_br(const ConvArgsH& a, hipStream_t stream) {
   }
   const size_t lds = s3_lds_bytes(CINH * 16, NT * 32);
   const long long xb = (long long)a.N * a.H * a.W * a.x_cs * 2;
-  auto kern = conv3x3_small_kernel<BF16, CINH, NT, NW, BR>;
+  auto kern = conv3x3_small_kernel<BF16, CINH, NT, NW>;
   static LdsAttrOnce once;
   if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), lds, "conv3x3_small_h16")) return rc;
   // workgroups per CU: by LDS (160 KB) and, for the 4-wave form, at most 4 (16 waves, <= 128 VGPRs each)
@@ -354,11 +312,6 @@ static int launch_s3_nw_br(const ConvArgsH& a, hipStream_t stream) {
                      make_fastdiv((unsigned)tiles_x), make_fastdiv((unsigned)(tiles_x * tiles_y)));
   YV4_CHECK_LAUNCH("conv3x3_small_h16");
   return YV4_OK;
-}
-
-template <bool BF16, int CINH, int NT, int NW>
-static int launch_s3_nw(const ConvArgsH& a, hipStream_t stream) {
-  return a.br.sums ? launch_s3_nw_br<BF16, CINH, NT, NW, true>(a, stream) : launch_s3_nw_br<BF16, CINH, NT, NW, false>(a, stream);
 }
 
 // 4-wave workgroups when at least two fit a CU (the 16- and 32-channel layers); YV4_S3_WAVES=8 keeps one of 8

@@ -14,28 +14,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int kHBK = 64;        // K slice in elements (128 bytes)
 constexpr int kHThreads = 256;
 
-// Data-gradient launches that also reduce the BatchNorm backward sums of the tensor they produce (yv4_bnred,
-// include/yv4.h): x = the BatchNorm's saved input at the launch's OUTPUT positions, sums = YV4_STATS_REPLICAS x
-// [dbeta (C) | dgamma (C)]; sums == nullptr: off.
-struct BnRedH {
-  const void* x;
-  int cs, co, C;
-  const float* mean;
-  const float* invstd;
-  const float* gamma;
-  const float* beta;
-  int act;
-  float slope;
-  double* sums;
-};
-
-__device__ __forceinline__ void bnred_pair(float dz0, float dz1, float y0, float y1, float mu0, float mu1, float is0,
-                                           float is1, float ga0, float ga1, float be0, float be1, int act, float slope,
-                                           bool ok0, bool ok1, float& db0, float& dg0, float& db1, float& dg1);
-__device__ __forceinline__ void bnred_flush(const BnRedH& br, int rep, int c, float db, float dg);
-
 struct ConvArgsH {
-  BnRedH br;
   const void* x;
   const void* w;
   const float* s1;
@@ -185,53 +164,9 @@ __device__ __forceinline__ void load_affine_h(const ConvArgsH& p, int co, bool h
 // STAGE / FINISH split the function for callers that give every accumulator tile of a wave its own patch: all tiles
 // are staged first (their LDS writes pipeline), then finished -- the LDS round trip is paid once per wave instead of
 // once per tile (conv3x3_h16.hip, where nothing else on the CU hides it).
-// BatchNorm constants and running sums of a lane's 8 output columns in the transposed epilogue layout (BnRedH)
-struct BnVecAcc { float mu[8], is[8], ga[8], be[8], db[8], dg[8]; };
-__device__ __forceinline__ void bnvec_load(const ConvArgsH& p, int co, BnVecAcc& a) {
-  const int cb = co >= p.br.C ? co - p.br.C : co;
-#pragma unroll
-  for (int u = 0; u < 8; u += 4) {
-    const float4 m = *reinterpret_cast<const float4*>(p.br.mean + cb + u), i = *reinterpret_cast<const float4*>(p.br.invstd + cb + u);
-    const float4 g = *reinterpret_cast<const float4*>(p.br.gamma + cb + u), b = *reinterpret_cast<const float4*>(p.br.beta + cb + u);
-    a.mu[u] = m.x; a.mu[u + 1] = m.y; a.mu[u + 2] = m.z; a.mu[u + 3] = m.w;
-    a.is[u] = i.x; a.is[u + 1] = i.y; a.is[u + 2] = i.z; a.is[u + 3] = i.w;
-    a.ga[u] = g.x; a.ga[u + 1] = g.y; a.ga[u + 2] = g.z; a.ga[u + 3] = g.w;
-    a.be[u] = b.x; a.be[u + 1] = b.y; a.be[u + 2] = b.z; a.be[u + 3] = b.w;
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) { a.db[u] = 0.f; a.dg[u] = 0.f; }
-}
-// The 16 lanes with equal (lane & 3) hold partial sums of the same 8 channels (different rows): a halving butterfly
-// over lane bits 2..5 (8 + 4 + 2 + 1 exchanges instead of 4 x 16) leaves ONE finished sum per lane -- sum kind
-// (db / dg) and channel given by the lane's row bits -- which it adds to replica `rep`.
-__device__ __forceinline__ void bnvec_flush(const ConvArgsH& p, int lane, int co, int rep, const BnVecAcc& a) {
-  float x[16];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) { x[u] = a.db[u]; x[8 + u] = a.dg[u]; }
-  int idx = 0;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int half = 8 >> s;
-    const bool bit = (lane >> (2 + s)) & 1;
-#pragma unroll
-    for (int i = 0; i < half; ++i) {
-      const float send = bit ? x[i] : x[i + half];
-      const float recv = __shfl_xor(send, 4 << s);
-      x[i] = (bit ? x[i + half] : x[i]) + recv;
-    }
-    idx += bit ? half : 0;
-  }
-  const int u = idx & 7;
-  const int c = co + u;
-  double* base = p.br.sums + (size_t)(rep & (YV4_STATS_REPLICAS - 1)) * 2 * p.br.C;
-  const int cb = c >= p.br.C ? c - p.br.C : c;
-  atomicAdd(&base[(idx >> 3) * p.br.C + cb], (double)x[0]);
-}
-
 template <bool BF16, bool STAGE = true, bool FINISH = true>
 __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16& acc, float* ep, int lane, int m_base,
-                                                int co_base, bool full, bool has2, const AffH& af,
-                                                BnVecAcc* bacc = nullptr) {
+                                                int co_base, bool full, bool has2, const AffH& af) {
   typedef typename Elem<BF16>::T T;
   typedef typename Elem<BF16>::V8 V8;
   const int r = lane & 31, h = lane >> 5;
@@ -291,16 +226,7 @@ __device__ __forceinline__ void epilogue_tile_h(const ConvArgsH& p, const f32x16
           V8 o;
 #pragma unroll
           for (int u = 0; u < 8; ++u) o[u] = (T)v[u];
-          const int64_t orow = out_row_h(p, m);
-          *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.y) + orow * p.y_cs + p.y_co + co) = o;
-          if (bacc) {        // BatchNorm backward sums of the STORED values (BnRedH); y at the same (scattered) row
-            const V8 yy = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.br.x) + orow * p.br.cs + p.br.co + co);
-#pragma unroll
-            for (int u = 0; u < 8; u += 2)
-              bnred_pair((float)o[u], (float)o[u + 1], (float)yy[u], (float)yy[u + 1], bacc->mu[u], bacc->mu[u + 1],
-                         bacc->is[u], bacc->is[u + 1], bacc->ga[u], bacc->ga[u + 1], bacc->be[u], bacc->be[u + 1], p.br.act,
-                         p.br.slope, true, true, bacc->db[u], bacc->dg[u], bacc->db[u + 1], bacc->dg[u + 1]);
-          }
+          *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.y) + out_row_h(p, m) * p.y_cs + p.y_co + co) = o;
         }
       }
     }
@@ -369,56 +295,9 @@ __device__ __forceinline__ void residual_prefetch_h(const ConvArgsH& p, int lane
   }
 }
 
-// the BatchNorm-input dwords at the same positions (BnRedH): requested together with the residual words
 template <bool BF16>
-__device__ __forceinline__ void bnred_prefetch_h(const ConvArgsH& p, int lane, int m_base, int co_base, unsigned (&brw)[8]) {
-  typedef typename Elem<BF16>::T T;
-  const int r = lane & 31, h = lane >> 5;
-  const bool odd = r & 1;
-  const int cp = co_base + r - (odd ? 1 : 0);
-  const bool c_ok = cp + 1 < p.Cout;
-  const int row0 = m_base + 4 * h + (odd ? 16 : 0);
-  const T* bp = reinterpret_cast<const T*>(p.br.x);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int m = row0 + (j & 3) + 8 * (j >> 2);
-    brw[j] = (c_ok && m < p.M) ? *reinterpret_cast<const unsigned*>(bp + (int64_t)m * p.br.cs + p.br.co + cp) : 0u;
-  }
-}
-// per-lane BatchNorm constants and running sums of a channel PAIR (cp, cp + 1) in the pairs layout
-struct BnPairAcc { float mu[2], is[2], ga[2], be[2], db[2], dg[2]; };
-__device__ __forceinline__ void bnpair_load(const ConvArgsH& p, int lane, int co_base, BnPairAcc& a) {
-  const int r = lane & 31;
-  const int cp = co_base + r - (r & 1);
-  const bool ok = cp + 1 < p.Cout;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    a.mu[k] = ok ? p.br.mean[cp + k] : 0.f;
-    a.is[k] = ok ? p.br.invstd[cp + k] : 0.f;
-    a.ga[k] = ok ? p.br.gamma[cp + k] : 0.f;
-    a.be[k] = ok ? p.br.beta[cp + k] : 0.f;
-    a.db[k] = 0.f; a.dg[k] = 0.f;
-  }
-}
-// the four lanes (r even / odd, h = 0 / 1) that own one channel pair combine; lane (r even, h = 0) adds to replica `rep`
-__device__ __forceinline__ void bnpair_flush(const ConvArgsH& p, int lane, int co_base, int rep, BnPairAcc& a) {
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    float db = a.db[k], dg = a.dg[k];
-    db += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, db), 0xB1, 0xF, 0xF, false));
-    dg += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dg), 0xB1, 0xF, 0xF, false));
-    db += __shfl_xor(db, 32);
-    dg += __shfl_xor(dg, 32);
-    const int c = co_base + r + k;
-    if (h == 0 && (r & 1) == 0 && c < p.Cout) bnred_flush(p.br, rep, c, db, dg);
-  }
-}
-
-template <bool BF16, bool BR = false>
 __device__ __forceinline__ void epilogue_pairs_h(const ConvArgsH& p, const f32x16& acc, int lane, int m_base, int co_base,
-                                                 bool has2, const float* aff, const unsigned (&resw)[8],
-                                                 const unsigned* brw = nullptr, BnPairAcc* bacc = nullptr) {
+                                                 bool has2, const float* aff, const unsigned (&resw)[8]) {
   typedef typename Elem<BF16>::T T;
   typedef T T2 __attribute__((ext_vector_type(2)));
   const int r = lane & 31, h = lane >> 5;
@@ -478,65 +357,8 @@ __device__ __forceinline__ void epilogue_pairs_h(const ConvArgsH& p, const f32x1
     T2 pk;
     pk[0] = (T)a[j];
     pk[1] = (T)b[j];
-    const bool ok = c_ok && row0 + dj < p.M;
-    if (ok) *reinterpret_cast<unsigned*>(y0 + (int64_t)dj * p.y_cs) = __builtin_bit_cast(unsigned, pk);
-    if (BR) {          // BatchNorm backward sums of the STORED values (BnRedH)
-      const T2 yy = __builtin_bit_cast(T2, brw[j]);
-      bnred_pair((float)pk[0], (float)pk[1], (float)yy[0], (float)yy[1], bacc->mu[0], bacc->mu[1], bacc->is[0], bacc->is[1],
-                 bacc->ga[0], bacc->ga[1], bacc->be[0], bacc->be[1], p.br.act, p.br.slope, ok, ok, bacc->db[0], bacc->dg[0],
-                 bacc->db[1], bacc->dg[1]);
-    }
+    if (c_ok && row0 + dj < p.M) *reinterpret_cast<unsigned*>(y0 + (int64_t)dj * p.y_cs) = __builtin_bit_cast(unsigned, pk);
   }
-}
-
-
-// ---- BatchNorm-backward sums in a data-gradient epilogue (BnRedH) ------------------------------------------------------
-// g = dz * act'(xh * gamma + beta), xh = (y - mean) * invstd;  db += g, dg += g * xh  -- the expressions of
-// bn_act_bwd_reduce_kernel (train.hip) on the STORED (rounded) dz.  Pairs of values share the packed Mish derivative.
-__device__ __forceinline__ void bnred_pair(float dz0, float dz1, float y0, float y1, float mu0, float mu1, float is0,
-                                           float is1, float ga0, float ga1, float be0, float be1, int act, float slope,
-                                           bool ok0, bool ok1, float& db0, float& dg0, float& db1, float& dg1) {
-  const float xh0 = (y0 - mu0) * is0, xh1 = (y1 - mu1) * is1;
-  float d0, d1;
-  if (act == YV4_ACT_MISH) {
-    f32x2_t z;
-    z.x = xh0 * ga0 + be0; z.y = xh1 * ga1 + be1;
-    const f32x2_t d = mish_grad2(z);
-    d0 = d.x; d1 = d.y;
-  } else {
-    d0 = act_grad(xh0 * ga0 + be0, act, slope);
-    d1 = act_grad(xh1 * ga1 + be1, act, slope);
-  }
-  const float g0 = ok0 ? dz0 * d0 : 0.f, g1 = ok1 ? dz1 * d1 : 0.f;
-  db0 += g0; dg0 += g0 * xh0;
-  db1 += g1; dg1 += g1 * xh1;
-}
-
-// C layout (conv1x1_ws_h16.hip, conv3x3_small_h16.hip): lane (r, h) holds v[16] = the STORED gradient values of its
-// channel c at 16 positions; `mine[j]` = the dword (channels c & ~1, (c & ~1) + 1) of the BatchNorm input at the
-// positions this lane stores after the pair exchange (the addresses of its residual / output dwords; 0 where out of
-// range); bit e of `okmask`: position e is inside the tensor.  The lane pair trades dwords exactly as the residual does.
-template <typename T>
-__device__ __forceinline__ void bnred_c_layout(const float (&v)[16], const unsigned (&mine)[8], bool odd, unsigned okmask,
-                                               float mu, float is, float ga, float be, int act, float slope, float& db,
-                                               float& dg) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const unsigned theirs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[j], 0xB1, 0xF, 0xF, false);
-    const unsigned a = odd ? (theirs >> 16) : (mine[j] & 0xffffu);
-    const unsigned b = odd ? (mine[j] >> 16) : (theirs & 0xffffu);
-    const unsigned short ua = (unsigned short)a, ub = (unsigned short)b;
-    bnred_pair(v[j], v[j + 8], (float)__builtin_bit_cast(T, ua), (float)__builtin_bit_cast(T, ub), mu, mu, is, is, ga, ga,
-               be, be, act, slope, (okmask >> j) & 1u, (okmask >> (j + 8)) & 1u, db, dg, db, dg);
-  }
-}
-
-// one double atomic per channel and sum into replica `rep` of br.sums; `c` = the launch's output channel
-__device__ __forceinline__ void bnred_flush(const BnRedH& br, int rep, int c, float db, float dg) {
-  double* base = br.sums + (size_t)(rep & (YV4_STATS_REPLICAS - 1)) * 2 * br.C;
-  const int cb = c >= br.C ? c - br.C : c;          // (row-pair view of a stride-2 data gradient: Cout = 2 C)
-  atomicAdd(&base[cb], (double)db);
-  atomicAdd(&base[br.C + cb], (double)dg);
 }
 
 }  // namespace yv4

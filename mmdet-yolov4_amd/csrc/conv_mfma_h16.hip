@@ -23,7 +23,7 @@ namespace yv4 {
 //   walk is scalar.  GENERAL_K = true: Cin % 8 == 0 only (stem with C padded to 8, Cin = 32
 //   layers, tiny models): every lane derives (tap, channel) of its own 8-element chunk per slice;
 //   chunks beyond K read zeros on both operands.
-template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, bool GENERAL_K, int NBUF, bool BR = false>
+template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, bool GENERAL_K, int NBUF>
 __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes) {
   typedef typename Elem<BF16>::V8 V8;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -299,24 +299,13 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
     const bool full = vec_ok && co + 7 < p.Cout;
     AffH af;
     if (full) load_affine_h(p, co, has2, af);        // once per column group, shared by the TM row tiles
-    if (BR && full) {
-      // data-gradient launch that also reduces the BatchNorm backward sums of its output (BnRedH): a lane's 8 columns
-      // are the same for the TM row tiles, their partial sums meet in registers before the butterfly + atomics
-      BnVecAcc ba;
-      bnvec_load(p, co, ba);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        epilogue_tile_h<BF16>(p, acc[i][jn], ep, lane, m0 + wm * TM * 32 + i * 32, cb, full, has2, af, &ba);
-      bnvec_flush(p, lane, co, tile_m * WAVES_M + wm, ba);
-      continue;
-    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
       epilogue_tile_h<BF16>(p, acc[i][jn], ep, lane, m0 + wm * TM * 32 + i * 32, cb, full, has2, af);
   }
 }
 
-template <bool BF16, int BM, int BN, bool GENERAL_K, int NBUF, bool BR = false>
+template <bool BF16, int BM, int BN, bool GENERAL_K, int NBUF>
 static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
   constexpr size_t lds = (size_t)NBUF * (BM + BN) * 128;
   static_assert(lds >= 4 * 32 * 36 * 4, "epilogue patches must fit the K-loop carve");
@@ -334,7 +323,7 @@ static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
     return YV4_E_INVALID;
   }
   const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 2, wb = (long long)p.Cout * p.Kw * 2;
-  auto kern = conv_mfma_h16_kernel<BF16, BM, BN, 2, 2, GENERAL_K, NBUF, BR>;
+  auto kern = conv_mfma_h16_kernel<BF16, BM, BN, 2, 2, GENERAL_K, NBUF>;
   static LdsAttrOnce once;
   if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), lds, "conv_mfma_h16")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kHThreads), lds, stream, p, (unsigned)xb, (unsigned)wb);
@@ -344,13 +333,6 @@ static int launch_h16(const ConvArgsH& a, hipStream_t stream) {
 
 template <bool BF16, int NBUF>
 static int dispatch_h16_n(const ConvArgsH& a, int shape, bool general, hipStream_t s) {
-  if (a.br.sums) {
-    // data gradients that reduce the BatchNorm sums of their output: the 128 x 64 and 64 x 64 tiles (the 128 x 128
-    // tile has no registers left for the per-lane constants)
-    if (shape == YV4_HTILE_64x64)
-      return general ? launch_h16<BF16, 64, 64, true, NBUF, true>(a, s) : launch_h16<BF16, 64, 64, false, NBUF, true>(a, s);
-    return general ? launch_h16<BF16, 128, 64, true, NBUF, true>(a, s) : launch_h16<BF16, 128, 64, false, NBUF, true>(a, s);
-  }
   switch (shape) {
     case YV4_HTILE_128x128:
       return general ? launch_h16<BF16, 128, 128, true, NBUF>(a, s) : launch_h16<BF16, 128, 128, false, NBUF>(a, s);
@@ -458,29 +440,9 @@ extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
   return pick_tile_h16((long long)d->N * d->Ho * d->Wo, d->Cout, (long long)d->KH * d->KW * d->Cin);
 }
 
-// fills a.br from a yv4_bnred (or switches it off); the fused reduction needs whole 16-byte vectors everywhere
-static int set_bnred_h16(ConvArgsH& a, const yv4_bnred* br, const yv4_conv_desc* d, int out_dtype, int dtype) {
-  a.br = BnRedH{};
-  if (!br) return YV4_OK;
-  YV4_REQUIRE(br->x && br->mean && br->invstd && br->gamma && br->beta && br->sums, "conv bnred: null argument");
-  YV4_REQUIRE(out_dtype == dtype, "conv bnred: the output must have the operand type");
-  YV4_REQUIRE(br->C > 0 && br->C % 8 == 0 && (d->Cout == br->C || d->Cout == 2 * br->C),
-              "conv bnred: C (%d) must be a multiple of 8 and Cout (%d) must be C or 2 C", br->C, d->Cout);
-  YV4_REQUIRE(((br->x_cstride | br->x_coff | d->y_cstride | d->y_coff) & 7) == 0 && ((uintptr_t)br->x & 15) == 0 &&
-              br->x_coff >= 0 && br->x_coff + d->Cout <= br->x_cstride, "conv bnred: the BatchNorm input view must be 8-aligned and "
-              "hold the launch's Cout channels per pixel");
-  YV4_REQUIRE((((uintptr_t)br->mean | (uintptr_t)br->invstd | (uintptr_t)br->gamma | (uintptr_t)br->beta) & 15) == 0,
-              "conv bnred: mean / invstd / gamma / beta must be 16-byte aligned");
-  YV4_REQUIRE(br->act >= 0 && br->act <= YV4_ACT_SWISH, "conv bnred: unknown activation id");
-  a.br.x = br->x; a.br.cs = br->x_cstride; a.br.co = br->x_coff; a.br.C = br->C;
-  a.br.mean = br->mean; a.br.invstd = br->invstd; a.br.gamma = br->gamma; a.br.beta = br->beta;
-  a.br.act = br->act; a.br.slope = br->slope; a.br.sums = br->sums;
-  return YV4_OK;
-}
-
 static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const void* x, const void* w,
                          const float* scale1, const float* shift1, const float* scale2, const float* shift2,
-                         const void* residual, void* y, double* stats, void* stream, const yv4_bnred* br = nullptr) {
+                         const void* residual, void* y, double* stats, void* stream) {
   YV4_REQUIRE(d && x && w && scale1 && shift1 && y, "conv h16: null argument");
   YV4_REQUIRE(dtype == YV4_F16 || dtype == YV4_BF16, "conv h16: dtype must be YV4_F16 or YV4_BF16");
   YV4_REQUIRE(out_dtype == dtype || out_dtype == YV4_F32, "conv h16: out_dtype must be the operand type or YV4_F32");
@@ -523,12 +485,6 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   static const int ablate = YV4_ENV_INT("YV4_H16_ABLATE", 0);
   a.ablate = ablate;
   a.stats = stats;
-  if (int rc = set_bnred_h16(a, br, d, out_dtype, dtype)) return rc;
-  if (br) {
-    YV4_REQUIRE(!stats && !scale2 && d->act1 == YV4_ACT_NONE && d->Cout == br->C, "conv bnred: identity epilogue, Cout == C");
-    YV4_REQUIRE(d->Cout % 8 == 0 && (!residual || ((d->r_cstride | d->r_coff) & 7) == 0), "conv bnred: Cout and the residual view "
-                "must be multiples of 8");
-  }
   const bool general = (d->Cin % kHBK) != 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d->tile == YV4_HTILE_PP3x3)
@@ -698,7 +654,6 @@ extern "C" int yv4_conv_bn_act_fwd_h16_splitk(const yv4_conv_desc* d, int dtype,
   a.r_cs = d->r_cstride; a.r_co = d->r_coff;
   a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
   a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.Kw = a.K; a.tiles_n = 0; a.ys_on = 0; a.stats = nullptr; a.ablate = 0;
-  a.br = BnRedH{};
   a.out_f32 = out_dtype == YV4_F32 ? 1 : 0;
   const int nk = a.K / kHBK;
   a.ks_slices = (nk + ks - 1) / ks;
@@ -716,9 +671,9 @@ extern "C" int yv4_conv_bn_act_fwd_h16_splitk(const yv4_conv_desc* d, int dtype,
 }
 
 // 16-bit form of yv4_conv_scatter_fwd (conv_mfma_f32.hip): one parity class of a stride-2 data gradient.
-static int conv_scatter_h16_impl(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
-                                 const float* scale1, const float* shift1, void* y, int Hy, int Wy, int sh, int sw,
-                                 int oh, int ow, const yv4_bnred* br, void* stream) {
+extern "C" int yv4_conv_scatter_fwd_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
+                                        const float* scale1, const float* shift1, void* y, int Hy, int Wy, int sh, int sw,
+                                        int oh, int ow, void* stream) {
   YV4_REQUIRE(d && x && w && scale1 && shift1 && y, "conv scatter h16: null argument");
   YV4_REQUIRE(dtype == YV4_F16 || dtype == YV4_BF16, "conv scatter h16: dtype must be YV4_F16 or YV4_BF16");
   YV4_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0,
@@ -745,29 +700,8 @@ static int conv_scatter_h16_impl(const yv4_conv_desc* d, int dtype, const void* 
   a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0; a.out_f32 = 0; a.ablate = 0;
   a.ksplit = 0; a.ks_slices = 0; a.ws_cs = 0; a.ws = nullptr;
   a.ys_on = 1; a.ys_H = Hy; a.ys_W = Wy; a.ys_sh = sh; a.ys_sw = sw; a.ys_oh = oh; a.ys_ow = ow;
-  if (int rc = set_bnred_h16(a, br, d, dtype, dtype)) return rc;
   const bool general = (d->Cin % kHBK) != 0;
   const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);
-}
-
-extern "C" int yv4_conv_scatter_fwd_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
-                                        const float* scale1, const float* shift1, void* y, int Hy, int Wy, int sh, int sw,
-                                        int oh, int ow, void* stream) {
-  return conv_scatter_h16_impl(d, dtype, x, w, scale1, shift1, y, Hy, Wy, sh, sw, oh, ow, nullptr, stream);
-}
-
-// ---- data gradients that also reduce the BatchNorm backward sums of their output (yv4_bnred, include/yv4.h) ----------
-extern "C" int yv4_conv_dgrad_bnred_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w, const float* ones,
-                                        const float* zeros, const void* residual, void* y, const yv4_bnred* br,
-                                        void* stream) {
-  YV4_REQUIRE(br, "conv dgrad bnred: null yv4_bnred");
-  return conv_h16_impl(d, dtype, dtype, x, w, ones, zeros, nullptr, nullptr, residual, y, nullptr, stream, br);
-}
-extern "C" int yv4_conv_scatter_bnred_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w,
-                                          const float* scale1, const float* shift1, void* y, int Hy, int Wy, int sh, int sw,
-                                          int oh, int ow, const yv4_bnred* br, void* stream) {
-  YV4_REQUIRE(br, "conv scatter bnred: null yv4_bnred");
-  return conv_scatter_h16_impl(d, dtype, x, w, scale1, shift1, y, Hy, Wy, sh, sw, oh, ow, br, stream);
 }

@@ -1080,7 +1080,51 @@ __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ 
 //            dx = gamma * invstd * (g - dbeta/M - xhat * dgamma/M)
 // act in {none, Mish, LeakyReLU, Swish}; Mish' as mmdet/ops/mish_cuda/src/mish.h:21-29.
 // ---------------------------------------------------------------------------------
-// (act_grad / mish_grad2: yv4_common.h -- shared with the data-gradient epilogues that reduce the BatchNorm sums)
+__device__ __forceinline__ float act_grad(float z, int act, float slope) {
+  switch (act) {
+    case YV4_ACT_MISH: {
+      // mish.h:21-29 with sp = log1p(e^z), a = 1 + e^z, w = a^2 + 1:  tanh(sp) = (a^2 - 1) / (a^2 + 1) = 1 - 2 / w  and
+      // (1 - tanh^2(sp)) * (1 - exp(-sp)) = (4 a^2 / w^2) * (e / a), so
+      //     mish'(z) = 1 - 2 / w + 4 z a e / w^2
+      // -- ONE reciprocal and one exp2 (hardware, 1 ulp each; quarter-rate instructions): |error| < 1e-6 against the libm
+      // form, well inside the 1e-4 gradient budget.  The two BN-backward kernels are bound by exactly this arithmetic
+      // (~35 issue slots per element at 16 lanes per SIMD and clock = their 0.6 ms on the 757 M-element layer); the
+      // earlier form spent two reciprocals and ~6 more slots here.
+      const float e = __builtin_amdgcn_exp2f(fminf(z, 20.f) * 1.44269504088896340736f);
+      const float a = e + 1.f;
+      const float iw = __builtin_amdgcn_rcpf(__builtin_fmaf(a, a, 1.f));
+      const float g = __builtin_fmaf(4.f * (z * (a * e)), iw * iw, __builtin_fmaf(-2.f, iw, 1.f));
+      return z >= 20.f ? 1.f : g;
+    }
+    case YV4_ACT_LEAKY: return z >= 0.f ? 1.f : slope;
+    case YV4_ACT_SWISH: {
+      const float s = 1.f / (1.f + expf(-z));
+      return s + z * s * (1.f - s);
+    }
+    default: return 1.f;
+  }
+}
+// Two channels at a time for the Mish passes of the BatchNorm kernels: the compiler does not pair the per-channel fp32
+// arithmetic by itself (no v_pk_* in the scalar loops), and these kernels are bound by their VALU issue slots (a wave
+// instruction takes four cycles on a 16-lane SIMD: ~30 slots per element = 0.6 ms on the 757 M-element layer, which is
+// also its HBM time).  Every operation below is the scalar path's, done on a pair -- v_pk_mul / v_pk_add / v_pk_fma --
+// so the results are bit for bit the scalar ones; the transcendentals stay one per element.
+__device__ __forceinline__ f32x2_t splat2(float v) { f32x2_t r; r.x = v; r.y = v; return r; }
+__device__ __forceinline__ f32x2_t mish_grad2(f32x2_t z) {
+  f32x2_t zc;
+  zc.x = fminf(z.x, 20.f); zc.y = fminf(z.y, 20.f);
+  const f32x2_t t = zc * 1.44269504088896340736f;
+  f32x2_t e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2_t a = e + 1.f;
+  const f32x2_t w = __builtin_elementwise_fma(a, a, splat2(1.f));
+  f32x2_t iw;
+  iw.x = __builtin_amdgcn_rcpf(w.x); iw.y = __builtin_amdgcn_rcpf(w.y);
+  f32x2_t g = __builtin_elementwise_fma(4.f * (z * (a * e)), iw * iw, __builtin_elementwise_fma(splat2(-2.f), iw, splat2(1.f)));
+  g.x = z.x >= 20.f ? 1.f : g.x;
+  g.y = z.y >= 20.f ? 1.f : g.y;
+  return g;
+}
 // mish_fast_f32 on a pair, expression for expression: e = exp2(x log2 e), n = e (e + 2), (x n) / (n + 2), x itself from 20 on
 __device__ __forceinline__ f32x2_t mish_fwd2(f32x2_t x) {
   const f32x2_t t = x * 1.44269504088896340736f;
@@ -1263,24 +1307,6 @@ __global__ void bn_finalize_kernel(double* __restrict__ sums, int64_t M_host, in
     running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
     running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
   }
-}
-
-// totals[i] = sum over the replicas of rep[r][i], i < n (= 2 C: dbeta | dgamma); the replicas are cleared as they are
-// read (the buffer is clean again for the next step's data-gradient epilogues, yv4_bnred).  bn_finalize_kernel's lane
-// map: 32 entries x 8 replica lanes per workgroup.
-__global__ void bn_bwd_fold_kernel(double* __restrict__ rep, int n, int replicas, double* __restrict__ totals) {
-  const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
-  const int rl = threadIdx.x & 7;
-  double s = 0.0;
-  if (i < n) {
-    for (int r = rl; r < replicas; r += 8) {
-      s += rep[(size_t)r * n + i];
-      rep[(size_t)r * n + i] = 0.0;
-    }
-  }
-#pragma unroll
-  for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (i < n && rl == 0) totals[i] = s;
 }
 
 struct BnArgs {
@@ -2360,36 +2386,6 @@ extern "C" int yv4_bn_act_bwd_accum(const void* x, int dtype, int x_cstride, int
   // flags: bit 0 = eval-mode BN, bit 1 = `work` is already zero (yv4_bn_finalize's zero_after cleared it)
   return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
                      dx_coff, dgamma, dbeta, work, M, C, act, slope, stream, flags & 1, 0, 0, nullptr, 1, (flags >> 1) & 1);
-}
-
-// The BatchNorm backward whose reduction ran in the epilogue of the data-gradient launch that produced dy (yv4_bnred):
-// fold the replicas, then the apply pass with the totals (publishing dgamma / dbeta from them).
-extern "C" int yv4_bn_act_bwd_prereduced(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
-                                         int dy_cstride, int dy_coff, const float* mean, const float* invstd,
-                                         const float* gamma, const float* beta, void* dx, int dx_cstride, int dx_coff,
-                                         float* dgamma, float* dbeta, double* replicas, double* totals, int64_t M, int C,
-                                         int act, float slope, int flags, void* stream) {
-  YV4_REQUIRE(replicas && totals && C > 0 && C <= 4096, "bn_act_bwd_prereduced: bad argument");
-  hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), replicas,
-                     2 * C, YV4_STATS_REPLICAS, totals);
-  // phase 0 with a zero-free `work`: bn_bwd_impl's phase 2 (apply only) does not publish dgamma / dbeta, so run the
-  // apply kernel of phase 0 directly on the folded totals
-  YV4_REQUIRE(x && dy && mean && invstd && gamma && beta && dx && dgamma && dbeta && M > 0, "bn_act_bwd_prereduced: null argument");
-  YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "bn_act_bwd_prereduced: dtype must be f32, f16 or bf16");
-  YV4_REQUIRE(((C | x_cstride | x_coff | dy_cstride | dy_coff | dx_cstride | dx_coff) & 3) == 0,
-              "bn_act_bwd_prereduced: channels must be multiples of 4");
-  BnArgs a = {};
-  a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.dy = dy; a.dy_cs = dy_cstride; a.dy_co = dy_coff;
-  a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dx_cs = dx_cstride; a.dx_co = dx_coff;
-  a.sums = totals; a.M = M; a.C = C; a.act = act; a.slope = slope; a.eval_mode = 0;
-  a.dgamma = dgamma; a.dbeta = dbeta; a.M_total = M; a.publish = (flags & 1) ? 2 : 1; a.rows = nullptr;
-  a.rows_per_block = bn_rows_per_block(M);
-  const dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
-  const bool v8 = dtype != YV4_F32 && g_bn_vec8 && ((C | x_cstride | x_coff | dy_cstride | dy_coff | dx_cstride | dx_coff) & 7) == 0;
-  YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, V>), grid, dim3(256), 0,
-                                                reinterpret_cast<hipStream_t>(stream), a));
-  YV4_CHECK_LAUNCH("bn_act_bwd_prereduced");
-  return YV4_OK;
 }
 
 extern "C" int yv4_bn_eval_act_bwd(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,

@@ -173,52 +173,4 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   }
 }
 
-// ---- activation derivatives (train-mode BatchNorm backward, csrc/train.hip; data-gradient epilogues) ----
-__device__ __forceinline__ float act_grad(float z, int act, float slope) {
-  switch (act) {
-    case YV4_ACT_MISH: {
-      // mish.h:21-29 with sp = log1p(e^z), a = 1 + e^z, w = a^2 + 1:  tanh(sp) = (a^2 - 1) / (a^2 + 1) = 1 - 2 / w  and
-      // (1 - tanh^2(sp)) * (1 - exp(-sp)) = (4 a^2 / w^2) * (e / a), so
-      //     mish'(z) = 1 - 2 / w + 4 z a e / w^2
-      // -- ONE reciprocal and one exp2 (hardware, 1 ulp each; quarter-rate instructions): |error| < 1e-6 against the libm
-      // form, well inside the 1e-4 gradient budget.  The two BN-backward kernels are bound by exactly this arithmetic
-      // (~35 issue slots per element at 16 lanes per SIMD and clock = their 0.6 ms on the 757 M-element layer); the
-      // earlier form spent two reciprocals and ~6 more slots here.
-      const float e = __builtin_amdgcn_exp2f(fminf(z, 20.f) * 1.44269504088896340736f);
-      const float a = e + 1.f;
-      const float iw = __builtin_amdgcn_rcpf(__builtin_fmaf(a, a, 1.f));
-      const float g = __builtin_fmaf(4.f * (z * (a * e)), iw * iw, __builtin_fmaf(-2.f, iw, 1.f));
-      return z >= 20.f ? 1.f : g;
-    }
-    case YV4_ACT_LEAKY: return z >= 0.f ? 1.f : slope;
-    case YV4_ACT_SWISH: {
-      const float s = 1.f / (1.f + expf(-z));
-      return s + z * s * (1.f - s);
-    }
-    default: return 1.f;
-  }
-}
-// Two channels at a time for the Mish passes of the BatchNorm kernels: the compiler does not pair the per-channel fp32
-// arithmetic by itself (no v_pk_* in the scalar loops), and these kernels are bound by their VALU issue slots (a wave
-// instruction takes four cycles on a 16-lane SIMD: ~30 slots per element = 0.6 ms on the 757 M-element layer, which is
-// also its HBM time).  Every operation below is the scalar path's, done on a pair -- v_pk_mul / v_pk_add / v_pk_fma --
-// so the results are bit for bit the scalar ones; the transcendentals stay one per element.
-__device__ __forceinline__ f32x2_t splat2(float v) { f32x2_t r; r.x = v; r.y = v; return r; }
-__device__ __forceinline__ f32x2_t mish_grad2(f32x2_t z) {
-  f32x2_t zc;
-  zc.x = fminf(z.x, 20.f); zc.y = fminf(z.y, 20.f);
-  const f32x2_t t = zc * 1.44269504088896340736f;
-  f32x2_t e;
-  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
-  const f32x2_t a = e + 1.f;
-  const f32x2_t w = __builtin_elementwise_fma(a, a, splat2(1.f));
-  f32x2_t iw;
-  iw.x = __builtin_amdgcn_rcpf(w.x); iw.y = __builtin_amdgcn_rcpf(w.y);
-  f32x2_t g = __builtin_elementwise_fma(4.f * (z * (a * e)), iw * iw, __builtin_elementwise_fma(splat2(-2.f), iw, splat2(1.f)));
-  g.x = z.x >= 20.f ? 1.f : g.x;
-  g.y = z.y >= 20.f ? 1.f : g.y;
-  return g;
-}
-
 }  // namespace yv4
-

@@ -93,15 +93,11 @@ class Conv(HipModule):
                          name=name or f'conv{self.kernel_size}x{self.kernel_size}',
                          bn1=(self.norm, 0, self.out_channels) if self.with_norm else None, bn2=bn2)
 
-    def fwd(self, x, residual=None, sink=None, res_sink=None, cat=None, grad_final=False):
+    def fwd(self, x, residual=None, sink=None, res_sink=None, cat=None):
         """``sink`` / ``res_sink``: a ``train_ops.GradSink`` this conv's data gradient consumes / the residual's
         gradient is parked in (both ends of a Bottleneck's shortcut, see ``Bottleneck.fwd``).  ``cat``: a
-        ``train_ops.CatSlot`` -- the activation is written into its concat buffer, which is returned.
-        ``grad_final``: the caller guarantees that this conv's data gradient -- with whatever ``sink`` joins to it -- is
-        the COMPLETE gradient of ``x`` (x has no other consumer): the launch then also reduces the backward sums of the
-        BatchNorm that produced x (``train_ops.BnLink``)."""
+        ``train_ops.CatSlot`` -- the activation is written into its concat buffer, which is returned."""
         w = self.conv.weight
-        bnlink = T.bnlink_of(x, grad_final)
         dt = T.train_dtype(self, x)
         al = 4 if dt == torch.float32 else 8
         if x.shape[1] % al:          # the 3-channel image: zero-pad x and the weight to one 16-byte chunk
@@ -127,13 +123,13 @@ class Conv(HipModule):
                 if stats is None or stats.device != x.device or stats.numel() != T.stats_numel(w.shape[0]):
                     stats = self._yv4_stats = T.conv_stats_buffer(w.shape[0], x.device, persistent=True)
             try:
-                y = T.conv2d(x, w, self.stride, self.padding, dtype=dt, stats=stats, sink=sink, bnlink=bnlink)
+                y = T.conv2d(x, w, self.stride, self.padding, dtype=dt, stats=stats, sink=sink)
                 return T.bn_act(y, bn, act_id(self.activate), residual, sums=stats, res_sink=res_sink, cat=cat)
             except Exception:
                 self._yv4_stats = None       # a half-used statistics buffer is not clean: drop it
                 raise
         assert cat is None, 'a concat slot needs the fused BN path'
-        y = T.conv2d(x, w, self.stride, self.padding, dtype=dt, bnlink=bnlink)
+        y = T.conv2d(x, w, self.stride, self.padding, dtype=dt)
         if self.conv.bias is not None:
             y = y + self.conv.bias.view(1, -1, 1, 1)
         if self.activate is not None:
@@ -152,9 +148,8 @@ def _spp_cat(mod, x):
     return torch.cat([x] + [mp(x) for mp in mod.maxpools], 1)
 
 
-def bare_conv_fwd(conv, x, cat=None, park=None, stats=None, grad_final=False):
-    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0], cat=cat, park=park, stats=stats,
-                    bnlink=T.bnlink_of(x, grad_final and park is None))   # follows x's dtype
+def bare_conv_fwd(conv, x, cat=None, park=None, stats=None):
+    return T.conv2d(x, conv.weight, conv.stride[0], conv.padding[0], cat=cat, park=park, stats=stats)   # follows x's dtype
 
 
 def _cat_stats(mod, channels, device):
@@ -217,21 +212,17 @@ class Bottleneck(HipModule):
         y = self.conv1.emit(plan, x)
         return self.conv2.emit(plan, y, out=out, residual=x if self.shortcut else None, post=post)
 
-    def fwd(self, x, cat=None, sink=None, xown=False):
+    def fwd(self, x, cat=None, sink=None):
         """``sink``: a ``GradSink`` another consumer of ``x`` parks its data gradient in (``_fanout_sink``); only
-        without a shortcut -- with one, conv1's single joining input is the shortcut's gradient.
-        ``xown``: ``x`` has no consumer outside this block (and the one that parks into ``sink``): conv1's data
-        gradient is then the complete gradient of x (``Conv.fwd`` ``grad_final``).  The hidden tensor is this block's
-        alone in any case."""
+        without a shortcut -- with one, conv1's single joining input is the shortcut's gradient."""
         if not self.shortcut:
-            return self.conv2.fwd(self.conv1.fwd(x, sink=sink, grad_final=xown), cat=cat, grad_final=True)
+            return self.conv2.fwd(self.conv1.fwd(x, sink=sink), cat=cat)
         assert sink is None
         # out = x + f(x): d_out reaches x twice; the second path is added inside conv1's data-gradient launch
         # (train_ops.GradSink) instead of by autograd's add kernel -- when both convs run the fused BN path
         sink = T.grad_sink_for(x) if (self.conv1.with_norm and self.conv2.with_norm and self.conv1.stride == 1
                                       and T.train_dtype(self, x) == x.dtype) else None
-        return self.conv2.fwd(self.conv1.fwd(x, sink=sink, grad_final=xown and sink is not None), residual=x, res_sink=sink,
-                              cat=cat, grad_final=True)
+        return self.conv2.fwd(self.conv1.fwd(x, sink=sink), residual=x, res_sink=sink, cat=cat)
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')
@@ -279,26 +270,24 @@ class BottleneckCSP(HipModule):
         emit_bare_conv(plan, self.conv2, x, half1, out=cat.slice(h, h), name='csp_conv2')
         return self.conv4.emit(plan, cat, out=out)
 
-    def fwd(self, x, xown=False):
-        """``xown``: ``x`` has no consumer outside this block (see ``Bottleneck.fwd``)."""
+    def fwd(self, x):
         h = self.hidden
         slot = _cat_ok(self, x)
         sink = _fanout_sink(self.conv1, x) if slot else None
-        # x feeds conv1 and the bare conv2; with the sink conv2's share joins conv1's data-gradient launch
-        y = self.conv1.fwd(x, sink=sink, grad_final=xown and sink is not None)
+        y = self.conv1.fwd(x, sink=sink)
         for b in self.bottlenecks:
-            y = b.fwd(y, xown=True)
+            y = b.fwd(y)
         if slot:                     # both bare convs write their half of the concat buffer ...
             st = _cat_stats(self, (h, h), x.device)      # ... and leave the joint BatchNorm's sums of their channels
-            z = bare_conv_fwd(self.conv3, y, cat=T.CatSlot(2 * h, 0), stats=st[0] if st else None, grad_final=True)
+            z = bare_conv_fwd(self.conv3, y, cat=T.CatSlot(2 * h, 0), stats=st[0] if st else None)
             z = bare_conv_fwd(self.conv2, x, cat=T.CatSlot(2 * h, h, z), park=sink, stats=st[1] if st else None)
             try:
-                return self.conv4.fwd(T.bn_act(z, self.bn, act_id(self.csp_act), sums=st), grad_final=True)
+                return self.conv4.fwd(T.bn_act(z, self.bn, act_id(self.csp_act), sums=st))
             except Exception:
                 self._yv4_cat_stats = None       # half-used statistics buffers are not clean: drop them
                 raise
-        z = torch.cat((bare_conv_fwd(self.conv3, y, grad_final=True), bare_conv_fwd(self.conv2, x)), dim=1)
-        return self.conv4.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)), grad_final=True)
+        z = torch.cat((bare_conv_fwd(self.conv3, y), bare_conv_fwd(self.conv2, x)), dim=1)
+        return self.conv4.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')
@@ -335,23 +324,20 @@ class BottleneckCSP2(HipModule):
         emit_bare_conv(plan, self.conv2, x1, half1, out=cat.slice(h, h), name='csp2_conv2')
         return self.conv3.emit(plan, cat, out=out)
 
-    def fwd(self, x, xown=False):
-        x1 = self.conv1.fwd(x, grad_final=xown)
+    def fwd(self, x):
+        x1 = self.conv1.fwd(x)
         y1 = x1
         h = self.hidden
         n = len(self.bottlenecks)
         slot = n > 0 and _cat_ok(self, x1) and all(b.conv2.with_norm for b in self.bottlenecks)
         sink = _fanout_sink(self.bottlenecks[0].conv1, x1) if slot and not self.bottlenecks[0].shortcut else None
         for i, b in enumerate(self.bottlenecks):     # the last bottleneck's activation lands in the concat buffer
-            # x1 feeds the first bottleneck and the bare conv2 (whose share joins through the sink); every later input
-            # is the previous bottleneck's output alone
-            y1 = b.fwd(y1, cat=T.CatSlot(2 * h, 0) if slot and i == n - 1 else None, sink=sink if i == 0 else None,
-                       xown=(sink is not None) if i == 0 else True)
+            y1 = b.fwd(y1, cat=T.CatSlot(2 * h, 0) if slot and i == n - 1 else None, sink=sink if i == 0 else None)
         if slot:
             z = bare_conv_fwd(self.conv2, x1, cat=T.CatSlot(2 * h, h, y1), park=sink)
         else:
             z = torch.cat((y1, bare_conv_fwd(self.conv2, x1)), dim=1)
-        return self.conv3.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)), grad_final=True)
+        return self.conv3.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')
@@ -378,8 +364,8 @@ class SPPV5(HipModule):
         plan.spp(cat, h)
         return self.conv2.emit(plan, cat, out=out)
 
-    def fwd(self, x, xown=False):
-        x = self.conv1.fwd(x, grad_final=xown)
+    def fwd(self, x):
+        x = self.conv1.fwd(x)
         return self.conv2.fwd(_spp_cat(self, x))
 
     def forward(self, x):
@@ -423,19 +409,18 @@ class SPPV4(HipModule):
         emit_bare_conv(plan, self.conv2, x, half1, out=cat.slice(h, h), name='sppv4_conv2')
         return self.conv7.emit(plan, cat, out=out)
 
-    def fwd(self, x, xown=False):
+    def fwd(self, x):
         slot = _cat_ok(self, x) and self.conv6.with_norm
         sink = _fanout_sink(self.conv1, x) if slot else None
-        x1 = self.conv4.fwd(self.conv3.fwd(self.conv1.fwd(x, sink=sink, grad_final=xown and sink is not None),
-                                           grad_final=True), grad_final=True)
+        x1 = self.conv4.fwd(self.conv3.fwd(self.conv1.fwd(x, sink=sink)))
         h = self.hidden
         if slot:
-            z = self.conv6.fwd(self.conv5.fwd(_spp_cat(self, x1)), cat=T.CatSlot(2 * h, 0), grad_final=True)
+            z = self.conv6.fwd(self.conv5.fwd(_spp_cat(self, x1)), cat=T.CatSlot(2 * h, 0))
             z = bare_conv_fwd(self.conv2, x, cat=T.CatSlot(2 * h, h, z), park=sink)
         else:
-            y1 = self.conv6.fwd(self.conv5.fwd(_spp_cat(self, x1)), grad_final=True)
+            y1 = self.conv6.fwd(self.conv5.fwd(_spp_cat(self, x1)))
             z = torch.cat((y1, bare_conv_fwd(self.conv2, x)), dim=1)
-        return self.conv7.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)), grad_final=True)
+        return self.conv7.fwd(T.bn_act(z, self.bn, act_id(self.csp_act)))
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')
@@ -471,8 +456,8 @@ class CSPStage(HipModule):
     def emit(self, plan, x, out=None):
         return self.conv_csp.emit(plan, self.conv_downscale.emit(plan, x), out=out)
 
-    def fwd(self, x, xown=False):
-        return self.conv_csp.fwd(self.conv_downscale.fwd(x, grad_final=xown), xown=True)
+    def fwd(self, x):
+        return self.conv_csp.fwd(self.conv_downscale.fwd(x))
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')
@@ -491,8 +476,8 @@ class SPPV5Stage(HipModule):
         y = self.conv_downscale.emit(plan, x)
         return self.conv_csp.emit(plan, self.spp.emit(plan, y), out=out)
 
-    def fwd(self, x, xown=False):
-        return self.conv_csp.fwd(self.spp.fwd(self.conv_downscale.fwd(x, grad_final=xown), xown=True), xown=True)
+    def fwd(self, x):
+        return self.conv_csp.fwd(self.spp.fwd(self.conv_downscale.fwd(x)))
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')
@@ -511,8 +496,8 @@ class SPPV4Stage(HipModule):
         y = self.conv_csp.emit(plan, self.conv_downscale.emit(plan, x))
         return self.spp.emit(plan, y, out=out)
 
-    def fwd(self, x, xown=False):
-        return self.spp.fwd(self.conv_csp.fwd(self.conv_downscale.fwd(x, grad_final=xown), xown=True), xown=True)
+    def fwd(self, x):
+        return self.spp.fwd(self.conv_csp.fwd(self.conv_downscale.fwd(x)))
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')
@@ -530,8 +515,8 @@ class BottleneckStage(HipModule):
     def emit(self, plan, x, out=None):
         return self.conv_bottleneck.emit(plan, self.conv_downscale.emit(plan, x), out=out)
 
-    def fwd(self, x, xown=False):
-        return self.conv_bottleneck.fwd(self.conv_downscale.fwd(x, grad_final=xown), xown=True)
+    def fwd(self, x):
+        return self.conv_bottleneck.fwd(self.conv_downscale.fwd(x))
 
     def forward(self, x):
         return self._dispatch((x,), 'flat')
@@ -617,11 +602,8 @@ class DarknetCSP(HipModule):
 
     def fwd(self, x):
         outs = []
-        own = False      # is x the previous stage's output with no other consumer?  (not the image, not an out_indices map)
         for i, layer_name in enumerate(self.layers):
-            layer = getattr(self, layer_name)
-            x = layer.fwd(x, xown=True) if (own and i > 0 and not isinstance(layer, (Conv, Focus))) else layer.fwd(x)
-            own = i not in self.out_indices
+            x = getattr(self, layer_name).fwd(x)
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)

@@ -83,7 +83,7 @@ _DCODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
 def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None, x_cs=None, residual=None, res_cs=None,
-                 y_cs=None, y_co=0, bnred=None):
+                 y_cs=None, y_co=0):
     """Identity-epilogue conv of a channels_last tensor; fp32, or fp16 / bf16 operands (fp32 accumulate).
     ``stats``: a float64 buffer of ``STATS_REPLICAS * 2 * Cout`` entries that receives the BatchNorm sums of the
     output (``yv4_conv_fwd_stats``: accumulated in the conv kernel's epilogue)."""
@@ -105,12 +105,6 @@ def _conv_launch(x, w_packed, Cin_p, Cout, KH, KW, stride, pad, out, stats=None,
         check(_lib.lib().yv4_conv_fwd_stats(C.byref(d), _DCODE[x.dtype], x.data_ptr(), w_packed.data_ptr(),
                                             ones.data_ptr(), zeros.data_ptr(), out.data_ptr(), stats.data_ptr(),
                                             clean, stream_ptr()), 'yv4_conv_fwd_stats')
-        return d
-    if bnred is not None:          # a data gradient that also reduces the BatchNorm sums of its output (BnLink)
-        assert x.dtype != torch.float32
-        check(_lib.lib().yv4_conv_dgrad_bnred_h16(C.byref(d), _DCODE[x.dtype], x.data_ptr(), w_packed.data_ptr(),
-                                                  ones.data_ptr(), zeros.data_ptr(), rptr, out.data_ptr(),
-                                                  C.byref(bnred), stream_ptr()), 'yv4_conv_dgrad_bnred_h16')
         return d
     if x.dtype == torch.float32:
         check(_lib.lib().yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w_packed.data_ptr(), ones.data_ptr(),
@@ -145,72 +139,6 @@ def grad_sink_for(x):
     if _GRAD_SINK_ON and torch.is_grad_enabled() and x.requires_grad:
         return GradSink()
     return None
-
-
-# ---- BatchNorm backward: the reduction pass inside the data-gradient launch that produces the gradient -------------
-# The backward of z = act(BN(y)) (+ residual) needs dbeta = sum dz act'(.), dgamma = sum dz act'(.) xhat before it can
-# write dy: a pass over dz and y (``bn_act_bwd_reduce_kernel``: 9 % of the bf16 train step in round 3).  When ONE launch
-# produces the complete dz -- the data gradient of z's only consumer, with whatever a ``GradSink`` joins to it -- that
-# launch has every value in registers in its epilogue: it reads y there and leaves the sums (``yv4_bnred``,
-# include/yv4.h).  ``BNActFunction.forward`` hands a ``BnLink`` to its output tensor (``_yv4_bnlink``); a module that
-# KNOWS the structure (``grad_final=True`` of ``Conv.fwd``: this conv's data gradient is the complete gradient of its
-# input) passes it to ``conv2d``; ``ConvFunction.backward`` then runs the fused launch and marks the link, and
-# ``BNActFunction.backward`` (which runs right after) skips its reduction pass.  Anything else -- fp32, SyncBN,
-# eval-mode BN, a tensor with a second consumer, strides / kernels without a fused form -- leaves the link unmarked
-# and takes the two-pass path.  YV4_BN_BWD_FUSE=0 switches it off; YV4_BN_BWD_CHECK=1 recomputes the sums by the
-# reduction pass and compares (tests: a wrong ``grad_final`` shows as a mismatch).
-_BN_BWD_FUSE = os.environ.get('YV4_BN_BWD_FUSE', '1') != '0'
-_BN_BWD_CHECK = os.environ.get('YV4_BN_BWD_CHECK', '0') == '1'
-bn_bwd_fuse_stats = dict(fused=0, unfused=0)        # per process: how many BatchNorm backwards took which path
-
-
-class BnLink:
-    __slots__ = ('x', 'mean', 'invstd', 'g', 'b', 'act', 'slope', 'rep', 'C', 'state')
-
-    def __init__(self, x, mean, invstd, g, b, act, slope, rep):
-        self.x, self.mean, self.invstd, self.g, self.b = x, mean, invstd, g, b
-        self.act, self.slope, self.rep, self.C = int(act), float(slope), rep, int(x.shape[1])
-        # [sums are in ``rep``]: a list the replica buffer's owner keeps too (``rep._yv4_state``), so that the owner can
-        # tell a dirty buffer without keeping this link -- and the activation it references -- alive
-        self.state = getattr(rep, '_yv4_state', None) or [False]
-        rep._yv4_state = self.state
-        self.state[0] = False
-
-    @property
-    def reduced(self):
-        return self.state[0]
-
-    @reduced.setter
-    def reduced(self, v):
-        self.state[0] = bool(v)
-
-    def bnred(self, cstride=None, C_=None):
-        """The ``yv4_bnred`` of this BatchNorm for a launch whose output has ``cstride`` channels per pixel."""
-        br = _lib.BnRed()
-        br.x = self.x.data_ptr()
-        br.x_cstride = int(cstride if cstride is not None else self.C)
-        br.x_coff = 0
-        br.C = self.C
-        br.mean, br.invstd, br.gamma, br.beta = (self.mean.data_ptr(), self.invstd.data_ptr(), self.g.data_ptr(),
-                                                 self.b.data_ptr())
-        br.act, br.slope = self.act, self.slope
-        br.sums = self.rep.data_ptr()
-        return br
-
-
-_new_link = [None]      # BNActFunction.forward -> bn_act: the link of the Function call that just returned
-
-
-def _link_for_dgrad(link, dtype, xshape, x_dtype):
-    """``link`` if the data gradient of a conv with input shape ``xshape`` can carry its reduction, else None."""
-    if link is None or not _BN_BWD_FUSE or dtype == torch.float32 or x_dtype != dtype:
-        return None
-    N, Cin, H, W = xshape
-    if link.x.dtype != dtype or tuple(link.x.shape) != (N, Cin, H, W) or Cin % 8 or not _is_nhwc(link.x):
-        return None
-    if any(t.data_ptr() % 16 for t in (link.mean, link.invstd, link.g, link.b, link.x)):
-        return None
-    return link
 
 
 # ---- packed weight operands, replayed in one launch per optimizer step -----------------------------------------------
@@ -373,7 +301,7 @@ def packed_weight(weight, dtype, transpose_flip=False, taps=None, owner=None, pa
     return out, cp
 
 
-def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None, residual=None, res_cs=None, owner=None, link=None):
+def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None, residual=None, res_cs=None, owner=None):
     """dX = correlate(dY zero-dilated by `stride`, W flipped in (kh,kw) and transposed in (co,ci)), pad k-1-p."""
     N, Cin, H, W = xshape
     Cout, _, KH, KW = weight.shape
@@ -400,13 +328,7 @@ def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None, residual=
     dxf = torch.empty((N, Cin, Hx, Wx), device=dy.device, dtype=dtype, memory_format=torch.channels_last)
     if residual is not None:
         assert (Hx, Wx) == (H, W)
-    if link is not None and stride == 1 and (Hx, Wx) == (H, W) and \
-            (residual is None or ((res_cs if res_cs is not None else Cin) % 8 == 0 and residual.data_ptr() % 16 == 0)):
-        _conv_launch(src, wtp, Cout, Cin, KH, KW, 1, p2, dxf, x_cs=src_cs, residual=residual, res_cs=res_cs,
-                     bnred=link.bnred())
-        link.reduced = True
-    else:
-        _conv_launch(src, wtp, Cout, Cin, KH, KW, 1, p2, dxf, x_cs=src_cs, residual=residual, res_cs=res_cs)
+    _conv_launch(src, wtp, Cout, Cin, KH, KW, 1, p2, dxf, x_cs=src_cs, residual=residual, res_cs=res_cs)
     if (Hx, Wx) != (H, W):
         # stride 2 with odd input size: the dilated grid is one row/column larger or smaller
         dx = torch.empty((N, Cin, H, W), device=dy.device, dtype=dtype, memory_format=torch.channels_last).zero_()
@@ -416,7 +338,7 @@ def _dgrad_dilated(dy, weight, xshape, stride, pad, dtype, dy_cs=None, residual=
     return dxf
 
 
-def _dgrad_s2_parity(dy, weight, xshape, dtype, dy_cs=None, owner=None, link=None):
+def _dgrad_s2_parity(dy, weight, xshape, dtype, dy_cs=None, owner=None):
     """Data gradient of a 3x3 / stride 2 / pad 1 convolution as four parity classes: with
     hi = 2*ho - 1 + kh, the input rows hi = 2i + a receive only the taps kh with (a + 1 - kh) even
     (a = 0: kh = 1 from dY row i;  a = 1: kh = 2 from row i and kh = 0 from row i + 1), likewise in x.
@@ -442,20 +364,13 @@ def _dgrad_s2_parity(dy, weight, xshape, dtype, dy_cs=None, owner=None, link=Non
             d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, Ho, Wo, Cout, Ha, Wb, Cin
             d.KH, d.KW, d.stride, d.pad = taps[a][2], taps[b][2], 1, 0
             d.x_cstride, d.y_cstride = (dy_cs if dy_cs is not None else Cout), Cin
-            if h16 and link is not None:    # every class adds its own positions to the BatchNorm sums (BnLink)
-                br = link.bnred()
-                check(L.yv4_conv_scatter_bnred_h16(C.byref(d), _DCODE[dtype], dy.data_ptr(), wp.data_ptr(), ones.data_ptr(),
-                                                   zeros.data_ptr(), dx.data_ptr(), H, W, 2, 2, a, b, C.byref(br),
-                                                   stream_ptr()), 'yv4_conv_scatter_bnred_h16')
-            elif h16:
+            if h16:
                 check(L.yv4_conv_scatter_fwd_h16(C.byref(d), _DCODE[dtype], dy.data_ptr(), wp.data_ptr(), ones.data_ptr(),
                                                  zeros.data_ptr(), dx.data_ptr(), H, W, 2, 2, a, b, stream_ptr()),
                       'yv4_conv_scatter_fwd_h16')
             else:
                 check(L.yv4_conv_scatter_fwd(C.byref(d), dy.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(),
                                              dx.data_ptr(), H, W, 2, 2, a, b, stream_ptr()), 'yv4_conv_scatter_fwd')
-    if h16 and link is not None:
-        link.reduced = True
     return dx
 
 
@@ -488,7 +403,7 @@ def _rowpair_weights(weight, dtype, owner):
     return tuple(out)
 
 
-def _dgrad_s2_rowpair(dy, weight, xshape, dtype, dy_cs=None, owner=None, link=None):
+def _dgrad_s2_rowpair(dy, weight, xshape, dtype, dy_cs=None, owner=None):
     """The same data gradient for FEW input channels (2 * Cin <= 64), even H and W: the two column parities of an input
     row pair are ONE output pixel of 2 * Cin channels -- dX viewed as (N, H, W / 2, 2 Cin) -- so each row parity a is a
     single stride-1 correlation of dY with a (1 + a) x 2 kernel into 2 Cin channels, scattered to the rows 2 i + a
@@ -508,21 +423,13 @@ def _dgrad_s2_rowpair(dy, weight, xshape, dtype, dy_cs=None, owner=None, link=No
         d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, Ho, Wo, Cout, H // 2, W // 2, 2 * Cin
         d.KH, d.KW, d.stride, d.pad = 1 + a, 2, 1, 0
         d.x_cstride, d.y_cstride = (dy_cs if dy_cs is not None else Cout), 2 * Cin
-        if h16 and link is not None:
-            # the BatchNorm input in the same row-pair view: 2 Cin channels per (pixel pair), channel c' -> c' % Cin
-            br = link.bnred(cstride=2 * Cin)
-            check(L.yv4_conv_scatter_bnred_h16(C.byref(d), _DCODE[dtype], dy.data_ptr(), w2[a].data_ptr(), ones.data_ptr(),
-                                               zeros.data_ptr(), dx.data_ptr(), H, W // 2, 2, 1, a, 0, C.byref(br),
-                                               stream_ptr()), 'yv4_conv_scatter_bnred_h16')
-        elif h16:
+        if h16:
             check(L.yv4_conv_scatter_fwd_h16(C.byref(d), _DCODE[dtype], dy.data_ptr(), w2[a].data_ptr(), ones.data_ptr(),
                                              zeros.data_ptr(), dx.data_ptr(), H, W // 2, 2, 1, a, 0, stream_ptr()),
                   'yv4_conv_scatter_fwd_h16')
         else:
             check(L.yv4_conv_scatter_fwd(C.byref(d), dy.data_ptr(), w2[a].data_ptr(), ones.data_ptr(), zeros.data_ptr(),
                                          dx.data_ptr(), H, W // 2, 2, 1, a, 0, stream_ptr()), 'yv4_conv_scatter_fwd')
-    if h16 and link is not None:
-        link.reduced = True
     return dx
 
 
@@ -600,7 +507,7 @@ class ConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride, pad, dtype, stats=None, direct=None, sink=None, cat_buf=None, cat_total=0,
-                cat_off=0, park=None, bnlink=None):
+                cat_off=0, park=None):
         """``direct``: a ``_ParamRef`` to the parameter whose ``.grad`` receives dW in place (then ``weight`` is the
         detached parameter: autograd does not track it through this Function, see ``conv2d``).
         ``cat_total`` > 0: the output is channels [cat_off, cat_off + Cout) of a (N, cat_total, Ho, Wo) concat buffer --
@@ -610,7 +517,6 @@ class ConvFunction(torch.autograd.Function):
         _need_cuda(x, 'x')
         ctx.direct = direct
         ctx.park = park
-        ctx.bnlink = bnlink if park is None else None     # (a parked data gradient is not the complete one)
         ctx.sink = sink if stride == 1 else None     # (the stride-2 parity form has no residual input)
         Cout, Cin, KH, KW = weight.shape
         al = 4 if dtype == torch.float32 else 8
@@ -703,18 +609,15 @@ class ConvFunction(torch.autograd.Function):
                 if joined.dtype != dtype or tuple(joined.shape) != (N, Cin, H, W):
                     joined = to_nhwc(joined.to(dtype))
                     jcs = None
-            link = _link_for_dgrad(ctx.bnlink, dtype, (N, Cin, H, W), ctx.x_dtype)
             if stride == 2 and (KH, KW, pad) == (3, 3, 1) and Cout % (8 if h16 else 32) == 0:
                 own = ctx.direct.p if ctx.direct is not None else None
-                if joined is not None:
-                    link = None                  # (joined by an add below: the launches' output is not the complete gradient)
                 if _ROWPAIR_ON and 2 * Cin <= 64 and H % 2 == 0 and W % 2 == 0 and Cin % (4 if h16 else 2) == 0:
-                    dx = _dgrad_s2_rowpair(dy, weight, (N, Cin, H, W), dtype, dy_cs, owner=own, link=link)
+                    dx = _dgrad_s2_rowpair(dy, weight, (N, Cin, H, W), dtype, dy_cs, owner=own)
                 else:
-                    dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype, dy_cs, owner=own, link=link)
+                    dx = _dgrad_s2_parity(dy, weight, (N, Cin, H, W), dtype, dy_cs, owner=own)
             else:
                 dx = _dgrad_dilated(dy, weight, (N, Cin, H, W), stride, pad, dtype, dy_cs, residual=joined, res_cs=jcs,
-                                    owner=ctx.direct.p if ctx.direct is not None else None, link=link)
+                                    owner=ctx.direct.p if ctx.direct is not None else None)
                 joined = None
             if joined is not None:
                 dx = dx + joined
@@ -724,7 +627,7 @@ class ConvFunction(torch.autograd.Function):
         if ctx.park is not None and dx is not None:
             ctx.park.value, ctx.park.cs = dx, None          # joins the other consumer's data gradient (GradSink)
             dx = None
-        return dx, dw, None, None, None, None, None, None, dcat, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, dcat, None, None, None
 
 
 def train_dtype(module, x):
@@ -751,7 +654,7 @@ class CatSlot:
         return self.buf, self.total, self.off
 
 
-def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None, sink=None, cat=None, park=None, bnlink=None):
+def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None, sink=None, cat=None, park=None):
     """``dtype`` None: follow ``x`` (a 16-bit activation keeps the path 16-bit, anything else is fp32).
     ``stats``: see ``_conv_launch`` / ``conv_stats_buffer``; pass the same buffer to ``bn_act(..., sums=)``.
     ``cat``: a ``CatSlot`` -- the result is the concat buffer with this conv's channels written."""
@@ -762,14 +665,8 @@ def conv2d(x, weight, stride=1, pad=0, dtype=None, stats=None, sink=None, cat=No
             and _direct_grad_target(weight, weight.shape[1]) is not None
             and weight.shape[1] % (4 if dtype == torch.float32 else 8) == 0):
         # dW goes straight into weight.grad (see the note above ConvFunction): the Function sees the detached weight
-        return ConvFunction.apply(x, weight.detach(), stride, pad, dtype, stats, _ParamRef(weight), sink, *cargs, park, bnlink)
-    return ConvFunction.apply(x, weight, stride, pad, dtype, stats, None, sink, *cargs, park, bnlink)
-
-
-def bnlink_of(x, grad_final):
-    """The ``BnLink`` of ``x`` for a conv whose data gradient (with what its sink joins) is the COMPLETE gradient of
-    ``x`` (``grad_final``: only the module that built the graph around ``x`` can know), else None."""
-    return getattr(x, '_yv4_bnlink', None) if (grad_final and _BN_BWD_FUSE) else None
+        return ConvFunction.apply(x, weight.detach(), stride, pad, dtype, stats, _ParamRef(weight), sink, *cargs, park)
+    return ConvFunction.apply(x, weight, stride, pad, dtype, stats, None, sink, *cargs, park)
 
 
 def stats_numel(cout):
@@ -793,8 +690,7 @@ class BNActFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, residual, training=True,
-                sync_group=None, sums=None, direct=None, res_sink=None, cat_buf=None, cat_total=0, cat_off=0,
-                link_rep=None):
+                sync_group=None, sums=None, direct=None, res_sink=None, cat_buf=None, cat_total=0, cat_off=0):
         """``sync_group``: None, or a (process group or 'world') to synchronise the batch statistics over
         (torch.nn.SyncBatchNorm semantics: statistics over all ranks' rows, local dgamma / dbeta).
         ``sums``: the replicated [sum | sum of squares] buffer the producing conv filled (``conv2d(stats=)``):
@@ -889,13 +785,6 @@ class BNActFunction(torch.autograd.Function):
                                    b.data_ptr(), res.data_ptr() if res is not None else None, Cc, 0, y.data_ptr(), y_cs,
                                    y_co, M, Cc, int(act), float(slope), stream_ptr()), 'yv4_bn_act_fwd')
         ctx.save_for_backward(x, mean, invstd, g, b)
-        # ``link_rep`` (the BatchNorm's clean replica buffer): offer the reduction pass of this backward to the data-gradient
-        # launch that will produce dy (BnLink) -- batch statistics of ONE rank, 16-bit activations, an output of its own
-        ctx.link = None
-        _new_link[0] = None
-        if (link_rep is not None and training and rows is None and not cat_total and x.dtype != torch.float32
-                and Cc % 8 == 0):
-            ctx.link = _new_link[0] = BnLink(x, mean, invstd, g, b, act, slope, link_rep)
         ctx.direct = direct      # (_ParamRef(weight), _ParamRef(bias)): dgamma / dbeta are added to their .grad in place
         ctx.bwd_work = bwd_work  # 2*C doubles already cleared by the finalize kernel, or None
         ctx.rows = rows
@@ -941,31 +830,7 @@ class BNActFunction(torch.autograd.Function):
                 gw, gb = ctx.direct[0].p.grad, ctx.direct[1].p.grad
                 if not (_flat_f32(gw, Cc) and _flat_f32(gb, Cc)):
                     gw = gb = None
-            link = ctx.link
-            if link is not None and link.reduced:
-                # the launch that produced dy already left the sums in the replica buffer (BnLink): fold + apply
-                link.reduced = False
-                bn_bwd_fuse_stats['fused'] += 1
-                if _BN_BWD_CHECK:
-                    chk_g, chk_b = torch.empty_like(dgamma), torch.empty_like(dbeta)
-                    chk = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
-                    check(L.yv4_bn_act_bwd_sums(x.data_ptr(), code, Cc, 0, dy.data_ptr(), dcs, 0, mean.data_ptr(),
-                                                invstd.data_ptr(), g.data_ptr(), b.data_ptr(), chk_g.data_ptr(),
-                                                chk_b.data_ptr(), chk.data_ptr(), M, Cc, act, slope, stream_ptr()),
-                          'yv4_bn_act_bwd_sums')
-                    got = link.rep.view(_lib.STATS_REPLICAS, 2 * Cc).sum(0)
-                    err = float((got - chk).abs().max() / (chk.abs().max() + 1e-30))
-                    assert err < 2e-3, f'BnLink: fused BatchNorm sums differ from the reduction pass by {err:.2e} of the ' \
-                                       f'largest sum (C = {Cc}, M = {M}): the linked data gradient was not the complete one'
-                totals = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
-                tg, tb = (gw, gb) if gw is not None else (dgamma, dbeta)
-                check(L.yv4_bn_act_bwd_prereduced(x.data_ptr(), code, Cc, 0, dy.data_ptr(), dcs, 0, mean.data_ptr(),
-                                                  invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
-                                                  tg.data_ptr(), tb.data_ptr(), link.rep.data_ptr(), totals.data_ptr(), M,
-                                                  Cc, act, slope, 1 if gw is not None else 0, stream_ptr()),
-                      'yv4_bn_act_bwd_prereduced')
-            elif gw is not None:       # dgamma / dbeta added to the parameters' gradients by the kernel itself
-                bn_bwd_fuse_stats['unfused'] += 1
+            if gw is not None:       # dgamma / dbeta added to the parameters' gradients by the kernel itself
                 flags = 0 if ctx.training else 1
                 wk = work
                 if ctx.bwd_work is not None:
@@ -993,7 +858,7 @@ class BNActFunction(torch.autograd.Function):
                 for cb in _direct_grad_listeners:
                     cb(ref.p)
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None, None, None, dcat, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None, None, None, dcat, None, None
 
 
 def _sync_group(bn):
@@ -1024,26 +889,11 @@ def bn_act(x, bn, act=(0, 0.0), residual=None, sums=None, res_sink=None, cat=Non
         # dgamma / dbeta go straight into the parameters' gradients (see the note above ConvFunction)
         direct = (_ParamRef(gamma), _ParamRef(beta))
         gamma, beta = gamma.detach(), beta.detach()
-    rep = None
-    if (_BN_BWD_FUSE and use_batch and cat is None and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)
-            and x.requires_grad and torch.is_grad_enabled() and x.shape[1] % 8 == 0):
-        # the replica buffer of the fused backward reduction (BnLink): this module's, zero between steps -- the fold
-        # kernel clears it as it reads; a link that was marked but never consumed (its backward did not run) leaves it
-        # dirty, so it is cleared here
-        rep = getattr(bn, '_yv4_bwd_rep', None)
-        if rep is None or rep.device != x.device or rep.numel() != _lib.STATS_REPLICAS * 2 * x.shape[1]:
-            rep = bn._yv4_bwd_rep = torch.zeros(_lib.STATS_REPLICAS * 2 * x.shape[1], dtype=torch.float64, device=x.device)
-        if getattr(rep, '_yv4_state', [False])[0]:
-            rep.zero_()
     out = BNActFunction.apply(x, gamma, beta, bn.running_mean if bn.track_running_stats else None,
                               bn.running_var if bn.track_running_stats else None, bn.eps, mom, act[0], act[1],
                               residual, use_batch, _sync_group(bn) if use_batch else None,
                               sums if use_batch else None, direct, res_sink,
-                              *(cat.args() if cat is not None else (None, 0, 0)), rep)
-    if rep is not None:
-        link, _new_link[0] = _new_link[0], None
-        if link is not None:
-            out._yv4_bnlink = link
+                              *(cat.args() if cat is not None else (None, 0, 0)))
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         if _fwd_depth[0] > 0:        # inside a registered module's training forward: one multi-tensor add at its end
             _nbt_pending.append(bn.num_batches_tracked)

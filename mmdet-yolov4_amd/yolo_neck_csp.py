@@ -193,10 +193,7 @@ class YOLOV4Neck(_PANBase):
                 z = torch.cat((down.fwd(x), saved), dim=1)
             x = self.post_downsample_concat_csp[i].fwd(z)
             outs.append(x)
-        res = tuple(self.out_convs[i].fwd(outs[i]) for i in range(len(outs)))
-        for r in res:        # nothing in here reads an output conv's map: whoever takes it next is its only consumer
-            r._yv4_single_use = True        # (the head's pred conv: train_ops.BnLink)
-        return res
+        return tuple(self.out_convs[i].fwd(outs[i]) for i in range(len(outs)))
 
 
 @NECKS.register_module()

@@ -305,9 +305,7 @@ class YOLOCSPHead(HipModule):
             padc = (-co) % (4 if dt == torch.float32 else 8)
             if padc:
                 w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, padc))
-            # (a neck output that nothing else reads: this conv's data gradient is its complete gradient, train_ops.BnLink)
-            link = T.bnlink_of(x, getattr(x, '_yv4_single_use', False))
-            outs.append(RawPredMap(T.conv2d(x, w, 1, 0, dtype=dt, bnlink=link), conv.bias, self.num_anchors[i], self.num_attrib))
+            outs.append(RawPredMap(T.conv2d(x, w, 1, 0, dtype=dt), conv.bias, self.num_anchors[i], self.num_attrib))
         return tuple(outs)
 
     def fwd(self, feats):
