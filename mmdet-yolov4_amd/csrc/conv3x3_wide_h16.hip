@@ -1,0 +1,515 @@
+// 3x3 / stride-1 / pad-1 fused convolution for gfx950 with 16-bit operands -- WIDE wave tiles on v_mfma_f32_16x16x32
+// (round 4; tile id YV4_HTILE_W3x3).  The layers: the bottleneck 3x3 convs of CSPDarknet53 / PAN
+// (mmdet/models/backbones/darknetcsp.py:38-64, mmdet/models/necks/yolo_neck_csp.py:11-238) and their data gradients.
+//
+// Why another 3x3 kernel.  conv3x3_pp_h16.hip (256 pixels x 128 channels, wave tile 64 x 64 on 32x32x16 MFMAs, two wave
+// groups a phase apart) spends more issue time feeding the matrix pipe than the pipe spends computing: one ds_read_b128
+// per 32 pipe cycles, ~40 % of the clocked matrix rate inside its K loop.  This kernel takes the shape
+// the guide's 256 x 256 GEMM template uses: a wave owns 16 PT pixels x 64 channels (PT = 8: 128 x 64) as PT x 4
+// accumulator tiles of 16 x 16, so a 64-deep K tile is 2 PT x 4 MFMAs of 16 pipe cycles fed by 2 PT + 8 fragment
+// reads (0.75 reads per 32 pipe cycles at PT = 8), and its LDS-DMA fill per FLOP halves (the weight tile of a tap is
+// shared by twice the pixels).  What it keeps from the ping-pong kernel: the three kw taps of a (64-channel chunk, kh)
+// group read ONE LDS image of the BM + 2 source pixels (fragment row = output row + kw, image borders masked by
+// redirecting a lane's read to a zero row), out-of-range DMA offsets as the zero padding, a persistent grid whose
+// issue side runs on across tiles.
+//
+// Operand roles.  The MFMA's A operand (16 rows) is the WEIGHT tile, its B operand (16 columns) the pixels, so a lane
+// of the 16 x 16 result holds 4 consecutive ROWS = output channels of ONE pixel.  The 16 MFMA rows of channel tile t
+// are mapped to the wave's channels 16 (i >> 2) + 4 t + (i & 3): over t = 0..3 a lane (fq = lane >> 4) then owns the 16
+// CONSECUTIVE channels 16 fq .. 16 fq + 15 of its pixel -- two 16-byte stores, a full 128-byte line per pixel and wave,
+// no LDS transposition and no lane exchange in the epilogue.
+//
+// Pipeline.  Tiles are square in work, not in shape: BM = 16 PT WAVES_M pixels x BN = 64 (8 / WAVES_M) channels, chosen
+// per layer so that the tile count fills whole rounds of CUs (256 x 256 leaves 29 % of the chip idle on a 181-tile
+// layer; 192 x 256 makes it 241 tiles).  Per K tile (one tap of one chunk) every wave issues the NEXT tap's weight
+// pieces (two LDS slots) and, when the tap opens a (chunk, kh) group, the next group's pixel image (two images); its
+// own DMAs are confirmed by a counted s_waitcnt vmcnt at the end of the K tile, then ONE workgroup barrier publishes
+// them -- a buffer is re-filled only in the K tile after the barrier that followed its last reads, a staged buffer is
+// read only after the barrier that followed its wait.  Inside a K tile there is no barrier: the two waves of a SIMD drift
+// apart by themselves, one reading fragments while the other's MFMAs occupy the pipe.
+#include "conv_h16_common.h"
+
+namespace yv4 {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <bool BF16> struct Mfma16;
+template <> struct Mfma16<true> {
+  static __device__ __forceinline__ f32x4v run(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<false> {
+  static __device__ __forceinline__ f32x4v run(f16x8 a, f16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+constexpr int kW3Threads = 512;
+
+template <int PT, int WAVES_M> struct W3Geom {
+  static constexpr int WAVES_N = 8 / WAVES_M;
+  static constexpr int BN = 64 * WAVES_N;
+  static constexpr int WMr = 16 * PT;               // pixel rows of a wave
+  static constexpr int BM = WMr * WAVES_M;
+  static constexpr int QA = (BM + 3 + 63) / 64;     // DMA passes (64 rows each) of an image of BM + 2 pixels + a zero row
+  static constexpr int ARows = 64 * QA;
+  static constexpr int ZeroRow = BM + 2;            // never a source pixel: only ever zero-filled
+  static constexpr int PB = BN / 64;                // weight pieces per wave and tap
+  static constexpr int ABytes = ARows * 128;
+  static constexpr int BBytes = BN * 128;
+  static constexpr int RingBytes = 2 * ABytes + 2 * BBytes;
+};
+
+// swizzle of the weight image: the 16 lanes of a ds_read_b128 group read rows {R..R+3, R+48..R+51} at chunk q and
+// {R+16..R+19, R+32..R+35} at chunk q + 1 (the channel permutation above), which (row >> 1) & 7 would fold onto each other
+__device__ __forceinline__ int w3_swz_b(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
+template <bool BF16, int PT, int WAVES_M>
+__global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
+  typedef typename Elem<BF16>::V8 V8;
+  typedef typename Elem<BF16>::T T;
+  typedef W3Geom<PT, WAVES_M> G_;
+  constexpr int WAVES_N = G_::WAVES_N, BN = G_::BN, BM = G_::BM, WMr = G_::WMr, QA = G_::QA, PB = G_::PB;
+  constexpr int PH = PT / 2;                 // pixel tiles per half
+  constexpr int kRowB = 128;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_w3[];
+  char* As = smem_w3;                        // [2][ARows][128 B]
+  char* Bs = smem_w3 + 2 * G_::ABytes;       // [2][BN][128 B]
+  float* aff = reinterpret_cast<float*>(smem_w3 + G_::RingBytes);   // [s1 | t1 | s2 | t2] x Cout
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+
+  const u32x4_t rsA = make_rsrc_h(p.x, x_bytes);
+  const u32x4_t rsB = make_rsrc_h(p.w, w_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_w3;
+  const int NHW = p.N * p.H * p.W;
+  const int nwg = (int)gridDim.x;
+
+  // virtual tile -> tile: each XCD (workgroups with equal id mod 8) walks a contiguous run of tiles, tile_n fastest
+  const unsigned q8 = (unsigned)ntiles >> 3, rem8 = (unsigned)ntiles & 7u;
+  auto tile_of = [&](int vt) -> unsigned {
+    const unsigned x = (unsigned)vt & 7u;
+    return (x < rem8 ? x * (q8 + 1) : rem8 * (q8 + 1) + (x - rem8) * q8) + ((unsigned)vt >> 3);
+  };
+
+  // ---- staging lanes: a DMA instruction of a wave fills 8 LDS rows (lane / 8) x 8 chunks (lane % 8) ----
+  const int srow = 8 * wave + (lane >> 3);               // 0..63, + 64 per pass
+  const int pc = lane & 7;
+  const int lcA = pc ^ ((srow >> 1) & 7);                // invariant under row + 64 q
+  const int lcB = pc ^ w3_swz_b(srow);                   // likewise
+  int a_s[QA];                                           // source pixel of LDS row (srow + 64 q) for kh = 1, NEXT group's tile
+  unsigned a_off[QA];
+  unsigned b_cur[PB], b_nxt[PB];                         // weight row offsets: current K tile's tile / next group's tile
+  auto issue_tile_setup = [&](int vt) {
+    const bool live = vt < ntiles;
+    const unsigned tile = live ? tile_of(vt) : 0u;
+    const int tn = (int)(tile % (unsigned)p.tiles_n);
+    const int m0i = (int)(tile / (unsigned)p.tiles_n) * BM;
+    const int n0i = tn * BN;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int row = srow + 64 * q;
+      a_s[q] = (live && row < BM + 2) ? m0i - 1 + row : (int)0x40000000;     // beyond the image for every kh: zero
+      a_off[q] = (unsigned)((((int64_t)(m0i - 1 + row)) * p.x_cs + p.x_co + lcA * 8) * 2);
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int co = n0i + srow + 64 * q;
+      b_nxt[q] = (live && co < p.Cout) ? (unsigned)(((int64_t)co * p.Kw + lcB * 8) * 2) : kOOB;
+    }
+  };
+
+  // ---- fragment read addresses (tile-independent) ----
+  unsigned a_rd[3][2];                       // pixel fragments: tap kw, k step; + pt * 2048 per pixel tile
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int row = wm * WMr + fr + kw;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a_rd[kw][ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ ((row >> 1) & 7)) << 4));
+  }
+  const unsigned zero_rd = (unsigned)(G_::ZeroRow * kRowB);
+  unsigned w_rd[2];                          // weight fragments: k step; + t * 512 per channel tile
+  {
+    const int row = wn * 64 + 16 * (fr >> 2) + (fr & 3);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) w_rd[ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ w3_swz_b(row)) << 4));
+  }
+
+  const int nchunks = p.Cin >> 6;
+  const int G = 3 * nchunks;                 // (chunk, kh) groups per tile
+
+  // ---- the layer's affine into LDS, once per workgroup ----
+  const bool has2 = p.s2 != nullptr;
+  for (int c = tid; c < p.Cout; c += kW3Threads) {
+    aff[c] = p.s1[c];
+    aff[p.Cout + c] = p.t1[c];
+    aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
+    aff[3 * p.Cout + c] = has2 ? p.t2[c] : 0.f;
+  }
+
+#define YV4_W3_ISSUE_B(SLOT, BOFF, KB)                                                              \
+  {                                                                                                 \
+    const unsigned lb_ = lds_base + (unsigned)(2 * G_::ABytes + (SLOT) * G_::BBytes + 8 * wave * kRowB); \
+    _Pragma("unroll") for (int q = 0; q < PB; ++q)                                                  \
+        lds_dma16_h(rsB, lb_ + 64 * q * kRowB, BOFF[q], (KB));   /* (the range check sees voffset only) */ \
+  }
+#define YV4_W3_ISSUE_A(ABUF, Q0, Q1, KH, C0)                                                        \
+  {                                                                                                 \
+    const unsigned la_ = lds_base + (unsigned)((ABUF) * G_::ABytes + 8 * wave * kRowB);              \
+    const int ds_ = ((KH) - 1) * p.W;                                                               \
+    const unsigned step_ = (unsigned)(((int64_t)ds_ * p.x_cs + (C0)) * 2);                          \
+    _Pragma("unroll") for (int q = (Q0); q < (Q1); ++q) {                                           \
+      const bool ok_ = (unsigned)(a_s[q] + ds_) < (unsigned)NHW;                                    \
+      lds_dma16_h(rsA, la_ + 64 * q * kRowB, ok_ ? a_off[q] + step_ : kOOB, 0u);                     \
+    }                                                                                               \
+  }
+
+  // ---- prologue: group 0's image and tap 0's weights of the first tile; the issue side then points at group 1 ----
+  int n_vt = (int)blockIdx.x;                // tile of the NEXT group (issue side)
+  issue_tile_setup(n_vt);
+#pragma unroll
+  for (int q = 0; q < PB; ++q) b_cur[q] = b_nxt[q];
+  YV4_W3_ISSUE_B(0, b_cur, 0u);
+  YV4_W3_ISSUE_A(0, 0, QA, 0, 0);
+  int n_g = 1, n_kh = 1, n_c0 = 0;           // G >= 3: group 1 is in the same tile
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();              // (also publishes the affine)
+
+  unsigned T_ = 0u, GG = 0u;                 // global K-tile / group counters: weight slot T_ & 1, image GG & 1
+  for (int vt = (int)blockIdx.x; vt < ntiles; vt += nwg) {
+    const unsigned tile = tile_of(vt);
+    const int tile_n = (int)(tile % (unsigned)p.tiles_n);
+    const int tile_m = (int)(tile / (unsigned)p.tiles_n);
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    unsigned mask9[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int m = m0 + wm * WMr + 16 * pt + fr;
+      unsigned mk = 0u;
+      if (m < p.M) {
+        const int hw = p.H * p.W;
+        const int n = fd_div(m, p.fd_hw);
+        const int rm = m - n * hw;
+        const int ho = fd_div(rm, p.fd_wo);
+        const int wo = rm - ho * p.W;
+        mk = (unsigned)tap_mask(ho - 1, wo - 1, 3, 3, p.H, p.W);
+      }
+      mask9[pt] = mk;
+    }
+    f32x4v acc[PT][4];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[pt][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    int c0 = 0, kh = 0;
+    for (int g = 0; g < G; ++g) {
+      const unsigned ab = GG & 1u;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const unsigned slot = T_ & 1u;
+        const char* as_ = As + ab * G_::ABytes;
+        const char* bs_ = Bs + slot * G_::BBytes;
+        const int tapbit = 3 * kh + kw;
+        // ---- DMA of the next K tile's weights (other slot) and, at kw == 0, of the next group's image (other image)
+        if (kw < 2) {
+          YV4_W3_ISSUE_B(slot ^ 1u, b_cur, (unsigned)((((kh * 3 + kw + 1) * p.Cin) + c0) * 2));
+        } else {
+          YV4_W3_ISSUE_B(slot ^ 1u, b_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 2));
+        }
+        V8 wf[4][2], pf[PH][2];
+        // ---- phase 1: weights of channel tiles 0, 1, pixels of the first half
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+          const bool ok = (mask9[i] >> tapbit) & 1u;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)(i * 2048) : zero_rd));
+        }
+        if (kw == 0) YV4_W3_ISSUE_A(ab ^ 1u, 0, (QA + 1) / 2, n_kh, n_c0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i) acc[i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[i][t]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 2: weights of channel tiles 2, 3
+#pragma unroll
+        for (int t = 2; t < 4; ++t)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
+        if (kw == 0) YV4_W3_ISSUE_A(ab ^ 1u, (QA + 1) / 2, QA, n_kh, n_c0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 2; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i) acc[i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[i][t]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 3: pixels of the second half
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+          const bool ok = (mask9[PH + i] >> tapbit) & 1u;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)((PH + i) * 2048) : zero_rd));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 2; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i) acc[PH + i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[PH + i][t]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 4: the last quadrant (both operand sets are in registers)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i) acc[PH + i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[PH + i][t]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's DMAs of the next K tile have landed (the next group's image, issued last at kw == 0, may still fly)
+        if (kw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        T_ += 1u;
+      }
+      // ---- group advance: current <- next; the issue side moves on by one group (possibly into the next tile) ----
+      GG += 1u;
+      kh = n_kh; c0 = n_c0;
+#pragma unroll
+      for (int q = 0; q < PB; ++q) b_cur[q] = b_nxt[q];
+      n_g += 1;
+      n_kh += 1;
+      if (n_kh == 3) { n_kh = 0; n_c0 += kHBK; }
+      if (n_g == G) {
+        n_g = 0; n_c0 = 0; n_kh = 0;
+        n_vt += nwg;
+        issue_tile_setup(n_vt);
+      }
+    }
+    // (kh, c0 now describe group 0 of this workgroup's next tile: reset by the assignments at the top of the loop)
+
+    // ---- epilogue: lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + fr, channels n0 + wn 64 + 16 fq .. + 15 ----
+    const int cl = n0 + wn * 64 + 16 * fq;
+    const bool c_ok = cl + 15 < p.Cout;
+    const int ca = c_ok ? cl : 0;
+    float s1[16], t1[16];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(aff + ca + u), b = *reinterpret_cast<const float4*>(aff + p.Cout + ca + u);
+      s1[u] = a.x; s1[u + 1] = a.y; s1[u + 2] = a.z; s1[u + 3] = a.w;
+      t1[u] = b.x; t1[u + 1] = b.y; t1[u + 2] = b.z; t1[u + 3] = b.w;
+    }
+    float st[32];                            // training forward: [sum | sum of squares] of the lane's 16 channels (stored values)
+#pragma unroll
+    for (int u = 0; u < 32; ++u) st[u] = 0.f;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int m = m0 + wm * WMr + 16 * pt + fr;
+      const bool ok = c_ok && m < p.M;
+      float v[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * t + j] = __builtin_fmaf(acc[pt][t][j], s1[4 * t + j], t1[4 * t + j]);
+      {
+        float lo[8], hi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[e + 8]; }
+        act_row8(lo, p.act1, p.slope1);
+        act_row8(hi, p.act1, p.slope1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] = lo[e]; v[e + 8] = hi[e]; }
+      }
+      if (p.res && ok) {
+        const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.r_cs + p.r_co + cl;
+        const V8 r0 = *reinterpret_cast<const V8*>(rp), r1 = *reinterpret_cast<const V8*>(rp + 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] += (float)r0[e]; v[e + 8] += (float)r1[e]; }
+      }
+      if (has2) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = __builtin_fmaf(v[u], aff[2 * p.Cout + ca + u], aff[3 * p.Cout + ca + u]);
+        float lo[8], hi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[e + 8]; }
+        act_row8(lo, p.act2, p.slope2);
+        act_row8(hi, p.act2, p.slope2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] = lo[e]; v[e + 8] = hi[e]; }
+      }
+      if (ok) {
+        V8 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o0[e] = (T)v[e]; o1[e] = (T)v[e + 8]; }
+        T* yp = reinterpret_cast<T*>(p.y) + (int64_t)m * p.y_cs + p.y_co + cl;
+        *reinterpret_cast<V8*>(yp) = o0;
+        *reinterpret_cast<V8*>(yp + 8) = o1;
+        if (p.stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float a = (float)o0[e], b = (float)o1[e];
+            st[e] += a; st[16 + e] += a * a;
+            st[8 + e] += b; st[24 + e] += b * b;
+          }
+        }
+      }
+    }
+    if (p.stats) {
+      // BatchNorm statistics of the tile (identity epilogue): the 16 lanes fr of a channel group fq hold partial sums of
+      // the same 32 quantities over different pixels -- a halving butterfly over lane bits 0..3 (16 + 8 + 4 + 2 exchanges)
+      // leaves two finished sums per lane, added to the replica of this wave's row slab (yv4_conv_fwd_stats)
+      int idx = 0;
+#pragma unroll
+      for (int sft = 0; sft < 4; ++sft) {
+        const int half = 16 >> sft;
+        const bool bit = (lane >> sft) & 1;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+          const float send = bit ? st[i] : st[i + half];
+          const float recv = __shfl_xor(send, 1 << sft);
+          st[i] = (bit ? st[i + half] : st[i]) + recv;
+        }
+        idx += bit ? half : 0;
+      }
+      if (c_ok) {
+        double* rep = p.stats + (size_t)((tile_m * WAVES_M + wm) & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int id = idx + k;            // 0..15: sums, 16..31: sums of squares, of channel cl + (id & 15)
+          atomicAdd(&rep[(id >> 4) * p.Cout + cl + (id & 15)], (double)st[k]);
+        }
+      }
+    }
+    c0 = 0; kh = 0;
+  }
+#undef YV4_W3_ISSUE_A
+#undef YV4_W3_ISSUE_B
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-filling tail DMAs must land before the LDS is released
+}
+
+// Is this layer in the kernel's domain?  3x3 / stride 1 / pad 1, 64-channel chunks of input, Cout in whole 16-channel
+// groups with 16-byte aligned output / residual views, 16-bit output, the layer's affine beside the ring in LDS.
+bool conv3x3_wide_h16_applies(const ConvArgsH& a) {
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && (a.Cin & 63) == 0 &&
+         a.Kw == 9 * a.Cin && !a.ys_on && !a.out_f32 && a.Cout >= 64 && (a.Cout & 15) == 0 &&
+         ((a.y_cs | a.y_co) & 7) == 0 && (a.res == nullptr || ((a.r_cs | a.r_co) & 7) == 0) && a.Cout <= 1024;
+}
+
+static int g_w3_cus = 0;
+static int w3_cus() {
+  if (g_w3_cus == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    g_w3_cus = cus;
+  }
+  return g_w3_cus;
+}
+
+template <bool BF16, int PT, int WAVES_M>
+static int launch_w3(const ConvArgsH& a, hipStream_t stream) {
+  typedef W3Geom<PT, WAVES_M> G_;
+  ConvArgsH p = a;
+  const int tiles_m = (p.M + G_::BM - 1) / G_::BM;
+  p.tiles_n = (p.Cout + G_::BN - 1) / G_::BN;
+  p.fd_hw = make_fastdiv((unsigned)(p.H * p.W));
+  p.fd_wo = make_fastdiv((unsigned)p.W);
+  const long long tiles = (long long)tiles_m * p.tiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffLL) {
+    set_error("conv3x3 wide h16: grid of %lld tiles out of range", tiles);
+    return YV4_E_INVALID;
+  }
+  const size_t lds = (size_t)G_::RingBytes + (size_t)4 * p.Cout * 4;
+  if (lds > 160 * 1024) {
+    set_error("conv3x3 wide h16: %zu bytes of LDS for this tile shape and Cout", lds);
+    return YV4_E_UNSUPPORTED;
+  }
+  const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 2, wb = (long long)p.Cout * p.Kw * 2;
+  auto kern = conv3x3_wide_h16_kernel<BF16, PT, WAVES_M>;
+  static LdsAttrOnce once;
+  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024, "conv3x3_wide_h16")) return rc;
+  const int cus = w3_cus();
+  const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kW3Threads), lds, stream, p, (unsigned)xb, (unsigned)wb, (int)tiles);
+  YV4_CHECK_LAUNCH("conv3x3_wide_h16");
+  return YV4_OK;
+}
+
+// Tile shape per layer: (pixel tiles per wave, waves along M) in {(8,2): 256 x 256, (6,2): 192 x 256, (4,2): 128 x 256,
+// (6,4): 384 x 128, (4,4): 256 x 128}.  Cost model = rounds of one workgroup per CU x the tile's work, with the
+// smaller wave tiles charged for their extra fragment reads per MFMA (measured ratios, tools/conv_bench.py).
+// Returns an index into the table, or -1 when no shape fits (LDS) -- `shape` >= 0 forces one (measurement / tests).
+struct W3Shape { int pt, wm; };
+static const W3Shape kW3Shapes[5] = {{8, 2}, {6, 2}, {4, 2}, {6, 4}, {4, 4}};
+static size_t w3_lds(int pt, int wmv, int Cout) {
+  const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
+  const int arows = 64 * ((bm + 3 + 63) / 64);
+  return (size_t)2 * arows * 128 + (size_t)2 * bn * 128 + (size_t)16 * Cout;
+}
+int conv3x3_wide_h16_pick(const ConvArgsH& a, double* rounds_eff) {
+  const int cus = w3_cus();
+  int best = -1;
+  double best_cost = 0.0;
+  for (int i = 0; i < 5; ++i) {
+    const int pt = kW3Shapes[i].pt, wmv = kW3Shapes[i].wm;
+    const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
+    if (w3_lds(pt, wmv, a.Cout) > 160 * 1024) continue;
+    if (bn > ((a.Cout + 127) / 128) * 128) continue;                  // a 256-wide tile on a 128-channel layer is half empty
+    const long long tiles = ((long long)a.M + bm - 1) / bm * ((a.Cout + bn - 1) / bn);
+    const long long rounds = (tiles + cus - 1) / cus;
+    const double eff = pt == 8 ? 1.0 : (pt == 6 ? 1.04 : 1.12);
+    const double cost = (double)rounds * bm * bn * eff;
+    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+  }
+  if (rounds_eff && best >= 0) *rounds_eff = best_cost / ((double)a.M * a.Cout / cus);
+  return best;
+}
+
+int conv3x3_wide_h16_launch(const ConvArgsH& a, bool bf16, int shape, hipStream_t s) {
+  if (shape < 0) shape = conv3x3_wide_h16_pick(a, nullptr);
+  if (shape < 0 || shape >= 5 || w3_lds(kW3Shapes[shape].pt, kW3Shapes[shape].wm, a.Cout) > 160 * 1024) {
+    set_error("conv3x3 wide h16: no tile shape of this layer fits the LDS");
+    return YV4_E_UNSUPPORTED;
+  }
+#define YV4_W3_CASE(I, PT_, WM_) case I: return bf16 ? launch_w3<true, PT_, WM_>(a, s) : launch_w3<false, PT_, WM_>(a, s);
+  switch (shape) {
+    YV4_W3_CASE(0, 8, 2)
+    YV4_W3_CASE(1, 6, 2)
+    YV4_W3_CASE(2, 4, 2)
+    YV4_W3_CASE(3, 6, 4)
+    YV4_W3_CASE(4, 4, 4)
+    default: break;
+  }
+#undef YV4_W3_CASE
+  return YV4_E_INVALID;
+}
+
+}  // namespace yv4

@@ -379,6 +379,28 @@ static bool prefer_pp3(const ConvArgsH& a) {
   return tiles >= 150 && tiles * 100 >= rounds * cus * 60;
 }
 
+// conv3x3_wide_h16.hip
+bool conv3x3_wide_h16_applies(const ConvArgsH& a);
+int conv3x3_wide_h16_pick(const ConvArgsH& a, double* rounds_eff);
+int conv3x3_wide_h16_launch(const ConvArgsH& a, bool bf16, int shape, hipStream_t s);
+
+// The wide-tile 3x3 kernel takes the layers in its domain with >= 128 input channels and at least YV4_W3_MINOUT outputs
+// per CU when one of its tile shapes fills the chip's rounds to within YV4_W3_MAXWASTE percent.  Measured per layer
+// against the ping-pong kernel (tools/conv_bench.py --dtype bf16 --tiles 4,5, one box, batch 32 / 64):
+// 128->128 @76 71 -> 60 / 133 -> 112 us, 256->256 @38 71 -> 52 / 110 -> 97, 128->256 @76 133 -> 116 / 261 -> 211,
+// 256->512 @38 109 -> 98 / 213 -> 182, 512->1024 @19 121 -> 93 / 195 -> 179, 512->512 @19 61 -> 64 (23 104 outputs per CU:
+// stays on the ping-pong kernel) / 120 -> 92.  YV4_W3=0 (measurement build) switches it off, YV4_W3_SHAPE forces a shape.
+static bool prefer_w3(const ConvArgsH& a) {
+  static const int mode = YV4_ENV_INT("YV4_W3", 1);
+  static const int waste = YV4_ENV_INT("YV4_W3_MAXWASTE", 25);
+  static const int min_out = YV4_ENV_INT("YV4_W3_MINOUT", 32768);
+  if (!mode || !conv3x3_wide_h16_applies(a) || a.Cin < 128) return false;
+  if ((long long)a.M * a.Cout < 256LL * min_out) return false;
+  double eff = 0.0;
+  if (conv3x3_wide_h16_pick(a, &eff) < 0) return false;
+  return eff * 100.0 <= 100.0 + waste;
+}
+
 // conv1x1_ws_h16.hip
 bool conv1x1_ws_applies(const ConvArgsH& a);
 int conv1x1_ws_launch(const ConvArgsH& a, bool bf16, hipStream_t s);
@@ -432,6 +454,7 @@ extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
     a.ksplit = 0; a.ws = nullptr;
     a.K = a.Kw = d->KH * d->KW * d->Cin; a.res = nullptr; a.out_f32 = (d->Cout & 1) ? 1 : 0;   // (odd Cout: a pred map)
     a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = d->r_cstride; a.r_co = d->r_coff;
+    if (prefer_w3(a)) return YV4_HTILE_W3x3;
     if (prefer_pp3(a)) return YV4_HTILE_PP3x3;
     if (prefer_ws(a)) return YV4_HTILE_WS_1x1;
     a.N = d->N; a.stats = nullptr; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = d->r_cstride; a.r_co = d->r_coff;
@@ -487,6 +510,14 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   a.stats = stats;
   const bool general = (d->Cin % kHBK) != 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int w3_forced = (d->tile > 8 && (d->tile & 7) == YV4_HTILE_W3x3 && d->tile <= YV4_HTILE_W3x3_SHAPE(4)) ? (d->tile >> 3) - 1 : -1;
+  if (d->tile == YV4_HTILE_W3x3 || w3_forced >= 0)
+    YV4_REQUIRE(conv3x3_wide_h16_applies(a), "conv h16: the wide 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with Cin %% 64 == 0, "
+                "Cout %% 16 == 0 (64 .. 1024), 16-bit output, 8-aligned channel strides / offsets and no statistics");
+  if (d->tile == YV4_HTILE_W3x3 || w3_forced >= 0 || (d->tile == YV4_TILE_AUTO && prefer_w3(a))) {
+    static const int shape = YV4_ENV_INT("YV4_W3_SHAPE", -1);
+    return conv3x3_wide_h16_launch(a, dtype == YV4_BF16, w3_forced >= 0 ? w3_forced : shape, s);
+  }
   if (d->tile == YV4_HTILE_PP3x3)
     YV4_REQUIRE(conv3x3_pp_h16_applies(a), "conv h16: the ping-pong 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with "
                 "Cin %% 64 == 0, even Cout >= 64, 16-bit output and even channel strides / offsets");

@@ -190,6 +190,37 @@ def test_h16_pp3x3_kernel_epilogues(gpu_device, dtype, tile, act):
     _h16_conv(gpu_device, dtype, 30, 38, 38, 64, 128, 3, 1, 1, act, tile, residual=True, two_stage=True, y_off=8)   # 170 tiles
 
 
+W3_TILES = [5, 13, 21, 29, 37, 45]      # YV4_HTILE_W3x3 (shape chosen by the cost model) and YV4_HTILE_W3x3_SHAPE(0..4)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('tile', W3_TILES)
+@pytest.mark.parametrize('shape', [s for s in PP3_SHAPES if s[4] % 16 == 0] + [(33, 19, 19, 128, 512), (2, 76, 76, 128, 128)])
+def test_h16_wide3x3_kernel_shapes(gpu_device, dtype, tile, shape):
+    """conv3x3_wide_h16.hip (16x16x32 MFMAs, wave tiles of 16 PT pixels x 64 channels, five workgroup tile shapes): the
+    ping-pong kernel's shape list -- image borders inside a tile, maps narrower than a fragment group, one-row images,
+    ragged row / column tiles, workgroups that walk several tiles -- against float64."""
+    N, H, W, Cin, Cout = shape
+    _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=tile)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('tile', W3_TILES)
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+def test_h16_wide3x3_kernel_epilogues(gpu_device, dtype, tile, act):
+    _h16_conv(gpu_device, dtype, 2, 13, 13, 64, 80, 3, 1, 1, act, tile, residual=True, two_stage=True, x_off=8, y_off=16)
+    _h16_conv(gpu_device, dtype, 1, 20, 9, 128, 128, 3, 1, 1, act, tile, residual=True, x_off=16)
+    _h16_conv(gpu_device, dtype, 30, 38, 38, 64, 128, 3, 1, 1, act, tile, residual=True, two_stage=True, y_off=8)
+
+
+def test_h16_wide3x3_kernel_is_refused_outside_its_domain(gpu_device):
+    for shape in [(1, 8, 8, 64, 64, 1, 1, 0), (1, 8, 8, 64, 64, 3, 2, 1), (1, 8, 8, 32, 64, 3, 1, 1), (1, 8, 8, 64, 72, 3, 1, 1)]:
+        with pytest.raises(L.Yv4Error):
+            _h16_conv(gpu_device, torch.bfloat16, *shape, act=1, tile=5)
+    with pytest.raises(L.Yv4Error):
+        _h16_conv(gpu_device, torch.bfloat16, 1, 9, 11, 64, 64, 3, 1, 1, act=1, tile=5, out_f32=True, y_off=4)
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_pp3x3_matches_generic_bitwise(gpu_device, dtype):
     """Same K order (chunk-major, taps inside, four 16-deep MFMA steps per tap) and the same epilogue expressions on the
@@ -209,8 +240,6 @@ def test_h16_pp3x3_kernel_is_refused_outside_its_domain(gpu_device):
             _h16_conv(gpu_device, torch.bfloat16, *shape, act=1, tile=4)
     with pytest.raises(L.Yv4Error):                                      # fp32 output (pred maps) stays on the generic tiles
         _h16_conv(gpu_device, torch.bfloat16, 1, 9, 11, 64, 64, 3, 1, 1, act=1, tile=4, out_f32=True, y_off=4)
-    with pytest.raises(L.Yv4Error):                                      # id 5 (round 2's 256 x 64 form) no longer exists
-        _h16_conv(gpu_device, torch.bfloat16, 1, 8, 8, 64, 64, 3, 1, 1, act=1, tile=5)
 
 
 def test_h16_pp3x3_auto_choice(gpu_device):
@@ -222,7 +251,7 @@ def test_h16_pp3x3_auto_choice(gpu_device):
     d.KH = d.KW = 3
     d.stride, d.pad = 1, 1
     d.x_cstride, d.y_cstride, d.r_cstride = 256, 256, 256
-    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 4           # 362 tiles
+    assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 5           # 46 208 outputs per CU: the wide-tile kernel (round 4)
     d.N, d.H, d.W, d.Ho, d.Wo, d.Cin, d.Cout = 32, 19, 19, 19, 19, 512, 512
     d.x_cstride, d.y_cstride = 512, 512
     assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) == 4           # 184 tiles: one round at 72 %
@@ -232,6 +261,7 @@ def test_h16_pp3x3_auto_choice(gpu_device):
     d.x_cstride, d.y_cstride = 64, 64
     assert L.lib().yv4_conv_h16_pick_tile(C.byref(d)) != 4           # 64 input channels: the few-channel kernel's layer
     _h16_conv(gpu_device, torch.bfloat16, 32, 38, 38, 128, 128, 3, 1, 1, act=1, tile=0)     # auto -> persistent kernel
+    _h16_conv(gpu_device, torch.bfloat16, 32, 38, 38, 256, 256, 3, 1, 1, act=1, tile=0)     # auto -> wide-tile kernel
 
 
 WS_SHAPES = [
