@@ -600,9 +600,10 @@ def main():
         with open(args.layers, 'w') as f:
             json.dump(rows, f, indent=1)
 
-    # the timed batch's output is the real thing: image 0 (and 1) of the batch-N step must equal what a batch-2 plan
-    # computes for the same two images (per-image NMS, eval-mode BN) -- bit for bit in fp32, where every conv tile walks
-    # K in the same order; a wrong fast path (cached outputs, skipped images) cannot pass this
+    # the timed batch's output is the real thing: image 0 (and 1) of the batch-N step must equal, bit for bit, what a
+    # batch-2 plan computes for the same two images (per-image NMS, eval-mode BN, every conv tile walks K in the same
+    # order -- the wide-tile 3x3 kernel's 16x16x32 MFMAs included: tests/test_gpu_h16.py::test_wide3x3_matches_generic_bitwise)
+    # -- a wrong fast path (cached outputs, skipped images) cannot pass this
     torch.cuda.synchronize()
     check_failed = None
     if args.batch >= 2 and not args.no_output_check:
@@ -610,40 +611,16 @@ def main():
                             dtype={'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.dtype])
         small.run(img[:2])
         torch.cuda.synchronize()
-        if args.dtype == 'f32' or not getattr(plan, 'pred_views', None):
-            for n in range(2):
-                k = int(host_count[n])
-                if int(small.post['count'][n]) != k:
-                    check_failed = f'image {n}: batch-{args.batch} step kept {k} detections, batch-2 plan {int(small.post["count"][n])}'
-                elif not (torch.equal(small.post['dets'][n, :k].cpu(), host_dets[n, :k]) and
-                          torch.equal(small.post['labels'][n, :k].cpu().to(torch.int32), host_labels[n, :k])):
-                    check_failed = f'image {n} of the batch-{args.batch} step differs from the batch-2 plan'
-            output_check = f'images 0-1 of the timed batch-{args.batch} step == a batch-2 plan on the same images (bit-exact; ' \
-                           f'{int(host_count[0])} + {int(host_count[1])} detections)'
-        else:
-            # 16-bit operands: the batch-32 plan runs its large 3x3 layers on the wide-tile kernel (16x16x32 MFMAs), the
-            # batch-2 plan on the generic tiles (32x32x16) -- the two shapes group the K sum differently, so a few outputs
-            # per layer round the other way; the pred maps of images 0-1 must agree to that noise (mean of
-            # |diff| / (1 + |logit|): measured 2e-3 fp16 / 1.5e-2 bf16 over ~110 layers; a skipped slice, a stale
-            # buffer or a cached output is orders of magnitude away) and the detection counts to 5 %
-            mean_b = 1e-2 if args.dtype == 'f16' else 6e-2
-            worst = 0.0
-            for va, vb in zip(plan.pred_views, small.pred_views):
-                a = va.buf.tensor.view(va.N, va.H, va.W, va.C)[:2].float()
-                b = vb.buf.tensor.view(vb.N, vb.H, vb.W, vb.C)[:2].float()
-                e = (a - b).abs() / (1 + b.abs())
-                if not bool(torch.isfinite(e).all()):
-                    check_failed = 'non-finite pred map'
-                worst = max(worst, float(e.mean()))
-            if worst > mean_b:
-                check_failed = f'pred maps of images 0-1 differ from the batch-2 plan: mean {worst:.2e} > {mean_b:g}'
-            for n in range(2):
-                k, k2 = int(host_count[n]), int(small.post['count'][n])
-                if abs(k - k2) > max(3, 0.05 * max(k, k2)):
-                    check_failed = f'image {n}: batch-{args.batch} step kept {k} detections, batch-2 plan {k2}'
-            output_check = f'pred maps of images 0-1 of the timed batch-{args.batch} step vs a batch-2 plan (other conv tiles): mean ' \
-                           f'{worst:.2e} of 1 + |logit| (bound {mean_b:g}); {int(host_count[0])} + {int(host_count[1])} detections'
+        for n in range(2):
+            k = int(host_count[n])
+            if int(small.post['count'][n]) != k:
+                check_failed = f'image {n}: batch-{args.batch} step kept {k} detections, batch-2 plan {int(small.post["count"][n])}'
+            elif not (torch.equal(small.post['dets'][n, :k].cpu(), host_dets[n, :k]) and
+                      torch.equal(small.post['labels'][n, :k].cpu().to(torch.int32), host_labels[n, :k])):
+                check_failed = f'image {n} of the batch-{args.batch} step differs from the batch-2 plan'
         del small
+        output_check = f'images 0-1 of the timed batch-{args.batch} step == a batch-2 plan on the same images (bit-exact; ' \
+                       f'{int(host_count[0])} + {int(host_count[1])} detections)'
         if check_failed:
             output_check = 'FAILED: ' + check_failed
     else:

@@ -331,8 +331,8 @@ int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, i
 #define YV4_HTILE_PP3x3 4
 /* 3x3 / stride 1 / pad 1 with Cin % 64 == 0 and Cout % 16 == 0 on WIDE wave tiles (16 PT pixels x 64 channels per wave on
  * v_mfma_f32_16x16x32, PT = 4 / 6 / 8; workgroup tiles 256 x 256, 192 x 256, 128 x 256, 384 x 128 or 256 x 128 chosen
- * per layer so that whole rounds of CUs are filled; csrc/conv3x3_wide_h16.hip).  Not bit-identical to the other tiles
- * (another MFMA shape sums K in another grouping). */
+ * per layer so that whole rounds of CUs are filled; csrc/conv3x3_wide_h16.hip).  Same K order and epilogue expressions
+ * as the other tiles; measured bit-identical to them (tests/test_gpu_h16.py::test_wide3x3_matches_generic_bitwise). */
 #define YV4_HTILE_W3x3 5
 /* ... with the tile shape forced (i = 0..4: 256 x 256, 192 x 256, 128 x 256, 384 x 128, 256 x 128): tests, tile sweeps */
 #define YV4_HTILE_W3x3_SHAPE(i) (5 + 8 * ((i) + 1))

@@ -266,9 +266,8 @@ def test_cfg3_yolov4s_416_fp16_b256_vs_oracle_emulation(v4s):
 
 
 def test_cfg3_batch_independence_and_nms_invariants(v4s):
-    """An image's detections do not depend on its position in the batch of 256 (bit-identical), and a batch-2 plan --
-    which runs the large 3x3 layers on the generic tiles where the batch-256 plan takes the wide-tile kernel (another
-    MFMA shape, another grouping of the K sum: round 4) -- agrees on them to the 16-bit rounding noise."""
+    """An image's detections do not depend on its position in the batch of 256 nor on the batch size (the batch-2 plan
+    may use other conv tiles; every tile walks K in the same order, so the result is bit-identical)."""
     det, img = v4s
     dev = img.device
     cfg = det.bbox_head.test_cfg
@@ -285,13 +284,10 @@ def test_cfg3_batch_independence_and_nms_invariants(v4s):
     small.run(img[[7, 200]])
     torch.cuda.synchronize()
     for j, n in enumerate((7, 200)):
-        k, k2 = int(c0[n]), int(small.post['count'][j])
-        assert abs(k - k2) <= max(3, 0.05 * k), (k, k2)
-        a, la = d0[n, :k].cpu().numpy(), l0[n, :k].cpu().numpy()
-        b, lb = small.post['dets'][j, :k2].cpu().numpy(), small.post['labels'][j, :k2].cpu().numpy()
-        matched = sum(bool(((lb == la[i]) & (np.abs(b[:, :4] - a[i, :4]).max(1) <= 1.0) & (np.abs(b[:, 4] - a[i, 4]) <= 2e-2)).any())
-                      for i in range(k))
-        assert matched >= 0.9 * k, (matched, k)      # near-ties at the max_per_img cut may swap in or out
+        k = int(c0[n])
+        assert int(small.post['count'][j]) == k
+        assert torch.equal(small.post['labels'][j, :k], l0[n, :k])
+        assert torch.equal(small.post['dets'][j, :k], d0[n, :k])
     # NMS invariants on every image of the batch
     dets, labels, cnt = d0.cpu().numpy(), l0.cpu().numpy(), c0.cpu().numpy()
     for n in range(0, 256, 17):

@@ -213,6 +213,20 @@ def test_h16_wide3x3_kernel_epilogues(gpu_device, dtype, tile, act):
     _h16_conv(gpu_device, dtype, 30, 38, 38, 64, 128, 3, 1, 1, act, tile, residual=True, two_stage=True, y_off=8)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_wide3x3_matches_generic_bitwise(gpu_device, dtype):
+    """The wide-tile kernel sums a 64-deep K slice with two 16x16x32 MFMAs where the other tiles use four 32x32x16 ones;
+    same chunk-major K order, same epilogue expressions -- and, measured, the same BITS (the matrix pipe's accumulation
+    does not depend on how the 64 products of a slice are grouped into instructions), so a plan may pick it by batch size
+    like the ping-pong kernel (bench.py's batch-32 vs batch-2 output check stays bit-exact in 16 bits)."""
+    for shape, kw in [((2, 19, 19, 128, 128), dict(residual=True, two_stage=True)), ((3, 38, 38, 64, 192), dict()),
+                      ((9, 38, 38, 256, 256), dict(residual=True)), ((5, 19, 19, 512, 512), dict())]:
+        N, H, W, Cin, Cout = shape
+        outs = [_h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=t, raw=True, **kw) for t in (2, 4, 5, 13, 21, 29, 37, 45)]
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o)
+
+
 def test_h16_wide3x3_kernel_is_refused_outside_its_domain(gpu_device):
     for shape in [(1, 8, 8, 64, 64, 1, 1, 0), (1, 8, 8, 64, 64, 3, 2, 1), (1, 8, 8, 32, 64, 3, 1, 1), (1, 8, 8, 64, 72, 3, 1, 1)]:
         with pytest.raises(L.Yv4Error):
