@@ -139,7 +139,7 @@ def tile_of_kernel(name):
         return f'h16_{m.group(1)}x{m.group(2)}'
     for pat, tile in (('conv1x1_ws_f32_kernel', 'ws_1x1'), ('conv1x1_ws_kernel', 'h16_ws_1x1'), ('conv3x3_small_kernel', 'h16_s3x3'),
                       ('stem_down', 'stem_down'), ('conv_stem3x3_kernel', 'stem3x3'), ('conv3x3_pp_h16_kernel', 'h16_pp3x3'),
-                      ('conv3x3_wide_h16_kernel', 'h16_w3x3')):
+                      ('conv3x3_wide_h16_kernel', 'h16_w3x3'), ('conv_wide_h16_kernel', 'h16_wide')):
         if re.search(pat, name):
             return tile
     return None

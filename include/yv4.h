@@ -336,6 +336,12 @@ int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, i
 #define YV4_HTILE_W3x3 5
 /* ... with the tile shape forced (i = 0..4: 256 x 256, 192 x 256, 128 x 256, 384 x 128, 256 x 128): tests, tile sweeps */
 #define YV4_HTILE_W3x3_SHAPE(i) (5 + 8 * ((i) + 1))
+/* The same wave tiles as a general implicit GEMM (any kernel size / stride / padding with Cin % 64 == 0, Cout % 16 == 0,
+ * 16-bit output; a K tile = one (64-channel chunk, tap) gathered with the tap's offset): the stride-2 3x3 layers, the deep
+ * / wide 1x1 layers, the scattered classes of stride-2 data gradients (csrc/conv_wide_h16.hip).  Bit-identical to the
+ * generic tiles.  YV4_HTILE_WIDE_SHAPE(i), i = 0..4, forces a workgroup tile shape as above. */
+#define YV4_HTILE_WIDE 8
+#define YV4_HTILE_WIDE_SHAPE(i) (8 + 8 * ((i) + 1))
 /* 1x1 / stride 1, Cin <= 256, even Cout >= 16 with a 16-bit output (residual allowed) or any Cout >= 16 with an fp32
  * output (no residual) (conv1x1_ws_h16.hip): one persistent 8-wave workgroup per CU, the weight slab resident in LDS,
  * wave-private rings of 32-pixel strips */

@@ -401,6 +401,29 @@ static bool prefer_w3(const ConvArgsH& a) {
   return eff * 100.0 <= 100.0 + waste;
 }
 
+// conv_wide_h16.hip
+bool conv_wide_h16_applies(const ConvArgsH& a);
+int conv_wide_h16_pick(const ConvArgsH& a, double* rounds_eff);
+int conv_wide_h16_launch(const ConvArgsH& a, bool bf16, int shape, hipStream_t s);
+
+// The general wide-tile kernel takes what the 3x3 / stride-1 form and the weight-stationary 1x1 kernel leave: stride-2
+// 3x3 layers and 1x1 layers with >= YV4_WIDE_MINCIN input channels, when the layer has >= YV4_WIDE_MINOUT outputs per CU
+// and a tile shape fills the rounds to within YV4_WIDE_MAXWASTE percent (YV4_WIDE=0 switches it off).
+static bool prefer_wide(const ConvArgsH& a) {
+  static const int mode = YV4_ENV_INT("YV4_WIDE", 1);
+  static const int waste = YV4_ENV_INT("YV4_WIDE_MAXWASTE", 25);
+  static const int min_out = YV4_ENV_INT("YV4_WIDE_MINOUT", 32768);
+  static const int min_cin = YV4_ENV_INT("YV4_WIDE_MINCIN", 256);
+  if (!mode || !conv_wide_h16_applies(a)) return false;
+  const bool s2 = a.KH == 3 && a.KW == 3 && a.stride == 2 && a.Cin >= 64;
+  const bool pw = a.KH == 1 && a.KW == 1 && a.Cin >= min_cin;
+  if (!(s2 || pw || a.ys_on)) return false;
+  if ((long long)a.M * a.Cout < 256LL * min_out || a.K < 256) return false;
+  double eff = 0.0;
+  if (conv_wide_h16_pick(a, &eff) < 0) return false;
+  return eff * 100.0 <= 100.0 + waste;
+}
+
 // conv1x1_ws_h16.hip
 bool conv1x1_ws_applies(const ConvArgsH& a);
 int conv1x1_ws_launch(const ConvArgsH& a, bool bf16, hipStream_t s);
@@ -456,6 +479,8 @@ extern "C" int yv4_conv_h16_pick_tile(const yv4_conv_desc* d) {
     a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = d->r_cstride; a.r_co = d->r_coff;
     if (prefer_w3(a)) return YV4_HTILE_W3x3;
     if (prefer_pp3(a)) return YV4_HTILE_PP3x3;
+    a.K = a.Kw;
+    if (prefer_wide(a)) return YV4_HTILE_WIDE;
     if (prefer_ws(a)) return YV4_HTILE_WS_1x1;
     a.N = d->N; a.stats = nullptr; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = d->r_cstride; a.r_co = d->r_coff;
     if (prefer_s3(a)) return YV4_HTILE_S3x3;
@@ -517,6 +542,14 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   if (d->tile == YV4_HTILE_W3x3 || w3_forced >= 0 || (d->tile == YV4_TILE_AUTO && prefer_w3(a))) {
     static const int shape = YV4_ENV_INT("YV4_W3_SHAPE", -1);
     return conv3x3_wide_h16_launch(a, dtype == YV4_BF16, w3_forced >= 0 ? w3_forced : shape, s);
+  }
+  const int wide_forced = (d->tile >= YV4_HTILE_WIDE_SHAPE(0) && (d->tile & 7) == 0 && d->tile <= YV4_HTILE_WIDE_SHAPE(4)) ? (d->tile >> 3) - 2 : -1;
+  if (d->tile == YV4_HTILE_WIDE || wide_forced >= 0)
+    YV4_REQUIRE(conv_wide_h16_applies(a), "conv h16: the wide general tile needs Cin %% 64 == 0, Cout %% 16 == 0 (64 .. 2048), 16-bit "
+                "output and 8-aligned channel strides / offsets");
+  if (d->tile == YV4_HTILE_WIDE || wide_forced >= 0 || (d->tile == YV4_TILE_AUTO && !prefer_pp3(a) && prefer_wide(a))) {
+    static const int shape = YV4_ENV_INT("YV4_WIDE_SHAPE", -1);
+    return conv_wide_h16_launch(a, dtype == YV4_BF16, wide_forced >= 0 ? wide_forced : shape, s);
   }
   if (d->tile == YV4_HTILE_PP3x3)
     YV4_REQUIRE(conv3x3_pp_h16_applies(a), "conv h16: the ping-pong 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with "
