@@ -765,7 +765,12 @@ extern "C" int yv4_conv_scatter_fwd_h16(const yv4_conv_desc* d, int dtype, const
   a.ksplit = 0; a.ks_slices = 0; a.ws_cs = 0; a.ws = nullptr;
   a.ys_on = 1; a.ys_H = Hy; a.ys_W = Wy; a.ys_sh = sh; a.ys_sw = sw; a.ys_oh = oh; a.ys_ow = ow;
   const bool general = (d->Cin % kHBK) != 0;
-  const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // the classes of the wide stride-2 layers' data gradients: the general wide-tile kernel (same bits as the generic tiles)
+  if (d->tile == YV4_HTILE_WIDE || (d->tile == YV4_TILE_AUTO && prefer_wide(a))) {
+    YV4_REQUIRE(conv_wide_h16_applies(a), "conv scatter h16: the wide tile needs Cin %% 64 == 0, Cout %% 16 == 0 and 8-aligned views");
+    return conv_wide_h16_launch(a, dtype == YV4_BF16, -1, s);
+  }
+  const int tile = d->tile == YV4_TILE_AUTO ? pick_tile_h16(M, d->Cout, K) : d->tile;
   return dtype == YV4_BF16 ? dispatch_h16<true>(a, tile, general, s) : dispatch_h16<false>(a, tile, general, s);
 }

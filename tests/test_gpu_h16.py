@@ -227,6 +227,56 @@ def test_wide3x3_matches_generic_bitwise(gpu_device, dtype):
             assert torch.equal(outs[0], o)
 
 
+WIDE_TILES = [8, 16, 24, 32, 40, 48]     # YV4_HTILE_WIDE (shape by the cost model) and YV4_HTILE_WIDE_SHAPE(0..4)
+WIDE_SHAPES = [
+    # N, H, W, Cin, Cout, k, stride, pad: the general wide-tile kernel's domain (Cin % 64 == 0, Cout % 16 == 0)
+    (2, 17, 23, 128, 64, 3, 2, 1),     # stride 2, odd sizes, ragged M
+    (3, 38, 38, 64, 128, 3, 2, 1),     # stride 2 downscale, image borders inside a tile
+    (2, 19, 19, 512, 256, 1, 1, 0),    # deep 1x1
+    (1, 16, 20, 64, 240, 1, 1, 0),     # Cout not a multiple of 64: ragged channel groups
+    (2, 19, 19, 64, 128, 3, 1, 1),     # 3x3 stride 1 as a general gather
+    (1, 12, 12, 64, 64, 5, 1, 2),      # 25 taps
+    (33, 19, 19, 256, 512, 1, 1, 0),   # several tiles per workgroup column
+    (40, 38, 38, 128, 256, 3, 2, 1),   # more tiles than CUs for the small shapes: the issue side crosses tiles
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('tile', WIDE_TILES)
+@pytest.mark.parametrize('shape', WIDE_SHAPES)
+def test_h16_wide_general_kernel_shapes(gpu_device, dtype, tile, shape):
+    """conv_wide_h16.hip: the wide wave tiles as a general implicit GEMM (one (chunk, tap) pixel tile per K tile, padding
+    and borders as out-of-range DMA offsets) against float64, every workgroup tile shape."""
+    _h16_conv(gpu_device, dtype, *shape, act=1, tile=tile)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('tile', WIDE_TILES)
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+def test_h16_wide_general_kernel_epilogues(gpu_device, dtype, tile, act):
+    _h16_conv(gpu_device, dtype, 2, 13, 13, 64, 80, 3, 2, 1, act, tile, residual=True, two_stage=True, x_off=8, y_off=16)
+    _h16_conv(gpu_device, dtype, 1, 20, 9, 128, 128, 1, 1, 0, act, tile, residual=True, x_off=16)
+    _h16_conv(gpu_device, dtype, 30, 38, 38, 64, 128, 3, 2, 1, act, tile, residual=True, two_stage=True, y_off=8)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_wide_general_matches_generic_bitwise(gpu_device, dtype):
+    """Same K order (chunk-major, taps inside) and epilogue expressions as the generic tiles: the same bits."""
+    for shape, kw in [((2, 19, 19, 128, 128, 3, 2, 1), dict(residual=True, two_stage=True)), ((3, 38, 38, 512, 256, 1, 1, 0), dict()),
+                      ((9, 38, 38, 256, 256, 1, 1, 0), dict(residual=True)), ((2, 38, 38, 64, 192, 3, 1, 1), dict())]:
+        outs = [_h16_conv(gpu_device, dtype, *shape, act=1, tile=t, raw=True, **kw) for t in (2, 8, 16, 24, 32, 40, 48)]
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o)
+
+
+def test_h16_wide_general_kernel_is_refused_outside_its_domain(gpu_device):
+    for shape in [(1, 8, 8, 32, 64, 3, 1, 1), (1, 8, 8, 64, 72, 3, 1, 1), (1, 8, 8, 64, 32, 1, 1, 0)]:
+        with pytest.raises(L.Yv4Error):
+            _h16_conv(gpu_device, torch.bfloat16, *shape, act=1, tile=8)
+    with pytest.raises(L.Yv4Error):
+        _h16_conv(gpu_device, torch.bfloat16, 1, 9, 11, 64, 64, 3, 1, 1, act=1, tile=8, out_f32=True, y_off=4)
+
+
 def test_h16_wide3x3_kernel_is_refused_outside_its_domain(gpu_device):
     for shape in [(1, 8, 8, 64, 64, 1, 1, 0), (1, 8, 8, 64, 64, 3, 2, 1), (1, 8, 8, 32, 64, 3, 1, 1), (1, 8, 8, 64, 72, 3, 1, 1)]:
         with pytest.raises(L.Yv4Error):
