@@ -125,6 +125,13 @@ typedef struct yv4_conv_desc {
 /* 1x1 / stride 1, Cin 64 / 128 / 256, Cout >= 32, no residual: one persistent 8-wave workgroup per CU, the weight slab
  * resident in LDS, wave-private rings of 32-pixel strips; same summation order as the DMA tiles (bit-identical) */
 #define YV4_TILE_WS_1x1 9
+/* fp32 3x3 / stride 1 / pad 1 with Cin % 32 == 0 and Cout % 16 == 0 on WIDE wave tiles (16 PT pixels x 64 channels per
+ * wave on v_mfma_f32_16x16x4_f32, one accumulator set; the fp32 form of YV4_HTILE_W3x3: csrc/conv3x3_wide_f32.hip).
+ * NOT bit-identical to the 32x32x2 tiles (the K sum is grouped differently); YV4_TILE_W3x3_SHAPE(i), i = 0..4 (256 x 256,
+ * 192 x 256, 128 x 256, 384 x 128, 256 x 128), pins the workgroup tile shape -- yv4_conv_pick_tile returns that form, so a
+ * plan that must reproduce another plan's bits can copy its tile ids. */
+#define YV4_TILE_W3x3 10
+#define YV4_TILE_W3x3_SHAPE(i) (10 + 16 * ((i) + 1))
 /* (id 10 was the fp32 ping-pong 3x3 form of round 2: measured at the same 117-125 TFLOP/s plateau as the DMA tiles on
  * every layer, DESIGN 9.12, and removed in round 3; the id is refused) */
 

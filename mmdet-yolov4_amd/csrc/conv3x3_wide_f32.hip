@@ -1,0 +1,481 @@
+// 3x3 / stride-1 / pad-1 fused convolution for gfx950 in fp32 on WIDE wave tiles (v_mfma_f32_16x16x4_f32): the fp32 form
+// of conv3x3_wide_h16.hip (round 4; tile id YV4_TILE_W3x3) for the MFMA-bound layers of the headline configuration
+// (mmdet/models/backbones/darknetcsp.py:38-64 bottleneck 3x3 convs, mmdet/models/necks/yolo_neck_csp.py:11-238).
+//
+// Same structure: a wave owns 16 PT pixels x 64 channels as PT x 4 accumulator tiles of 16 x 16, the weight tile is the
+// MFMA's A operand with the channel permutation that leaves a lane 16 consecutive channels of one pixel (four 16-byte
+// stores), the three kw taps of a (32-channel chunk, kh) group read one LDS image of the BM + 2 source pixels, one
+// workgroup barrier per K tile, persistent grid, tile shapes chosen per layer to fill whole rounds of CUs.  What
+// changes with the element type: an LDS row of 128 bytes is a 32-channel chunk; a lane's ds_read_b128 (chunk q + 4 ks of
+// its row) holds FOUR K values that feed four consecutive 16x16x4 MFMAs -- MFMA step (ks, j) sums k = 16 ks + 4 q + j over
+// the four lane groups q, the same four K values on both operands, so no operand needs another read -- and a K tile is
+// 8 PT x 4 MFMAs of 32 pipe cycles: 8x the matrix time of the 16-bit kernel per byte staged, i.e. the loop is matrix-bound
+// with the LDS / DMA / barrier work far in the shade.  One accumulator set: a 16x16x4 MFMA adds four products per
+// rounding, so the K = 4 608 chain has the 1 152 roundings of the 32x32x2 kernels' two alternating sets.
+// NOT bit-identical to the 32x32x2 tiles (fp32 products are not exact; the grouping of the K sum differs): a plan that
+// must reproduce another plan's bits pins the tile id (bench.py's batch-2 check plan does).
+#include "conv_f32_common.h"
+
+
+namespace yv4 {
+
+typedef float f32x4f __attribute__((ext_vector_type(4)));
+
+constexpr int kF3Threads = 512;
+constexpr int kF3BK = 32;          // channels per chunk = floats per 128-byte LDS row
+
+template <int PT, int WAVES_M> struct F3Geom {
+  static constexpr int WAVES_N = 8 / WAVES_M;
+  static constexpr int BN = 64 * WAVES_N;
+  static constexpr int WMr = 16 * PT;               // pixel rows of a wave
+  static constexpr int BM = WMr * WAVES_M;
+  static constexpr int QA = (BM + 3 + 63) / 64;     // DMA passes (64 rows each) of an image of BM + 2 pixels + a zero row
+  static constexpr int ARows = 64 * QA;
+  static constexpr int ZeroRow = BM + 2;            // never a source pixel: only ever zero-filled
+  static constexpr int PB = BN / 64;                // weight pieces per wave and tap
+  static constexpr int ABytes = ARows * 128;
+  static constexpr int BBytes = BN * 128;
+  static constexpr int RingBytes = 2 * ABytes + 2 * BBytes;
+};
+
+// swizzle of the weight image: the 16 lanes of a ds_read_b128 group read rows {R..R+3, R+48..R+51} at chunk q and
+// {R+16..R+19, R+32..R+35} at chunk q + 1 (the channel permutation above), which (row >> 1) & 7 would fold onto each other
+__device__ __forceinline__ int f3_swz_b(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
+template <int PT, int WAVES_M>
+__global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
+  typedef float4 V8;                         // one fragment read: four K values of a row
+  typedef F3Geom<PT, WAVES_M> G_;
+  constexpr int WAVES_N = G_::WAVES_N, BN = G_::BN, BM = G_::BM, WMr = G_::WMr, QA = G_::QA, PB = G_::PB;
+  constexpr int PH = PT / 2;                 // pixel tiles per half
+  constexpr int kRowB = 128;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_f3[];
+  char* As = smem_f3;                        // [2][ARows][128 B]
+  char* Bs = smem_f3 + 2 * G_::ABytes;       // [2][BN][128 B]
+  float* aff = reinterpret_cast<float*>(smem_f3 + G_::RingBytes);   // [s1 | t1 | s2 | t2] x Cout
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+
+  const u32x4_t rsA = make_rsrc(p.x, x_bytes);
+  const u32x4_t rsB = make_rsrc(p.w, w_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_f3;
+  const int NHW = p.N * p.H * p.W;
+  const int nwg = (int)gridDim.x;
+
+  // virtual tile -> tile: each XCD (workgroups with equal id mod 8) walks a contiguous run of tiles, tile_n fastest
+  const unsigned q8 = (unsigned)ntiles >> 3, rem8 = (unsigned)ntiles & 7u;
+  auto tile_of = [&](int vt) -> unsigned {
+    const unsigned x = (unsigned)vt & 7u;
+    return (x < rem8 ? x * (q8 + 1) : rem8 * (q8 + 1) + (x - rem8) * q8) + ((unsigned)vt >> 3);
+  };
+
+  // ---- staging lanes: a DMA instruction of a wave fills 8 LDS rows (lane / 8) x 8 chunks (lane % 8) ----
+  const int srow = 8 * wave + (lane >> 3);               // 0..63, + 64 per pass
+  const int pc = lane & 7;
+  const int lcA = pc ^ ((srow >> 1) & 7);                // invariant under row + 64 q
+  const int lcB = pc ^ f3_swz_b(srow);                   // likewise
+  int a_s[QA];                                           // source pixel of LDS row (srow + 64 q) for kh = 1, NEXT group's tile
+  unsigned a_off[QA];
+  unsigned b_cur[PB], b_nxt[PB];                         // weight row offsets: current K tile's tile / next group's tile
+  auto issue_tile_setup = [&](int vt) {
+    const bool live = vt < ntiles;
+    const unsigned tile = live ? tile_of(vt) : 0u;
+    const int tn = (int)(tile % (unsigned)p.tiles_n);
+    const int m0i = (int)(tile / (unsigned)p.tiles_n) * BM;
+    const int n0i = tn * BN;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int row = srow + 64 * q;
+      a_s[q] = (live && row < BM + 2) ? m0i - 1 + row : (int)0x40000000;     // beyond the image for every kh: zero
+      a_off[q] = (unsigned)((((int64_t)(m0i - 1 + row)) * p.x_cs + p.x_co + lcA * 4) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int co = n0i + srow + 64 * q;
+      b_nxt[q] = (live && co < p.Cout) ? (unsigned)(((int64_t)co * p.Kw + lcB * 4) * 4) : kOOB;
+    }
+  };
+
+  // ---- fragment read addresses (tile-independent) ----
+  unsigned a_rd[3][2];                       // pixel fragments: tap kw, k step; + pt * 2048 per pixel tile
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int row = wm * WMr + fr + kw;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a_rd[kw][ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ ((row >> 1) & 7)) << 4));
+  }
+  const unsigned zero_rd = (unsigned)(G_::ZeroRow * kRowB);
+  unsigned w_rd[2];                          // weight fragments: k step; + t * 512 per channel tile
+  {
+    const int row = wn * 64 + 16 * (fr >> 2) + (fr & 3);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) w_rd[ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ f3_swz_b(row)) << 4));
+  }
+
+  const int nchunks = p.Cin >> 5;
+  const int G = 3 * nchunks;                 // (chunk, kh) groups per tile
+
+  // ---- the layer's affine into LDS, once per workgroup ----
+  const bool has2 = p.s2 != nullptr;
+  for (int c = tid; c < p.Cout; c += kF3Threads) {
+    aff[c] = p.s1[c];
+    aff[p.Cout + c] = p.t1[c];
+    aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
+    aff[3 * p.Cout + c] = has2 ? p.t2[c] : 0.f;
+  }
+
+// four K values of a fragment read = four MFMAs (the same K on both operands)
+#define YV4_F3_MFMA4(ACC, WF, PF)                                                                    \
+  {                                                                                                 \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((WF).x, (PF).x, ACC, 0, 0, 0);                       \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((WF).y, (PF).y, ACC, 0, 0, 0);                       \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((WF).z, (PF).z, ACC, 0, 0, 0);                       \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((WF).w, (PF).w, ACC, 0, 0, 0);                       \
+  }
+#define YV4_W3_ISSUE_B(SLOT, BOFF, KB)                                                              \
+  {                                                                                                 \
+    const unsigned lb_ = lds_base + (unsigned)(2 * G_::ABytes + (SLOT) * G_::BBytes + 8 * wave * kRowB); \
+    _Pragma("unroll") for (int q = 0; q < PB; ++q)                                                  \
+        lds_dma16(rsB, lb_ + 64 * q * kRowB, BOFF[q], (KB));   /* (the range check sees voffset only) */ \
+  }
+#define YV4_W3_ISSUE_A(ABUF, Q0, Q1, KH, C0)                                                        \
+  {                                                                                                 \
+    const unsigned la_ = lds_base + (unsigned)((ABUF) * G_::ABytes + 8 * wave * kRowB);              \
+    const int ds_ = ((KH) - 1) * p.W;                                                               \
+    const unsigned step_ = (unsigned)(((int64_t)ds_ * p.x_cs + (C0)) * 4);                          \
+    _Pragma("unroll") for (int q = (Q0); q < (Q1); ++q) {                                           \
+      const bool ok_ = (unsigned)(a_s[q] + ds_) < (unsigned)NHW;                                    \
+      lds_dma16(rsA, la_ + 64 * q * kRowB, ok_ ? a_off[q] + step_ : kOOB, 0u);                     \
+    }                                                                                               \
+  }
+
+  // ---- prologue: group 0's image and tap 0's weights of the first tile; the issue side then points at group 1 ----
+  int n_vt = (int)blockIdx.x;                // tile of the NEXT group (issue side)
+  issue_tile_setup(n_vt);
+#pragma unroll
+  for (int q = 0; q < PB; ++q) b_cur[q] = b_nxt[q];
+  YV4_W3_ISSUE_B(0, b_cur, 0u);
+  YV4_W3_ISSUE_A(0, 0, QA, 0, 0);
+  int n_g = 1, n_kh = 1, n_c0 = 0;           // G >= 3: group 1 is in the same tile
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();              // (also publishes the affine)
+
+  unsigned T_ = 0u, GG = 0u;                 // global K-tile / group counters: weight slot T_ & 1, image GG & 1
+  for (int vt = (int)blockIdx.x; vt < ntiles; vt += nwg) {
+    const unsigned tile = tile_of(vt);
+    const int tile_n = (int)(tile % (unsigned)p.tiles_n);
+    const int tile_m = (int)(tile / (unsigned)p.tiles_n);
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    unsigned mask9[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int m = m0 + wm * WMr + 16 * pt + fr;
+      unsigned mk = 0u;
+      if (m < p.M) {
+        const int hw = p.H * p.W;
+        const int n = fd_div(m, p.fd_hw);
+        const int rm = m - n * hw;
+        const int ho = fd_div(rm, p.fd_wo);
+        const int wo = rm - ho * p.W;
+        mk = (unsigned)tap_mask(ho - 1, wo - 1, 3, 3, p.H, p.W);
+      }
+      mask9[pt] = mk;
+    }
+    f32x4f acc[PT][4];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[pt][t] = f32x4f{0.f, 0.f, 0.f, 0.f};
+
+    int c0 = 0, kh = 0;
+    for (int g = 0; g < G; ++g) {
+      const unsigned ab = GG & 1u;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const unsigned slot = T_ & 1u;
+        const char* as_ = As + ab * G_::ABytes;
+        const char* bs_ = Bs + slot * G_::BBytes;
+        const int tapbit = 3 * kh + kw;
+        // ---- DMA of the next K tile's weights (other slot) and, at kw == 0, of the next group's image (other image)
+        if (kw < 2) {
+          YV4_W3_ISSUE_B(slot ^ 1u, b_cur, (unsigned)((((kh * 3 + kw + 1) * p.Cin) + c0) * 4));
+        } else {
+          YV4_W3_ISSUE_B(slot ^ 1u, b_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 4));
+        }
+        V8 wf[4][2], pf[PH][2];
+        // ---- phase 1: weights of channel tiles 0, 1, pixels of the first half
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+          const bool ok = (mask9[i] >> tapbit) & 1u;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)(i * 2048) : zero_rd));
+        }
+        if (kw == 0) YV4_W3_ISSUE_A(ab ^ 1u, 0, (QA + 1) / 2, n_kh, n_c0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i) YV4_F3_MFMA4(acc[i][t], wf[t][ks], pf[i][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 2: weights of channel tiles 2, 3
+#pragma unroll
+        for (int t = 2; t < 4; ++t)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
+        if (kw == 0) YV4_W3_ISSUE_A(ab ^ 1u, (QA + 1) / 2, QA, n_kh, n_c0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 2; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i) YV4_F3_MFMA4(acc[i][t], wf[t][ks], pf[i][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 3: pixels of the second half
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+          const bool ok = (mask9[PH + i] >> tapbit) & 1u;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)((PH + i) * 2048) : zero_rd));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 2; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i) YV4_F3_MFMA4(acc[PH + i][t], wf[t][ks], pf[i][ks]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 4: the last quadrant (both operand sets are in registers)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i) YV4_F3_MFMA4(acc[PH + i][t], wf[t][ks], pf[i][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's DMAs of the next K tile have landed (the next group's image, issued last at kw == 0, may still fly)
+        if (kw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        T_ += 1u;
+      }
+      // ---- group advance: current <- next; the issue side moves on by one group (possibly into the next tile) ----
+      GG += 1u;
+      kh = n_kh; c0 = n_c0;
+#pragma unroll
+      for (int q = 0; q < PB; ++q) b_cur[q] = b_nxt[q];
+      n_g += 1;
+      n_kh += 1;
+      if (n_kh == 3) { n_kh = 0; n_c0 += kF3BK; }
+      if (n_g == G) {
+        n_g = 0; n_c0 = 0; n_kh = 0;
+        n_vt += nwg;
+        issue_tile_setup(n_vt);
+      }
+    }
+    // (kh, c0 now describe group 0 of this workgroup's next tile: reset by the assignments at the top of the loop)
+
+    // ---- epilogue: lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + fr, channels n0 + wn 64 + 16 fq .. + 15 (fp32: four
+    // 16-byte stores).  Expressions: fmaf(acc, s1, t1) -> act (the contraction-free scalar Mish of the fp32 kernels) ->
+    // + residual -> fmaf(., s2, t2) -> act, as conv_mfma_f32.hip's epilogue_tile ----
+    const int cl = n0 + wn * 64 + 16 * fq;
+    const bool c_ok = cl + 15 < p.Cout;
+    const int ca = c_ok ? cl : 0;
+    float s1[16], t1[16];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(aff + ca + u), b = *reinterpret_cast<const float4*>(aff + p.Cout + ca + u);
+      s1[u] = a.x; s1[u + 1] = a.y; s1[u + 2] = a.z; s1[u + 3] = a.w;
+      t1[u] = b.x; t1[u + 1] = b.y; t1[u + 2] = b.z; t1[u + 3] = b.w;
+    }
+    float st[32];                            // training forward: [sum | sum of squares] of the lane's 16 channels
+#pragma unroll
+    for (int u = 0; u < 32; ++u) st[u] = 0.f;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int m = m0 + wm * WMr + 16 * pt + fr;
+      const bool ok = c_ok && m < p.M;
+      float v[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * t + j] = apply_act(__builtin_fmaf(acc[pt][t][j], s1[4 * t + j], t1[4 * t + j]), p.act1, p.slope1);
+      if (p.res && ok) {
+        const float* rp = p.res + (int64_t)m * p.r_cs + p.r_co + cl;
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+          const float4 r4 = *reinterpret_cast<const float4*>(rp + u);
+          v[u] += r4.x; v[u + 1] += r4.y; v[u + 2] += r4.z; v[u + 3] += r4.w;
+        }
+      }
+      if (has2) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          v[u] = apply_act(__builtin_fmaf(v[u], aff[2 * p.Cout + ca + u], aff[3 * p.Cout + ca + u]), p.act2, p.slope2);
+      }
+      if (ok) {
+        float* yp = p.y + (int64_t)m * p.y_cs + p.y_co + cl;
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) *reinterpret_cast<float4*>(yp + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+        if (p.stats) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { st[e] += v[e]; st[16 + e] += v[e] * v[e]; }
+        }
+      }
+    }
+    if (p.stats) {
+      int idx = 0;
+#pragma unroll
+      for (int sft = 0; sft < 4; ++sft) {
+        const int half = 16 >> sft;
+        const bool bit = (lane >> sft) & 1;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+          const float send = bit ? st[i] : st[i + half];
+          const float recv = __shfl_xor(send, 1 << sft);
+          st[i] = (bit ? st[i + half] : st[i]) + recv;
+        }
+        idx += bit ? half : 0;
+      }
+      if (c_ok) {
+        double* rep = p.stats + (size_t)((tile_m * WAVES_M + wm) & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int id = idx + k;
+          atomicAdd(&rep[(id >> 4) * p.Cout + cl + (id & 15)], (double)st[k]);
+        }
+      }
+    }
+    c0 = 0; kh = 0;
+  }
+#undef YV4_W3_ISSUE_A
+#undef YV4_F3_MFMA4
+#undef YV4_W3_ISSUE_B
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-filling tail DMAs must land before the LDS is released
+}
+
+// Domain: 3x3 / stride 1 / pad 1, 32-channel chunks of input, Cout in whole 16-channel groups (64 .. 1024), 16-byte
+// aligned output / residual views, no scattered output, no split-K.
+bool conv3x3_wide_f32_applies(const ConvArgs& a) {
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && (a.Cin & 31) == 0 &&
+         a.Kw == 9 * a.Cin && !a.ys_on && a.ksplit <= 1 && a.Cout >= 64 && (a.Cout & 15) == 0 && a.Cout <= 1024 &&
+         ((a.y_cs | a.y_co) & 3) == 0 && (a.res == nullptr || ((a.r_cs | a.r_co) & 3) == 0);
+}
+
+static int g_f3_cus = 0;
+static int f3_cus() {
+  if (g_f3_cus == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    g_f3_cus = cus;
+  }
+  return g_f3_cus;
+}
+
+template <int PT, int WAVES_M>
+static int launch_f3(const ConvArgs& a, hipStream_t stream) {
+  typedef F3Geom<PT, WAVES_M> G_;
+  ConvArgs p = a;
+  const int tiles_m = (p.M + G_::BM - 1) / G_::BM;
+  p.tiles_n = (p.Cout + G_::BN - 1) / G_::BN;
+  p.fd_hw = make_fastdiv((unsigned)(p.H * p.W));
+  p.fd_wo = make_fastdiv((unsigned)p.W);
+  const long long tiles = (long long)tiles_m * p.tiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffLL) {
+    set_error("conv3x3 wide f32: grid of %lld tiles out of range", tiles);
+    return YV4_E_INVALID;
+  }
+  const size_t lds = (size_t)G_::RingBytes + (size_t)4 * p.Cout * 4;
+  if (lds > 160 * 1024) {
+    set_error("conv3x3 wide f32: %zu bytes of LDS for this tile shape and Cout", lds);
+    return YV4_E_UNSUPPORTED;
+  }
+  const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 4, wb = (long long)p.Cout * p.Kw * 4;
+  if (xb >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) {
+    set_error("conv3x3 wide f32: tensors of 4 GiB or more are not addressable through a buffer descriptor");
+    return YV4_E_UNSUPPORTED;
+  }
+  auto kern = conv3x3_wide_f32_kernel<PT, WAVES_M>;
+  static LdsAttrOnce once;
+  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024, "conv3x3_wide_f32")) return rc;
+  const int cus = f3_cus();
+  const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kF3Threads), lds, stream, p, (unsigned)xb, (unsigned)wb, (int)tiles);
+  YV4_CHECK_LAUNCH("conv3x3_wide_f32");
+  return YV4_OK;
+}
+
+// tile shapes as conv3x3_wide_h16.hip: 256 x 256, 192 x 256, 128 x 256, 384 x 128, 256 x 128
+struct F3Shape { int pt, wm; };
+static const F3Shape kF3Shapes[5] = {{8, 2}, {6, 2}, {4, 2}, {6, 4}, {4, 4}};
+static size_t f3_lds(int pt, int wmv, int Cout) {
+  const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
+  const int arows = 64 * ((bm + 3 + 63) / 64);
+  return (size_t)2 * arows * 128 + (size_t)2 * bn * 128 + (size_t)16 * Cout;
+}
+int conv3x3_wide_f32_pick(const ConvArgs& a, double* rounds_eff) {
+  const int cus = f3_cus();
+  int best = -1;
+  double best_cost = 0.0;
+  for (int i = 0; i < 5; ++i) {
+    const int pt = kF3Shapes[i].pt, wmv = kF3Shapes[i].wm;
+    const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
+    if (f3_lds(pt, wmv, a.Cout) > 160 * 1024) continue;
+    if (bn > ((a.Cout + 127) / 128) * 128) continue;
+    const long long tiles = ((long long)a.M + bm - 1) / bm * ((a.Cout + bn - 1) / bn);
+    const long long rounds = (tiles + cus - 1) / cus;
+    const double cost = (double)rounds * bm * bn;      // matrix-bound: the wave tile's read ratio does not show
+    if (best < 0 || cost < best_cost * 0.999) { best = i; best_cost = cost; }
+  }
+  if (rounds_eff && best >= 0) *rounds_eff = best_cost / ((double)a.M * a.Cout / cus);
+  return best;
+}
+
+int conv3x3_wide_f32_launch(const ConvArgs& a, int shape, hipStream_t s) {
+  if (shape < 0) shape = conv3x3_wide_f32_pick(a, nullptr);
+  if (shape < 0 || shape >= 5 || f3_lds(kF3Shapes[shape].pt, kF3Shapes[shape].wm, a.Cout) > 160 * 1024) {
+    set_error("conv3x3 wide f32: no tile shape of this layer fits the LDS");
+    return YV4_E_UNSUPPORTED;
+  }
+  switch (shape) {
+    case 0: return launch_f3<8, 2>(a, s);
+    case 1: return launch_f3<6, 2>(a, s);
+    case 2: return launch_f3<4, 2>(a, s);
+    case 3: return launch_f3<6, 4>(a, s);
+    case 4: return launch_f3<4, 4>(a, s);
+    default: break;
+  }
+  return YV4_E_INVALID;
+}
+
+}  // namespace yv4

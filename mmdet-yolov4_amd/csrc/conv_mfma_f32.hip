@@ -18,53 +18,11 @@
 // D[row=(reg&3)+8*(reg>>2)+4*(lane>>5)][col=lane&31]; rows are pixels and columns
 // are output channels, so every accumulator register stores 2 x 128 contiguous
 // bytes of NHWC output.
-#include "yv4_common.h"
+#include "conv_f32_common.h"
 
 namespace yv4 {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kBK = 32;   // K slice staged per step (floats)
-constexpr int kLDK = 36;  // LDS row pitch in floats: 32 + 4 pad (144 B, 16B aligned)
-constexpr int kThreads = 256;
-
-struct ConvArgs {
-  const float* x;
-  const float* w;
-  const float* s1;
-  const float* t1;
-  const float* s2;
-  const float* t2;
-  const float* res;
-  float* y;
-  int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
-  int x_cs, x_co, y_cs, y_co, r_cs, r_co;
-  int act1, act2;
-  float slope1, slope2;
-  int M, K, Kw;  // Kw: row pitch of w (== K)
-  int tiles_n;
-  // scattered output (sub-pixel / parity convolutions of the stride-2 data gradient): output pixel
-  // (n, ho, wo) is stored at row ((n*ys_H + ho*ys_sh + ys_oh)*ys_W + wo*ys_sw + ys_ow) of y
-  int ys_on, ys_H, ys_W, ys_sh, ys_sw, ys_oh, ys_ow;
-  double* stats;   // training: [YV4_STATS_REPLICAS][sum (Cout) | sum of squares (Cout)] of the outputs, or null
-  FastDiv fd_hw, fd_wo;   // m / (Ho*Wo), r / Wo (LDS-DMA kernels; set by launch_conv_dma)
-  // split-K (LDS-DMA kernels, single-image plans): workgroup (tile, split) reduces K slices
-  // [split * ks_slices, ...) and stores its RAW partial tile into slab `split` of ws ([ksplit][M][ws_cs]);
-  // splitk_finish_kernel adds the slabs in slab order and applies the epilogue.  ksplit <= 1: off.
-  int ksplit = 0, ks_slices = 0, ws_cs = 0;
-  float* ws = nullptr;
-  FastDiv fd_taps, fd_kw;   // slice -> (chunk, tap), tap -> (kh, kw) at a split's first slice
-};
-
-__device__ __forceinline__ int64_t out_row(const ConvArgs& p, int m) {
-  if (!p.ys_on) return m;
-  const int hw = p.Ho * p.Wo;
-  const int n = m / hw;
-  const int r = m - n * hw;
-  const int ho = r / p.Wo;
-  const int wo = r - ho * p.Wo;
-  return ((int64_t)n * p.ys_H + ho * p.ys_sh + p.ys_oh) * p.ys_W + wo * p.ys_sw + p.ys_ow;
-}
+// (ConvArgs, out_row, lds_dma16, make_rsrc: conv_f32_common.h -- shared with conv3x3_wide_f32.hip)
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool UNIFORM_TAP>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_kernel(ConvArgs p) {
@@ -257,30 +215,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_kernel(ConvArgs p) 
   }
 }
 
-
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-// One LDS-DMA wave-instruction: lane l's 16 bytes at (descriptor base + voff + soff) land at
-// LDS byte address lds_addr + 16*l.  Issued through inline asm on purpose: hipcc would
-// otherwise wait vmcnt(0) before the next ds_read of ANY LDS address (it cannot tell the two
-// halves of the double buffer apart), exposing the whole memory latency every K step.  The
-// kernel counts these loads itself: s_waitcnt vmcnt(0) + s_barrier before the slice is read.
-__device__ __forceinline__ void lds_dma16(u32x4_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :
-               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory");
-}
-
-__device__ __forceinline__ u32x4_t make_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-  u32x4_t v;
-  v.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-  v.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-  v.z = __builtin_amdgcn_readfirstlane(bytes);
-  v.w = 0x00020000u;
-  return v;
-}
 
 // Epilogue of one 32x32 accumulator tile through a wave-private LDS patch: the MFMA result has
 // the output channel on the lane and 16 pixels in registers, which stores as 16 dword
@@ -1165,6 +1099,27 @@ extern "C" double yv4_conv_flops(const yv4_conv_desc* d) {
   return 2.0 * (double)d->N * d->Ho * d->Wo * d->Cout * (double)d->KH * d->KW * d->Cin;
 }
 
+namespace yv4 {
+// conv3x3_wide_f32.hip
+bool conv3x3_wide_f32_applies(const ConvArgs& a);
+int conv3x3_wide_f32_pick(const ConvArgs& a, double* rounds_eff);
+int conv3x3_wide_f32_launch(const ConvArgs& a, int shape, hipStream_t s);
+
+// The wide-tile fp32 3x3 kernel takes the layers in its domain with >= 64 input channels and at least YV4_W3F_MINOUT
+// outputs per CU when one of its tile shapes fills the rounds to within YV4_W3F_MAXWASTE percent (YV4_W3F=0: off).
+static int prefer_w3_f32(const ConvArgs& a) {      // the shape index, or -1
+  static const int mode = YV4_ENV_INT("YV4_W3F", 1);
+  static const int waste = YV4_ENV_INT("YV4_W3F_MAXWASTE", 25);
+  static const int min_out = YV4_ENV_INT("YV4_W3F_MINOUT", 32768);
+  if (!mode || !conv3x3_wide_f32_applies(a) || a.Cin < 64) return -1;
+  if ((long long)a.M * a.Cout < 256LL * min_out) return -1;
+  double eff = 0.0;
+  const int shape = conv3x3_wide_f32_pick(a, &eff);
+  if (shape < 0 || eff * 100.0 > 100.0 + waste) return -1;
+  return shape;
+}
+}  // namespace yv4
+
 extern "C" int yv4_conv_pick_tile(const yv4_conv_desc* d) {
   if (!d) return YV4_TILE_AUTO;
   const bool fast_ok = d->Cin % kBK == 0 && (long long)d->N * d->H * d->W * d->x_cstride * 4 < 0xFFFFFFF0LL &&
@@ -1175,6 +1130,10 @@ extern "C" int yv4_conv_pick_tile(const yv4_conv_desc* d) {
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.Cin = d->Cin; a.Cout = d->Cout;
     a.K = a.Kw = d->KH * d->KW * d->Cin; a.M = (int)((long long)d->N * d->Ho * d->Wo);
     if (fast_ok && prefer_ws_f32(a)) return YV4_TILE_WS_1x1;     // (a residual, unknown here, keeps the tile kernels)
+    a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.y_cs = d->y_cstride; a.y_co = d->y_coff;
+    a.r_cs = d->r_cstride; a.r_co = d->r_coff; a.ys_on = 0;
+    const int w3 = fast_ok ? prefer_w3_f32(a) : -1;
+    if (w3 >= 0) return YV4_TILE_W3x3_SHAPE(w3);                  // the pinned form: a plan can copy it (see include/yv4.h)
   }
   return pick_tile((long long)d->N * d->Ho * d->Wo, d->Cout, fast_ok, (long long)d->KH * d->KW * d->Cin);
 }
@@ -1227,6 +1186,18 @@ static int conv_f32_impl(const yv4_conv_desc* d, const float* x, const float* w,
   const bool can_stem = stem_ok(d, residual != nullptr, scale2 != nullptr);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (stats_done) *stats_done = false;
+  {
+    const int forced = (d->tile > 16 && (d->tile & 15) == YV4_TILE_W3x3 && d->tile <= YV4_TILE_W3x3_SHAPE(4)) ? (d->tile >> 4) - 1 : -1;
+    if (d->tile == YV4_TILE_W3x3 || forced >= 0)
+      YV4_REQUIRE(fast_ok && conv3x3_wide_f32_applies(a), "conv: the wide 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with "
+                  "Cin %% 32 == 0, Cout %% 16 == 0 (64 .. 1024) and 4-aligned channel strides / offsets");
+    const int autoshape = (d->tile == YV4_TILE_AUTO && fast_ok) ? prefer_w3_f32(a) : -1;
+    if (d->tile == YV4_TILE_W3x3 || forced >= 0 || autoshape >= 0) {
+      if (stats) { a.stats = stats; *stats_done = true; }
+      static const int env_shape = YV4_ENV_INT("YV4_W3F_SHAPE", -1);
+      return conv3x3_wide_f32_launch(a, forced >= 0 ? forced : (autoshape >= 0 && env_shape < 0 ? autoshape : env_shape), s);
+    }
+  }
   if (d->tile == YV4_TILE_WS_1x1)
     YV4_REQUIRE(fast_ok && conv1x1_ws_f32_applies(a), "conv: the weight-stationary tile needs a 1x1 / stride 1 conv with Cin 64, "
                 "128 or 256, Cout >= 32 and no residual");

@@ -74,7 +74,7 @@ def test_mish_empty(gpu_device):
 # fused conv, op level
 # ---------------------------------------------------------------------------------------------
 def _conv_case(dev, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=False, two_stage=False, x_off=0,
-               y_off=0, seed=0, raw=False):
+               y_off=0, seed=0, raw=False, out_extra=3):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5
@@ -100,7 +100,7 @@ def _conv_case(dev, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=Fals
         wide = plan.new_buf(N, H, W, cp + x_off + 4, 'wide')
         plan.resample(xin, wide.slice(x_off, cp))
         xin = wide.slice(x_off, cp)
-    out_buf = plan.new_buf(N, Ho, Wo, Cout + y_off + 3, 'out')
+    out_buf = plan.new_buf(N, Ho, Wo, Cout + y_off + out_extra, 'out')     # (+ 3: rows that are not 16-byte aligned)
     out = out_buf.slice(y_off, Cout)
     rv = plan.add_input_nchw(N, Cout, Ho, Wo, name='res', pad4=False) if residual else None
     plan.conv(xin, w, s1, t1, (act, 0.1), stride=stride, pad=pad, residual=rv,
@@ -116,6 +116,69 @@ def _conv_case(dev, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=Fals
     if raw:
         return got.clone()
     return close(got, ref, 1e-4, f'conv {N}x{Cin}x{H}x{W}->{Cout} k{k}s{stride} tile{tile}')
+
+
+W3F_TILES = [10, 26, 42, 58, 74, 90]      # YV4_TILE_W3x3 (shape by the cost model) and YV4_TILE_W3x3_SHAPE(0..4)
+W3F_SHAPES = [
+    # N, H, W, Cin, Cout  (3x3, stride 1, pad 1): conv3x3_wide_f32.hip
+    (2, 19, 19, 64, 128),      # image borders inside a tile, ragged last tile
+    (3, 7, 5, 128, 64),        # map narrower than a fragment row group
+    (1, 38, 38, 32, 192),      # one 32-channel chunk; Cout not a multiple of 128
+    (2, 16, 16, 96, 80),       # three chunks, Cout tail inside a 64-column wave slab
+    (1, 1, 300, 64, 64),       # one image row
+    (5, 3, 3, 64, 64),         # tiny images
+    (24, 38, 38, 64, 256),     # more tiles than CUs for the small shapes: the issue side crosses tiles
+]
+
+
+@pytest.mark.parametrize('tile', W3F_TILES)
+@pytest.mark.parametrize('shape', W3F_SHAPES)
+def test_conv_wide3x3_f32_kernel(gpu_device, shape, tile):
+    """The fp32 wide-tile 3x3 kernel (16x16x4 MFMAs, one accumulator set, five workgroup tile shapes) against the float64
+    convolution at 1e-4, plus residual / two-stage epilogue / channel-offset views."""
+    N, H, W, Cin, Cout = shape
+    _conv_case(gpu_device, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=tile, out_extra=4)
+
+
+@pytest.mark.parametrize('tile', W3F_TILES)
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+def test_conv_wide3x3_f32_kernel_epilogues(gpu_device, tile, act):
+    _conv_case(gpu_device, 2, 13, 13, 64, 80, 3, 1, 1, act, tile, residual=True, two_stage=True, x_off=8, y_off=16, out_extra=4)
+    _conv_case(gpu_device, 1, 20, 9, 128, 128, 3, 1, 1, act, tile, residual=True, x_off=16, out_extra=4)
+    _conv_case(gpu_device, 30, 38, 38, 32, 128, 3, 1, 1, act, tile, residual=True, two_stage=True, y_off=8, out_extra=4)
+
+
+def test_conv_wide3x3_f32_is_batch_invariant_per_tile_id(gpu_device):
+    """A pinned tile id gives the same bits whatever the batch (what bench.py's batch-2 check plan relies on); the auto
+    choice reports the pinned form."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 64, 19, 19, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) * (1.0 / 576) ** 0.5
+    s1, t1 = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+
+    def run(xb, tile):
+        plan = pkg.Plan(gpu_device)
+        xin = plan.add_input_nchw(xb.shape[0], 64, 19, 19)
+        out = plan.conv(xin, w, s1, t1, (1, 0.1), stride=1, pad=1, tile=tile)
+        plan.add_output_nchw(out)
+        plan.finalize()
+        y = plan.run(xb.to(gpu_device))[0].clone()
+        torch.cuda.synchronize()
+        return y
+
+    for tile in (26, 42, 74):
+        big = run(x, tile)
+        assert torch.equal(run(x[:2], tile), big[:2]) and torch.equal(run(x[4:5], tile), big[4:5])
+    d = L.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 32, 38, 38, 256, 38, 38, 256
+    d.KH = d.KW = 3
+    d.stride, d.pad = 1, 1
+    d.x_cstride, d.y_cstride, d.r_cstride = 256, 256, 256
+    import ctypes
+    t = L.lib().yv4_conv_pick_tile(ctypes.byref(d))
+    assert t in (26, 42, 58, 74, 90), t
+    d.N = 2
+    assert L.lib().yv4_conv_pick_tile(ctypes.byref(d)) in (5, 6, 7)        # small batches keep the 32x32x2 tiles
 
 
 @pytest.mark.parametrize('tile', [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64, L.TILE_DMA_64x64, L.TILE_DMA_128x64, L.TILE_DMA_128x128, L.TILE_STEM])
