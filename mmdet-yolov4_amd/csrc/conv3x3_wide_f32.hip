@@ -10,7 +10,10 @@
 // its row) holds FOUR K values that feed four consecutive 16x16x4 MFMAs -- MFMA step (ks, j) sums k = 16 ks + 4 q + j over
 // the four lane groups q, the same four K values on both operands, so no operand needs another read -- and a K tile is
 // 8 PT x 4 MFMAs of 32 pipe cycles: 8x the matrix time of the 16-bit kernel per byte staged, i.e. the loop is matrix-bound
-// with the LDS / DMA / barrier work far in the shade.  One accumulator set: a 16x16x4 MFMA adds four products per
+// with the LDS / DMA / barrier work far in the shade.  The MFMAs of a phase walk the K value OUTERMOST and the 2 x PT / 2
+// accumulator tiles inside: a 16x16x4 fp32 MFMA issues every 32 cycles but its result is ready after 40, so four
+// back-to-back MFMAs on ONE accumulator (the natural order of a float4 fragment) would stall 8 cycles each.  One
+// accumulator set: a 16x16x4 MFMA adds four products per
 // rounding, so the K = 4 608 chain has the 1 152 roundings of the 32x32x2 kernels' two alternating sets.
 // NOT bit-identical to the 32x32x2 tiles (fp32 products are not exact; the grouping of the K sum differs): a plan that
 // must reproduce another plan's bits pins the tile id (bench.py's batch-2 check plan does).
@@ -44,7 +47,7 @@ __device__ __forceinline__ int f3_swz_b(int row) { return ((row >> 1) & 1) | (((
 
 template <int PT, int WAVES_M>
 __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
-  typedef float4 V8;                         // one fragment read: four K values of a row
+  typedef f32x4f V8;                         // one fragment read: four K values of a row
   typedef F3Geom<PT, WAVES_M> G_;
   constexpr int WAVES_N = G_::WAVES_N, BN = G_::BN, BM = G_::BM, WMr = G_::WMr, QA = G_::QA, PB = G_::PB;
   constexpr int PH = PT / 2;                 // pixel tiles per half
@@ -133,14 +136,6 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
     aff[3 * p.Cout + c] = has2 ? p.t2[c] : 0.f;
   }
 
-// four K values of a fragment read = four MFMAs (the same K on both operands)
-#define YV4_F3_MFMA4(ACC, WF, PF)                                                                    \
-  {                                                                                                 \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((WF).x, (PF).x, ACC, 0, 0, 0);                       \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((WF).y, (PF).y, ACC, 0, 0, 0);                       \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((WF).z, (PF).z, ACC, 0, 0, 0);                       \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((WF).w, (PF).w, ACC, 0, 0, 0);                       \
-  }
 #define YV4_W3_ISSUE_B(SLOT, BOFF, KB)                                                              \
   {                                                                                                 \
     const unsigned lb_ = lds_base + (unsigned)(2 * G_::ABytes + (SLOT) * G_::BBytes + 8 * wave * kRowB); \
@@ -231,9 +226,12 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int j = 0; j < 4; ++j)          // K value outermost: consecutive MFMAs write DIFFERENT accumulators
 #pragma unroll
-            for (int i = 0; i < PH; ++i) YV4_F3_MFMA4(acc[i][t], wf[t][ks], pf[i][ks]);
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int i = 0; i < PH; ++i)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][ks][j], pf[i][ks][j], acc[i][t], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 2: weights of channel tiles 2, 3
@@ -247,9 +245,12 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int t = 2; t < 4; ++t)
+          for (int j = 0; j < 4; ++j)          // K value outermost: consecutive MFMAs write DIFFERENT accumulators
 #pragma unroll
-            for (int i = 0; i < PH; ++i) YV4_F3_MFMA4(acc[i][t], wf[t][ks], pf[i][ks]);
+            for (int t = 2; t < 4; ++t)
+#pragma unroll
+              for (int i = 0; i < PH; ++i)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][ks][j], pf[i][ks][j], acc[i][t], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 3: pixels of the second half
@@ -265,17 +266,23 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int t = 2; t < 4; ++t)
+          for (int j = 0; j < 4; ++j)          // K value outermost: consecutive MFMAs write DIFFERENT accumulators
 #pragma unroll
-            for (int i = 0; i < PH; ++i) YV4_F3_MFMA4(acc[PH + i][t], wf[t][ks], pf[i][ks]);
+            for (int t = 2; t < 4; ++t)
+#pragma unroll
+              for (int i = 0; i < PH; ++i)
+                acc[PH + i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][ks][j], pf[i][ks][j], acc[PH + i][t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 4: the last quadrant (both operand sets are in registers)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int j = 0; j < 4; ++j)          // K value outermost: consecutive MFMAs write DIFFERENT accumulators
 #pragma unroll
-            for (int i = 0; i < PH; ++i) YV4_F3_MFMA4(acc[PH + i][t], wf[t][ks], pf[i][ks]);
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int i = 0; i < PH; ++i)
+                acc[PH + i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][ks][j], pf[i][ks][j], acc[PH + i][t], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // this wave's DMAs of the next K tile have landed (the next group's image, issued last at kw == 0, may still fly)
@@ -375,7 +382,6 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
     c0 = 0; kh = 0;
   }
 #undef YV4_W3_ISSUE_A
-#undef YV4_F3_MFMA4
 #undef YV4_W3_ISSUE_B
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-filling tail DMAs must land before the LDS is released
 }
