@@ -219,15 +219,23 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
         const char* bs_ = Bs + slot * G_::BBytes;
         const int tapbit = 3 * kh + kw;
         // ---- DMA of the next K tile's weights (other slot) and, at kw == 0, of the next group's image (other image)
-        if (kw < 2) {
-          YV4_W3_ISSUE_B(slot ^ 1u, b_cur, (unsigned)((((kh * 3 + kw + 1) * p.Cin) + c0) * 2));
-        } else {
-          YV4_W3_ISSUE_B(slot ^ 1u, b_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 2));
+        // (measurement build, YV4_H16_ABLATE: 1 no weight DMA in the loop, 128 no image DMA, 2 no MFMA, 4 no barrier -- wrong
+        // results on purpose, to time the loop without one of its parts)
+        if (!YV4_ABLATE(p.ablate, 1)) {
+          if (kw < 2) {
+            YV4_W3_ISSUE_B(slot ^ 1u, b_cur, (unsigned)((((kh * 3 + kw + 1) * p.Cin) + c0) * 2));
+          } else {
+            YV4_W3_ISSUE_B(slot ^ 1u, b_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 2));
+          }
         }
-        V8 wf[4][2], pf[PH][2];
+        V8 wf[4][2] = {}, pf[PH][2] = {};
+        const bool rd_ = !YV4_ABLATE(p.ablate, 8);
         // ---- phase 1: weights of channel tiles 0, 1, pixels of the first half
+        if (rd_) {
+        // (all four channel tiles' weight fragments now: they stay in registers for phases 2-4 anyway, and phase 2 then
+        // starts its MFMAs without an LDS round trip)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
 #pragma unroll
@@ -237,7 +245,8 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
           for (int ks = 0; ks < 2; ++ks)
             pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)(i * 2048) : zero_rd));
         }
-        if (kw == 0) YV4_W3_ISSUE_A(ab ^ 1u, 0, (QA + 1) / 2, n_kh, n_c0);
+        }
+        if (kw == 0 && !YV4_ABLATE(p.ablate, 128)) YV4_W3_ISSUE_A(ab ^ 1u, 0, (QA + 1) / 2, n_kh, n_c0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -245,15 +254,11 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < PH; ++i) acc[i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[i][t]);
+            for (int i = 0; i < PH; ++i) if (!YV4_ABLATE(p.ablate, 2)) acc[i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[i][t]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 2: weights of channel tiles 2, 3
-#pragma unroll
-        for (int t = 2; t < 4; ++t)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
-        if (kw == 0) YV4_W3_ISSUE_A(ab ^ 1u, (QA + 1) / 2, QA, n_kh, n_c0);
+        // ---- phase 2: channel tiles 2, 3 (fragments already in registers)
+        if (kw == 0 && !YV4_ABLATE(p.ablate, 128)) YV4_W3_ISSUE_A(ab ^ 1u, (QA + 1) / 2, QA, n_kh, n_c0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -261,16 +266,18 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
 #pragma unroll
           for (int t = 2; t < 4; ++t)
 #pragma unroll
-            for (int i = 0; i < PH; ++i) acc[i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[i][t]);
+            for (int i = 0; i < PH; ++i) if (!YV4_ABLATE(p.ablate, 2)) acc[i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[i][t]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 3: pixels of the second half
+        if (rd_) {
 #pragma unroll
         for (int i = 0; i < PH; ++i) {
           const bool ok = (mask9[PH + i] >> tapbit) & 1u;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
             pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)((PH + i) * 2048) : zero_rd));
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
 #pragma unroll
           for (int t = 2; t < 4; ++t)
 #pragma unroll
-            for (int i = 0; i < PH; ++i) acc[PH + i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[PH + i][t]);
+            for (int i = 0; i < PH; ++i) if (!YV4_ABLATE(p.ablate, 2)) acc[PH + i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[PH + i][t]);
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 4: the last quadrant (both operand sets are in registers)
 #pragma unroll
@@ -287,13 +294,13 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < PH; ++i) acc[PH + i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[PH + i][t]);
+            for (int i = 0; i < PH; ++i) if (!YV4_ABLATE(p.ablate, 2)) acc[PH + i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[PH + i][t]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // this wave's DMAs of the next K tile have landed (the next group's image, issued last at kw == 0, may still fly)
         if (kw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!YV4_ABLATE(p.ablate, 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         T_ += 1u;
       }
@@ -327,6 +334,11 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
     float st[32];                            // training forward: [sum | sum of squares] of the lane's 16 channels (stored values)
 #pragma unroll
     for (int u = 0; u < 32; ++u) st[u] = 0.f;
+    if (YV4_ABLATE(p.ablate, 16)) {           // (measurement: no epilogue; keep the accumulators live)
+      if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.y)[0] = acc[PT - 1][3][3] + acc[1][1][1];
+      c0 = 0; kh = 0;
+      continue;
+    }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const int m = m0 + wm * WMr + 16 * pt + fr;

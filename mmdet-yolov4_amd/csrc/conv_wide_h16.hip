@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wide_h16_kernel(ConvArgsH 
       V8 wf[4][2], pf[PH][2];
       // ---- phase 1
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 4; ++t)      // all four channel tiles now: phase 2 starts without an LDS round trip
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
 #pragma unroll
@@ -207,12 +207,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wide_h16_kernel(ConvArgsH 
           for (int i = 0; i < PH; ++i) acc[i][t] = MfmaW<BF16>::run(wf[t][ks], pf[i][ks], acc[i][t]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      // ---- phase 2
-#pragma unroll
-      for (int t = 2; t < 4; ++t)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
-      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase 2 (fragments already in registers)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
