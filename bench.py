@@ -137,7 +137,7 @@ def tile_of_kernel(name):
     m = re.search(r'conv_mfma_h16_kernel<(?:true|false), (\d+), (\d+)', name)
     if m:
         return f'h16_{m.group(1)}x{m.group(2)}'
-    for pat, tile in (('conv1x1_ws_f32_kernel', 'ws_1x1'), ('conv3x3_wide_f32_kernel', 'w3x3'), ('conv1x1_ws_kernel', 'h16_ws_1x1'), ('conv3x3_small_kernel', 'h16_s3x3'),
+    for pat, tile in (('conv1x1_ws_f32_kernel', 'ws_1x1'), ('conv3x3_wide_f32_kernel', 'w3x3'), ('conv_wide_f32_kernel', 'wide'), ('conv1x1_ws_kernel', 'h16_ws_1x1'), ('conv3x3_small_kernel', 'h16_s3x3'),
                       ('stem_down', 'stem_down'), ('conv_stem3x3_kernel', 'stem3x3'), ('conv3x3_pp_h16_kernel', 'h16_pp3x3'),
                       ('conv3x3_wide_h16_kernel', 'h16_w3x3'), ('conv_wide_h16_kernel', 'h16_wide')):
         if re.search(pat, name):
@@ -570,7 +570,7 @@ def main():
                                   share_of_conv_time=round(tt / conv_time, 4))
     run_key = f'{args.model}_{args.size}_b{args.batch}_{args.dtype}'
     traffic, traffic_src = pmc_traffic(dom, run_key, dbytes / dn, dn // n_instr_steps)
-    kname = {'w3x3': 'conv3x3_wide_f32_kernel', 'h16_w3x3': 'conv3x3_wide_h16_kernel', 'h16_wide': 'conv_wide_h16_kernel',
+    kname = {'w3x3': 'conv3x3_wide_f32_kernel', 'wide': 'conv_wide_f32_kernel', 'h16_w3x3': 'conv3x3_wide_h16_kernel', 'h16_wide': 'conv_wide_h16_kernel',
              'h16_pp3x3': 'conv3x3_pp_h16_kernel'}.get(dom, f'conv_mfma_{"h16" if h16 else "f32"}_kernel<{dom}>')
     roofline = dict(bound='mfma', kernel=kname,
                     achieved=round(dflops / dtime / 1e12, 2), peak=peak, unit='TFLOP/s',

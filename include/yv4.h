@@ -132,6 +132,12 @@ typedef struct yv4_conv_desc {
  * plan that must reproduce another plan's bits can copy its tile ids. */
 #define YV4_TILE_W3x3 10
 #define YV4_TILE_W3x3_SHAPE(i) (10 + 16 * ((i) + 1))
+/* fp32 GENERAL convolution on the same wide wave tiles (csrc/conv_wide_f32.hip, the fp32 form of YV4_HTILE_WIDE): any
+ * kernel / stride / padding with Cin % 32 == 0, Cout % 16 == 0 (64 .. 2048), 4-aligned channel strides / offsets; the
+ * automatic choice gives it the stride-2 3x3 layers and the deep 1x1 layers.  Not bit-identical to the 32x32x2 tiles;
+ * YV4_TILE_WIDE_SHAPE(i) pins the workgroup tile shape as above and is what yv4_conv_pick_tile reports. */
+#define YV4_TILE_WIDE 11
+#define YV4_TILE_WIDE_SHAPE(i) (11 + 16 * ((i) + 1))
 /* (id 10 was the fp32 ping-pong 3x3 form of round 2: measured at the same 117-125 TFLOP/s plateau as the DMA tiles on
  * every layer, DESIGN 9.12, and removed in round 3; the id is refused) */
 

@@ -1105,6 +1105,11 @@ bool conv3x3_wide_f32_applies(const ConvArgs& a);
 int conv3x3_wide_f32_pick(const ConvArgs& a, double* rounds_eff);
 int conv3x3_wide_f32_launch(const ConvArgs& a, int shape, hipStream_t s);
 
+// conv_wide_f32.hip
+bool conv_wide_f32_applies(const ConvArgs& a);
+int conv_wide_f32_pick(const ConvArgs& a, double* rounds_eff);
+int conv_wide_f32_launch(const ConvArgs& a, int shape, hipStream_t s);
+
 // The wide-tile fp32 3x3 kernel takes the layers in its domain with >= 64 input channels and at least YV4_W3F_MINOUT
 // outputs per CU when one of its tile shapes fills the rounds to within YV4_W3F_MAXWASTE percent (YV4_W3F=0: off).
 static int prefer_w3_f32(const ConvArgs& a) {      // the shape index, or -1
@@ -1115,6 +1120,27 @@ static int prefer_w3_f32(const ConvArgs& a) {      // the shape index, or -1
   if ((long long)a.M * a.Cout < 256LL * min_out) return -1;
   double eff = 0.0;
   const int shape = conv3x3_wide_f32_pick(a, &eff);
+  if (shape < 0 || eff * 100.0 > 100.0 + waste) return -1;
+  return shape;
+}
+
+// The general wide-tile fp32 kernel takes the stride-2 3x3 layers with >= YV4_WGF_S2CIN input channels and the 1x1
+// layers with >= YV4_WGF_P1CIN, under the same fill rule (YV4_WGF=0: off).  Measured per layer at batch 32 x 608 (round 4,
+// profiles/r04_layers_wide_f32.md): stride-2 3x3 with Cin >= 128 gain 4 - 32 %, 64->128@304 and the 256-channel 1x1
+// layers lose 2 - 4 % against the DMA tiles, the 512 / 1024-channel 1x1 layers gain 1 - 3 %.
+static int prefer_wide_f32(const ConvArgs& a) {    // the shape index, or -1
+  static const int mode = YV4_ENV_INT("YV4_WGF", 1);
+  static const int waste = YV4_ENV_INT("YV4_WGF_MAXWASTE", 25);
+  static const int min_out = YV4_ENV_INT("YV4_WGF_MINOUT", 32768);
+  static const int s2cin = YV4_ENV_INT("YV4_WGF_S2CIN", 128);
+  static const int p1cin = YV4_ENV_INT("YV4_WGF_P1CIN", 512);
+  if (!mode || !conv_wide_f32_applies(a)) return -1;
+  const bool s2 = a.KH == 3 && a.KW == 3 && a.stride == 2 && a.Cin >= s2cin;
+  const bool p1 = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.Cin >= p1cin;
+  if (!s2 && !p1) return -1;
+  if ((long long)a.M * a.Cout < 256LL * min_out) return -1;
+  double eff = 0.0;
+  const int shape = conv_wide_f32_pick(a, &eff);
   if (shape < 0 || eff * 100.0 > 100.0 + waste) return -1;
   return shape;
 }
@@ -1134,6 +1160,8 @@ extern "C" int yv4_conv_pick_tile(const yv4_conv_desc* d) {
     a.r_cs = d->r_cstride; a.r_co = d->r_coff; a.ys_on = 0;
     const int w3 = fast_ok ? prefer_w3_f32(a) : -1;
     if (w3 >= 0) return YV4_TILE_W3x3_SHAPE(w3);                  // the pinned form: a plan can copy it (see include/yv4.h)
+    const int wg = fast_ok ? prefer_wide_f32(a) : -1;             // (a residual, unknown here, keeps the tile kernels)
+    if (wg >= 0) return YV4_TILE_WIDE_SHAPE(wg);
   }
   return pick_tile((long long)d->N * d->Ho * d->Wo, d->Cout, fast_ok, (long long)d->KH * d->KW * d->Cin);
 }
@@ -1196,6 +1224,18 @@ static int conv_f32_impl(const yv4_conv_desc* d, const float* x, const float* w,
       if (stats) { a.stats = stats; *stats_done = true; }
       static const int env_shape = YV4_ENV_INT("YV4_W3F_SHAPE", -1);
       return conv3x3_wide_f32_launch(a, forced >= 0 ? forced : (autoshape >= 0 && env_shape < 0 ? autoshape : env_shape), s);
+    }
+  }
+  {
+    const int forced = (d->tile > 16 && (d->tile & 15) == YV4_TILE_WIDE && d->tile <= YV4_TILE_WIDE_SHAPE(4)) ? (d->tile >> 4) - 1 : -1;
+    if (d->tile == YV4_TILE_WIDE || forced >= 0)
+      YV4_REQUIRE(fast_ok && conv_wide_f32_applies(a), "conv: the wide tile needs Cin %% 32 == 0, Cout %% 16 == 0 (64 .. 2048) and "
+                  "4-aligned channel strides / offsets");
+    const int autoshape = (d->tile == YV4_TILE_AUTO && fast_ok && !(prefer_ws_f32(a) && conv1x1_ws_f32_applies(a))) ? prefer_wide_f32(a) : -1;
+    if (d->tile == YV4_TILE_WIDE || forced >= 0 || autoshape >= 0) {
+      if (stats) { a.stats = stats; *stats_done = true; }
+      static const int env_shape = YV4_ENV_INT("YV4_WGF_SHAPE", -1);
+      return conv_wide_f32_launch(a, forced >= 0 ? forced : (autoshape >= 0 && env_shape < 0 ? autoshape : env_shape), s);
     }
   }
   if (d->tile == YV4_TILE_WS_1x1)

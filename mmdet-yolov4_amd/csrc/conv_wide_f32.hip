@@ -1,0 +1,420 @@
+// General fused convolution in fp32 on WIDE wave tiles (v_mfma_f32_16x16x4_f32): the fp32 form of conv_wide_h16.hip, tile
+// id YV4_TILE_WIDE (round 4) -- the stride-2 3x3 layers and the deep 1x1 layers of the headline configuration
+// (mmdet/models/backbones/darknetcsp.py:262-335, mmdet/models/necks/yolo_neck_csp.py:11-238).  Structure as
+// conv3x3_wide_f32.hip (four K values per fragment read, K value outermost in the MFMA phases, one accumulator set) with
+// conv_wide_h16.hip's pixel operand: one BM x 32-channel tile per (chunk, tap), gathered with the tap's offset; padding,
+// borders and the M tail are out-of-range DMA offsets.  NOT bit-identical to the 32x32x2 tiles; yv4_conv_pick_tile
+// reports the pinned shape id (YV4_TILE_WIDE_SHAPE(i)).
+#include "conv_f32_common.h"
+
+
+namespace yv4 {
+
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+
+constexpr int kFgThreads = 512;
+constexpr int kFgBK = 32;
+
+template <int PT, int WAVES_M> struct FgGeom {
+  static constexpr int WAVES_N = 8 / WAVES_M;
+  static constexpr int BN = 64 * WAVES_N;
+  static constexpr int WMr = 16 * PT;
+  static constexpr int BM = WMr * WAVES_M;
+  static constexpr int QA = BM / 64;                // pixel pieces per wave and K tile
+  static constexpr int PB = BN / 64;                // weight pieces per wave and K tile
+  static constexpr int ABytes = BM * 128;
+  static constexpr int BBytes = BN * 128;
+  static constexpr int RingBytes = 2 * ABytes + 2 * BBytes;
+};
+
+__device__ __forceinline__ int fg_swz_b(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
+template <int PT, int WAVES_M>
+__global__ __launch_bounds__(kFgThreads, 2) void conv_wide_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
+  typedef f32x4g V8;                         // one fragment read: four K values of a row
+  typedef FgGeom<PT, WAVES_M> G_;
+  constexpr int WAVES_N = G_::WAVES_N, BN = G_::BN, BM = G_::BM, WMr = G_::WMr, QA = G_::QA, PB = G_::PB;
+  constexpr int PH = PT / 2;
+  constexpr int kRowB = 128;
+  static_assert(BM % 64 == 0, "whole DMA passes");
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_fg[];
+  char* As = smem_fg;                        // [2][BM][128 B]
+  char* Bs = smem_fg + 2 * G_::ABytes;       // [2][BN][128 B]
+  float* aff = reinterpret_cast<float*>(smem_fg + G_::RingBytes);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+
+  const u32x4_t rsA = make_rsrc(p.x, x_bytes);
+  const u32x4_t rsB = make_rsrc(p.w, w_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_fg;
+  const int nwg = (int)gridDim.x;
+
+  const unsigned q8 = (unsigned)ntiles >> 3, rem8 = (unsigned)ntiles & 7u;
+  auto tile_of = [&](int vt) -> unsigned {
+    const unsigned x = (unsigned)vt & 7u;
+    return (x < rem8 ? x * (q8 + 1) : rem8 * (q8 + 1) + (x - rem8) * q8) + ((unsigned)vt >> 3);
+  };
+
+  // ---- staging lanes (the tile of the NEXT K tile) ----
+  const int srow = 8 * wave + (lane >> 3);
+  const int pc = lane & 7;
+  const int lcA = pc ^ ((srow >> 1) & 7);
+  const int lcB = pc ^ fg_swz_b(srow);
+  unsigned a_off[QA];
+  unsigned long long a_mask[QA];
+  unsigned b_off[PB];
+  auto issue_tile_setup = [&](int vt) {
+    const bool live = vt < ntiles;
+    const unsigned tile = live ? tile_of(vt) : 0u;
+    const int tn = (int)(tile % (unsigned)p.tiles_n);
+    const int m0i = (int)(tile / (unsigned)p.tiles_n) * BM;
+    const int n0i = tn * BN;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int m = m0i + srow + 64 * q;
+      unsigned long long mk = 0ull;
+      unsigned off = 0u;
+      if (live && m < p.M) {
+        const int hw = p.Ho * p.Wo;
+        const int n = fd_div(m, p.fd_hw);
+        const int rm = m - n * hw;
+        const int ho = fd_div(rm, p.fd_wo);
+        const int wo = rm - ho * p.Wo;
+        const int hi0 = ho * p.stride - p.pad;
+        const int wi0 = wo * p.stride - p.pad;
+        off = (unsigned)((((int64_t)(n * p.H + hi0) * p.W + wi0) * p.x_cs + p.x_co + lcA * 4) * 4);
+        mk = tap_mask(hi0, wi0, p.KH, p.KW, p.H, p.W);
+      }
+      a_off[q] = off;
+      a_mask[q] = mk;
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int co = n0i + srow + 64 * q;
+      b_off[q] = (live && co < p.Cout) ? (unsigned)(((int64_t)co * p.Kw + lcB * 4) * 4) : kOOB;
+    }
+  };
+
+  // ---- fragment read addresses ----
+  unsigned a_rd[2], w_rd[2];
+  {
+    const int row = wm * WMr + fr;
+    const int rw = wn * 64 + 16 * (fr >> 2) + (fr & 3);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      a_rd[ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ ((row >> 1) & 7)) << 4));
+      w_rd[ks] = (unsigned)(rw * kRowB + (((fq + 4 * ks) ^ fg_swz_b(rw)) << 4));
+    }
+  }
+
+  const int nchunks = p.Cin >> 5;
+  const int ntaps = p.KH * p.KW;
+  const int NK = nchunks * ntaps;            // K tiles per output tile (chunk-major, taps inside)
+
+  const bool has2 = p.s2 != nullptr;
+  for (int c = tid; c < p.Cout; c += kFgThreads) {
+    aff[c] = p.s1[c];
+    aff[p.Cout + c] = p.t1[c];
+    aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
+    aff[3 * p.Cout + c] = has2 ? p.t2[c] : 0.f;
+  }
+
+  // issue-side walk: the K tile after the one being computed
+  int n_vt = (int)blockIdx.x, n_k = 0, n_tap = 0, n_kh = 0, n_kw = 0, n_c0 = 0;
+#define YV4_WG_ISSUE(SLOT)                                                                          \
+  {                                                                                                 \
+    const unsigned la_ = lds_base + (unsigned)((SLOT) * G_::ABytes + 8 * wave * kRowB);              \
+    const unsigned lb_ = lds_base + (unsigned)(2 * G_::ABytes + (SLOT) * G_::BBytes + 8 * wave * kRowB); \
+    const unsigned step_ = (unsigned)((((int64_t)n_kh * p.W + n_kw) * p.x_cs + n_c0) * 4);           \
+    const unsigned kb_ = (unsigned)((n_tap * p.Cin + n_c0) * 4);                                     \
+    _Pragma("unroll") for (int q = 0; q < PB; ++q) lds_dma16(rsB, lb_ + 64 * q * kRowB, b_off[q], kb_); \
+    _Pragma("unroll") for (int q = 0; q < QA; ++q) {                                                \
+      const bool ok_ = (a_mask[q] >> n_tap) & 1ull;                                                 \
+      lds_dma16(rsA, la_ + 64 * q * kRowB, ok_ ? a_off[q] + step_ : kOOB, 0u);                     \
+    }                                                                                               \
+    n_k += 1; n_tap += 1; n_kw += 1;                                                                \
+    if (n_kw == p.KW) { n_kw = 0; n_kh += 1; }                                                      \
+    if (n_tap == ntaps) { n_tap = 0; n_kh = 0; n_c0 += kFgBK; }                                     \
+    if (n_k == NK) {                                                                                \
+      n_k = 0; n_c0 = 0;                                                                            \
+      n_vt += nwg;                                                                                  \
+      issue_tile_setup(n_vt);                                                                       \
+    }                                                                                               \
+  }
+
+  issue_tile_setup(n_vt);
+  YV4_WG_ISSUE(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();              // (also publishes the affine)
+
+  unsigned T_ = 0u;
+  for (int vt = (int)blockIdx.x; vt < ntiles; vt += nwg) {
+    const unsigned tile = tile_of(vt);
+    const int tile_n = (int)(tile % (unsigned)p.tiles_n);
+    const int tile_m = (int)(tile / (unsigned)p.tiles_n);
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    f32x4g acc[PT][4];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[pt][t] = f32x4g{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < NK; ++kt) {
+      const unsigned slot = T_ & 1u;
+      const char* as_ = As + slot * G_::ABytes;
+      const char* bs_ = Bs + slot * G_::BBytes;
+      YV4_WG_ISSUE(slot ^ 1u);
+      V8 wf[4][2], pf[PH][2];
+      // ---- phase 1
+#pragma unroll
+      for (int t = 0; t < 4; ++t)      // all four channel tiles now: phase 2 starts without an LDS round trip
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
+#pragma unroll
+      for (int i = 0; i < PH; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) pf[i][ks] = *reinterpret_cast<const V8*>(as_ + a_rd[ks] + i * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i)
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][ks][j], pf[i][ks][j], acc[i][t], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase 2 (fragments already in registers)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 2; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i)
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][ks][j], pf[i][ks][j], acc[i][t], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase 3
+#pragma unroll
+      for (int i = 0; i < PH; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) pf[i][ks] = *reinterpret_cast<const V8*>(as_ + a_rd[ks] + (PH + i) * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 2; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i)
+              acc[PH + i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][ks][j], pf[i][ks][j], acc[PH + i][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase 4
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < PH; ++i)
+              acc[PH + i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][ks][j], pf[i][ks][j], acc[PH + i][t], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      T_ += 1u;
+    }
+
+    // ---- epilogue: lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + fr, channels n0 + wn 64 + 16 fq .. + 15 (fp32: four
+    // 16-byte stores).  Expressions: fmaf(acc, s1, t1) -> act (the contraction-free scalar Mish of the fp32 kernels) ->
+    // + residual -> fmaf(., s2, t2) -> act, as conv_mfma_f32.hip's epilogue_tile ----
+    const int cl = n0 + wn * 64 + 16 * fq;
+    const bool c_ok = cl + 15 < p.Cout;
+    const int ca = c_ok ? cl : 0;
+    float s1[16], t1[16];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(aff + ca + u), b = *reinterpret_cast<const float4*>(aff + p.Cout + ca + u);
+      s1[u] = a.x; s1[u + 1] = a.y; s1[u + 2] = a.z; s1[u + 3] = a.w;
+      t1[u] = b.x; t1[u + 1] = b.y; t1[u + 2] = b.z; t1[u + 3] = b.w;
+    }
+    float st[32];                            // training forward: [sum | sum of squares] of the lane's 16 channels
+#pragma unroll
+    for (int u = 0; u < 32; ++u) st[u] = 0.f;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int m = m0 + wm * WMr + 16 * pt + fr;
+      const bool ok = c_ok && m < p.M;
+      float v[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * t + j] = apply_act(__builtin_fmaf(acc[pt][t][j], s1[4 * t + j], t1[4 * t + j]), p.act1, p.slope1);
+      if (p.res && ok) {
+        const float* rp = p.res + (int64_t)m * p.r_cs + p.r_co + cl;
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+          const float4 r4 = *reinterpret_cast<const float4*>(rp + u);
+          v[u] += r4.x; v[u + 1] += r4.y; v[u + 2] += r4.z; v[u + 3] += r4.w;
+        }
+      }
+      if (has2) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          v[u] = apply_act(__builtin_fmaf(v[u], aff[2 * p.Cout + ca + u], aff[3 * p.Cout + ca + u]), p.act2, p.slope2);
+      }
+      if (ok) {
+        float* yp = p.y + out_row(p, m) * p.y_cs + p.y_co + cl;
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) *reinterpret_cast<float4*>(yp + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+        if (p.stats) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { st[e] += v[e]; st[16 + e] += v[e] * v[e]; }
+        }
+      }
+    }
+    if (p.stats) {
+      int idx = 0;
+#pragma unroll
+      for (int sft = 0; sft < 4; ++sft) {
+        const int half = 16 >> sft;
+        const bool bit = (lane >> sft) & 1;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+          const float send = bit ? st[i] : st[i + half];
+          const float recv = __shfl_xor(send, 1 << sft);
+          st[i] = (bit ? st[i + half] : st[i]) + recv;
+        }
+        idx += bit ? half : 0;
+      }
+      if (c_ok) {
+        double* rep = p.stats + (size_t)((tile_m * WAVES_M + wm) & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int id = idx + k;
+          atomicAdd(&rep[(id >> 4) * p.Cout + cl + (id & 15)], (double)st[k]);
+        }
+      }
+    }
+  }
+#undef YV4_WG_ISSUE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Domain: 32-channel chunks of input, Cout in whole 16-channel groups (64 .. 2048), 16-byte aligned output / residual
+// views, at most 64 taps; any stride / padding; a scattered output without a residual; no split-K.
+bool conv_wide_f32_applies(const ConvArgs& a) {
+  return (a.Cin & 31) == 0 && a.Kw == a.KH * a.KW * a.Cin && a.KH * a.KW <= 64 && a.Cout >= 64 && (a.Cout & 15) == 0 &&
+         a.Cout <= 2048 && ((a.y_cs | a.y_co) & 3) == 0 && (a.res == nullptr || (((a.r_cs | a.r_co) & 3) == 0 && !a.ys_on)) &&
+         a.ksplit <= 1 && !(a.ys_on && a.stats);
+}
+
+static int g_fg_cus = 0;
+static int fg_cus() {
+  if (g_fg_cus == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    g_fg_cus = cus;
+  }
+  return g_fg_cus;
+}
+
+template <int PT, int WAVES_M>
+static int launch_fg(const ConvArgs& a, hipStream_t stream) {
+  typedef FgGeom<PT, WAVES_M> G_;
+  ConvArgs p = a;
+  const int tiles_m = (p.M + G_::BM - 1) / G_::BM;
+  p.tiles_n = (p.Cout + G_::BN - 1) / G_::BN;
+  p.fd_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
+  p.fd_wo = make_fastdiv((unsigned)p.Wo);
+  const long long tiles = (long long)tiles_m * p.tiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffLL) {
+    set_error("conv wide f32: grid of %lld tiles out of range", tiles);
+    return YV4_E_INVALID;
+  }
+  const size_t lds = (size_t)G_::RingBytes + (size_t)4 * p.Cout * 4;
+  if (lds > 160 * 1024) {
+    set_error("conv wide f32: %zu bytes of LDS for this tile shape and Cout", lds);
+    return YV4_E_UNSUPPORTED;
+  }
+  const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 4, wb = (long long)p.Cout * p.Kw * 4;
+  if (xb >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) {
+    set_error("conv wide f32: tensors of 4 GiB or more are not addressable through a buffer descriptor");
+    return YV4_E_UNSUPPORTED;
+  }
+  auto kern = conv_wide_f32_kernel<PT, WAVES_M>;
+  static LdsAttrOnce once;
+  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024, "conv_wide_f32")) return rc;
+  const int cus = fg_cus();
+  const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kFgThreads), lds, stream, p, (unsigned)xb, (unsigned)wb, (int)tiles);
+  YV4_CHECK_LAUNCH("conv_wide_f32");
+  return YV4_OK;
+}
+
+struct FgShape { int pt, wm; };
+static const FgShape kFgShapes[5] = {{8, 2}, {6, 2}, {4, 2}, {6, 4}, {4, 4}};
+static size_t fg_lds(int pt, int wmv, int Cout) {
+  const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
+  return (size_t)2 * (bm + bn) * 128 + (size_t)16 * Cout;
+}
+int conv_wide_f32_pick(const ConvArgs& a, double* rounds_eff) {
+  const int cus = fg_cus();
+  int best = -1;
+  double best_cost = 0.0;
+  for (int i = 0; i < 5; ++i) {
+    const int pt = kFgShapes[i].pt, wmv = kFgShapes[i].wm;
+    const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
+    if (fg_lds(pt, wmv, a.Cout) > 160 * 1024) continue;
+    if (bn > ((a.Cout + 127) / 128) * 128) continue;
+    const long long tiles = ((long long)a.M + bm - 1) / bm * ((a.Cout + bn - 1) / bn);
+    const long long rounds = (tiles + cus - 1) / cus;
+    const double cost = (double)rounds * bm * bn;
+    if (best < 0 || cost < best_cost * 0.999) { best = i; best_cost = cost; }
+  }
+  if (rounds_eff && best >= 0) *rounds_eff = best_cost / ((double)a.M * a.Cout / cus);
+  return best;
+}
+
+int conv_wide_f32_launch(const ConvArgs& a, int shape, hipStream_t s) {
+  if (shape < 0) shape = conv_wide_f32_pick(a, nullptr);
+  if (shape < 0 || shape >= 5 || fg_lds(kFgShapes[shape].pt, kFgShapes[shape].wm, a.Cout) > 160 * 1024) {
+    set_error("conv wide f32: no tile shape of this layer fits the LDS");
+    return YV4_E_UNSUPPORTED;
+  }
+  switch (shape) {
+    case 0: return launch_fg<8, 2>(a, s);
+    case 1: return launch_fg<6, 2>(a, s);
+    case 2: return launch_fg<4, 2>(a, s);
+    case 3: return launch_fg<6, 4>(a, s);
+    case 4: return launch_fg<4, 4>(a, s);
+    default: break;
+  }
+  return YV4_E_INVALID;
+}
+
+}  // namespace yv4

@@ -181,6 +181,44 @@ def test_conv_wide3x3_f32_is_batch_invariant_per_tile_id(gpu_device):
     assert L.lib().yv4_conv_pick_tile(ctypes.byref(d)) in (5, 6, 7)        # small batches keep the 32x32x2 tiles
 
 
+WGF_TILES = [11, 27, 43, 59, 75, 91]      # YV4_TILE_WIDE (shape by the cost model) and YV4_TILE_WIDE_SHAPE(0..4)
+WGF_SHAPES = [
+    # N, H, W, Cin, Cout, k, stride, pad: conv_wide_f32.hip
+    (2, 19, 19, 64, 128, 3, 2, 1),     # stride 2, odd map: borders and the ragged last tile
+    (3, 38, 38, 64, 64, 3, 2, 1),      # Cout below one workgroup tile
+    (2, 17, 23, 32, 80, 1, 1, 0),      # 1x1, one K tile, Cout not a multiple of 64
+    (1, 24, 24, 256, 256, 1, 1, 0),    # the deep 1x1 shape
+    (2, 13, 13, 96, 144, 3, 1, 1),     # 3x3 stride 1 through the general kernel
+    (1, 21, 21, 32, 64, 5, 2, 2),      # 25 taps, pad 2
+    (40, 19, 19, 32, 320, 1, 1, 0),    # several rounds of the persistent grid, three column tiles of 128
+]
+
+
+@pytest.mark.parametrize('tile', WGF_TILES)
+@pytest.mark.parametrize('shape', WGF_SHAPES)
+def test_conv_wide_f32_kernel(gpu_device, shape, tile):
+    """The general fp32 wide-tile kernel (the fp32 form of the 16-bit general wide kernel) against the float64 convolution
+    at 1e-4."""
+    N, H, W, Cin, Cout, k, stride, pad = shape
+    _conv_case(gpu_device, N, H, W, Cin, Cout, k, stride, pad, act=1, tile=tile, out_extra=4)
+
+
+@pytest.mark.parametrize('tile', WGF_TILES)
+@pytest.mark.parametrize('act', [0, 1, 2, 3])
+def test_conv_wide_f32_kernel_epilogues(gpu_device, tile, act):
+    _conv_case(gpu_device, 2, 13, 13, 64, 80, 3, 2, 1, act, tile, residual=True, two_stage=True, x_off=8, y_off=16, out_extra=4)
+    _conv_case(gpu_device, 1, 20, 9, 128, 128, 1, 1, 0, act, tile, residual=True, x_off=16, out_extra=4)
+
+
+def test_conv_wide_f32_refuses_what_it_cannot_address(gpu_device):
+    with pytest.raises(L.Yv4Error):
+        _conv_case(gpu_device, 1, 12, 12, 24, 64, 3, 1, 1, 1, 11, out_extra=4)       # Cin % 32
+    with pytest.raises(L.Yv4Error):
+        _conv_case(gpu_device, 1, 12, 12, 32, 72, 3, 1, 1, 1, 27, out_extra=4)       # Cout % 16
+    with pytest.raises(L.Yv4Error):
+        _conv_case(gpu_device, 1, 12, 12, 32, 64, 3, 1, 1, 1, 43, out_extra=3)       # rows that are not 16-byte aligned
+
+
 @pytest.mark.parametrize('tile', [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64, L.TILE_DMA_64x64, L.TILE_DMA_128x64, L.TILE_DMA_128x128, L.TILE_STEM])
 @pytest.mark.parametrize('shape', [
     # N, H, W, Cin, Cout, k, stride, pad
