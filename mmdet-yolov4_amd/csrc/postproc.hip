@@ -66,6 +66,7 @@ struct DecodeArgs {
   int v3;                 // YOLOV3Head semantics (yolo_head.py:254-391) instead of YOLOCSPHead's
   int topk_per_level;     // topk has N * num_levels entries (YOLOv3 selects the top-k per level)
   float conf_thr;         // v3: boxes with objectness < conf_thr are dropped (<= 0: off)
+  int ablate;             // measurement only (YV4_DEC_ABLATE): 1 no sigmoid, 2 no candidate output, 4 no class loop, 8 no box stores
 };
 
 __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
@@ -84,7 +85,30 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
       const int at = i % attr;
       sm[i] = (at == 2 || at == 3) ? src[i] : sigmoid_f32(src[i]);   // v3: exp(t_w), exp(t_h) need the raw logit
     }
-  } else {        // (no per-element modulo on the YOLOCSPHead path: every attribute goes through the sigmoid)
+  } else if ((((uintptr_t)src) & 15) == 0) {
+    // every attribute goes through the sigmoid: no per-element index work, and the workgroup's values (64 x 85 floats,
+    // a multiple of 16 bytes from an aligned start for all but odd images of an odd-sized level) are read as 16-byte
+    // words, all of a thread's loads issued before the first sigmoid -- the scalar loop was a chain of ~21 load ->
+    // sigmoid -> LDS-store rounds per thread and set the kernel's time (one memory round trip each)
+    const int nq = nval >> 2;                                // whole 16-byte words; nval % 4 != 0 only in a level's last block
+    constexpr int kQ = (kDecBoxes * (5 + 80) / 4 + 255) / 256;   // 6 words per thread cover 80 classes; more classes: loop
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    for (int q0 = threadIdx.x; q0 < nq; q0 += 256 * kQ) {
+      float4 v[kQ];
+#pragma unroll
+      for (int u = 0; u < kQ; ++u) {
+        const int q = q0 + 256 * u;
+        v[u] = q < nq ? src4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < kQ; ++u) {
+        const int q = q0 + 256 * u;
+        if (q < nq)
+          reinterpret_cast<float4*>(sm)[q] = YV4_ABLATE(p.ablate, 1) ? v[u] : make_float4(sigmoid_f32(v[u].x), sigmoid_f32(v[u].y), sigmoid_f32(v[u].z), sigmoid_f32(v[u].w));
+      }
+    }
+    for (int i = (nq << 2) + threadIdx.x; i < nval; i += 256) sm[i] = sigmoid_f32(src[i]);
+  } else {
     for (int i = threadIdx.x; i < nval; i += 256) sm[i] = sigmoid_f32(src[i]);
   }
   __syncthreads();
@@ -131,7 +155,7 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   const float cf = s[4];
   const int j = p.level_base[lvl] + jl;
   const size_t gj = (size_t)n * p.total_anchors + j;
-  if (part == 0 && live) {
+  if (part == 0 && live && !YV4_ABLATE(p.ablate, 8)) {
     reinterpret_cast<float4*>(p.boxes)[gj] = make_float4(x1, y1, x2, y2);
     if (p.conf) p.conf[gj] = cf;
   }
@@ -149,7 +173,7 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   if (threadIdx.x == 0) wg_count = 0;
   __syncthreads();
   int mine = 0;
-  if (admitted) {
+  if (admitted && !YV4_ABLATE(p.ablate, 4)) {
     if (p.C == 0) {                 // class_agnostic (yolocsp_head.py:357-360): one column, score = conf
       mine = (part == 0 && cf > p.score_thr) ? 1 : 0;
     } else {
@@ -162,9 +186,10 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
       }
     }
   }
+  if (YV4_ABLATE(p.ablate, 2)) return;
   int slot = mine ? atomicAdd(&wg_count, mine) : 0;
   __syncthreads();
-  if (threadIdx.x == 0) wg_base = wg_count ? atomicAdd(&p.counts[n], wg_count) : 0;
+  if (threadIdx.x == 0) wg_base = YV4_ABLATE(p.ablate, 16) ? (int)((blockIdx.x * 16) & 1023) : (wg_count ? atomicAdd(&p.counts[n], wg_count) : 0);
   __syncthreads();
   if (mine) {
     slot += wg_base;
@@ -183,12 +208,21 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
       }
     }
   }
-  // boxes.max() over the surviving candidates (mmcv batched_nms): reduced over the wavefront first -- one atomic per
-  // candidate meant ~2000 serialised same-address atomics per image
+  // boxes.max() over the surviving candidates (mmcv batched_nms): reduced over the wavefront, then over the workgroup's
+  // four waves -- ONE atomic per workgroup.  Device-scope atomics on this 8-XCD part execute at the memory side, and the
+  // images' maxima are neighbouring words of one cache line: one atomic per wave with a candidate (~35 000 per step at
+  // batch 32) was 55 of the kernel's 175 us.  (Reading the running maximum first, to skip atomics that cannot raise it,
+  // is slower still: the coherent read of that line queues behind the same atomics -- 153 us read late, 425 read early.)
   float mx = mine ? fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)) : -__builtin_huge_valf();
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if ((threadIdx.x & 63) == 0 && mx > -__builtin_huge_valf()) atomic_max_float(&p.max_coord[n], mx);
+  __shared__ float wg_max[4];
+  if ((threadIdx.x & 63) == 0) wg_max[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0 && !YV4_ABLATE(p.ablate, 32)) {
+    mx = fmaxf(fmaxf(wg_max[0], wg_max[1]), fmaxf(wg_max[2], wg_max[3]));
+    if (mx > -__builtin_huge_valf()) atomic_max_float(&p.max_coord[n], mx);
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -279,6 +313,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
   float4* kbox = reinterpret_cast<float4*>(clabel + kChunk);               // [kKeptLds]
   float* karea = reinterpret_cast<float*>(kbox + kKeptLds);                // [kKeptLds]
   int32_t* kcount = reinterpret_cast<int32_t*>(karea + kKeptLds);          // [1]
+  int16_t* csel = reinterpret_cast<int16_t*>(kcount + 4);                  // [256] kept candidates of the chunk, in order
 
   const float off_unit = p.max_coord[img] + 1.f;  // max_coordinate + 1 (mmcv batched_nms)
   const float* ibox = p.boxes + (size_t)img * p.boxes_per_image * 4;
@@ -372,7 +407,10 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
       cmask[i * 4 + w] = bits;
     }
     __syncthreads();
-    // (c) sequential resolve by one thread
+    // (c) the greedy resolve is sequential, but only its DECISIONS are: one thread walks the live bits and records the
+    // kept candidates of the chunk (a ctz, four mask words and a list entry per kept box); the outputs -- five floats,
+    // label, index and the LDS copy per kept box -- are then written by one thread per kept box.  (With the stores inside
+    // the walk a kept box cost ~30 dependent LDS / global operations: ~100 us of a 180 us launch at 300 kept per image.)
     if (tid == 0) {
       uint64_t removed[4] = {0, 0, 0, 0};
       int k = kept;
@@ -381,20 +419,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
         while (cur && k < p.max_out) {
           const int b = __builtin_ctzll(cur);
           const int i = w * 64 + b;
-          // keep candidate i
-          const float4 ob = cobox[i];
-          const uint64_t key = ckey[i];
-          odet[k * 5 + 0] = ob.x;
-          odet[k * 5 + 1] = ob.y;
-          odet[k * 5 + 2] = ob.z;
-          odet[k * 5 + 3] = ob.w;
-          odet[k * 5 + 4] = key_to_score((uint32_t)(key >> 32));
-          olab[k] = clabel[i];
-          oidx[k] = (int64_t)(uint32_t)key;
-          if (k < kKeptLds) {
-            kbox[k] = cbox[i];
-            karea[k] = carea[i];
-          }
+          csel[k - kept] = (int16_t)i;
           ++k;
           removed[0] |= cmask[i * 4 + 0];
           removed[1] |= cmask[i * 4 + 1];
@@ -406,6 +431,27 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
       }
       *kcount = k;
     }
+    __syncthreads();
+    {
+      const int knew = *kcount;
+      if (tid < knew - kept) {
+        const int k = kept + tid;
+        const int i = csel[tid];
+        const float4 ob = cobox[i];
+        const uint64_t key = ckey[i];
+        odet[k * 5 + 0] = ob.x;
+        odet[k * 5 + 1] = ob.y;
+        odet[k * 5 + 2] = ob.z;
+        odet[k * 5 + 3] = ob.w;
+        odet[k * 5 + 4] = key_to_score((uint32_t)(key >> 32));
+        olab[k] = clabel[i];
+        oidx[k] = (int64_t)(uint32_t)key;
+        if (k < kKeptLds) {
+          kbox[k] = cbox[i];
+          karea[k] = carea[i];
+        }
+      }
+    }
     __threadfence_block();
     __syncthreads();
   }
@@ -413,7 +459,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
 }
 
 constexpr size_t kNmsLdsSort = (size_t)kSortCap * sizeof(uint64_t);
-constexpr size_t kNmsLdsChunk = (size_t)kChunk * (16 + 4 + 32 + 16 + 8 + 4) + 32 + (size_t)kKeptLds * 20 + 16;
+constexpr size_t kNmsLdsChunk = (size_t)kChunk * (16 + 4 + 32 + 16 + 8 + 4) + 32 + (size_t)kKeptLds * 20 + 16 + (size_t)kChunk * 2;
 constexpr size_t kNmsLds = kNmsLdsSort > kNmsLdsChunk ? kNmsLdsSort : kNmsLdsChunk;
 
 // keys / max for the standalone batched_nms op
@@ -483,6 +529,8 @@ static int decode_impl(const yv4_level_desc* levels, int num_levels, int N, int 
   a.keys = keys; a.key_cap = key_cap; a.counts = counts; a.max_coord = max_coord;
   a.topk = topk_keys;
   a.v3 = v3; a.conf_thr = conf_thr; a.topk_per_level = topk_per_level;
+  static const int ablate = YV4_ENV_INT("YV4_DEC_ABLATE", 0);
+  a.ablate = ablate;
   const size_t lds = (size_t)kDecBoxes * (5 + num_classes) * sizeof(float);
   YV4_REQUIRE(lds <= 64 * 1024, "decode_filter: num_classes %d too large for the LDS tile", num_classes);
   hipLaunchKernelGGL(decode_filter_kernel, dim3(blocks, N), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
