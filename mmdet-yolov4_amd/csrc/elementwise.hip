@@ -5,6 +5,7 @@
 #include <hip/hip_bf16.h>
 
 #include "yv4_common.h"
+#include "spp_lds.h"
 
 namespace yv4 {
 
@@ -382,6 +383,12 @@ extern "C" int yv4_spp_pool_fwd(float* buf, int N, int H, int W, int C, int cstr
   YV4_REQUIRE(C % 4 == 0 && cstride % 4 == 0 && coff % 4 == 0, "spp: C, cstride, coff must be multiples of 4");
   YV4_REQUIRE(coff >= 0 && coff + 4 * C <= cstride, "spp: the 4*C concat slice exceeds the pixel stride");
   YV4_REQUIRE(((uintptr_t)buf & 15) == 0, "spp: buffer must be 16-byte aligned");
+  if (H * W <= kSppLdsMaxHW && N <= 65535) {      // the whole map of a channel slice in LDS: one launch (spp_lds.h)
+    typedef float f32x4_e __attribute__((ext_vector_type(4)));
+    if (int rc = spp_lds_launch<float, f32x4_e, 4>(buf, N, H, W, C, cstride, coff, reinterpret_cast<hipStream_t>(stream), "spp_pool")) return rc;
+    YV4_CHECK_LAUNCH("spp_pool");
+    return YV4_OK;
+  }
   if ((long long)N * H <= 65535) {      // three chained 5x5 pools: x -> mp5 -> mp9 -> mp13
     const dim3 grid((unsigned)((W * (C / 4) + 255) / 256), (unsigned)(N * H));
     for (int k = 0; k < 3; ++k)

@@ -5,6 +5,7 @@
 // fp32 view with C/2 channels, so the host calls yv4_resample_nearest_fwd with halved channel
 // arguments.
 #include "yv4_common.h"
+#include "spp_lds.h"
 
 namespace yv4 {
 
@@ -234,6 +235,13 @@ extern "C" int yv4_spp_pool_fwd_h16(void* buf, int N, int H, int W, int C, int c
   YV4_REQUIRE(coff >= 0 && coff + 4 * C <= cstride, "spp_h16: the 4C-channel concat view exceeds the pixel stride");
   YV4_REQUIRE(((uintptr_t)buf & 15) == 0, "spp_h16: buffer must be 16-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (H * W <= kSppLdsMaxHW && N <= 65535) {      // the whole map of a channel slice in LDS: one launch (spp_lds.h)
+    if (int rc = dtype == YV4_BF16 ? spp_lds_launch<__bf16, bf16x8_e, 8>((__bf16*)buf, N, H, W, C, cstride, coff, s, "spp_pool_h16")
+                                   : spp_lds_launch<_Float16, f16x8_e, 8>((_Float16*)buf, N, H, W, C, cstride, coff, s, "spp_pool_h16"))
+      return rc;
+    YV4_CHECK_LAUNCH("spp_pool_h16");
+    return YV4_OK;
+  }
   if ((long long)N * H <= 65535) {      // three chained 5x5 pools
     const dim3 grid((unsigned)((W * (C / 8) + 255) / 256), (unsigned)(N * H));
     for (int k = 0; k < 3; ++k) {

@@ -511,24 +511,28 @@ def test_detector_in_16_bit_vs_oracle_emulation(golden, gpu_device, dtype, tol_f
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
-def test_h16_layout_and_spp_kernels(gpu_device, dtype):
+@pytest.mark.parametrize('shape', [(16, 13, 11), (40, 19, 19), (64, 20, 20), (8, 30, 30)])
+def test_h16_layout_and_spp_kernels(gpu_device, dtype, shape):
+    """(the SPP of a map of <= 512 pixels is one LDS-tiled launch -- a partial, one-and-a-bit and two 32-channel slices
+    here -- above that three chained launches)"""
     torch.manual_seed(0)
+    C, H, W = shape
     plan = pkg.Plan(gpu_device, dtype)
-    x = plan.add_input_nchw(2, 16, 13, 11)
-    cat = plan.new_buf(2, 13, 11, 64, 'cat')
-    plan.resample(x, cat.slice(0, 16))
-    plan.spp(cat, 16)
-    up = plan.new_buf(2, 26, 22, 64, 'up')
+    x = plan.add_input_nchw(2, C, H, W)
+    cat = plan.new_buf(2, H, W, 4 * C, 'cat')
+    plan.resample(x, cat.slice(0, C))
+    plan.spp(cat, C)
+    up = plan.new_buf(2, 2 * H, 2 * W, 4 * C, 'up')
     plan.resample(cat, up)
     plan.add_output_nchw(cat)
     plan.add_output_nchw(up)
     plan.finalize()
-    inp = torch.randn(2, 16, 13, 11, device=gpu_device)
+    inp = torch.randn(2, C, H, W, device=gpu_device)
     got_cat, got_up = plan.run(inp)
     xr = inp.to(dtype).float()
     ref = torch.cat([xr] + [F.max_pool2d(xr, k, 1, k // 2) for k in (5, 9, 13)], 1)
     assert torch.equal(got_cat, ref)
-    assert torch.equal(got_up, F.interpolate(ref, size=(26, 22), mode='nearest'))
+    assert torch.equal(got_up, F.interpolate(ref, size=(2 * H, 2 * W), mode='nearest'))
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])

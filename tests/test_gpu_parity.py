@@ -309,10 +309,12 @@ def test_conv_rejects_bad_arguments(gpu_device):
 # ---------------------------------------------------------------------------------------------
 # SPP / resample / layout
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('hw', [(19, 19), (13, 13), (5, 7), (20, 20)])
-def test_spp_pools(gpu_device, hw):
+@pytest.mark.parametrize('C', [24, 64, 8])
+@pytest.mark.parametrize('hw', [(19, 19), (13, 13), (5, 7), (20, 20), (1, 1), (22, 23), (23, 23), (40, 12)])
+def test_spp_pools(gpu_device, hw, C):
+    """One LDS-tiled launch for maps of <= 512 pixels (whole, partial and several 16-channel slices per pixel), the three
+    chained 5x5 launches above that; max is exact."""
     H, W = hw
-    C = 24
     x = torch.randn(2, C, H, W)
     plan = pkg.Plan(gpu_device)
     xin = plan.add_input_nchw(2, C, H, W)

@@ -9,5 +9,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg3" -- python3 b
 for n in bf16 cfg3; do
   f=$(find "$OUT/$n" -name '*kernel_stats.csv' | head -1)
   echo "== $n ($f)"
-  if [ -n "$f" ]; then grep -E "decode_filter|nms_images|pool5|resample|decode_reset|copyBuffer|nchw" "$f" | cut -c1-140; cp "$f" "$OUT/${n}_kernel_stats.csv"; fi
+  if [ -n "$f" ]; then grep -E "decode_filter|nms_images|pool5|spp_|resample|decode_reset|copyBuffer|nchw" "$f" | cut -c1-140; cp "$f" "$OUT/${n}_kernel_stats.csv"; fi
 done
