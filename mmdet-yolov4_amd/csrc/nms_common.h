@@ -29,6 +29,9 @@ __device__ __forceinline__ bool iou_gt(const float4 bi, const float ai, const fl
   const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
   const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
   const float inter = w * h;
+  // disjoint boxes (most pairs), division form: 0 / uni is +-0 or NaN, none of which is > thr >= 0 -- the same answer
+  // without the division.  (The product form keeps its expression: thr * uni is negative for a malformed box.)
+  if (!form && !(inter > 0.f) && thr >= 0.f) return false;
   const float uni = ai + aj - inter;
   if (form) return inter > thr * uni;
   const float ovr = inter / uni;

@@ -251,6 +251,7 @@ struct NmsArgs {
   int fused_classes;
   float iou_thr;
   int iou_form;
+  int ablate;     // measurement only (YV4_NMS_ABLATE): 1 stop after the sort, 2 no chunk-vs-kept test, 4 no chunk mask, 8 one chunk only
   int max_out;
   int split_thr;
   float* out_dets;
@@ -282,10 +283,14 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
     if (P < 2) P = 2;
     for (int i = tid; i < P; i += kNmsThreads) sk[i] = i < n ? gkeys[i] : ~0ull;
     __syncthreads();
-    for (int k = 2; k <= P; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
+    // Bitonic network.  Thread t of a pass handles the pair (i, i + j), i = (t / j) 2j + t mod j: for j <= 64 the 64
+    // threads of a wave stay inside their own 128 elements, step after step -- such steps need no workgroup barrier
+    // between them (a wave's LDS accesses complete in order), only the steps with j >= 128 exchange between waves.
+    // 15 barriers instead of 66 at P = 2048.
+    for (int k = 2, lk = 1; k <= P; k <<= 1, ++lk) {
+      for (int j = k >> 1, lj = lk - 1; j > 0; j >>= 1, --lj) {
         for (int t = tid; t < (P >> 1); t += kNmsThreads) {
-          const int i = ((t / j) * (j << 1)) + (t % j);
+          const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1));      // (t / j) 2j + t mod j, j = 2^lj
           const int ixj = i + j;
           const bool up = (i & k) == 0;
           const uint64_t a = sk[i], b = sk[ixj];
@@ -294,13 +299,21 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
             sk[ixj] = a;
           }
         }
-        __syncthreads();
+        const int next_j = j > 1 ? (j >> 1) : k;          // the step after this one ((2k, k) after (k, 1))
+        if (j >= 128 || next_j >= 128) {
+          __syncthreads();
+        } else {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
       }
     }
+    __syncthreads();
     for (int i = tid; i < n; i += kNmsThreads) gkeys[i] = sk[i];
     __syncthreads();
   }
 
+  if (YV4_ABLATE(p.ablate, 1)) { if (tid == 0) p.out_count[img] = 0; return; }
   // ---- 2. greedy NMS over sorted chunks -------------------------------------------
   // LDS carve (aliases the sort buffer)
   float4* cbox = reinterpret_cast<float4*>(lds_raw);                       // [256] class-offset boxes
@@ -324,39 +337,51 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
   if (tid == 0) *kcount = 0;
   __syncthreads();
 
+  // A chunk's candidates (key -> box: two dependent global reads) are fetched one chunk AHEAD into registers of the first
+  // 256 threads: the ~3 us round trip used to open every chunk.
+  float4 f_ob = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint64_t f_key = 0;
+  int f_lab = 0;
+  auto fetch = [&](int c0) {
+    f_ob = make_float4(0.f, 0.f, 0.f, 0.f);
+    f_key = 0;
+    f_lab = 0;
+    if (tid < kChunk && c0 + tid < n) {
+      f_key = gkeys[c0 + tid];
+      const uint32_t flat = (uint32_t)f_key;
+      uint32_t bi;
+      if (p.fused_classes > 0) {
+        bi = flat / (uint32_t)p.fused_classes;
+        f_lab = (int)(flat - bi * (uint32_t)p.fused_classes);
+      } else {
+        bi = flat;
+        f_lab = ilab ? ilab[flat] : 0;
+      }
+      f_ob = reinterpret_cast<const float4*>(ibox)[bi];
+    }
+  };
+  fetch(0);
   for (int c0 = 0; c0 < n; c0 += kChunk) {
     const int cn = min(kChunk, n - c0);
     const int kept = *kcount;
-    if (kept >= p.max_out) break;
-    // load the chunk
+    if (kept >= p.max_out || (YV4_ABLATE(p.ablate, 8) && c0 > 0)) break;
+    // stage the chunk
     if (tid < kChunk) {
-      float4 ob = make_float4(0.f, 0.f, 0.f, 0.f), bb = ob;
+      float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
       float ar = 0.f;
-      uint64_t key = 0;
-      int lab = 0;
       if (tid < cn) {
-        key = gkeys[c0 + tid];
-        const uint32_t flat = (uint32_t)key;
-        uint32_t bi;
-        if (p.fused_classes > 0) {
-          bi = flat / (uint32_t)p.fused_classes;
-          lab = (int)(flat - bi * (uint32_t)p.fused_classes);
-        } else {
-          bi = flat;
-          lab = ilab ? ilab[flat] : 0;
-        }
-        ob = reinterpret_cast<const float4*>(ibox)[bi];
-        const float off = (float)lab * off_unit;  // idxs.to(boxes) * (max + 1)
-        bb = make_float4(ob.x + off, ob.y + off, ob.z + off, ob.w + off);
+        const float off = (float)f_lab * off_unit;  // idxs.to(boxes) * (max + 1)
+        bb = make_float4(f_ob.x + off, f_ob.y + off, f_ob.z + off, f_ob.w + off);
         ar = (bb.z - bb.x) * (bb.w - bb.y);
       }
       cbox[tid] = bb;
       carea[tid] = ar;
-      cobox[tid] = ob;
-      ckey[tid] = key;
-      clabel[tid] = lab;
+      cobox[tid] = f_ob;
+      ckey[tid] = f_key;
+      clabel[tid] = f_lab;
     }
     __syncthreads();
+    fetch(c0 + kChunk);
     // (a) chunk vs kept: thread -> (candidate i = tid & 255, quarter q = tid >> 8)
     {
       const int i = tid & (kChunk - 1);
@@ -365,7 +390,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
       if (i < cn) {
         const float4 bj = cbox[i];
         const float aj = carea[i];
-        for (int k = q; k < kept && !dead; k += 4) {
+        for (int k = q; k < kept && !dead && !YV4_ABLATE(p.ablate, 2); k += 4) {
           float4 bk;
           float ak;
           if (k < kKeptLds) {
@@ -399,7 +424,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
         const float4 bi = cbox[i];
         const float ai = carea[i];
         const int j0 = w * 64;
-        for (int jj = 0; jj < 64; ++jj) {
+        for (int jj = 0; jj < 64 && !YV4_ABLATE(p.ablate, 4); ++jj) {
           const int j = j0 + jj;
           if (j > i && j < cn && iou_gt(bi, ai, cbox[j], carea[j], p.iou_thr, p.iou_form)) bits |= 1ull << jj;
         }
@@ -407,29 +432,62 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
       cmask[i * 4 + w] = bits;
     }
     __syncthreads();
-    // (c) the greedy resolve is sequential, but only its DECISIONS are: one thread walks the live bits and records the
-    // kept candidates of the chunk (a ctz, four mask words and a list entry per kept box); the outputs -- five floats,
+    // (c) the greedy resolve is sequential, but only its DECISIONS are: the walk over the live bits records the kept
+    // candidates of the chunk (a ctz, four mask words and a list entry per kept box); the outputs -- five floats,
     // label, index and the LDS copy per kept box -- are then written by one thread per kept box.  (With the stores inside
     // the walk a kept box cost ~30 dependent LDS / global operations: ~100 us of a 180 us launch at 300 kept per image.)
-    if (tid == 0) {
-      uint64_t removed[4] = {0, 0, 0, 0};
+    if (tid < 64) {
+      // Wave 0, all lanes in step: lane L holds the mask rows 4L .. 4L+3 in registers and the row of a kept candidate
+      // comes by v_readlane (the candidate index is wave-uniform) instead of four dependent LDS reads per kept box.
+      uint64_t rows[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) rows[r][w] = cmask[(4 * tid + r) * 4 + w];
+      auto uni64 = [](uint64_t v, int lane) -> uint64_t {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+        return ((uint64_t)hi << 32) | lo;
+      };
+      uint64_t alive[4], removed[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) alive[w] = uni64(calive[w], 0);
       int k = kept;
-      for (int w = 0; w < 4 && k < p.max_out; ++w) {
-        uint64_t cur = calive[w] & ~removed[w];
-        while (cur && k < p.max_out) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        uint64_t cur = k < p.max_out ? alive[w] & ~removed[w] : 0ull;
+        while (cur) {
           const int b = __builtin_ctzll(cur);
           const int i = w * 64 + b;
-          csel[k - kept] = (int16_t)i;
+          if (tid == 0) csel[k - kept] = (int16_t)i;
           ++k;
-          removed[0] |= cmask[i * 4 + 0];
-          removed[1] |= cmask[i * 4 + 1];
-          removed[2] |= cmask[i * 4 + 2];
-          removed[3] |= cmask[i * 4 + 3];
+          const int src = i >> 2;
+          uint64_t m[4];
+          switch (i & 3) {
+            case 0:
+#pragma unroll
+              for (int ww = 0; ww < 4; ++ww) m[ww] = uni64(rows[0][ww], src);
+              break;
+            case 1:
+#pragma unroll
+              for (int ww = 0; ww < 4; ++ww) m[ww] = uni64(rows[1][ww], src);
+              break;
+            case 2:
+#pragma unroll
+              for (int ww = 0; ww < 4; ++ww) m[ww] = uni64(rows[2][ww], src);
+              break;
+            default:
+#pragma unroll
+              for (int ww = 0; ww < 4; ++ww) m[ww] = uni64(rows[3][ww], src);
+              break;
+          }
+#pragma unroll
+          for (int ww = 0; ww < 4; ++ww) removed[ww] |= m[ww];
           const uint64_t above = b == 63 ? 0ull : (~0ull << (b + 1));
-          cur = calive[w] & ~removed[w] & above;
+          cur = k < p.max_out ? alive[w] & ~removed[w] & above : 0ull;
         }
       }
-      *kcount = k;
+      if (tid == 0) *kcount = k;
     }
     __syncthreads();
     {
@@ -568,7 +626,9 @@ extern "C" int yv4_nms_images(uint64_t* keys, int64_t key_cap, const int32_t* co
   NmsArgs a;
   a.keys = keys; a.key_cap = key_cap; a.counts = counts; a.max_coord = max_coord; a.boxes = boxes;
   a.boxes_per_image = boxes_per_image; a.labels = labels; a.label_stride = label_stride;
-  a.fused_classes = fused_classes; a.iou_thr = iou_thr; a.iou_form = nms_iou_form(); a.max_out = max_out; a.split_thr = split_thr;
+  a.fused_classes = fused_classes; a.iou_thr = iou_thr; a.iou_form = nms_iou_form(); a.max_out = max_out;
+  static const int nms_ablate = YV4_ENV_INT("YV4_NMS_ABLATE", 0);
+  a.ablate = nms_ablate; a.split_thr = split_thr;
   a.out_dets = out_dets; a.out_labels = out_labels; a.out_index = out_index; a.out_count = out_count;
   static LdsAttrOnce once;
   if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(nms_images_kernel), kNmsLds, "nms_images")) return rc;
