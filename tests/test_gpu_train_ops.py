@@ -226,7 +226,9 @@ def test_detector_with_frozen_stage_and_norm_eval_trains(gpu_device):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [(3, 32, 64, 19, 3, 1), (2, 64, 40, 23, 1, 1), (2, 16, 32, 30, 3, 2), (1, 128, 256, 38, 3, 1),
                                    (4, 32, 64, 250, 3, 1),      # 1 024 tiles: the few-channel 3x3 kernel (16-bit)
-                                   (2, 64, 64, 260, 1, 1)])     # 4 225 strips: the weight-stationary 1x1 kernels
+                                   (2, 64, 64, 260, 1, 1),      # 4 225 strips: the weight-stationary 1x1 kernels
+                                   (8, 128, 256, 152, 3, 2),    # the automatic choice is the general wide-tile kernel (fp32 and 16-bit)
+                                   (16, 128, 128, 76, 3, 1)])   # ... and the wide-tile 3x3 kernel
 def test_conv_epilogue_leaves_the_bn_sums(dtype, shape):
     """yv4_conv_fwd_stats: the conv kernel's epilogue accumulates [sum | sum of squares] of the STORED outputs
     (rounded to the output type) over YV4_STATS_REPLICAS copies; kernels without that epilogue (Cin % 32 != 0 in
