@@ -420,7 +420,7 @@ int conv_wide_h16_launch(const ConvArgsH& a, bool bf16, int shape, hipStream_t s
 // and a tile shape fills the rounds to within YV4_WIDE_MAXWASTE percent (YV4_WIDE=0 switches it off).
 static bool prefer_wide(const ConvArgsH& a) {
   static const int mode = YV4_ENV_INT("YV4_WIDE", 1);
-  static const int waste = YV4_ENV_INT("YV4_WIDE_MAXWASTE", 25);
+  static const int waste = YV4_ENV_INT("YV4_WIDE_MAXWASTE", 35);     // 25 -> 35: YOLOv5-L 640 (256->256 1x1 @40 = 200 tiles of 256 x 256), DESIGN 11.5f
   static const int min_out = YV4_ENV_INT("YV4_WIDE_MINOUT", 32768);
   static const int min_cin = YV4_ENV_INT("YV4_WIDE_MINCIN", 256);
   if (!mode || !conv_wide_h16_applies(a)) return false;
