@@ -69,14 +69,47 @@ struct DecodeArgs {
   int ablate;             // measurement only (YV4_DEC_ABLATE): 1 no sigmoid, 2 no candidate output, 4 no class loop, 8 no box stores
 };
 
+// A workgroup walks kDecTiles consecutive 64-box tiles of one image.  Candidates collect in an LDS key buffer and leave with
+// ONE reservation on the image's counter per workgroup (a returning device-scope atomic per 64 boxes -- 11 400 per step on
+// the 32 words of one cache line at batch 32 -- was most of what the kernel did beyond reading its logits); a tile with
+// more candidates than the buffer holds reserves and writes directly, a full buffer is flushed early.  Two tiles: 121 ->
+// 104 us at batch 32; four 108, eight 128 (the tiles of a workgroup are serial round trips).  Tried and dropped: raw logits
+// in the tile and sigmoids only where a value is used (a box whose conf fails the threshold has no candidate) -- 130 us:
+// on the benchmark's pred maps most boxes pass on conf, and their class scores are then computed twice.
+constexpr int kDecTiles = 2;
+constexpr int kDecKeyBuf = 1024;
+
 __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [64][attr] sigmoid values
+  __shared__ uint64_t kbuf[kDecKeyBuf];
+  __shared__ int wg_count, wg_base, kcnt;
   const int n = blockIdx.y;
-  int lvl = 0;
-  while (lvl + 1 < p.num_levels && (int)blockIdx.x >= p.block_base[lvl + 1]) ++lvl;
   const int attr = 5 + p.C;
+  const int nblocks = p.block_base[p.num_levels];
+  uint64_t* const ikeys = p.keys + (size_t)n * p.key_cap;
+  if (threadIdx.x == 0) kcnt = 0;
+  // the buffered keys leave: one reservation, coalesced stores (uniform: every thread calls it)
+  auto flush = [&]() {
+    const int cnt = kcnt;
+    if (cnt > 0) {
+      if (threadIdx.x == 0) wg_base = atomicAdd(&p.counts[n], cnt);
+      __syncthreads();
+      const int base = wg_base;
+      for (int i = threadIdx.x; i < cnt; i += 256)
+        if (base + i < p.key_cap) ikeys[base + i] = kbuf[i];
+      __syncthreads();
+      if (threadIdx.x == 0) kcnt = 0;
+      __syncthreads();
+    }
+  };
+  float mx_acc = -__builtin_huge_valf();
+  for (int tl = 0; tl < kDecTiles; ++tl) {
+  const int bx = (int)blockIdx.x * kDecTiles + tl;
+  if (bx >= nblocks) break;
+  int lvl = 0;
+  while (lvl + 1 < p.num_levels && bx >= p.block_base[lvl + 1]) ++lvl;
   const int boxes_lvl = p.H[lvl] * p.W[lvl] * p.A;
-  const int b0 = ((int)blockIdx.x - p.block_base[lvl]) * kDecBoxes;  // first box of this workgroup in the level
+  const int b0 = (bx - p.block_base[lvl]) * kDecBoxes;  // first box of this tile in the level
   const int nb = min(kDecBoxes, boxes_lvl - b0);
   const float* src = p.pred[lvl] + ((size_t)n * boxes_lvl + b0) * attr;
   const int nval = nb * attr;
@@ -111,6 +144,7 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   } else {
     for (int i = threadIdx.x; i < nval; i += 256) sm[i] = sigmoid_f32(src[i]);
   }
+  if (threadIdx.x == 0) wg_count = 0;
   __syncthreads();
 
   const int part = threadIdx.x & 3;
@@ -165,13 +199,9 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
   const bool in_topk = !p.topk || ckey <= p.topk[p.topk_per_level ? n * p.num_levels + lvl : n];
   // v3: per-image objectness threshold applied after the top-k (yolo_head.py:366-377, `ge`)
   const bool admitted = live && in_topk && !(p.v3 && p.conf_thr > 0.f && !(cf >= p.conf_thr));
-  // Candidates are appended in two passes so that the per-image counter sees ONE atomic per
-  // workgroup instead of one per candidate (thousands of same-address atomics per image serialise:
-  // the single-pass form spent ~0.5 ms of a 34 ms step there).  Pass 1 counts, the workgroup reserves
-  // a range, pass 2 writes.  The order of keys inside an image's buffer is irrelevant (NMS sorts them).
-  __shared__ int wg_count, wg_base;
-  if (threadIdx.x == 0) wg_count = 0;
-  __syncthreads();
+  // Pass 1 counts this tile's candidates (one LDS atomic per thread that has any), pass 2 writes the keys -- into the
+  // LDS buffer, or straight to the image's key buffer when the tile alone exceeds it.  The order of keys inside an
+  // image's buffer is irrelevant (NMS sorts them).
   int mine = 0;
   if (admitted && !YV4_ABLATE(p.ablate, 4)) {
     if (p.C == 0) {                 // class_agnostic (yolocsp_head.py:357-360): one column, score = conf
@@ -186,34 +216,49 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs p) {
       }
     }
   }
-  if (YV4_ABLATE(p.ablate, 2)) return;
+  if (YV4_ABLATE(p.ablate, 2)) mine = 0;
   int slot = mine ? atomicAdd(&wg_count, mine) : 0;
   __syncthreads();
-  if (threadIdx.x == 0) wg_base = YV4_ABLATE(p.ablate, 16) ? (int)((blockIdx.x * 16) & 1023) : (wg_count ? atomicAdd(&p.counts[n], wg_count) : 0);
-  __syncthreads();
+  const int tc = wg_count;                       // this tile's candidates (uniform)
+  const bool direct = tc > kDecKeyBuf;
+  if (!direct && kcnt + tc > kDecKeyBuf) flush();
+  if (direct) {
+    if (threadIdx.x == 0) wg_base = atomicAdd(&p.counts[n], tc);
+    __syncthreads();
+  }
+  const int base = direct ? wg_base : kcnt;
   if (mine) {
-    slot += wg_base;
+    slot += base;
     if (p.C == 0) {
-      if (slot < p.key_cap) p.keys[(size_t)n * p.key_cap + slot] = ((uint64_t)score_to_key(cf) << 32) | (uint32_t)j;
+      const uint64_t key = ((uint64_t)score_to_key(cf) << 32) | (uint32_t)j;
+      if (!direct) kbuf[slot] = key;
+      else if (slot < p.key_cap) ikeys[slot] = key;
     } else {
       for (int c = part; c < p.C; c += 4) {
-        const float score = s[5 + c] * cf;
-        if ((p.v3 ? s[5 + c] : score) > p.score_thr) {
-          if (slot < p.key_cap) {
-            const uint32_t flat = (uint32_t)j * (uint32_t)p.C + (uint32_t)c;
-            p.keys[(size_t)n * p.key_cap + slot] = ((uint64_t)score_to_key(score) << 32) | flat;
-          }
+        const float sc = s[5 + c];
+        const float score = sc * cf;
+        if ((p.v3 ? sc : score) > p.score_thr) {
+          const uint32_t flat = (uint32_t)j * (uint32_t)p.C + (uint32_t)c;
+          const uint64_t key = ((uint64_t)score_to_key(score) << 32) | flat;
+          if (!direct) kbuf[slot] = key;
+          else if (slot < p.key_cap) ikeys[slot] = key;
           ++slot;
         }
       }
     }
+    mx_acc = fmaxf(mx_acc, fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
   }
+  __syncthreads();                               // the tile's values and `kcnt` have been read by everyone
+  if (threadIdx.x == 0 && !direct) kcnt = base + tc;
+  }  // tiles
+  __syncthreads();
+  flush();
   // boxes.max() over the surviving candidates (mmcv batched_nms): reduced over the wavefront, then over the workgroup's
   // four waves -- ONE atomic per workgroup.  Device-scope atomics on this 8-XCD part execute at the memory side, and the
   // images' maxima are neighbouring words of one cache line: one atomic per wave with a candidate (~35 000 per step at
   // batch 32) was 55 of the kernel's 175 us.  (Reading the running maximum first, to skip atomics that cannot raise it,
   // is slower still: the coherent read of that line queues behind the same atomics -- 153 us read late, 425 read early.)
-  float mx = mine ? fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)) : -__builtin_huge_valf();
+  float mx = mx_acc;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   __shared__ float wg_max[4];
@@ -591,7 +636,7 @@ static int decode_impl(const yv4_level_desc* levels, int num_levels, int N, int 
   a.ablate = ablate;
   const size_t lds = (size_t)kDecBoxes * (5 + num_classes) * sizeof(float);
   YV4_REQUIRE(lds <= 64 * 1024, "decode_filter: num_classes %d too large for the LDS tile", num_classes);
-  hipLaunchKernelGGL(decode_filter_kernel, dim3(blocks, N), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(decode_filter_kernel, dim3((blocks + kDecTiles - 1) / kDecTiles, N), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
   YV4_CHECK_LAUNCH("decode_filter");
   return YV4_OK;
 }
