@@ -66,6 +66,13 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
   const int wn = wave % WAVES_N;
   const int fr = lane & 15;
   const int fq = lane >> 4;
+  // Pixel of MFMA column fr inside its 16-pixel tile.  A ds_read_b128 is served in four groups of 16 lanes that are NOT
+  // contiguous ({0-3, 12-15, 20-27}, ...): a group is eight lanes of one fq reading chunk q and eight of the next reading
+  // chunk q ^ 1.  With pixel = column, the kw = 1 and kw = 2 taps (rows shifted by one and two against the swizzle's
+  // row pairs) put two lanes of a group on one 16-byte slot: SQ_LDS_BANK_CONFLICT was 32 % of the LDS-active cycles.
+  // Columns {0-3, 12-15} take the EVEN pixels and {4-11} the odd ones: the eight lanes that read one chunk then sit on
+  // rows of one parity -- one half of the banks, eight consecutive row pairs, eight different slots -- at every shift.
+  const int pr = fr < 4 ? 2 * fr : (fr >= 12 ? 2 * fr - 16 : 2 * fr - 7);
 
   const u32x4_t rsA = make_rsrc(p.x, x_bytes);
   const u32x4_t rsB = make_rsrc(p.w, w_bytes);
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
   unsigned a_rd[3][2];                       // pixel fragments: tap kw, k step; + pt * 2048 per pixel tile
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
-    const int row = wm * WMr + fr + kw;
+    const int row = wm * WMr + pr + kw;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a_rd[kw][ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ ((row >> 1) & 7)) << 4));
   }
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
     unsigned mask9[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const int m = m0 + wm * WMr + 16 * pt + fr;
+      const int m = m0 + wm * WMr + 16 * pt + pr;
       unsigned mk = 0u;
       if (m < p.M) {
         const int hw = p.H * p.W;
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
     }
     // (kh, c0 now describe group 0 of this workgroup's next tile: reset by the assignments at the top of the loop)
 
-    // ---- epilogue: lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + fr, channels n0 + wn 64 + 16 fq .. + 15 (fp32: four
+    // ---- epilogue: lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + pr, channels n0 + wn 64 + 16 fq .. + 15 (fp32: four
     // 16-byte stores).  Expressions: fmaf(acc, s1, t1) -> act (the contraction-free scalar Mish of the fp32 kernels) ->
     // + residual -> fmaf(., s2, t2) -> act, as conv_mfma_f32.hip's epilogue_tile ----
     const int cl = n0 + wn * 64 + 16 * fq;
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
     for (int u = 0; u < 32; ++u) st[u] = 0.f;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const int m = m0 + wm * WMr + 16 * pt + fr;
+      const int m = m0 + wm * WMr + 16 * pt + pr;
       const bool ok = c_ok && m < p.M;
       float v[16];
 #pragma unroll

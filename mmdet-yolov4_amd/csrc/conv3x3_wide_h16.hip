@@ -83,6 +83,13 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
   const int wn = wave % WAVES_N;
   const int fr = lane & 15;
   const int fq = lane >> 4;
+  // Pixel of MFMA column fr inside its 16-pixel tile.  A ds_read_b128 is served in four groups of 16 lanes that are NOT
+  // contiguous ({0-3, 12-15, 20-27}, ...): a group is eight lanes of one fq reading chunk q and eight of the next reading
+  // chunk q ^ 1.  With pixel = column, the kw = 1 and kw = 2 taps (rows shifted by one and two against the swizzle's
+  // row pairs) put two lanes of a group on one 16-byte slot: SQ_LDS_BANK_CONFLICT was 32 % of the LDS-active cycles.
+  // Columns {0-3, 12-15} take the EVEN pixels and {4-11} the odd ones: the eight lanes that read one chunk then sit on
+  // rows of one parity -- one half of the banks, eight consecutive row pairs, eight different slots -- at every shift.
+  const int pr = fr < 4 ? 2 * fr : (fr >= 12 ? 2 * fr - 16 : 2 * fr - 7);
 
   const u32x4_t rsA = make_rsrc_h(p.x, x_bytes);
   const u32x4_t rsB = make_rsrc_h(p.w, w_bytes);
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
   unsigned a_rd[3][2];                       // pixel fragments: tap kw, k step; + pt * 2048 per pixel tile
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
-    const int row = wm * WMr + fr + kw;
+    const int row = wm * WMr + pr + kw;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a_rd[kw][ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ ((row >> 1) & 7)) << 4));
   }
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
     unsigned mask9[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const int m = m0 + wm * WMr + 16 * pt + fr;
+      const int m = m0 + wm * WMr + 16 * pt + pr;
       unsigned mk = 0u;
       if (m < p.M) {
         const int hw = p.H * p.W;
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
     }
     // (kh, c0 now describe group 0 of this workgroup's next tile: reset by the assignments at the top of the loop)
 
-    // ---- epilogue: lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + fr, channels n0 + wn 64 + 16 fq .. + 15 ----
+    // ---- epilogue: lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + pr, channels n0 + wn 64 + 16 fq .. + 15 ----
     const int cl = n0 + wn * 64 + 16 * fq;
     const bool c_ok = cl + 15 < p.Cout;
     const int ca = c_ok ? cl : 0;
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
     }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const int m = m0 + wm * WMr + 16 * pt + fr;
+      const int m = m0 + wm * WMr + 16 * pt + pr;
       const bool ok = c_ok && m < p.M;
       float v[16];
 #pragma unroll
