@@ -62,14 +62,20 @@ def calibrate_bn(plan, *inputs):
         ones = torch.ones(Cout, device=dev)
         zeros = torch.zeros(Cout, device=dev)
         if op.info['bn1'] is not None:
-            bn, lo, hi = op.info['bn1']
             L.update(d=_copy_desc(d, act1=0, act2=0), s1=ones, t1=zeros, s2=None, t2=None, res=None)
             op.fn(stream)
             torch.cuda.synchronize()
-            _set_stats(bn, lo, hi, _view_tensor(op.info['out']))
-            s, t = bn_affine(bn)
-            saved['s1'].copy_(s[lo:hi].to(dev))
-            saved['t1'].copy_(t[lo:hi].to(dev))
+            # one BatchNorm range, or several behind consecutive output channels (two sibling 1x1 convs in one launch)
+            parts = op.info['bn1'] if isinstance(op.info['bn1'], list) else [op.info['bn1']]
+            raw = _view_tensor(op.info['out'])
+            c0 = 0
+            for bn, lo, hi in parts:
+                _set_stats(bn, lo, hi, raw[:, c0:c0 + hi - lo])
+                s, t = bn_affine(bn)
+                saved['s1'][c0:c0 + hi - lo].copy_(s[lo:hi].to(dev))
+                saved['t1'][c0:c0 + hi - lo].copy_(t[lo:hi].to(dev))
+                c0 += hi - lo
+            assert c0 == Cout
         if op.info['bn2'] is not None:
             bn, lo, hi = op.info['bn2']
             L.update(saved)

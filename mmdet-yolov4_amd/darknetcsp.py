@@ -190,6 +190,33 @@ def emit_bare_conv(plan, conv, x, stage, out=None, name='conv1x1_bare'):
                      bn1=bn)
 
 
+def _fuse_siblings():
+    return os.environ.get('YV4_FUSE_SIBLINGS', '1') != '0'
+
+
+def emit_sibling_pair(plan, x, first, second_conv, second_stage, h, name, bufname):
+    """Two 1x1 convs that read the same tensor -- a ``Conv`` (``first``: conv + BN + act) and a bare ``nn.Conv2d`` whose
+    epilogue is its half of a CSP-level BN (``second_conv`` / ``second_stage``) -- as ONE launch: the input is read once,
+    one launch boundary goes.  A new buffer holds [y1 | y2 | t] (3 h channels): the launch writes channels [h, 3h) =
+    [second's output (the concat's half 1) | first's output (a temporary)], so whatever later produces half 0 never
+    writes what it reads.  Returns (the concat view [y1 | y2], the view of ``first``'s output), or (None, None) when the
+    pair does not fit
+    (darknetcsp.py:67-153: conv1 / conv2 of BottleneckCSP, bottlenecks[0].conv1 / conv2 of BottleneckCSP2)."""
+    s2, t2, a2, bn2 = second_stage
+    s1, t1, a1 = first.stage1()
+    if not (_fuse_siblings() and first.kernel_size == 1 and first.stride == 1 and first.padding == 0 and first.with_norm
+            and second_conv.kernel_size == (1, 1) and second_conv.stride == (1, 1) and second_conv.padding == (0, 0)
+            and second_conv.bias is None and second_conv.groups == 1 and tuple(a1) == tuple(a2)
+            and first.out_channels == h and second_conv.out_channels == h and h % 8 == 0):
+        return None, None
+    buf = plan.new_buf(x.N, x.H, x.W, 3 * h, bufname)
+    w = torch.cat([second_conv.weight.detach(), first.conv.weight.detach()], 0)
+    s = torch.cat([s2.float().cpu(), s1.float().cpu()])
+    t = torch.cat([t2.float().cpu(), t1.float().cpu()])
+    plan.conv(x, w, s, t, a1, out=buf.slice(h, 2 * h), name=name, bn1=[bn2, (first.norm, 0, h)])
+    return buf.slice(0, 2 * h), buf.slice(2 * h, h)
+
+
 def csp_halves(bn, act, hidden):
     """Split the CSP-level BN over the two concat halves (inference only)."""
     s, t = bn_affine(bn)
@@ -262,12 +289,14 @@ class BottleneckCSP(HipModule):
 
     def emit(self, plan, x, out=None):
         h = self.hidden
-        cat = plan.new_buf(x.N, x.H, x.W, 2 * h, 'csp_cat')
         half0, half1 = csp_halves(self.bn, self.csp_act, h)
-        y = self.conv1.emit(plan, x)
+        cat, y = emit_sibling_pair(plan, x, self.conv1, self.conv2, half1, h, 'csp_conv1+2', 'csp_cat')
+        if y is None:
+            cat = plan.new_buf(x.N, x.H, x.W, 2 * h, 'csp_cat')
+            y = self.conv1.emit(plan, x)
+            emit_bare_conv(plan, self.conv2, x, half1, out=cat.slice(h, h), name='csp_conv2')
         y = _emit_chain(plan, self.bottlenecks, y)
         emit_bare_conv(plan, self.conv3, y, half0, out=cat.slice(0, h), name='csp_conv3')
-        emit_bare_conv(plan, self.conv2, x, half1, out=cat.slice(h, h), name='csp_conv2')
         return self.conv4.emit(plan, cat, out=out)
 
     def fwd(self, x):
@@ -312,8 +341,22 @@ class BottleneckCSP2(HipModule):
 
     def emit(self, plan, x, out=None):
         h = self.hidden
-        cat = plan.new_buf(x.N, x.H, x.W, 2 * h, 'csp2_cat')
         half0, half1 = csp_halves(self.bn, self.csp_act, h)
+        if len(self.bottlenecks) > 0 and not self.bottlenecks[0].shortcut:
+            x1 = self.conv1.emit(plan, x)
+            b0 = self.bottlenecks[0]
+            cat, t0 = emit_sibling_pair(plan, x1, b0.conv1, self.conv2, half1, h, 'csp2_conv2+b0', 'csp2_cat')
+            if t0 is not None:
+                last = len(self.bottlenecks) == 1
+                y = b0.conv2.emit(plan, t0, out=cat.slice(0, h) if last else None, post=half0 if last else None)
+                if not last:
+                    _emit_chain(plan, self.bottlenecks[1:], y, out=cat.slice(0, h), post=half0)
+                return self.conv3.emit(plan, cat, out=out)
+            cat = plan.new_buf(x.N, x.H, x.W, 2 * h, 'csp2_cat')
+            _emit_chain(plan, self.bottlenecks, x1, out=cat.slice(0, h), post=half0)
+            emit_bare_conv(plan, self.conv2, x1, half1, out=cat.slice(h, h), name='csp2_conv2')
+            return self.conv3.emit(plan, cat, out=out)
+        cat = plan.new_buf(x.N, x.H, x.W, 2 * h, 'csp2_cat')
         if len(self.bottlenecks) == 0:
             # y1 == x1: conv1 itself produces half 0 (two-stage epilogue) and a private copy for conv2
             x1 = self.conv1.emit(plan, x)

@@ -392,6 +392,36 @@ def _match_dets(got, ref, box_tol=1e-3, score_tol=1e-5):
 
 
 @pytest.mark.parametrize('name', ['tiny_v4', 'tiny_v5'])
+def test_sibling_1x1_convs_as_one_launch_give_the_same_maps(golden, gpu_device, name, monkeypatch):
+    """conv1 / conv2 of a BottleneckCSP and bottlenecks[0].conv1 / conv2 of a BottleneckCSP2 read one tensor: the plans run
+    each pair as ONE conv over the concatenated output channels (``darknetcsp.emit_sibling_pair``).  Same per-element
+    arithmetic: the feature maps of the fused and of the plain plan are equal bit for bit on these shapes (every fp32
+    tile kernel they select sums in the same order), and both match the reference's golden maps."""
+    g = golden(name)
+    det = _build_from_golden(g, name, gpu_device)
+    img = torch.from_numpy(g['img']).to(gpu_device)
+
+    def run(flag):
+        monkeypatch.setenv('YV4_FUSE_SIBLINGS', flag)
+        plan = pkg.Plan(gpu_device)
+        x = plan.add_input_nchw(*img.shape)
+        preds = det.emit(plan, x)
+        for v in preds:
+            plan.add_output_nchw(v)
+        plan.finalize()
+        outs = [o.clone() for o in plan.run(img)]
+        torch.cuda.synchronize()
+        return outs, sum(o.kind == 'conv' for o in plan.ops)
+
+    plain, n_plain = run('0')
+    fused, n_fused = run('1')
+    assert n_fused < n_plain
+    for i, (a, b) in enumerate(zip(plain, fused)):
+        assert torch.equal(a, b), f'{name} pred{i}: {float((a - b).abs().max())}'
+        close(b, g[f'pred{i}'], 1e-4, f'{name} pred{i} (fused plan)')
+
+
+@pytest.mark.parametrize('name', ['tiny_v4', 'tiny_v5'])
 def test_detector_against_reference_golden(golden, gpu_device, name):
     g = golden(name)
     det = _build_from_golden(g, name, gpu_device)

@@ -67,7 +67,9 @@ def test_state_dict_layout_equals_reference(golden, name):
         mod.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, strict=True)
 
 
-def test_v4l_plan_fusion_and_flops():
+@pytest.mark.parametrize('siblings', ['0', '1'])
+def test_v4l_plan_fusion_and_flops(monkeypatch, siblings):
+    monkeypatch.setenv('YV4_FUSE_SIBLINGS', siblings)
     det = pkg.build_detector(V4L).eval()
     plan = pkg.Plan('cpu')
     x = plan.add_input_nchw(1, 3, 608, 608)
@@ -76,8 +78,11 @@ def test_v4l_plan_fusion_and_flops():
     kinds = {}
     for o in plan.ops:
         kinds[o.kind] = kinds.get(o.kind, 0) + 1
-    # 115 convs; no BN / Mish / cat / add launches at all
-    assert kinds == {'to_nhwc': 1, 'conv': 115, 'spp': 1, 'resample': 4, 'reset': 1, 'decode': 1, 'nms': 1}
+    # 115 convs; no BN / Mish / cat / add launches at all.  The eight pairs of 1x1 convs that read one
+    # tensor (conv1 / conv2 of the five BottleneckCSP blocks, bottlenecks[0].conv1 / conv2 of three BottleneckCSP2 blocks)
+    # are one launch each: same FLOPs, 107 launches
+    nconv = 115 if siblings == '0' else 107
+    assert kinds == {'to_nhwc': 1, 'conv': nconv, 'spp': 1, 'resample': 4, 'reset': 1, 'decode': 1, 'nms': 1}
     assert abs(plan.total_flops() / 1e9 - 108.516) < 1e-3
     k3 = sum(o.flops for o in plan.ops if o.kind == 'conv' and o.info['k'] == 3) / 1e9
     assert abs(k3 - 87.513) < 1e-3
@@ -89,7 +94,9 @@ def test_16_bit_plan_fuses_the_first_two_layers_at_finalize(monkeypatch):
     """Host logic of Plan._fuse_stem_down (no launch): a 16-bit plan of YOLOv4-L replaces [repack, fp32 stem, stride-2
     conv] by ONE op that carries their FLOPs, keeps the replaced ops reachable, drops the two intermediate buffers
     from the allocation, and leaves the rest of the launch list alone; YV4_STEM_FUSE=0 and fp32 plans keep the three
-    launches; calibrate_bn refuses a fused plan with a message that says what to do."""
+    launches; calibrate_bn refuses a fused plan with a message that says what to do.  (Sibling 1x1 fusion off: this test
+    counts launches and unallocated buffers of the stem fusion alone.)"""
+    monkeypatch.setenv('YV4_FUSE_SIBLINGS', '0')
     det = pkg.build_detector(V4L).eval()
 
     def build(dtype):
