@@ -441,15 +441,17 @@ class SPPV4(HipModule):
     def emit(self, plan, x, out=None):
         h = self.hidden
         sppcat = plan.new_buf(x.N, x.H, x.W, 4 * h, 'sppv4_poolcat')
-        cat = plan.new_buf(x.N, x.H, x.W, 2 * h, 'sppv4_cat')
         half0, half1 = csp_halves(self.bn, self.csp_act, h)
-        y = self.conv1.emit(plan, x)
+        cat, y = emit_sibling_pair(plan, x, self.conv1, self.conv2, half1, h, 'sppv4_conv1+2', 'sppv4_cat')
+        if y is None:
+            cat = plan.new_buf(x.N, x.H, x.W, 2 * h, 'sppv4_cat')
+            y = self.conv1.emit(plan, x)
+            emit_bare_conv(plan, self.conv2, x, half1, out=cat.slice(h, h), name='sppv4_conv2')
         y = self.conv3.emit(plan, y)
         self.conv4.emit(plan, y, out=sppcat.slice(0, h))
         plan.spp(sppcat, h)
         y = self.conv5.emit(plan, sppcat)
         self.conv6.emit(plan, y, out=cat.slice(0, h), post=half0)
-        emit_bare_conv(plan, self.conv2, x, half1, out=cat.slice(h, h), name='sppv4_conv2')
         return self.conv7.emit(plan, cat, out=out)
 
     def fwd(self, x):
