@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YV4_ABI_VERSION 5
+#define YV4_ABI_VERSION 6
 
 /* error codes */
 #define YV4_OK 0
@@ -286,6 +286,22 @@ int yv4_nms_split(const uint64_t* keys, int64_t n, float max_coord,
 int yv4_nms_set_iou_form(int form);
 int yv4_nms_get_iou_form(void);
 
+/* ---- deterministic mode (ABI 6) ----------------------------------------------------------------
+ * The reference's training step is bit-reproducible run to run wherever torch's is (torch.nn.BatchNorm2d,
+ * mmdet/models/backbones/darknetcsp.py:15-35, sums its statistics in a fixed order); this library's default sums
+ * the BatchNorm statistics, the BatchNorm backward's dbeta / dgamma, the loss sums, the positives' row gradients,
+ * the head's bias gradients, the SPP backward scatter and the gradient norm with atomics in arrival order: equal
+ * to rounding, not to the bit -- and a 110-layer network under batch statistics turns one ulp into percents of
+ * the loss within a hundred steps.  yv4_set_deterministic(1) switches all of those accumulations to 64-bit
+ * FIXED-POINT integer words (integer addition is associative: the result does not depend on the arrival order;
+ * a non-finite or out-of-range addend reads back as NaN) and the gradient norm to per-workgroup partials added
+ * in index order.  With the deterministic weight gradient (yv4_conv_wgrad_det, the default of the Python host)
+ * two runs of a training step from the same state give the same bits.  Process-wide; switch it between steps.
+ * SCRATCH SIZES below ("work", "sums", "dbias", "gpos", "zero_after") are stated for both modes: the
+ * deterministic forms need twice the 64-bit words (hi | lo), so callers allocate the larger size always. */
+int yv4_set_deterministic(int on);
+int yv4_get_deterministic(void);
+
 /* Build candidate keys for the standalone batched_nms op from plain
  * boxes/scores (n candidates of one image): keys[i] = ~bits(score_i)<<32 | i,
  * counts[0] = n, max_coord[0] = max over all box coordinates. */
@@ -306,7 +322,8 @@ int yv4_nms_prepare(const float* boxes, const float* scores, int64_t n,
  *   K-1-p); for stride 2 dY is zero-dilated first:
  * yv4_dilate2_fwd: dst (N,2H,2W,C dense) [n,2y,2x,c] = src[n,y,x,c], zeros elsewhere.
  * yv4_bn_train_stats: per-channel batch mean / 1/sqrt(biased var + eps) of an NHWC view with M
- *   rows; updates running_mean/var (unbiased var, `momentum`) when given. work: 2*C doubles.
+ *   rows; updates running_mean/var (unbiased var, `momentum`) when given. work: 4*C doubles (2*C used unless
+ *   deterministic).
  * yv4_bn_act_fwd:  y = act((x-mean)*invstd*gamma+beta) (+ residual).
  * yv4_bn_act_bwd:  from dy (gradient w.r.t. y), the saved conv output x and the batch
  *   statistics: dx, dgamma, dbeta (the activation is recomputed, nothing else is saved).  */
@@ -461,8 +478,11 @@ int yv4_conv_fwd_stats(const yv4_conv_desc* d, int dtype, const void* x, const v
 int yv4_bn_finalize(double* work, int replicas, int64_t M_total, const double* rows_dev, int C,
                     float eps, float momentum, float* mean, float* invstd, float* running_mean,
                     float* running_var, int clear_work /* zero `work` once read */,
-                    double* zero_after /* NULL, or 2*C doubles to clear for the layer's backward reduction */,
+                    double* zero_after /* NULL, or 4*C doubles to clear for the layer's backward reduction */,
                     void* stream);
+/* The totals of a yv4_conv_fwd_stats buffer as 2*C doubles [sum | sum of squares] (what SyncBN all-reduces before
+ * yv4_bn_finalize(replicas = 1)), in either mode; clear_stats: the replicas are zeroed as they are read. */
+int yv4_conv_stats_fold(double* stats, int C, int clear_stats, double* out, void* stream);
 int yv4_bn_act_bwd_sums(const void* x, int dtype, int x_cstride, int x_coff, const void* dy,
                         int dy_cstride, int dy_coff, const float* mean, const float* invstd,
                         const float* gamma, const float* beta, float* dgamma, float* dbeta,
@@ -548,7 +568,8 @@ int yv4_spp_pool_bwd(const void* xcat, int x_cstride, int x_coff, const void* dc
  *
  * yv4_grad_prepare: GradScaler.unscale_ + clip_grad_norm_(max_norm, 2) folded into one
  *   multiplier.  scale_state = {scale, growth_tracker} on the device or NULL (scale 1);
- *   max_norm <= 0 disables clipping; work: 2 doubles; ctrl (4 floats, device) receives
+ *   max_norm <= 0 disables clipping; work: 2 + YV4_GRAD_PREPARE_MAX_WG doubles (2 used unless deterministic: then
+ *   one partial per workgroup, added in index order); ctrl (4 floats, device) receives
  *   {grad multiplier = clip_coef/scale, total L2 norm of the unscaled gradients,
  *    found_inf (0/1), 1/scale}.
  * yv4_sgd_step: p -= lr*(nesterov ? g + m*b : b), b = m*b + g, g = grad*ctrl[0] + wd*p, with
@@ -557,6 +578,7 @@ int yv4_spp_pool_bwd(const void* xcat, int x_cstride, int x_coff, const void* dc
  *   No-op when ctrl[2] != 0 (GradScaler.step semantics).  ctrl may be NULL (multiplier 1).
  * yv4_loss_scale_update: GradScaler.update for the dynamic loss scale.
  * yv4_ema_update: ema = momentum*ema + (1-momentum)*online over n floats.                */
+#define YV4_GRAD_PREPARE_MAX_WG 2048
 int yv4_grad_prepare(const float* grad, int64_t n, const float* scale_state, float max_norm,
                      double* work, float* ctrl, void* stream);
 int yv4_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
@@ -579,8 +601,10 @@ int yv4_ema_update(float* ema, const float* online, int64_t n, float momentum, v
  *   positive has in the reference's index lists; duplicates of one anchor box resolve to the largest s
  *   (what the reference's index_put gives when run in order), deterministically.
  * work buffers (device): slot_anchor, conf_t: L*5*A*G; winner: N*anchors-per-image int32; npos: L int32;
- *   sums: L*3 double = [sum of class BCE | sum of objectness BCE | sum of (1 - GIoU)] per level;
- *   gpos (backward): L*5*A*G*(5+C) float.
+ *   sums: L*3 double = [sum of class BCE | sum of objectness BCE | sum of (1 - GIoU)] per level, in a buffer of
+ *   2*L*3 doubles; gpos (backward): L*5*A*G*(5+C) float in a buffer of 4x that many floats; dbias: A*(5+C)
+ *   doubles per level in a buffer of twice as many (the second halves are the deterministic mode's lo words;
+ *   results are always the doubles / floats at the front).
  * Losses (host, from sums/npos): cls = w_cls*sum/(npos*C), conf = w_conf*sum/(N*H*W*A), bbox = w_bbox*sum/npos.
  * yv4_yolo_loss_bwd: grad_out (L,3) float (device) = upstream gradients of [cls, conf, bbox] per level. */
 #define YV4_LOSS_MAX_LEVELS 5
@@ -588,7 +612,7 @@ typedef struct yv4_loss_level {
   const void* raw;
   void* draw;          /* backward: gradient of raw, same shape / dtype */
   const float* bias;   /* A*(5+C) */
-  double* dbias;       /* backward: A*(5+C) */
+  double* dbias;       /* backward: A*(5+C) results, 2*A*(5+C) doubles of room */
   int32_t H, W, Cp, stride;
   float base_anchors[8][4];
 } yv4_loss_level;

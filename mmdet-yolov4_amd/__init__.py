@@ -11,7 +11,7 @@ from .registry import (ACTIVATION_LAYERS, ANCHOR_GENERATORS, BACKBONES, BBOX_COD
                        build_bbox_coder, build_detector, build_from_cfg, build_head, build_neck)
 from .bricks import Mish, build_activation_layer, build_norm_layer, wrap_fp16_model
 from .ops import (MishFunction, batched_nms, get_nms_iou_form, mish_backward, mish_forward, multiclass_nms, nms,
-                  set_nms_iou_form)
+                  set_nms_iou_form, set_deterministic, deterministic)
 from .anchor_generator import YOLOAnchorGenerator, YOLOV4AnchorGenerator
 from .bbox_coder import YOLOV4BBoxCoder
 from .darknetcsp import (Bottleneck, BottleneckCSP, BottleneckCSP2, Conv, CSPStage, DarknetCSP, Focus, SPPV4,

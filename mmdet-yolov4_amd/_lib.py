@@ -15,8 +15,9 @@ LIB_PATH = os.environ.get('YV4_LIB_PATH') or os.path.join(LIB_DIR, 'libyv4_hip.s
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 # ---- constants mirrored from include/yv4.h -------------------------------------
-ABI_VERSION = 5
+ABI_VERSION = 6
 STATS_REPLICAS = 64        # YV4_STATS_REPLICAS
+GRAD_PREPARE_MAX_WG = 2048  # YV4_GRAD_PREPARE_MAX_WG
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_MISH, ACT_LEAKY, ACT_SWISH = 0, 1, 2, 3
 NMS_IOU_DIV, NMS_IOU_MUL = 0, 1
@@ -121,6 +122,9 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _vp]),
     'yv4_nms_prepare': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     'yv4_nms_set_iou_form': (C.c_int, [_i]),
+    'yv4_set_deterministic': (C.c_int, [_i]),
+    'yv4_get_deterministic': (C.c_int, []),
+    'yv4_conv_stats_fold': (C.c_int, [_vp, _i, _i, _vp, _vp]),
     'yv4_nms_get_iou_form': (C.c_int, []),
     'yv4_conv_wgrad': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     'yv4_conv_wgrad_workspace': (_sz, [C.POINTER(ConvDesc), _i]),

@@ -17,6 +17,9 @@ void set_error(const char* fmt, ...) {
 
 static std::atomic<int> g_nms_iou_form{YV4_NMS_IOU_DIV};
 int nms_iou_form() { return g_nms_iou_form.load(std::memory_order_relaxed); }
+
+static std::atomic<int> g_deterministic{0};
+bool deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
 }  // namespace yv4
 
 extern "C" int yv4_abi_version(void) { return YV4_ABI_VERSION; }
@@ -29,3 +32,12 @@ extern "C" int yv4_nms_set_iou_form(int form) {
   return YV4_OK;
 }
 extern "C" int yv4_nms_get_iou_form(void) { return yv4::nms_iou_form(); }
+
+// Deterministic mode (yv4_common.h, "deterministic mode"): every floating-point accumulation that meets in atomics runs
+// on fixed-point integer words, so a training step is bit-reproducible run to run.  Process-wide; switch it between
+// steps, not while a statistics buffer filled in the other mode is still waiting for its yv4_bn_finalize.
+extern "C" int yv4_set_deterministic(int on) {
+  yv4::g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed);
+  return YV4_OK;
+}
+extern "C" int yv4_get_deterministic(void) { return yv4::deterministic() ? 1 : 0; }

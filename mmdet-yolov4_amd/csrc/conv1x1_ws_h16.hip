@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if (p.stats && my_n > 0) {
-    double* rep = p.stats + (size_t)(gw & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+    const StatRep rep = stat_rep(p.stats, (unsigned)(gw), p.Cout);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float su = st_su[t], sq = st_sq[t];
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void conv1x1_ws_kernel(ConvArgsH p, 
       sq += __shfl_xor(sq, 32);
       const int c = n0 + t * 32 + r;
       if (h == 0 && c < p.Cout) {
-        atomicAdd(&rep[c], (double)su);
-        atomicAdd(&rep[p.Cout + c], (double)sq);
+        stat_add(rep, c, su);
+        stat_add(rep, p.Cout + c, sq);
       }
     }
   }

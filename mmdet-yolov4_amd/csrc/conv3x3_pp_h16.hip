@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
     // ---- BatchNorm statistics of the tile (training forward, identity epilogue), as conv_mfma_h16.hip ----
     if (p.stats) {
       typedef typename Elem<BF16>::T TS;
-      double* rep = p.stats + (size_t)(tile_m & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+      const StatRep rep = stat_rep(p.stats, (unsigned)(tile_m), p.Cout);
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn) {
         float su = 0.f, sq = 0.f;
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(kP3Threads, 2) void conv3x3_pp_h16_kernel(ConvArgsH
         sq += __shfl_xor(sq, 32);
         const int col = n0 + wn * 64 + jn * 32 + r;
         if (h == 0 && col < p.Cout) {
-          atomicAdd(&rep[col], (double)su);
-          atomicAdd(&rep[p.Cout + col], (double)sq);
+          stat_add(rep, col, su);
+          stat_add(rep, p.Cout + col, sq);
         }
       }
     }

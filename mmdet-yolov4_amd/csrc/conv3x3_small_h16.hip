@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_small_kernel
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (p.stats) {
-    double* rep = p.stats + (size_t)((blockIdx.x * NW + wave) & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+    const StatRep rep = stat_rep(p.stats, (unsigned)((blockIdx.x * NW + wave)), p.Cout);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float su = st_su[t], sq = st_sq[t];
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_small_kernel
       sq += __shfl_xor(sq, 32);
       const int c = t * 32 + r;
       if (h == 0 && c < p.Cout) {
-        atomicAdd(&rep[c], (double)su);
-        atomicAdd(&rep[p.Cout + c], (double)sq);
+        stat_add(rep, c, su);
+        stat_add(rep, p.Cout + c, sq);
       }
     }
   }

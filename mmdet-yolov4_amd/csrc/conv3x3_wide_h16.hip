@@ -416,11 +416,11 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
         idx += bit ? half : 0;
       }
       if (c_ok) {
-        double* rep = p.stats + (size_t)((tile_m * WAVES_M + wm) & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+        const StatRep rep = stat_rep(p.stats, (unsigned)((tile_m * WAVES_M + wm)), p.Cout);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int id = idx + k;            // 0..15: sums, 16..31: sums of squares, of channel cl + (id & 15)
-          atomicAdd(&rep[(id >> 4) * p.Cout + cl + (id & 15)], (double)st[k]);
+          stat_add(rep, (id >> 4) * p.Cout + cl + (id & 15), st[k]);
         }
       }
     }

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
   // BatchNorm statistics of the tile while it is in registers (identity-epilogue training convs; see the same
   // block in conv_mfma_h16.hip)
   if (p.stats) {
-    double* rep = p.stats + (size_t)(tile_m & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+    const StatRep rep = stat_rep(p.stats, (unsigned)(tile_m), p.Cout);
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
       float su = 0.f, sq = 0.f;
@@ -561,8 +561,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
       sq += __shfl_xor(sq, 32);
       const int col = n0 + wn * TN * 32 + jn * 32 + r;
       if (h == 0 && col < p.Cout) {
-        atomicAdd(&rep[col], (double)su);
-        atomicAdd(&rep[p.Cout + col], (double)sq);
+        stat_add(rep, col, su);
+        stat_add(rep, p.Cout + col, sq);
       }
     }
   }
@@ -992,7 +992,7 @@ __global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's out-of-range stage DMAs still write this wave's ring
 
   if (p.stats && my_n > 0) {
-    double* rep = p.stats + (size_t)(gw & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+    const StatRep rep = stat_rep(p.stats, (unsigned)(gw), p.Cout);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float su = st_su[t], sq = st_sq[t];
@@ -1000,8 +1000,8 @@ __global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs
       sq += __shfl_xor(sq, 32);
       const int c = n0 + t * 32 + r;
       if (h == 0 && c < p.Cout) {
-        atomicAdd(&rep[c], (double)su);
-        atomicAdd(&rep[p.Cout + c], (double)sq);
+        stat_add(rep, c, su);
+        stat_add(rep, p.Cout + c, sq);
       }
     }
   }
@@ -1380,6 +1380,8 @@ extern "C" int yv4_conv_bn_act_fwd_splitk(const yv4_conv_desc* d, const float* x
 
 int conv_stats_h16(const yv4_conv_desc* d, int dtype, const void* x, const void* w, const float* ones, const float* zeros,
                    void* y, double* stats, void* stream);
+int bn_partial_sums_replica0(const void* x, int dtype, int64_t M, int C, int x_cstride, int x_coff, double* stats,
+                             void* stream);   // train.hip
 
 // Training-mode convolution feeding a BatchNorm: y = conv(x, w) (identity epilogue, `ones` / `zeros` = Cout unit
 // scales / zero shifts) and the per-channel sums of y for the batch statistics, accumulated by the conv kernel's
@@ -1397,12 +1399,15 @@ extern "C" int yv4_conv_fwd_stats(const yv4_conv_desc* d, int dtype, const void*
     set_error("conv_fwd_stats: memset failed");
     return YV4_E_LAUNCH;
   }
-  if (dtype != YV4_F32) return conv_stats_h16(d, dtype, x, w, ones, zeros, y, stats, stream);
+  // deterministic mode: the kernels receive the pointer with bit 0 set (stat_rep) and fill fixed-point replica pairs
+  double* const kstats = tag_stats(stats);
+  if (dtype != YV4_F32) return conv_stats_h16(d, dtype, x, w, ones, zeros, y, kstats, stream);
   bool done = false;
   const int rc = conv_f32_impl(d, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(w), ones, zeros, nullptr,
-                               nullptr, nullptr, reinterpret_cast<float*>(y), stats, &done, stream);
+                               nullptr, nullptr, reinterpret_cast<float*>(y), kstats, &done, stream);
   if (rc != YV4_OK || done) return rc;
-  return yv4_bn_partial_sums(y, YV4_F32, (int64_t)d->N * d->Ho * d->Wo, d->Cout, d->y_cstride, d->y_coff, stats, stream);
+  // (a tile without the statistics epilogue: one pass over y into replica 0 -- replica pair 0 in deterministic mode)
+  return bn_partial_sums_replica0(y, YV4_F32, (int64_t)d->N * d->Ho * d->Wo, d->Cout, d->y_cstride, d->y_coff, stats, stream);
 }
 
 // The stem of the 16-bit path: fp32 image (NHWC, C padded to 4) and fp32 weights in, fp32 MFMA,

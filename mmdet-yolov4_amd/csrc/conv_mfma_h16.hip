@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
   // YV4_STATS_REPLICAS copies (indexed by the row tile) so that same-address atomics do not serialise.
   if (p.stats) {
     typedef typename Elem<BF16>::T TS;
-    double* rep = p.stats + (size_t)(tile_m & (YV4_STATS_REPLICAS - 1)) * 2 * p.Cout;
+    const StatRep rep = stat_rep(p.stats, (unsigned)(tile_m), p.Cout);
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
       float su = 0.f, sq = 0.f;
@@ -281,8 +281,8 @@ __global__ __launch_bounds__(kHThreads, 2) void conv_mfma_h16_kernel(ConvArgsH p
       sq += __shfl_xor(sq, 32);
       const int col = n0 + wn * TN * 32 + jn * 32 + r;
       if (h == 0 && col < p.Cout) {
-        atomicAdd(&rep[col], (double)su);
-        atomicAdd(&rep[p.Cout + col], (double)sq);
+        stat_add(rep, col, su);
+        stat_add(rep, p.Cout + col, sq);
       }
     }
   }

@@ -47,7 +47,22 @@ struct LossArgs {
   float shape_thr, smooth, ratio, eps, w_cls, w_conf, w_bbox;
   int32_t* slot_anchor; int32_t* winner; int32_t* npos; float* conf_t; float* gpos; double* sums;
   const float* gout;
+  int det;                // yv4_set_deterministic: sums / dbias / gpos are fixed-point words, [hi (n) | lo (n)] each
+  long long gpos_n;       // L * S * attr
 };
+
+// loss sums (3 per level): doubles, or fixed-point words with the lo words 3*L entries further on
+__device__ __forceinline__ void loss_sum_add(const LossArgs& p, int i, double v) {
+  if (p.det) fx_add<kFxStat>(reinterpret_cast<u64_t*>(p.sums) + i, reinterpret_cast<u64_t*>(p.sums) + 3 * p.L + i, v);
+  else atomicAdd(&p.sums[i], v);
+}
+template <int SHIFT>
+__global__ void loss_fx_decode_kernel(double* __restrict__ buf, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64_t* w = reinterpret_cast<const u64_t*>(buf);
+  buf[i] = fx_value<SHIFT>(w[i], w[n + i]);
+}
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
 
@@ -211,8 +226,8 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(LossArgs p) {
     if (lane == 0) {
       if (l != part_l) {          // a wave's slots rarely straddle two levels: flush, then start the new level
         if (part_l >= 0) {
-          if (p.C > 0) atomicAdd(&p.sums[part_l * 3 + 0], (double)part_cls);
-          atomicAdd(&p.sums[part_l * 3 + 2], (double)part_box);
+          if (p.C > 0) loss_sum_add(p, part_l * 3 + 0, (double)part_cls);
+          loss_sum_add(p, part_l * 3 + 2, (double)part_box);
         }
         part_l = l; part_cls = 0.f; part_box = 0.f;
       }
@@ -226,29 +241,40 @@ __global__ __launch_bounds__(256) void yolo_pos_kernel(LossArgs p) {
     const int np = p.npos[l];
     const float k_box = p.gout[l * 3 + 2] * p.w_bbox / (float)np;
     const int wslot = p.winner[img * p.TA + lv.anchor_off + anchor];
-    float* grow = p.gpos + ((size_t)l * S + wslot) * p.attr;
-    if (lane < 4) atomicAdd(&grow[lane], bt.dt[lane] * k_box);
+    const size_t grow0 = ((size_t)l * S + wslot) * p.attr;
+    float* grow = p.gpos + grow0;
+    // several positives of one anchor box add into the winner's row: float atomics in arrival order, or -- deterministic
+    // mode -- integer atomics on fixed-point words (gpos is then 2 * gpos_n 64-bit words)
+    u64_t* ghi = reinterpret_cast<u64_t*>(p.gpos) + grow0;
+    u64_t* glo = ghi + p.gpos_n;
+    if (lane < 4) {
+      if (p.det) fx_add<kFxGrad>(ghi + lane, glo + lane, (double)(bt.dt[lane] * k_box));
+      else atomicAdd(&grow[lane], bt.dt[lane] * k_box);
+    }
     if (p.C > 0) {
       const float k_cls = p.gout[l * 3 + 0] * p.w_cls / ((float)np * (float)p.C);
       for (int c = lane; c < p.C; c += 64) {
         const float x = ldf(row + 5 + c) + bias[5 + c];
-        atomicAdd(&grow[5 + c], (sigmoid_f32(x) - (c == label ? t_on : t_off)) * k_cls);
+        const float gv = (sigmoid_f32(x) - (c == label ? t_on : t_off)) * k_cls;
+        if (p.det) fx_add<kFxGrad>(ghi + 5 + c, glo + 5 + c, (double)gv);
+        else atomicAdd(&grow[5 + c], gv);
       }
     }
   }
   }   // slots of this wave
   if (!BWD && lane == 0 && part_l >= 0) {
-    if (p.C > 0) atomicAdd(&p.sums[part_l * 3 + 0], (double)part_cls);
-    atomicAdd(&p.sums[part_l * 3 + 2], (double)part_box);
+    if (p.C > 0) loss_sum_add(p, part_l * 3 + 0, (double)part_cls);
+    loss_sum_add(p, part_l * 3 + 2, (double)part_box);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void yolo_dense_fwd_kernel(LossArgs p) {
-  __shared__ double part[kLossLevels];
-  if (threadIdx.x < kLossLevels) part[threadIdx.x] = 0.0;
+  __shared__ double part[2 * kLossLevels];     // deterministic mode: hi words, then lo words
+  if (threadIdx.x < 2 * kLossLevels) part[threadIdx.x] = 0.0;
   __syncthreads();
+  u64_t* pw = reinterpret_cast<u64_t*>(part);
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < p.TA * p.N) {
     const int n = fd_div((int)i, p.fd_TA);                 // N * TA < 2^31 (host)
@@ -263,9 +289,21 @@ __global__ __launch_bounds__(256) void yolo_dense_fwd_kernel(LossArgs p) {
     const float x = ldf(reinterpret_cast<const T*>(lv.raw) + ((size_t)n * lv.H * lv.W + cell) * lv.Cp + c) + lv.bias[c];
     const int w = p.winner[i];
     const float tgt = w >= 0 ? p.conf_t[(size_t)l * p.S + w] : 0.f;
-    atomicAdd(&part[l], (double)bce_logits(x, tgt));
+    if (p.det) fx_add<kFxStat>(pw + l, pw + kLossLevels + l, (double)bce_logits(x, tgt));
+    else atomicAdd(&part[l], (double)bce_logits(x, tgt));
   }
   __syncthreads();
+  if (p.det) {
+    if (threadIdx.x < p.L) {
+      u64_t* g = reinterpret_cast<u64_t*>(p.sums);
+      const u64_t h = pw[threadIdx.x], lo = pw[kLossLevels + threadIdx.x];
+      const int i = threadIdx.x * 3 + 1;
+      if (h) atomicAdd(g + i, h);
+      if (lo >> 63) atomicOr(g + 3 * p.L + i, 1ull << 63);
+      if (lo & ~(1ull << 63)) atomicAdd(g + 3 * p.L + i, lo & ~(1ull << 63));
+    }
+    return;
+  }
   if (threadIdx.x < p.L && part[threadIdx.x] != 0.0) atomicAdd(&p.sums[threadIdx.x * 3 + 1], part[threadIdx.x]);
 }
 
@@ -277,11 +315,13 @@ template <> struct Chunk<__bf16> { static constexpr int n = 8; };
 template <typename T>
 __global__ __launch_bounds__(256) void yolo_dense_bwd_kernel(LossArgs p) {
   constexpr int CH = Chunk<T>::n;
-  extern __shared__ float db[];                      // [Cp] bias-gradient partials of the workgroup
+  extern __shared__ float db[];                      // [Cp] bias-gradient partials of the workgroup (det: [2][Cp] words)
+  u64_t* dbw = reinterpret_cast<u64_t*>(db);
   int l = 0;
   while (l + 1 < p.L && (long long)blockIdx.x >= p.lv[l + 1].block0) ++l;
   const LossLv& lv = p.lv[l];
-  for (int c = threadIdx.x; c < lv.Cp; c += 256) db[c] = 0.f;
+  if (p.det) for (int c = threadIdx.x; c < 2 * lv.Cp; c += 256) dbw[c] = 0;
+  else for (int c = threadIdx.x; c < lv.Cp; c += 256) db[c] = 0.f;
   __syncthreads();
   const int cpr = lv.Cp / CH;
   const int rows = p.N * lv.H * lv.W;                      // rows * cpr < 2^31 (host)
@@ -312,9 +352,18 @@ __global__ __launch_bounds__(256) void yolo_dense_bwd_kernel(LossArgs p) {
         const float tgt = w_cached >= 0 ? p.conf_t[(size_t)l * p.S + w_cached] : 0.f;
         v[u] = (sigmoid_f32(x) - tgt) * k_conf;
       } else if (w_cached >= 0) {
-        v[u] = p.gpos[((size_t)l * p.S + w_cached) * p.attr + j];
+        const size_t gi = ((size_t)l * p.S + w_cached) * p.attr + j;
+        if (p.det) {
+          const u64_t* gw = reinterpret_cast<const u64_t*>(p.gpos);
+          v[u] = (float)fx_value<kFxGrad>(gw[gi], gw[p.gpos_n + gi]);
+        } else {
+          v[u] = p.gpos[gi];
+        }
       }
-      if (v[u] != 0.f) atomicAdd(&db[c], v[u]);
+      if (v[u] != 0.f) {
+        if (p.det) fx_add<kFxGrad>(dbw + c, dbw + lv.Cp + c, (double)v[u]);
+        else atomicAdd(&db[c], v[u]);
+      }
     }
     T* dst = reinterpret_cast<T*>(lv.draw) + (size_t)row * lv.Cp + c0;
     alignas(16) T o[CH];
@@ -324,6 +373,17 @@ __global__ __launch_bounds__(256) void yolo_dense_bwd_kernel(LossArgs p) {
   }
   }   // chunks of this workgroup
   __syncthreads();
+  if (p.det) {        // dbias: [hi (A*attr) | lo (A*attr)] words, decoded in place after the launch
+    u64_t* g = reinterpret_cast<u64_t*>(lv.dbias);
+    const int nb = p.A * p.attr;
+    for (int c = threadIdx.x; c < nb; c += 256) {
+      const u64_t h = dbw[c], lo = dbw[lv.Cp + c];
+      if (h) atomicAdd(g + c, h);
+      if (lo >> 63) atomicOr(g + nb + c, 1ull << 63);
+      if (lo & ~(1ull << 63)) atomicAdd(g + nb + c, lo & ~(1ull << 63));
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < p.A * p.attr; c += 256)
     if (db[c] != 0.f) atomicAdd(&lv.dbias[c], (double)db[c]);
 }
@@ -368,6 +428,8 @@ static int fill_args(const yv4_loss_desc* d, LossArgs& a, const char* who) {
   a.w_cls = d->w_cls; a.w_conf = d->w_conf; a.w_bbox = d->w_bbox;
   a.slot_anchor = d->slot_anchor; a.winner = d->winner; a.npos = d->npos; a.conf_t = d->conf_t; a.gpos = d->gpos;
   a.sums = d->sums;
+  a.det = deterministic() ? 1 : 0;
+  a.gpos_n = a.S * a.L * a.attr;
   return YV4_OK;
 }
 
@@ -388,7 +450,7 @@ extern "C" int yv4_yolo_loss_fwd(const yv4_loss_desc* d, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   bool ok = hipMemsetAsync(a.winner, 0xFF, sizeof(int32_t) * a.TA * a.N, s) == hipSuccess;
   ok = ok && hipMemsetAsync(a.npos, 0, sizeof(int32_t) * a.L, s) == hipSuccess;
-  ok = ok && hipMemsetAsync(a.sums, 0, sizeof(double) * 3 * a.L, s) == hipSuccess;
+  ok = ok && hipMemsetAsync(a.sums, 0, sizeof(double) * (a.det ? 6 : 3) * a.L, s) == hipSuccess;
   if (!ok) { set_error("yolo_loss_fwd: memset failed"); return YV4_E_LAUNCH; }
   const long long slots = a.S * a.L;
   if (slots > 0) {
@@ -399,6 +461,7 @@ extern "C" int yv4_yolo_loss_fwd(const yv4_loss_desc* d, void* stream) {
   const long long boxes = a.TA * a.N;
   YV4_LOSS_DISPATCH(d->dtype, hipLaunchKernelGGL(yolo_dense_fwd_kernel<T>, dim3((unsigned)((boxes + 255) / 256)), dim3(256), 0,
                                                  s, a));
+  if (a.det) hipLaunchKernelGGL(loss_fx_decode_kernel<kFxStat>, dim3(1), dim3(256), 0, s, a.sums, 3 * a.L);
   YV4_CHECK_LAUNCH("yolo_loss_fwd");
   return YV4_OK;
 }
@@ -423,17 +486,21 @@ extern "C" int yv4_yolo_loss_bwd(const yv4_loss_desc* d, const float* grad_out, 
     if (nb > 2048) nb = 2048;
     blocks += nb;
     if (a.lv[l].Cp > max_cp) max_cp = a.lv[l].Cp;
-    ok = ok && hipMemsetAsync(a.lv[l].dbias, 0, sizeof(double) * a.A * a.attr, s) == hipSuccess;
+    ok = ok && hipMemsetAsync(a.lv[l].dbias, 0, sizeof(double) * (a.det ? 2 : 1) * a.A * a.attr, s) == hipSuccess;
   }
   const long long slots = a.S * a.L;
-  if (slots > 0) ok = ok && hipMemsetAsync(a.gpos, 0, sizeof(float) * slots * a.attr, s) == hipSuccess;
+  if (slots > 0) ok = ok && hipMemsetAsync(a.gpos, 0, (a.det ? 16 : sizeof(float)) * slots * a.attr, s) == hipSuccess;
   if (!ok) { set_error("yolo_loss_bwd: memset failed"); return YV4_E_LAUNCH; }
   YV4_REQUIRE(blocks < (1LL << 31), "yolo_loss_bwd: too many workgroups");
   if (slots > 0)
     YV4_LOSS_DISPATCH(d->dtype, hipLaunchKernelGGL((yolo_pos_kernel<T, true>), dim3((unsigned)((slots + 4 * kSlotsPerWave - 1) / (4 * kSlotsPerWave))),
                                                   dim3(256), 0, s, a));
   YV4_LOSS_DISPATCH(d->dtype, hipLaunchKernelGGL(yolo_dense_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256),
-                                                 sizeof(float) * max_cp, s, a));
+                                                 (a.det ? 16 : sizeof(float)) * max_cp, s, a));
+  if (a.det)
+    for (int l = 0; l < a.L; ++l)
+      hipLaunchKernelGGL(loss_fx_decode_kernel<kFxGrad>, dim3((a.A * a.attr + 255) / 256), dim3(256), 0, s, a.lv[l].dbias,
+                         a.A * a.attr);
   YV4_CHECK_LAUNCH("yolo_loss_bwd");
   return YV4_OK;
 }

@@ -18,7 +18,9 @@ namespace yv4 {
 // ---------------------------------------------------------------------------------
 // sum of squares (double) + count of non-finite values of a flat fp32 array
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n4, double* __restrict__ work) {
+constexpr int kSumsqMaxWg = YV4_GRAD_PREPARE_MAX_WG;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n4, double* __restrict__ work,
+                                                    int det) {
   // four independent 16-byte loads in flight per thread and four accumulators (one load per trip was a chain of memory
   // round trips: 214 us for the 256 MB of YOLOv4-L's gradients), one atomic per WORKGROUP (device-scope double atomics on
   // one word execute at the memory side, one after the other)
@@ -54,7 +56,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = a; wbad[threadIdx.x >> 6] = bad; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&work[0], (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+    // deterministic mode: the workgroup's partial goes to its own slot, grad_ctrl_kernel adds the slots in index order
+    if (det) work[2 + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    else atomicAdd(&work[0], (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
     const unsigned b = wbad[0] + wbad[1] + wbad[2] + wbad[3];
     if (b) atomicAdd(&work[1], (double)b);
   }
@@ -64,11 +68,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // ctrl[1] = total L2 norm of the unscaled gradients (what the reference logs as grad_norm)
 // ctrl[2] = 1 if any gradient is non-finite (the update and the EMA of this step are skipped)
 // ctrl[3] = 1/scale used
-__global__ void grad_ctrl_kernel(const double* __restrict__ work, const float* __restrict__ scale_state, float max_norm,
-                                 float* __restrict__ ctrl) {
+__global__ __launch_bounds__(64) void grad_ctrl_kernel(const double* __restrict__ work, const float* __restrict__ scale_state,
+                                                       float max_norm, float* __restrict__ ctrl, int det_slots) {
+  // one wave.  det_slots > 0: the sum of squares is the per-workgroup partials work[2 ..], each lane adding its slots in
+  // index order and the lanes combined by a fixed butterfly -- the same bits every run
+  double ss = work[0];
+  if (det_slots > 0) {
+    ss = 0.0;
+    for (int i = threadIdx.x; i < det_slots; i += 64) ss += work[2 + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  }
+  if (threadIdx.x != 0) return;
   const float inv_scale = scale_state ? 1.f / scale_state[0] : 1.f;
   const bool bad = work[1] > 0.0;
-  const float norm = (float)sqrt(work[0]) * inv_scale;
+  const float norm = (float)sqrt(ss) * inv_scale;
   float coef = 1.f;
   if (max_norm > 0.f) {
     // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
@@ -184,12 +198,14 @@ int yv4_grad_prepare(const float* grad, int64_t n, const float* scale_state, flo
     set_error("grad_prepare: memset failed");
     return YV4_E_LAUNCH;
   }
+  const int det = deterministic() ? 1 : 0;
+  unsigned grid = 0;
   if (n > 0) {
-    unsigned grid = stream_grid((n / 4 + 3) / 4);          // four 16-byte words per thread and trip
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, grad, n / 4, work);
+    grid = stream_grid((n / 4 + 3) / 4);          // four 16-byte words per thread and trip
+    if (grid > (unsigned)kSumsqMaxWg) grid = kSumsqMaxWg;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, grad, n / 4, work, det);
   }
-  hipLaunchKernelGGL(grad_ctrl_kernel, dim3(1), dim3(1), 0, s, work, scale_state, max_norm, ctrl);
+  hipLaunchKernelGGL(grad_ctrl_kernel, dim3(1), dim3(64), 0, s, work, scale_state, max_norm, ctrl, det ? (int)grid : 0);
   YV4_CHECK_LAUNCH("grad_prepare");
   return YV4_OK;
 }

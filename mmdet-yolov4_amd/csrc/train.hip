@@ -1187,15 +1187,30 @@ __device__ __forceinline__ RedMap red_map(int C4) {
 
 // Block-level combine of per-thread partials (a: first C values, b: second C values) and one
 // double atomic per channel per workgroup.  part[] lives in LDS: [2][C] doubles.
+// det (yv4_set_deterministic): part[] is [2][2*C] 64-bit words -- hi words of (a | b), then their lo words (fx_add)
+template <int SHIFT>
 __device__ __forceinline__ void red_flush(double* part, int C, int c, const double (&a)[4], const double (&b)[4],
-                                          bool active) {
+                                          bool active, int det) {
   if (active) {
+    u64_t* w = reinterpret_cast<u64_t*>(part);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      atomicAdd(&part[c + k], a[k]);
-      atomicAdd(&part[C + c + k], b[k]);
+      if (det) {
+        fx_add<SHIFT>(w + c + k, w + 2 * C + c + k, a[k]);
+        fx_add<SHIFT>(w + C + c + k, w + 3 * C + c + k, b[k]);
+      } else {
+        atomicAdd(&part[c + k], a[k]);
+        atomicAdd(&part[C + c + k], b[k]);
+      }
     }
   }
+}
+// a workgroup's fixed-point words -> the global accumulator's (the sticky non-finite bit travels as an OR)
+__device__ __forceinline__ void fx_merge(u64_t* ghi, u64_t* glo, u64_t h, u64_t l) {
+  if (h) atomicAdd(ghi, h);
+  if (l >> 63) atomicOr(glo, 1ull << 63);
+  l &= ~(1ull << 63);
+  if (l) atomicAdd(glo, l);
 }
 constexpr int kBnFloatRun = 16;  // unrolled iterations (x4 rows) a thread sums in fp32 before folding into its doubles
 
@@ -1221,10 +1236,10 @@ static inline int bn_rows_per_block(int64_t M) {
 // sums[c] += sum x, sums[C + c] += sum x^2   (double)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t M, int C, int cs, int co,
-                                                       double* __restrict__ sums, int rows_per_block) {
-  extern __shared__ double part[];   // [2][C]
+                                                       double* __restrict__ sums, int rows_per_block, int det) {
+  extern __shared__ double part[];   // [2][C]; det: [4][C] words
   const int C4 = C >> 2;
-  for (int i = threadIdx.x; i < 2 * C; i += 256) part[i] = 0.0;
+  for (int i = threadIdx.x; i < (det ? 4 : 2) * C; i += 256) part[i] = 0.0;
   __syncthreads();
   const RedMap mp = red_map(C4);
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -1255,45 +1270,81 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) { ds[k] += fs[k]; dq[k] += fq[k]; }
-      red_flush(part, C, cq * 4, ds, dq, true);
+      red_flush<kFxStat>(part, C, cq * 4, ds, dq, true, det);
     }
   }
   __syncthreads();
+  if (det) {      // sums: [hi words (2*C) | lo words (2*C)]
+    const u64_t* w = reinterpret_cast<const u64_t*>(part);
+    u64_t* g = reinterpret_cast<u64_t*>(sums);
+    for (int i = threadIdx.x; i < 2 * C; i += 256) fx_merge(g + i, g + 2 * C + i, w[i], w[2 * C + i]);
+    return;
+  }
   for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[i], part[i]);
+}
+// det: the words of [hi (n) | lo (n)] -> n doubles in place (consumers outside the library: SyncBN's all-reduce)
+template <int SHIFT>
+__global__ void fx_decode_kernel(double* __restrict__ buf, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64_t* w = reinterpret_cast<const u64_t*>(buf);
+  buf[i] = fx_value<SHIFT>(w[i], w[n + i]);
 }
 
 // mean / biased var / invstd from the sums; running stats update (unbiased var, momentum)
 // `rows`: optional device-resident row count (SyncBN: the all-reduced count travels with the sums)
 // clear_work: the replicas are zeroed as they are read (a persistent statistics buffer is clean again for the next
-// forward); zero_after: 2*C doubles cleared for the backward reduction of the same layer -- both replace memsets.
+// forward); zero_after: 4*C doubles cleared for the backward reduction of the same layer -- both replace memsets.
 __global__ void bn_finalize_kernel(double* __restrict__ sums, int64_t M_host, int C, float eps, float momentum,
                                    float* mean, float* invstd, float* running_mean, float* running_var,
                                    const double* __restrict__ rows, int replicas, int clear_work,
-                                   double* __restrict__ zero_after) {
+                                   double* __restrict__ zero_after, int det) {
   // 256 threads = 32 channels x 8 replica lanes: a lane adds every 8th replica (independent loads in flight), the 8
   // lanes of a channel combine by shuffle.  (One thread per channel walking 64 replicas was a chain of 128 dependent
   // loads: 18 us per call, 2 ms of the bf16 train step over its 108 BatchNorms.)
   const int c = blockIdx.x * 32 + (threadIdx.x >> 3);
   const int rl = threadIdx.x & 7;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-    for (int r = rl; r < replicas; r += 8) {
-      s1 += sums[(size_t)r * 2 * C + c];
-      s2 += sums[(size_t)r * 2 * C + C + c];
-      if (clear_work) {
-        sums[(size_t)r * 2 * C + c] = 0.0;
-        sums[(size_t)r * 2 * C + C + c] = 0.0;
+  if (det) {
+    // replica PAIRS of fixed-point words (stat_rep / bn_stats_kernel): integer sums over the pairs, any order
+    u64_t h1 = 0, l1 = 0, h2 = 0, l2 = 0;
+    if (c < C) {
+      u64_t* w = reinterpret_cast<u64_t*>(sums);
+      for (int r = rl; r < replicas / 2; r += 8) {
+        u64_t* hp = w + (size_t)(2 * r) * 2 * C;
+        u64_t* lp = hp + 2 * C;
+        fx_fold(h1, l1, hp[c], lp[c]);
+        fx_fold(h2, l2, hp[C + c], lp[C + c]);
+        if (clear_work) { hp[c] = 0; hp[C + c] = 0; lp[c] = 0; lp[C + c] = 0; }
       }
     }
-    if (zero_after && rl == 0) {
-      zero_after[c] = 0.0;
-      zero_after[C + c] = 0.0;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      fx_fold(h1, l1, __shfl_xor(h1, o), __shfl_xor(l1, o));
+      fx_fold(h2, l2, __shfl_xor(h2, o), __shfl_xor(l2, o));
+    }
+    s1 = fx_value<kFxStat>(h1, l1);
+    s2 = fx_value<kFxStat>(h2, l2);
+  } else {
+    if (c < C) {
+      for (int r = rl; r < replicas; r += 8) {
+        s1 += sums[(size_t)r * 2 * C + c];
+        s2 += sums[(size_t)r * 2 * C + C + c];
+        if (clear_work) {
+          sums[(size_t)r * 2 * C + c] = 0.0;
+          sums[(size_t)r * 2 * C + C + c] = 0.0;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
     }
   }
+  if (c < C && zero_after && rl == 0) {      // 4*C words: [dbeta | dgamma] and, in deterministic mode, their lo words
 #pragma unroll
-  for (int o = 4; o > 0; o >>= 1) {
-    s1 += __shfl_xor(s1, o);
-    s2 += __shfl_xor(s2, o);
+    for (int k = 0; k < 4; ++k) zero_after[k * C + c] = 0.0;
   }
   if (c >= C || rl != 0) return;
   const double M = rows ? *rows : (double)M_host;
@@ -1306,6 +1357,30 @@ __global__ void bn_finalize_kernel(double* __restrict__ sums, int64_t M_host, in
     const double unbiased = M > 1 ? var * M / (M - 1) : var;
     running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
     running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+// totals of a conv epilogue's replicas as 2*C doubles (SyncBN: they are all-reduced before the finalize)
+__global__ void stats_fold_kernel(double* __restrict__ sums, int C, int replicas, int clear_work, double* __restrict__ out,
+                                  int det) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * C) return;
+  if (det) {
+    u64_t* w = reinterpret_cast<u64_t*>(sums);
+    u64_t h = 0, l = 0;
+    for (int r = 0; r < replicas / 2; ++r) {
+      u64_t* hp = w + (size_t)(2 * r) * 2 * C + i;
+      fx_fold(h, l, hp[0], hp[2 * C]);
+      if (clear_work) { hp[0] = 0; hp[2 * C] = 0; }
+    }
+    out[i] = fx_value<kFxStat>(h, l);
+  } else {
+    double a = 0.0;
+    for (int r = 0; r < replicas; ++r) {
+      a += sums[(size_t)r * 2 * C + i];
+      if (clear_work) sums[(size_t)r * 2 * C + i] = 0.0;
+    }
+    out[i] = a;
   }
 }
 
@@ -1325,7 +1400,15 @@ struct BnArgs {
   const double* rows; // optional device-resident M_total
   int publish;       // the apply pass writes dgamma / dbeta from `sums` (not when `sums` were all-reduced)
   int red_cg;        // bn_act_bwd_reduce_kernel: channels per workgroup (grid.y groups)
+  int det;           // `sums` holds fixed-point words: [hi (2*C) | lo (2*C)] (yv4_set_deterministic)
 };
+
+// entry i of the backward sums [dbeta (C) | dgamma (C)]
+__device__ __forceinline__ double bn_sum(const BnArgs& p, int i) {
+  if (!p.det) return p.sums[i];
+  const u64_t* w = reinterpret_cast<const u64_t*>(p.sums);
+  return fx_value<kFxGrad>(w[i], w[2 * p.C + i]);
+}
 
 // Elementwise passes use the reductions' thread map too: a thread keeps ONE channel group of V channels (its
 // mean / invstd / gamma / beta live in registers) and walks rows -- no per-element index division,
@@ -1413,7 +1496,7 @@ __global__ __launch_bounds__(256, YV4_BN_RED_WAVES) void bn_act_bwd_reduce_kerne
   const T* px = reinterpret_cast<const T*>(p.x) + p.x_co + cb;
   const T* pdy = reinterpret_cast<const T*>(p.dy) + p.dy_co + cb;
   const int CV = Cl / V;
-  for (int i = threadIdx.x; i < 2 * Cl; i += 256) part[i] = 0.0;
+  for (int i = threadIdx.x; i < (p.det ? 4 : 2) * Cl; i += 256) part[i] = 0.0;
   __syncthreads();
   const RedMap mp = red_map(CV);
   const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
@@ -1473,11 +1556,20 @@ __global__ __launch_bounds__(256, YV4_BN_RED_WAVES) void bn_act_bwd_reduce_kerne
 #pragma unroll
       for (int h = 0; h < V; h += 4) {
         const double ddb[4] = {db[h], db[h + 1], db[h + 2], db[h + 3]}, ddg[4] = {dg[h], dg[h + 1], dg[h + 2], dg[h + 3]};
-        red_flush(part, Cl, c + h, ddb, ddg, true);
+        red_flush<kFxGrad>(part, Cl, c + h, ddb, ddg, true, p.det);
       }
     }
   }
   __syncthreads();
+  if (p.det) {
+    const u64_t* w = reinterpret_cast<const u64_t*>(part);
+    u64_t* g = reinterpret_cast<u64_t*>(p.sums);
+    for (int i = threadIdx.x; i < Cl; i += 256) {
+      fx_merge(g + cb + i, g + 2 * p.C + cb + i, w[i], w[2 * Cl + i]);
+      fx_merge(g + p.C + cb + i, g + 3 * p.C + cb + i, w[Cl + i], w[3 * Cl + i]);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < Cl; i += 256) {
     atomicAdd(&p.sums[cb + i], part[i]);
     atomicAdd(&p.sums[p.C + cb + i], part[Cl + i]);
@@ -1496,12 +1588,13 @@ __global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_bwd_apply_kern
   const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
   if (blockIdx.x == 0 && p.publish) {   // the reduction kernel has completed (stream order): publish dbeta / dgamma as fp32
     for (int i = threadIdx.x; i < p.C; i += 256) {
+      const double sb = bn_sum(p, i), sg = bn_sum(p, p.C + i);
       if (p.publish == 2) {             // accumulate into existing gradients (the parameter's .grad itself)
-        p.dbeta[i] += (float)p.sums[i];
-        p.dgamma[i] += (float)p.sums[p.C + i];
+        p.dbeta[i] += (float)sb;
+        p.dgamma[i] += (float)sg;
       } else {
-        p.dbeta[i] = (float)p.sums[i];
-        p.dgamma[i] = (float)p.sums[p.C + i];
+        p.dbeta[i] = (float)sb;
+        p.dgamma[i] = (float)sg;
       }
     }
   }
@@ -1515,8 +1608,8 @@ __global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_bwd_apply_kern
     for (int k = 0; k < V; ++k) {
       mu[k] = p.mean[c + k]; is[k] = p.invstd[c + k]; ga[k] = p.gamma[c + k]; be[k] = p.beta[c + k];
       k1[k] = ga[k] * is[k];
-      dbm[k] = p.eval_mode ? 0.f : (float)(p.sums[c + k] * invM);
-      dgm[k] = p.eval_mode ? 0.f : (float)(p.sums[p.C + c + k] * invM);
+      dbm[k] = p.eval_mode ? 0.f : (float)(bn_sum(p, c + k) * invM);
+      dgm[k] = p.eval_mode ? 0.f : (float)(bn_sum(p, p.C + c + k) * invM);
     }
     for (int64_t rr = r0 + mp.rsub; rr < r1; rr += (int64_t)mp.rstep * kBnUnroll) {
       typename RV::raw xv[kBnUnroll], gv[kBnUnroll];
@@ -1653,7 +1746,11 @@ constexpr int kSppItems = 16;      // (position, channel) items per thread: H*W*
 template <typename T>
 __global__ __launch_bounds__(256) void spp_pool_bwd_lds_kernel(const T* __restrict__ xcat, int x_cs, int x_co,
                                                                const T* __restrict__ dcat, int d_cs, int d_co,
-                                                               float* __restrict__ dx, int H, int W, int C) {
+                                                               float* __restrict__ dx, int H, int W, int C, int det) {
+  // det (yv4_set_deterministic): the accumulator plane holds 64-bit FIXED-POINT integers with one exponent for the
+  // workgroup -- 2^40 / (the power of two above the largest |gradient| it will add, found by an integer max) -- so the
+  // scatter's atomics are integer adds and the plane's value does not depend on their order.  A non-finite gradient
+  // anywhere in the block makes the block's outputs NaN (the step is skipped by the loss scaler either way).
   typedef SppKey<T> SK;
   typedef typename SK::K K;
   constexpr int CG = SK::CG;
@@ -1663,6 +1760,11 @@ __global__ __launch_bounds__(256) void spp_pool_bwd_lds_kernel(const T* __restri
   K* kb = ka + (size_t)HW * CG;
   K* kc = kb + (size_t)HW * CG;
   float* acc = reinterpret_cast<float*>(kc + (size_t)HW * CG);
+  long long* acc64 = reinterpret_cast<long long*>(acc);
+  __shared__ unsigned smax;
+  if (det && threadIdx.x == 0) smax = 0u;
+  if (det) __syncthreads();
+  unsigned gmax = 0u;
   const int n = blockIdx.y;
   const int cg0 = blockIdx.x * CG;
   const int nc = min(CG, C - cg0);
@@ -1673,6 +1775,7 @@ __global__ __launch_bounds__(256) void spp_pool_bwd_lds_kernel(const T* __restri
   // a thread keeps the same items (i = tid + 256 j) through every pass: their coordinates and their three pool gradients
   // are fetched once, all loads in flight together
   float g[3][kSppItems];
+  float gid0[kSppItems];           // (deterministic mode only)
   short iy[kSppItems], ix[kSppItems];
 #pragma unroll
   for (int j = 0; j < kSppItems; ++j) {
@@ -1683,10 +1786,31 @@ __global__ __launch_bounds__(256) void spp_pool_bwd_lds_kernel(const T* __restri
     ix[j] = (short)(pos - y * W);
     const bool ok = i < items && c < nc;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g[k][j] = ok ? (float)gb[(size_t)pos * d_cs + (size_t)(k + 1) * C + c] : 0.f;
+    for (int k = 0; k < 3; ++k) {
+      g[k][j] = ok ? (float)gb[(size_t)pos * d_cs + (size_t)(k + 1) * C + c] : 0.f;
+      gmax = max(gmax, __float_as_uint(g[k][j]) & 0x7fffffffu);
+    }
     if (i < items) {
       ka[i] = ok ? SK::make(xb[(size_t)pos * x_cs + c], pos) : (K)0;
-      acc[i] = ok ? (float)gb[(size_t)pos * d_cs + c] : 0.f;     // the identity branch's gradient
+      const float gid = ok ? (float)gb[(size_t)pos * d_cs + c] : 0.f;     // the identity branch's gradient
+      if (det) { gid0[j] = gid; gmax = max(gmax, __float_as_uint(gid) & 0x7fffffffu); }
+      else acc[i] = gid;
+    }
+  }
+  double fx_scale = 1.0;
+  bool fx_bad = false;
+  if (det) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gmax = max(gmax, (unsigned)__shfl_xor((int)gmax, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&smax, gmax);
+    __syncthreads();
+    const unsigned mb = smax;
+    fx_bad = mb >= 0x7f800000u;
+    fx_scale = __builtin_ldexp(1.0, 166 - (int)(mb >> 23));      // |g| < 2^(e - 126)  ->  |g * scale| < 2^40
+#pragma unroll
+    for (int j = 0; j < kSppItems; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < items) acc64[i] = fx_bad ? 0ll : (long long)__builtin_rint((double)gid0[j] * fx_scale);
     }
   }
   __syncthreads();
@@ -1729,7 +1853,13 @@ __global__ __launch_bounds__(256) void spp_pool_bwd_lds_kernel(const T* __restri
         }
         out[i] = m;
         const float gv = k == 0 ? g[0][j] : (k == 1 ? g[1][j] : g[2][j]);
-        if (c < nc) atomicAdd(&acc[SK::pos(m) * CG + c], gv);
+        if (c < nc) {
+          if (det) {
+            if (!fx_bad) atomicAdd(reinterpret_cast<u64_t*>(&acc64[SK::pos(m) * CG + c]), (u64_t)(long long)__builtin_rint((double)gv * fx_scale));
+          } else {
+            atomicAdd(&acc[SK::pos(m) * CG + c], gv);
+          }
+        }
       }
     }
     __syncthreads();
@@ -1741,7 +1871,7 @@ __global__ __launch_bounds__(256) void spp_pool_bwd_lds_kernel(const T* __restri
     const int i = threadIdx.x + 256 * j;
     if (i < items) {
       const int pos = i / CG, c = i - pos * CG;
-      if (c < nc) o[(size_t)pos * C + c] = acc[i];
+      if (c < nc) o[(size_t)pos * C + c] = !det ? acc[i] : (fx_bad ? __builtin_nanf("") : (float)((double)acc64[i] / fx_scale));
     }
   }
 }
@@ -2166,24 +2296,28 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
   return finish();
 }
 
-// phase: 0 = sums + finalize (one rank), 1 = sums only (SyncBN: the caller all-reduces `work`)
+// phase: 0 = sums + finalize (one rank), 1 = sums only (SyncBN: the caller all-reduces `work`), 2 = sums only, in the
+// layout of a conv epilogue's replica 0 (fixed-point words stay words)
 static int bn_stats_impl(int dtype, const void* x, int64_t M, int C, int x_cstride, int x_coff, float eps, float momentum,
                          double* work, float* mean, float* invstd, float* running_mean, float* running_var,
                          void* stream, int phase = 0) {
-  YV4_REQUIRE(x && work && (phase == 1 || (mean && invstd)) && M > 0 && C > 0, "bn_train_stats: bad argument");
+  YV4_REQUIRE(x && work && (phase != 0 || (mean && invstd)) && M > 0 && C > 0, "bn_train_stats: bad argument");
   YV4_REQUIRE(dtype == YV4_F32 || dtype == YV4_F16 || dtype == YV4_BF16, "bn_train_stats: dtype must be f32, f16 or bf16");
   YV4_REQUIRE(C % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0, "bn_train_stats: channels must be multiples of 4");
   YV4_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_stats: running stats come together");
   YV4_REQUIRE(C <= 4096, "bn_train_stats: more than 4096 channels");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) { set_error("bn_train_stats: memset failed"); return YV4_E_LAUNCH; }
+  const int det = deterministic() ? 1 : 0;      // work: [hi (2*C) | lo (2*C)] fixed-point words
+  if (hipMemsetAsync(work, 0, sizeof(double) * (det ? 4 : 2) * C, s) != hipSuccess) { set_error("bn_train_stats: memset failed"); return YV4_E_LAUNCH; }
   const int rpb = bn_rows_per_block(M);
   dim3 grid((unsigned)((M + rpb - 1) / rpb));
-  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, grid, dim3(256), sizeof(double) * 2 * C, s,
-                                           reinterpret_cast<const T*>(x), M, C, x_cstride, x_coff, work, rpb));
+  YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, grid, dim3(256), sizeof(double) * (det ? 4 : 2) * C, s,
+                                           reinterpret_cast<const T*>(x), M, C, x_cstride, x_coff, work, rpb, det));
   if (phase == 0)
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, work, M, C, eps, momentum, mean, invstd,
-                       running_mean, running_var, (const double*)nullptr, 1, 0, (double*)nullptr);
+                       running_mean, running_var, (const double*)nullptr, det ? 2 : 1, 0, (double*)nullptr, det);
+  else if (det && phase == 1)     // the caller (SyncBN) all-reduces doubles
+    hipLaunchKernelGGL(fx_decode_kernel<kFxStat>, dim3((2 * C + 255) / 256), dim3(256), 0, s, work, 2 * C);
   YV4_CHECK_LAUNCH("bn_train_stats");
   return YV4_OK;
 }
@@ -2226,7 +2360,10 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
               "bn_act_bwd: channels must be multiples of 4");
   YV4_REQUIRE(C <= 4096, "bn_act_bwd: more than 4096 channels");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (phase != 2 && !work_is_zero && hipMemsetAsync(work, 0, sizeof(double) * 2 * C, s) != hipSuccess) {
+  // deterministic mode: `work` is [hi (2*C) | lo (2*C)] fixed-point words between the reduction and the apply pass of
+  // ONE call; what leaves the library (phase 1) or enters it (phase 2) is doubles
+  const int det = deterministic() && phase != 2 ? 1 : 0;
+  if (phase != 2 && !work_is_zero && hipMemsetAsync(work, 0, sizeof(double) * (det ? 4 : 2) * C, s) != hipSuccess) {
     set_error("bn_act_bwd: memset failed");
     return YV4_E_LAUNCH;
   }
@@ -2234,7 +2371,7 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   a.x = x; a.x_cs = x_cstride; a.x_co = x_coff; a.dy = dy; a.dy_cs = dy_cstride; a.dy_co = dy_coff;
   a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dx_cs = dx_cstride; a.dx_co = dx_coff;
   a.sums = work; a.M = M; a.C = C; a.act = act; a.slope = slope; a.eval_mode = eval_mode;
-  a.dgamma = dgamma; a.dbeta = dbeta;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.det = det;
   a.M_total = phase == 2 ? M_total : M;
   a.publish = phase == 0 ? (accumulate ? 2 : 1) : 0;
   a.rows = phase == 2 ? rows_dev : nullptr;
@@ -2254,9 +2391,10 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
     if (rpb > g_bn_rows_cap) rpb = g_bn_rows_cap;
     r.rows_per_block = (int)rpb;
     const dim3 rgrid((unsigned)((M + rpb - 1) / rpb), (unsigned)groups);
-    YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, V>), rgrid, dim3(256), sizeof(double) * 2 * r.red_cg, s, r));
+    YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, V>), rgrid, dim3(256), sizeof(double) * (det ? 4 : 2) * r.red_cg, s, r));
   }
   if (phase == 1) {
+    if (det) hipLaunchKernelGGL(fx_decode_kernel<kFxGrad>, dim3((2 * C + 255) / 256), dim3(256), 0, s, work, 2 * C);
     hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
     hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
   } else {
@@ -2303,7 +2441,7 @@ extern "C" int yv4_dilate2_fwd(const float* src, float* dst, int N, int H, int W
 }
 
 extern "C" int yv4_bn_train_stats(const float* x, int64_t M, int C, int x_cstride, int x_coff, float eps, float momentum,
-                                  double* work /* 2*C doubles */, float* mean, float* invstd, float* running_mean,
+                                  double* work /* 4*C doubles */, float* mean, float* invstd, float* running_mean,
                                   float* running_var, void* stream) {
   return bn_stats_impl(YV4_F32, x, M, C, x_cstride, x_coff, eps, momentum, work, mean, invstd, running_mean, running_var,
                        stream);
@@ -2332,7 +2470,7 @@ extern "C" int yv4_bn_act_fwd_h16(const void* x, int dtype, int x_cstride, int x
 extern "C" int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, int dy_cstride, int dy_coff,
                               const float* mean, const float* invstd, const float* gamma, const float* beta,
                               float* dx, int dx_cstride, int dx_coff, float* dgamma, float* dbeta,
-                              double* work /* 2*C doubles */, int64_t M, int C, int act, float slope, void* stream) {
+                              double* work /* 4*C doubles */, int64_t M, int C, int act, float slope, void* stream) {
   return bn_bwd_impl(YV4_F32, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
                      dx_coff, dgamma, dbeta, work, M, C, act, slope, stream);
 }
@@ -2342,6 +2480,13 @@ extern "C" int yv4_bn_act_bwd_h16(const void* x, int dtype, int x_cstride, int x
                                   double* work, int64_t M, int C, int act, float slope, void* stream) {
   return bn_bwd_impl(dtype, x, x_cstride, x_coff, dy, dy_cstride, dy_coff, mean, invstd, gamma, beta, dx, dx_cstride,
                      dx_coff, dgamma, dbeta, work, M, C, act, slope, stream);
+}
+
+// yv4_conv_fwd_stats' fallback: the sums of y into the first replica (pair) of a cleared statistics buffer, left in the
+// form yv4_bn_finalize(replicas = YV4_STATS_REPLICAS) reads
+int bn_partial_sums_replica0(const void* x, int dtype, int64_t M, int C, int x_cstride, int x_coff, double* stats,
+                             void* stream) {
+  return bn_stats_impl(dtype, x, M, C, x_cstride, x_coff, 0.f, 0.f, stats, nullptr, nullptr, nullptr, nullptr, stream, 2);
 }
 
 // ---- SyncBN: the same kernels with the cross-rank exchange between their two halves -----------------
@@ -2354,10 +2499,20 @@ extern "C" int yv4_bn_finalize(double* work, int replicas, int64_t M_total, cons
                                int clear_work, double* zero_after, void* stream) {
   YV4_REQUIRE(work && mean && invstd && (rows_dev || M_total > 0) && C > 0 && replicas >= 1, "bn_finalize: bad argument");
   YV4_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come together");
+  // replicas == YV4_STATS_REPLICAS: the buffer a conv epilogue filled (yv4_conv_fwd_stats) -- fixed-point replica pairs
+  // in deterministic mode; any other count: plain doubles (SyncBN's all-reduced totals)
+  const int det = deterministic() && replicas == YV4_STATS_REPLICAS ? 1 : 0;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), work,
                      M_total, C, eps, momentum, mean, invstd, running_mean, running_var, rows_dev, replicas, clear_work ? 1 : 0,
-                     zero_after);
+                     zero_after, det);
   YV4_CHECK_LAUNCH("bn_finalize");
+  return YV4_OK;
+}
+extern "C" int yv4_conv_stats_fold(double* stats, int C, int clear_stats, double* out, void* stream) {
+  YV4_REQUIRE(stats && out && C > 0, "conv_stats_fold: bad argument");
+  hipLaunchKernelGGL(stats_fold_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), stats,
+                     C, YV4_STATS_REPLICAS, clear_stats ? 1 : 0, out, deterministic() ? 1 : 0);
+  YV4_CHECK_LAUNCH("conv_stats_fold");
   return YV4_OK;
 }
 extern "C" int yv4_bn_act_bwd_sums(const void* x, int dtype, int x_cstride, int x_coff, const void* dy, int dy_cstride,
@@ -2435,15 +2590,21 @@ extern "C" int yv4_spp_pool_bwd(const void* xcat, int x_cstride, int x_coff, con
   YV4_REQUIRE((long long)H * W < (1LL << 31), "spp_pool_bwd: H*W does not fit 31 bits");
   const bool f32 = dtype == YV4_F32;
   const int cg = f32 ? SppKey<float>::CG : SppKey<__bf16>::CG;
-  const size_t lds = (size_t)H * W * cg * (3 * (f32 ? 8 : 4) + 4);
+  const int det = deterministic() ? 1 : 0;
+  const size_t lds = (size_t)H * W * cg * (3 * (f32 ? 8 : 4) + (det ? 8 : 4));
   if (lds <= 64 * 1024 && N <= 65535 && (long long)H * W * cg <= 256 * kSppItems) {   // small maps: keys and accumulator LDS-resident
     dim3 grid((unsigned)((C + cg - 1) / cg), (unsigned)N);
     YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(spp_pool_bwd_lds_kernel<T>, grid, dim3(256), lds,
                                              reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(xcat),
                                              x_cstride, x_coff, reinterpret_cast<const T*>(dcat), d_cstride, d_coff, dx, H,
-                                             W, C));
+                                             W, C, det));
     YV4_CHECK_LAUNCH("spp_pool_bwd");
     return YV4_OK;
+  }
+  if (det) {
+    set_error("spp_pool_bwd: deterministic mode needs the LDS-resident form (H*W*%d <= %d, got %dx%d): the large-map "
+              "kernel scatters with float atomics", cg, 256 * kSppItems, H, W);
+    return YV4_E_UNSUPPORTED;
   }
   const size_t total = (size_t)N * H * W * (C / 4);
   YV4_DISPATCH_T(dtype, hipLaunchKernelGGL(spp_pool_bwd_kernel<T>, dim3(ew_grid_t(total)), dim3(256), 0,

@@ -93,6 +93,72 @@ static inline int ensure_dyn_lds(LdsAttrOnce& g, const void* fn, size_t bytes, c
   return YV4_OK;
 }
 
+// ---- deterministic mode (yv4_set_deterministic) -------------------------------
+// Every floating-point sum that meets in atomics (BatchNorm statistics from the conv epilogues, the BatchNorm
+// backward's dbeta / dgamma, the loss sums, the positives' row gradients, the bias gradients, the SPP scatter) is
+// order-dependent in its last bits, and a 110-layer network under batch statistics amplifies one ulp to percents
+// of the loss within a hundred steps.  With the mode on, those accumulators are FIXED-POINT INTEGERS: an addend v
+// becomes round(v * 2^SHIFT) split into two 64-bit words (hi = floor(t / 2^32), lo = t - hi * 2^32 in [0, 2^32)),
+// both added with integer atomics.  Integer addition is associative and commutative, so the result is the same bits
+// whatever the arrival order, the workgroup-to-CU assignment or the replica an addend lands in -- no second pass, no
+// ordered reduction, the kernels keep their structure.  Range |v| < 2^(94 - SHIFT), resolution 2^-SHIFT; a non-finite
+// or out-of-range addend sets bit 63 of the lo word (an idempotent OR: lo sums stay below 2^63 for < 2^31 addends, so
+// no carry ever reaches the bit) and the value reads back as NaN -- overflow stays loud, as in the double path.
+bool deterministic();          // api.hip: the process-wide switch, read by the launchers
+constexpr int kFxStat = 40;    // forward statistics, loss sums: |v| < 1.8e16, resolution 9.1e-13
+constexpr int kFxGrad = 60;    // gradient sums (loss-scaled): |v| < 1.7e10, resolution 8.7e-19
+typedef unsigned long long u64_t;
+
+template <int SHIFT>
+__device__ __forceinline__ void fx_add(u64_t* hi, u64_t* lo, double v) {
+  double t = v * __builtin_ldexp(1.0, SHIFT);
+  if (!(__builtin_fabs(t) < 0x1p94)) {          // NaN, infinity, out of range
+    atomicOr(lo, 1ull << 63);
+    return;
+  }
+  t = __builtin_rint(t);
+  const double h = __builtin_floor(t * 0x1p-32);
+  const double l = t - h * 0x1p32;              // exact, in [0, 2^32)
+  const long long hv = (long long)h;
+  if (hv) atomicAdd(hi, (u64_t)hv);
+  atomicAdd(lo, (u64_t)(long long)l);
+}
+// words -> value.  (hi, lo) may be sums of several accumulators' words (fx_fold).
+template <int SHIFT>
+__device__ __forceinline__ double fx_value(u64_t hi, u64_t lo) {
+  if (lo >> 63) return __builtin_nan("");
+  const long long H = (long long)hi + (long long)(lo >> 32);
+  return ((double)H * 0x1p32 + (double)(lo & 0xffffffffull)) * __builtin_ldexp(1.0, -SHIFT);
+}
+__device__ __forceinline__ void fx_fold(u64_t& hi, u64_t& lo, u64_t h2, u64_t l2) {
+  hi += h2;
+  lo = ((lo & ~(1ull << 63)) + (l2 & ~(1ull << 63))) | ((lo | l2) & (1ull << 63));
+}
+
+// BatchNorm statistics replicas of the conv epilogues: stats = [YV4_STATS_REPLICAS][sum (C) | sum of squares (C)] doubles.
+// The launcher tags bit 0 of the pointer when the mode is on; replicas are then used in PAIRS (even: hi words, odd: lo
+// words, same [sum | sum of squares] layout) -- the buffer keeps its size, bn_finalize_kernel decodes.
+struct StatRep { double* p; int lo_off; };      // lo_off = 0: plain doubles
+__device__ __forceinline__ StatRep stat_rep(double* stats, unsigned idx, int C) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(stats);
+  StatRep r;
+  if (a & 1ull) {
+    r.p = reinterpret_cast<double*>(a & ~7ull) + (size_t)(idx & (YV4_STATS_REPLICAS - 2)) * 2 * C;
+    r.lo_off = 2 * C;
+  } else {
+    r.p = stats + (size_t)(idx & (YV4_STATS_REPLICAS - 1)) * 2 * C;
+    r.lo_off = 0;
+  }
+  return r;
+}
+__device__ __forceinline__ void stat_add(const StatRep& r, int i, float v) {
+  if (r.lo_off) fx_add<kFxStat>(reinterpret_cast<u64_t*>(r.p) + i, reinterpret_cast<u64_t*>(r.p) + r.lo_off + i, (double)v);
+  else atomicAdd(&r.p[i], (double)v);
+}
+static inline double* tag_stats(double* stats) {
+  return deterministic() && stats ? reinterpret_cast<double*>(reinterpret_cast<unsigned long long>(stats) | 1ull) : stats;
+}
+
 // ---- device math -------------------------------------------------------------
 // Mish, mmdet/ops/mish_cuda/src/mish.h:16-18:  x * tanh(x < 20 ? log1p(exp(x)) : x).
 // tanh(log1p(e)) == (e*e + 2e) / (e*e + 2e + 2) exactly, which needs one exp and

@@ -175,7 +175,8 @@ class Fp16GradAccumulateOptimizerHook(Hook):
             self.scale_state = torch.tensor([self.scaler_cfg['init_scale'], 0.], dtype=torch.float32,
                                             device=flat.device)
             self.ctrl = torch.zeros(4, dtype=torch.float32, device=flat.device)
-            self.work = torch.zeros(2, dtype=torch.float64, device=flat.device)
+            # 2 sums + one slot per workgroup of the deterministic mode's gradient norm (include/yv4.h)
+            self.work = torch.zeros(2 + _lib.GRAD_PREPARE_MAX_WG, dtype=torch.float64, device=flat.device)
             if self.distributed and (_world_size() > 1 or os.environ.get('YV4_REDUCER_AT_WORLD1') == '1'):
                 # (YV4_REDUCER_AT_WORLD1=1: build the reducer with one rank too -- tools/train_bench.py --overlap-report
                 # measures where in backward each bucket becomes exchangeable; nothing is exchanged)

@@ -168,6 +168,20 @@ def nms(boxes, scores, iou_threshold, offset=0, score_threshold=0, max_num=-1):
     return dets, keep
 
 
+def set_deterministic(on=True):
+    """``yv4_set_deterministic``: every floating-point sum that meets in atomics (BatchNorm statistics and their backward,
+    loss sums and row gradients, bias gradients, the SPP scatter, the gradient norm) runs on fixed-point integer words or
+    in a fixed order, so a training step gives the same bits run to run (the weight gradient's ordered form is this
+    host's default already).  The counterpart of ``torch.use_deterministic_algorithms`` for the reference's step, whose
+    BatchNorm (torch.nn.BatchNorm2d via mmdet/models/backbones/darknetcsp.py:15-35) is deterministic.  Process-wide;
+    switch it between steps."""
+    check(_lib.lib().yv4_set_deterministic(1 if on else 0), 'yv4_set_deterministic')
+
+
+def deterministic():
+    return bool(_lib.lib().yv4_get_deterministic())
+
+
 def set_nms_iou_form(form):
     """Choose which of mmcv-full 1.3.x's two suppression predicates every NMS launch of this process applies:
     'div' (default) -- ``inter / (Sa + Sb - inter) > thr``, mmcv's CPU kernel and the documented definition of this

@@ -705,7 +705,7 @@ class BNActFunction(torch.autograd.Function):
         M = N * H * W
         dev = x.device
         L = _lib.lib()
-        work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+        work = torch.empty(4 * Cc, dtype=torch.float64, device=dev)     # (4*C: room for the deterministic mode's lo words)
         mean = torch.empty(Cc, dtype=torch.float32, device=dev)
         invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
         rows = None
@@ -714,12 +714,11 @@ class BNActFunction(torch.autograd.Function):
             import torch.distributed as dist
             group = None if sync_group == 'world' else sync_group
             pre = sums
-            sums = torch.empty(2 * Cc + 1, dtype=torch.float64, device=dev)       # [sum | sum of squares | rows]
+            sums = torch.empty(4 * Cc + 1, dtype=torch.float64, device=dev)[:2 * Cc + 1]   # [sum | sum of squares | rows]
             if pre is not None:
-                torch.sum(pre.view(_lib.STATS_REPLICAS, 2 * Cc), dim=0, out=sums[:2 * Cc])
-                if getattr(pre, '_yv4_kept_clean', False):
-                    pre.zero_()
-            else:
+                check(L.yv4_conv_stats_fold(pre.data_ptr(), Cc, 1 if getattr(pre, '_yv4_kept_clean', False) else 0,
+                                            sums.data_ptr(), stream_ptr()), 'yv4_conv_stats_fold')
+            else:       # (works in 4*C doubles: the tensor above is a view of 4*C + 1)
                 check(L.yv4_bn_partial_sums(x.data_ptr(), code, M, Cc, Cc, 0, sums.data_ptr(), stream_ptr()),
                       'yv4_bn_partial_sums')
             sums[2 * Cc:].fill_(float(M))
@@ -734,7 +733,9 @@ class BNActFunction(torch.autograd.Function):
         elif training and isinstance(sums, (list, tuple)):
             # x is a concat buffer whose channel ranges were produced by several convs, each leaving its own sums
             # (``CatSlot`` + ``conv2d(stats=)``): one finalize per range, on the ranges of mean / invstd / running stats
-            bwd_work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+            # (the finalize kernel clears the 4*c words at the pointer it is handed: the ranges' pieces tile the 4*Cc words
+            # of the backward's accumulator)
+            bwd_work = torch.empty(4 * Cc, dtype=torch.float64, device=dev)
             off = 0
             for buf in sums:
                 c = buf.numel() // (2 * _lib.STATS_REPLICAS)
@@ -743,12 +744,12 @@ class BNActFunction(torch.autograd.Function):
                                         running_mean.data_ptr() + 4 * off if running_mean is not None else None,
                                         running_var.data_ptr() + 4 * off if running_var is not None else None,
                                         1 if getattr(buf, '_yv4_kept_clean', False) else 0,
-                                        bwd_work.data_ptr() + 16 * off, stream_ptr()), 'yv4_bn_finalize')
+                                        bwd_work.data_ptr() + 32 * off, stream_ptr()), 'yv4_bn_finalize')
                 off += c
             assert off == Cc, 'the statistics buffers do not cover the concat buffer'
         elif training and sums is not None:
             # the finalize kernel also clears the backward's reduction buffer (and a persistent statistics buffer)
-            bwd_work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+            bwd_work = torch.empty(4 * Cc, dtype=torch.float64, device=dev)
             check(L.yv4_bn_finalize(sums.data_ptr(), _lib.STATS_REPLICAS, M, None, Cc, float(eps), float(momentum),
                                     mean.data_ptr(), invstd.data_ptr(),
                                     running_mean.data_ptr() if running_mean is not None else None,
@@ -811,7 +812,7 @@ class BNActFunction(torch.autograd.Function):
         dx = torch.empty_like(x, memory_format=torch.channels_last)
         dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
         dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
-        work = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+        work = torch.empty(4 * Cc, dtype=torch.float64, device=dev)
         L = _lib.lib()
         gw = gb = None
         if ctx.rows is not None:            # SyncBN: local sums -> all-reduce -> apply with the totals

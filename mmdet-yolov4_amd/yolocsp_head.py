@@ -114,7 +114,7 @@ class YoloLossFunction(torch.autograd.Function):
         winner = torch.empty(N * TA, **i32)
         npos = torch.empty(L, **i32)
         conf_t = torch.empty(max(L * S, 1), dtype=torch.float32, device=dev)
-        sums = torch.empty(L, 3, dtype=torch.float64, device=dev)
+        sums = torch.empty(2, L, 3, dtype=torch.float64, device=dev)[0]   # (second half: deterministic mode's lo words)
         gt = gt.detach().float().contiguous()
         gt_label = gt_label.long().contiguous()
         d.gt, d.gt_label, d.gt_img = gt.data_ptr(), gt_label.data_ptr(), gt_img.data_ptr()
@@ -145,8 +145,9 @@ class YoloLossFunction(torch.autograd.Function):
         dev = raws[0].device
         gout = gout.float().contiguous()
         draws = [torch.empty_like(r) for r in raws]
-        dbias = [torch.empty(A * attr, dtype=torch.float64, device=dev) for _ in range(L)]
-        gpos = torch.empty(max(L * S * attr, 1), dtype=torch.float32, device=dev)
+        # scratch sized for the deterministic mode's fixed-point words (include/yv4.h: 2 x dbias, 4 x gpos)
+        dbias = [torch.empty(2, A * attr, dtype=torch.float64, device=dev)[0] for _ in range(L)]
+        gpos = torch.empty(max(L * S * attr, 1) * (4 if ops.deterministic() else 1), dtype=torch.float32, device=dev)
         for l in range(L):
             d.levels[l].draw, d.levels[l].dbias = draws[l].data_ptr(), dbias[l].data_ptr()
         d.gpos = gpos.data_ptr()

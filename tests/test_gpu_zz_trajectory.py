@@ -1,0 +1,222 @@
+"""Does the 16-bit step TRAIN?  Evidence that does not depend on comparing chaotic curves.
+
+The recipe: YOLOv4-L 608, one fixed batch of 8, SGD-Nesterov with one group per parameter, weight decay on the conv
+weights only, clip 35, dynamic loss scale (mmdet/core/custom_hooks/accum_optim_hooks.py:9-60,
+configs/yolov4/yolov4l_coco_mosaic.py:86-149), lr 1e-3.
+
+Why not curve against curve.  Round 4 asserted "fp16 / bf16 loss curves stay within 5 % of fp32's over 150 steps" and
+went red on the driver's box.  Measured since (profiles/r05_traj_spread.md, one box, three runs per precision, default
+mode): the last-10-step mean of the SAME precision moves 3.5 % (fp32), 5.5 % (fp16), 0.1 % (bf16) run to run, no step
+is skipped and the loss scale never moves -- a randomly initialised 110-layer network under batch-of-8 statistics turns
+the last bit of an atomically summed BatchNorm statistic into percents of the loss within a hundred steps.  A 5 % band
+between two such curves is a coin toss.  This file replaces it with:
+
+  1. ONE fp32 trajectory in deterministic mode (``yv4_set_deterministic``: bit-reproducible, test_gpu_deterministic.py),
+     150 steps; its 30-step block means must fall.
+  2. TEACHER-FORCED gradients: at steps {0, 25, 50, 100, 149} of that trajectory the fp32 weights and running
+     statistics are loaded into an fp16 and a bf16 model and ONE forward + backward runs on the same batch.  No
+     trajectory is followed in 16 bits, so nothing compounds: what is compared is one step's loss and gradient at the
+     SAME point of parameter space.
+  3. every precision's own 150-step run (deterministic mode) trains: block means fall, with the tolerance stated there.
+
+Bounds of (2), stated BEFORE measuring (the measurement is profiles/r05_teacher_forced.md):
+  * the loss of the forward pass: the head sums ~1.1 M objectness terms and ~1 k positives; feature noise of relative
+    size d at the pred maps moves the mean BCE by O(d^2) + O(d / sqrt(n)).  Bound: 1 % (bf16), 0.5 % (fp16).
+  * noise model of the gradient: g16 = b * g32 + n, n uncorrelated with g32, |n| = delta * |g32|.  A WRONG kernel (a
+    missing term, a scale off by 2, a dropped residual) shows in b, the projection coefficient <g16, g32> / <g32, g32>,
+    whatever delta is; rounding noise shows in delta only.  One rounding to a p-bit mantissa per fused layer enters at
+    ~110 layers forward and ~110 backward and is amplified by the batch-statistics chain (test_gpu_fullsize.py: fp32
+    against float64 grows 150 x from the stem to the pred maps): delta is NOT small for bf16 and is calibrated in the
+    test itself -- the PROBE is the fp32 model with its weights rounded once to the 16-bit type (one injection per
+    layer instead of the ~3 of the real step: weights, activations, gradients), same batch, same snapshot.
+    Bounds: delta16 <= 4 * delta_probe + 0.02 per group and globally (2 x for the three-fold injection count, 2 x
+    margin); |b - 1| <= 0.1 + 3 * delta16 / sqrt(64) (a group's projection averages its noise over >= 64 effectively
+    independent directions: every group here has >= 864 elements spread over >= 32 output channels);
+    global norm ratio within sqrt(1 + (4 delta_probe)^2) + 0.05.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import mmdet_yolov4_amd as pkg
+from mmdet_yolov4_amd import hooks as H
+from mmdet_yolov4_amd.optim import build_optimizer
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+SIZE, LR, MOM, WD, CLIP, SCALE = 608, 1e-3, 0.937, 5e-4, 35.0, 65536.0
+STEPS, SNAPS, BATCH = 150, (0, 25, 50, 100, 149), 8
+DT = dict(fp32=torch.float32, fp16=torch.float16, bf16=torch.bfloat16)
+
+
+def _data(batch):
+    img = bench.synthetic_images(batch, SIZE, 1000, DEV)
+    gtb, gtl = bench.synthetic_gts(batch, SIZE, 2000, DEV)
+    return dict(img=img, img_metas=[dict() for _ in range(batch)], gt_bboxes=gtb, gt_labels=gtl)
+
+
+def _model(dtype):
+    torch.manual_seed(0)
+    det = pkg.build_detector(bench.model_cfg('yolov4l'))
+    det.init_weights()
+    det.train().to(DEV)
+    if dtype != torch.float32:
+        pkg.wrap_fp16_model(det, dtype)
+    return det
+
+
+def recipe_run(dtype, steps, batch, snaps=()):
+    """``steps`` optimizer steps of the recipe; returns the losses (BEFORE each update), the skipped-step count and the
+    state dicts at ``snaps`` (state BEFORE step s's update = the state the loss of step s was computed at)."""
+    det = _model(dtype)
+    opt = build_optimizer(det, dict(type='SGD', lr=LR, momentum=MOM, weight_decay=WD, nesterov=True,
+                                    paramwise_cfg=dict(bias_decay_mult=0., norm_decay_mult=0.)))
+    runner = H.Runner(det, opt, max_epochs=1)
+    runner.log_buffer = None
+    hook = H.Fp16GradAccumulateOptimizerHook(accumulation=1, grad_clip=dict(max_norm=CLIP, norm_type=2), loss_scale='dynamic')
+    runner.register_hook(hook, 'ABOVE_NORMAL')
+    data = _data(batch)
+    runner.data_loader = H.BatchSource([data], batch)
+    runner.call_hook('before_run')
+    runner.call_hook('before_train_epoch')
+    losses, states, skipped = [], {}, 0
+    for s in range(steps):
+        if s in snaps:
+            states[s] = {k: v.detach().clone() for k, v in det.state_dict().items()}
+        runner.call_hook('before_train_iter')
+        runner.outputs = det.train_step(data, opt)
+        runner.call_hook('after_train_iter')
+        runner.iter += 1
+        losses.append(float(runner.outputs['log_vars']['loss']))
+        skipped += int(float(hook.ctrl[2]) != 0)
+    return np.array(losses), skipped, states
+
+
+def fp32_trajectory(steps, batch, snaps):
+    losses, skipped, states = recipe_run(torch.float32, steps, batch, snaps)
+    assert skipped == 0
+    return losses, states
+
+
+def _group(name):
+    parts = name.split('.')
+    return '.'.join(parts[:2]) if parts[0] == 'backbone' else parts[0]
+
+
+def _one_step_grads(det, data):
+    for p in det.parameters():
+        p.grad = None
+    out = det.train_step(data, None)
+    (out['loss'] * SCALE).backward()                     # the recipe's loss scale (a power of two: exact)
+    grads = {n: (p.grad.detach().double() / SCALE) for n, p in det.named_parameters()}
+    return float(out['log_vars']['loss']), grads
+
+
+def _round_weights(state, dtype):
+    """conv weights rounded once to ``dtype`` (what the 16-bit model's packed operands hold), everything else untouched"""
+    return {k: (v.to(dtype).to(v.dtype) if v.is_floating_point() and v.dim() == 4 else v) for k, v in state.items()}
+
+
+def teacher_forced_stats(state, batch):
+    """Rows of per-group statistics for fp16 / bf16 (the real 16-bit step) and probe_fp16 / probe_bf16 (fp32 step, weights
+    rounded once), all against the fp32 step at ``state``."""
+    data = _data(batch)
+    res = {}
+    for name, dt, st in (('fp32', torch.float32, state), ('fp16', torch.float16, state), ('bf16', torch.bfloat16, state),
+                         ('probe_fp16', torch.float32, _round_weights(state, torch.float16)),
+                         ('probe_bf16', torch.float32, _round_weights(state, torch.bfloat16))):
+        det = _model(dt)
+        det.load_state_dict(st, strict=True)
+        res[name] = _one_step_grads(det, data)
+        del det
+        torch.cuda.empty_cache()
+    l32, g32 = res['fp32']
+    groups = sorted({_group(n) for n in g32})
+    rows = []
+    for name in ('fp16', 'bf16', 'probe_fp16', 'probe_bf16'):
+        l16, g16 = res[name]
+        row = dict(kind=name, loss32=l32, loss16=l16, groups={})
+        acc = dict(dd=0.0, aa=0.0, bb=0.0, ab=0.0)
+        for g in groups + ['matrix', 'vector']:
+            dd = aa = bb = ab = 0.0
+            for n in g32:
+                if g == 'matrix':
+                    if g32[n].dim() < 2:
+                        continue
+                elif g == 'vector':
+                    if g32[n].dim() >= 2:
+                        continue
+                elif _group(n) != g:
+                    continue
+                a, b = g32[n], g16[n]
+                dd += float((b - a).pow(2).sum())
+                aa += float(a.pow(2).sum())
+                bb += float(b.pow(2).sum())
+                ab += float((a * b).sum())
+            row['groups'][g] = dict(delta=(dd / aa) ** 0.5, cos=ab / (aa * bb) ** 0.5, ratio=(bb / aa) ** 0.5, proj=ab / aa)
+            if g in groups:
+                for k, v in (('dd', dd), ('aa', aa), ('bb', bb), ('ab', ab)):
+                    acc[k] += v
+        row['global'] = dict(delta=(acc['dd'] / acc['aa']) ** 0.5, cos=acc['ab'] / (acc['aa'] * acc['bb']) ** 0.5,
+                             ratio=(acc['bb'] / acc['aa']) ** 0.5, proj=acc['ab'] / acc['aa'])
+        rows.append(row)
+    return rows
+
+
+@pytest.fixture(scope='module')
+def det_mode_module():
+    pkg.set_deterministic(True)
+    yield
+    pkg.set_deterministic(False)
+
+
+@pytest.fixture(scope='module')
+def trajectory(det_mode_module):
+    return fp32_trajectory(STEPS, BATCH, SNAPS)
+
+
+def test_fp32_trajectory_trains(trajectory):
+    losses, _ = trajectory
+    assert np.isfinite(losses).all()
+    blocks = losses.reshape(5, 30).mean(1)
+    print('fp32 every 10th step:', np.round(losses[::10], 3), 'block means', np.round(blocks, 3))
+    assert (np.diff(blocks) < 0).all(), blocks
+    assert losses[-10:].mean() <= 0.95 * losses[:10].mean()
+
+
+@pytest.mark.parametrize('step', SNAPS)
+def test_teacher_forced_16bit_gradients(trajectory, step):
+    _, states = trajectory
+    rows = {r['kind']: r for r in teacher_forced_stats(states[step], BATCH)}
+    for name, loss_tol in (('fp16', 5e-3), ('bf16', 1e-2)):
+        r, pr = rows[name], rows['probe_' + name]
+        print(f'step {step} {name}: loss {r["loss16"]:.5f} vs fp32 {r["loss32"]:.5f}; global {r["global"]} probe {pr["global"]}')
+        assert abs(r['loss16'] - r['loss32']) <= loss_tol * r['loss32'], (name, r['loss16'], r['loss32'])
+        for g, st in list(r['groups'].items()) + [('global', r['global'])]:
+            dp = pr['global']['delta'] if g == 'global' else pr['groups'][g]['delta']
+            print(f'    {g:32s} delta {st["delta"]:.4f} (probe {dp:.4f}) cos {st["cos"]:.4f} ratio {st["ratio"]:.4f} proj {st["proj"]:.4f}')
+            assert st['delta'] <= 4 * dp + 0.02, (name, g, st, dp)
+            assert abs(st['proj'] - 1) <= 0.1 + 3 * st['delta'] / 8, (name, g, st)
+        dpg = pr['global']['delta']
+        assert abs(r['global']['ratio'] - 1) <= (1 + (4 * dpg) ** 2) ** 0.5 - 1 + 0.05, (name, r['global'], dpg)
+
+
+@pytest.mark.parametrize('name', ['fp16', 'bf16'])
+def test_16bit_runs_train(det_mode_module, name):
+    """Every precision's own 150-step run: finite, no skipped step at this loss scale, the 30-step block means fall.
+    Tolerance from the measured run-to-run spread of a block mean in the DEFAULT mode (profiles/r05_traj_spread.md, three
+    runs per precision on one box): <= 0.4 % for blocks 1-4, 1.9 % (fp32) / 3.2 % (fp16) / 0.05 % (bf16) for the last;
+    consecutive blocks fall by 1.4-2 %.  A block may therefore rise by at most 3 x 0.4 % = 1.2 % over its predecessor,
+    and the last block must end >= 4 % below the first (measured: 5.5-9.6 % in all nine runs)."""
+    losses, skipped, _ = recipe_run(DT[name], STEPS, BATCH)
+    assert np.isfinite(losses).all() and skipped == 0
+    blocks = losses.reshape(5, 30).mean(1)
+    print(name, 'every 10th step:', np.round(losses[::10], 3), 'block means', np.round(blocks, 3))
+    assert (np.diff(blocks) <= 3 * 0.012 * blocks[:-1]).all(), blocks
+    assert blocks[-1] <= 0.96 * blocks[0], blocks
