@@ -174,7 +174,7 @@ def test_det_train_step_matches_reference(golden, det_mode):
 
 
 def _recipe_steps(dtype, steps, batch, model='yolov4l', size=608):
-    """tests/test_gpu_trajectory.py's recipe (SGD-Nesterov per-parameter groups, clip 35, dynamic loss scale) for a few
+    """tests/test_gpu_zz_trajectory.py's recipe (SGD-Nesterov per-parameter groups, clip 35, dynamic loss scale) for a few
     optimizer steps; returns the losses and the whole flat state (parameters, momentum, buffers)."""
     torch.manual_seed(0)
     det = pkg.build_detector(bench.model_cfg(model))

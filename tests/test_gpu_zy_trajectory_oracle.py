@@ -9,10 +9,9 @@ trajectory on a fixed batch), lr 1e-3.
   * fp32 HIP vs the ORACLE (oracle/yolov4_oracle.forward_train + torch autograd + the hooks oracle's clip / SGD on the
     CPU, the arithmetic the golden fixtures pin to the reference) in float32 and float64: batch 2, the first
     ORACLE_STEPS optimizer steps, anchored on the float64 run (the trajectory is chaotic: see the test);
-  * fp32 / fp16 / bf16 HIP: one fixed batch of 8, STEPS optimizer steps from the same initialisation.  Every run must
-    train (last-10 mean >= 5 % below the first-10 mean, 30-step block means strictly falling), the 16-bit runs' final
-    loss within 5 % of the fp32 run's and their curves within 5 % of the fp32 curve at every tenth step (smoothed over
-    5 steps).  Measured: final 16.09 fp32 / 16.28 fp16 / 16.43 bf16."""
+  * (round 4's second test -- fp16 / bf16 150-step curves within 5 % of fp32's -- compared samples of a chaotic family
+    whose run-to-run spread on ONE box is 3.5-5.5 % (profiles/r05_traj_spread.md) and went red on the driver's box; it
+    is replaced by tests/test_gpu_zz_trajectory.py: deterministic fp32 trajectory + teacher-forced 16-bit gradients.)"""
 import os
 import sys
 
@@ -32,7 +31,7 @@ import bench  # noqa: E402
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 SIZE, LR, MOM, WD, CLIP = 608, 1e-3, 0.937, 5e-4, 35.0
-STEPS, ORACLE_STEPS = 150, 4
+ORACLE_STEPS = 4
 
 
 def _data(batch, dev):
@@ -114,26 +113,3 @@ def test_fp32_hip_trajectory_tracks_the_oracle():
     print('oracle32 vs 64:', e_cpu)
     assert e_hip[0] <= 1e-5 and e_hip[1] <= 1e-4                 # the first step and the first UPDATE are the recipe's
     assert (e_hip <= 3 * e_cpu + 1e-4).all(), (e_hip, e_cpu)
-
-
-def test_16bit_trajectories_track_fp32():
-    runs = {}
-    for name, dt in (('fp32', torch.float32), ('fp16', torch.float16), ('bf16', torch.bfloat16)):
-        runs[name], _ = _hip_run(dt, STEPS, 8)
-        assert np.isfinite(runs[name]).all(), name
-        print(name, 'every 10th step:', np.round(runs[name][::10], 3), 'last', round(float(runs[name][-1]), 3))
-    first = {k: float(v[:10].mean()) for k, v in runs.items()}
-    last = {k: float(v[-10:].mean()) for k, v in runs.items()}
-    print('first-10 mean', first, 'last-10 mean', last)
-    for k, v in runs.items():
-        # every precision trains on the fixed batch: 17.66 -> 16.09 (fp32), 16.28 (fp16), 16.43 (bf16) measured over the
-        # 150 steps of this lr = 1e-3, clip-35 recipe; the means of consecutive 30-step blocks fall strictly
-        assert last[k] <= 0.95 * first[k], (k, first[k], last[k])
-        blocks = v.reshape(5, 30).mean(1)
-        assert (np.diff(blocks) < 0).all(), (k, blocks)
-    sm = {k: np.convolve(v, np.ones(5) / 5, mode='valid') for k, v in runs.items()}
-    for k in ('fp16', 'bf16'):
-        assert abs(last[k] - last['fp32']) <= 0.05 * last['fp32'], (k, last)
-        dev = np.abs(sm[k][::10] - sm['fp32'][::10]) / sm['fp32'][::10]
-        print(k, 'smoothed curve vs fp32, every 10th step:', np.round(dev, 4))
-        assert dev.max() <= 0.05, (k, dev)

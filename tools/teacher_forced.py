@@ -1,6 +1,6 @@
 """Teacher-forced gradient comparison along ONE fp32 trajectory (VERDICT round 4, item 1 iii): the measurement behind
 tests/test_gpu_zz_trajectory.py.  Deterministic mode on; YOLOv4-L 608, fixed batch of 8, the recipe of
-tests/test_gpu_trajectory.py.  At the snapshot steps the fp32 weights are loaded into an fp32 / fp16 / bf16 model and
+tests/test_gpu_zz_trajectory.py.  At the snapshot steps the fp32 weights are loaded into an fp32 / fp16 / bf16 model and
 ONE forward + backward is run: per parameter group the relative distance, cosine, norm ratio and projection of the
 16-bit gradient on the fp32 one -- and the same for an fp32 model whose weights carry one 16-bit rounding (the probe).
 

@@ -1,4 +1,4 @@
-"""Run-to-run spread of the 150-step recipe trajectory (tests/test_gpu_trajectory.py's recipe: YOLOv4-L 608, one fixed
+"""Run-to-run spread of the 150-step recipe trajectory (tests/test_gpu_zz_trajectory.py's recipe: YOLOv4-L 608, one fixed
 batch of 8, SGD-Nesterov lr 1e-3, clip 35, dynamic loss scale): every precision REPS times in ONE process on ONE box,
 per step loss / skipped flag / loss scale.  Prints one JSON line per run and a summary; `--det` turns the library's
 deterministic mode on first.
