@@ -584,9 +584,11 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
     return mk;
   };
 
-  s16x8_t fa[2][2], fb[2][3];                        // fragment sets: step s computes from set s & 1
+  // measurement-only bits (YV4_W3_ABLATE): 1 no MFMAs, 2 no fragment reads, 4 no DMA after the prologue, 8 no border
+  // masks, 16 no output
+  s16x8_t fa[2][2] = {}, fb[2][3] = {};              // fragment sets: step s computes from set s & 1
 #define YV4_W3_LOAD(SET, BUFP, S, MK)                                                                         \
-  {                                                                                                           \
+  if (!YV4_ABLATE(p.ablate, 2)) {                                                                             \
     const char* db_ = (BUFP);                                                                                 \
     _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                           \
       const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(db_ + d_rd[a][S][0]));           \
@@ -607,6 +609,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
   {                                                                                                           \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                             \
       _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                      \
+        if (YV4_ABLATE(p.ablate, 1)) { acc[a][kw][0] += __builtin_bit_cast(float, (int)(fa[SET][a][0] + fb[SET][kw][0])); continue; } \
         if (BF16)                                                                                             \
           acc[a][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, fa[SET][a]),      \
                                                                __builtin_bit_cast(bf16x8_w, fb[SET][kw]), acc[a][kw], 0, 0, 0); \
@@ -635,11 +638,12 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
   for (int sl = 0; sl < nsl; ++sl) {
     const char* bufp = smem_w3 + (sl & (kW3NBuf - 1)) * kW3BufBytes;
     const char* nbufp = smem_w3 + ((sl + 1) & (kW3NBuf - 1)) * kW3BufBytes;
-    const unsigned mkn = slice_masks(sl + 1);
+    const unsigned mkn = YV4_ABLATE(p.ablate, 8) ? 0xFFFFFFu : slice_masks(sl + 1);
     YV4_W3_LOAD(1, bufp, 1, mk);
     __builtin_amdgcn_sched_barrier(0);
     YV4_W3_MFMA(0);
-    issue(sl + 3, nsl);                               // into the buffer slice sl - 1 read (freed by the previous barrier)
+    if (!YV4_ABLATE(p.ablate, 4)) issue(sl + 3, nsl);   // into the buffer slice sl - 1 read (freed by the previous barrier)
+    else issue(nsl, nsl);                             // (the counted waits need the instruction count: all lanes out of range)
     __builtin_amdgcn_sched_barrier(0);
     YV4_W3_LOAD(0, bufp, 2, mk);
     __builtin_amdgcn_sched_barrier(0);
@@ -662,6 +666,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
 
   // D[row = co][col = ci]: row = (e&3) + 8*(e>>2) + 4*(lane>>5), col = lane&31
   const int r = lane & 31, h5 = lane >> 5;
+  if (YV4_ABLATE(p.ablate, 16) && acc[0][0][0] != 123.f) return;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1640,6 +1645,319 @@ __global__ __launch_bounds__(256, YV4_BN_APPLY_WAVES) void bn_act_bwd_apply_kern
 }
 
 // ---------------------------------------------------------------------------------
+// The three BatchNorm + Mish row passes for 16-bit maps, second form (round 5).  The general kernels above were measured
+// at 5.3 / 5.5 / 7.1 ms per bf16 step and priced at "~35 issue slots per element"; the disassembly says otherwise: the
+// Mish derivative is 15 packed fp32 operations, 4 transcendentals (8 issue cycles each on this part, not 16), 6 scalar
+// compare / select / min and 4 conversions per PAIR of elements = ~150 issue cycles per pair and wave, 2.7 ms per pass on
+// the whole chip -- and 4 bytes per element at 5.5 TB/s are 4.2 ms.  The passes run at neither roof but at most of their
+// SUM: a wave loads its rows, waits, computes, stores, and 4-5 waves per SIMD do not cover one another's waits.  Here:
+//   * the row loop is software-pipelined: the loads of rows i + U .. i + 2U are in flight while rows i .. i + U are
+//     computed (two register sets, the loop unrolled by two so that no set is ever copied);
+//   * per-channel constants are folded (z = A x + B with A = gamma * invstd, B = beta - mean * A; the backward's
+//     dx = k1 g + (c1 x + c0)): 2-5 registers per channel instead of 3-7, one fma instead of subtract + multiply + fma;
+//   * Mish and its derivative clamp the exponent's argument instead of selecting the asymptote afterwards (for z >= 20 the
+//     expressions round to z and to 1 by themselves): two v_min per pair instead of two compares and two selects;
+//   * no run-time activation switch inside the loops (Mish only; anything else stays on the general kernels).
+// 16-bit outputs are the fp32 expression rounded once; against the general kernels they differ by the re-association of
+// the affine map (<= 1 ulp of the 16-bit type, tests/test_gpu_train_ops.py::test_bn16_*).  fp32 maps never come here.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ f32x2_t exp_clamped2(f32x2_t z) {       // e^min(z, 20)
+  f32x2_t zc;
+  zc.x = fminf(z.x, 20.f); zc.y = fminf(z.y, 20.f);
+  const f32x2_t t = zc * 1.44269504088896340736f;
+  f32x2_t e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  return e;
+}
+__device__ __forceinline__ f32x2_t mish_fwd2c(f32x2_t z) {          // z n / (n + 2), n = e (e + 2)
+  const f32x2_t e = exp_clamped2(z);
+  const f32x2_t n = e * (e + 2.f);
+  const f32x2_t d = n + 2.f;
+  f32x2_t r;
+  r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+  return z * (n * r);
+}
+__device__ __forceinline__ f32x2_t mish_grad2c(f32x2_t z) {         // 1 - u + z a e u^2, a = 1 + e, u = 2 / (a^2 + 1)
+  f32x2_t zc;
+  zc.x = fminf(z.x, 20.f); zc.y = fminf(z.y, 20.f);
+  const f32x2_t t = zc * 1.44269504088896340736f;
+  f32x2_t e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2_t a = e + 1.f;
+  const f32x2_t w = __builtin_elementwise_fma(a, a, splat2(1.f));
+  f32x2_t iw;
+  iw.x = __builtin_amdgcn_rcpf(w.x); iw.y = __builtin_amdgcn_rcpf(w.y);
+  const f32x2_t u = iw + iw;
+  return __builtin_elementwise_fma(zc * (a * e), u * u, splat2(1.f) - u);
+}
+
+template <typename T, int V, int U>
+__global__ __launch_bounds__(256) void bn16_fwd_kernel(BnArgs p) {
+  typedef RowVec<T, V> RV;
+  typedef typename RV::raw raw;
+  const T* px = reinterpret_cast<const T*>(p.x);
+  const T* pres = reinterpret_cast<const T*>(p.res);
+  T* py = reinterpret_cast<T*>(p.y);
+  const int CV = p.C / V;
+  const RedMap mp = red_map(CV);
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+  const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
+  if (!mp.active) return;
+  const bool has_res = pres != nullptr;
+  const int64_t step = (int64_t)mp.rstep * U;
+  for (int cq = mp.cq0; cq < CV; cq += mp.cq_step) {
+    const int c = cq * V;
+    f32x2_t A[V / 2], B[V / 2];
+#pragma unroll
+    for (int k = 0; k < V; k += 2) {
+      A[k / 2].x = p.invstd[c + k] * p.gamma[c + k];
+      A[k / 2].y = p.invstd[c + k + 1] * p.gamma[c + k + 1];
+      B[k / 2].x = p.beta[c + k] - p.mean[c + k] * A[k / 2].x;
+      B[k / 2].y = p.beta[c + k + 1] - p.mean[c + k + 1] * A[k / 2].y;
+    }
+    // (no range checks in here: a select between a loaded value and zero makes the wave wait for the load where it is
+    // ISSUED, which is exactly what the pipeline is there to avoid -- the main loop only runs on whole stages)
+    auto load = [&](int64_t rr, raw (&xv)[U], raw (&rv)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t row = rr + (int64_t)u * mp.rstep;
+        xv[u] = RV::ld(px + row * p.x_cs + p.x_co + c);
+        rv[u] = has_res ? RV::ld(pres + row * p.r_cs + p.r_co + c) : RV::zero();
+      }
+    };
+    auto work = [&](int64_t rr, const raw (&xv)[U], const raw (&rv)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t row = rr + (int64_t)u * mp.rstep;
+        float o[V];
+#pragma unroll
+        for (int k = 0; k < V; k += 2) {
+          f32x2_t x2, r2;
+          x2.x = (float)xv[u][k]; x2.y = (float)xv[u][k + 1];
+          r2.x = (float)rv[u][k]; r2.y = (float)rv[u][k + 1];
+          const f32x2_t y2 = mish_fwd2c(__builtin_elementwise_fma(x2, A[k / 2], B[k / 2])) + r2;
+          o[k] = y2.x; o[k + 1] = y2.y;
+        }
+        RV::st(py + row * p.y_cs + p.y_co + c, o);
+      }
+    };
+    raw xa[U], ra[U], xb[U], rb[U];
+    int64_t rr = r0 + mp.rsub;
+    const int64_t span = (int64_t)(2 * U - 1) * mp.rstep;      // a double stage starting at rr touches rows rr .. rr + span
+    if (rr + span < r1) {
+      load(rr, xa, ra);
+      for (;;) {
+        load(rr + step, xb, rb);
+        work(rr, xa, ra);
+        const int64_t nx = rr + 2 * step;
+        const bool more = nx + span < r1;
+        load(more ? nx : rr, xa, ra);      // (always issued -- past the end it re-reads this stage: a branch here makes the
+                                             // compiler wait for EVERY load at the join, the next stage's included)
+        work(rr + step, xb, rb);
+        rr = nx;
+        if (!more) break;
+      }
+    }
+    for (; rr < r1; rr += mp.rstep) {                           // the rows that do not fill a double stage
+      const raw xv = RV::ld(px + rr * p.x_cs + p.x_co + c);
+      const raw rv = has_res ? RV::ld(pres + rr * p.r_cs + p.r_co + c) : RV::zero();
+      float o[V];
+#pragma unroll
+      for (int k = 0; k < V; k += 2) {
+        f32x2_t x2, r2;
+        x2.x = (float)xv[k]; x2.y = (float)xv[k + 1];
+        r2.x = (float)rv[k]; r2.y = (float)rv[k + 1];
+        const f32x2_t y2 = mish_fwd2c(__builtin_elementwise_fma(x2, A[k / 2], B[k / 2])) + r2;
+        o[k] = y2.x; o[k + 1] = y2.y;
+      }
+      RV::st(py + rr * p.y_cs + p.y_co + c, o);
+    }
+  }
+}
+
+template <typename T, int V, int U>
+__global__ __launch_bounds__(256) void bn16_bwd_reduce_kernel(BnArgs p) {
+  typedef RowVec<T, V> RV;
+  typedef typename RV::raw raw;
+  extern __shared__ double part[];   // [2][Cl]: dbeta | dgamma of this workgroup's channels (det: [4][Cl] words)
+  const int cb = (int)blockIdx.y * p.red_cg;
+  const int Cl = min(p.red_cg, p.C - cb);
+  const T* px = reinterpret_cast<const T*>(p.x) + p.x_co + cb;
+  const T* pdy = reinterpret_cast<const T*>(p.dy) + p.dy_co + cb;
+  const int CV = Cl / V;
+  for (int i = threadIdx.x; i < (p.det ? 4 : 2) * Cl; i += 256) part[i] = 0.0;
+  __syncthreads();
+  const RedMap mp = red_map(CV);
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+  const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
+  const int64_t step = (int64_t)mp.rstep * U;
+  if (mp.active) {
+    for (int cq = mp.cq0; cq < CV; cq += mp.cq_step) {
+      const int c = cq * V;
+      // z = A x + B, xhat = I x + J
+      f32x2_t A[V / 2], B[V / 2], I[V / 2], J[V / 2], db[V / 2], dg[V / 2];
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float is = p.invstd[cb + c + k], mu = p.mean[cb + c + k], ga = p.gamma[cb + c + k], be = p.beta[cb + c + k];
+        const float a_ = is * ga;
+        if (k & 1) { A[k / 2].y = a_; B[k / 2].y = be - mu * a_; I[k / 2].y = is; J[k / 2].y = -mu * is; }
+        else { A[k / 2].x = a_; B[k / 2].x = be - mu * a_; I[k / 2].x = is; J[k / 2].x = -mu * is; }
+      }
+#pragma unroll
+      for (int k = 0; k < V / 2; ++k) { db[k] = splat2(0.f); dg[k] = splat2(0.f); }
+      auto load = [&](int64_t rr, raw (&xv)[U], raw (&gv)[U]) {       // (whole stages only: see bn16_fwd_kernel)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t row = rr + (int64_t)u * mp.rstep;
+          xv[u] = RV::ld(px + row * p.x_cs + c);
+          gv[u] = RV::ld(pdy + row * p.dy_cs + c);
+        }
+      };
+      auto row_terms = [&](const raw& xv, const raw& gv) {
+#pragma unroll
+        for (int k = 0; k < V; k += 2) {
+          f32x2_t x2, g2;
+          x2.x = (float)xv[k]; x2.y = (float)xv[k + 1];
+          g2.x = (float)gv[k]; g2.y = (float)gv[k + 1];
+          const f32x2_t gg = g2 * mish_grad2c(__builtin_elementwise_fma(x2, A[k / 2], B[k / 2]));
+          db[k / 2] = db[k / 2] + gg;
+          dg[k / 2] = __builtin_elementwise_fma(gg, __builtin_elementwise_fma(x2, I[k / 2], J[k / 2]), dg[k / 2]);
+        }
+      };
+      auto work = [&](const raw (&xv)[U], const raw (&gv)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) row_terms(xv[u], gv[u]);
+      };
+      raw xa[U], ga[U], xb[U], gb[U];
+      int64_t rr = r0 + mp.rsub;
+      const int64_t span = (int64_t)(2 * U - 1) * mp.rstep;
+      if (rr + span < r1) {
+        load(rr, xa, ga);
+        for (;;) {
+          load(rr + step, xb, gb);
+          work(xa, ga);
+          const int64_t nx = rr + 2 * step;
+          const bool more = nx + span < r1;
+          load(more ? nx : rr, xa, ga);      // (always issued -- past the end it re-reads this stage: a branch here makes the
+                                             // compiler wait for EVERY load at the join, the next stage's included)
+          work(xb, gb);
+          rr = nx;
+          if (!more) break;
+        }
+      }
+      for (; rr < r1; rr += mp.rstep) row_terms(RV::ld(px + rr * p.x_cs + c), RV::ld(pdy + rr * p.dy_cs + c));
+#pragma unroll
+      for (int h = 0; h < V; h += 4) {
+        const double ddb[4] = {db[h / 2].x, db[h / 2].y, db[h / 2 + 1].x, db[h / 2 + 1].y};
+        const double ddg[4] = {dg[h / 2].x, dg[h / 2].y, dg[h / 2 + 1].x, dg[h / 2 + 1].y};
+        red_flush<kFxGrad>(part, Cl, c + h, ddb, ddg, true, p.det);
+      }
+    }
+  }
+  __syncthreads();
+  if (p.det) {
+    const u64_t* w = reinterpret_cast<const u64_t*>(part);
+    u64_t* g = reinterpret_cast<u64_t*>(p.sums);
+    for (int i = threadIdx.x; i < Cl; i += 256) {
+      fx_merge(g + cb + i, g + 2 * p.C + cb + i, w[i], w[2 * Cl + i]);
+      fx_merge(g + p.C + cb + i, g + 3 * p.C + cb + i, w[Cl + i], w[3 * Cl + i]);
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < Cl; i += 256) {
+    atomicAdd(&p.sums[cb + i], part[i]);
+    atomicAdd(&p.sums[p.C + cb + i], part[Cl + i]);
+  }
+}
+
+template <typename T, int V, int U>
+__global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(BnArgs p) {
+  typedef RowVec<T, V> RV;
+  typedef typename RV::raw raw;
+  const T* px = reinterpret_cast<const T*>(p.x);
+  const T* pdy = reinterpret_cast<const T*>(p.dy);
+  T* pdx = reinterpret_cast<T*>(p.dx);
+  const int CV = p.C / V;
+  const RedMap mp = red_map(CV);
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+  const int64_t r1 = r0 + p.rows_per_block < p.M ? r0 + p.rows_per_block : p.M;
+  if (blockIdx.x == 0 && p.publish) {   // the reduction kernel has completed (stream order): publish dbeta / dgamma as fp32
+    for (int i = threadIdx.x; i < p.C; i += 256) {
+      const double sb = bn_sum(p, i), sg = bn_sum(p, p.C + i);
+      if (p.publish == 2) {
+        p.dbeta[i] += (float)sb;
+        p.dgamma[i] += (float)sg;
+      } else {
+        p.dbeta[i] = (float)sb;
+        p.dgamma[i] = (float)sg;
+      }
+    }
+  }
+  if (!mp.active) return;
+  const double invM = 1.0 / (p.rows ? *p.rows : (double)p.M_total);
+  const int64_t step = (int64_t)mp.rstep * U;
+  for (int cq = mp.cq0; cq < CV; cq += mp.cq_step) {
+    const int c = cq * V;
+    // dx = k1 (g - dbm - xhat dgm) = k1 g + (c1 x + c0),  c1 = -k1 dgm invstd,  c0 = -k1 dbm + k1 dgm mean invstd
+    f32x2_t A[V / 2], B[V / 2], K1[V / 2], C0[V / 2], C1[V / 2];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float is = p.invstd[c + k], mu = p.mean[c + k], ga = p.gamma[c + k], be = p.beta[c + k];
+      const float a_ = is * ga;
+      const float dbm = p.eval_mode ? 0.f : (float)(bn_sum(p, c + k) * invM);
+      const float dgm = p.eval_mode ? 0.f : (float)(bn_sum(p, p.C + c + k) * invM);
+      const float k1 = a_, c1 = -(k1 * dgm) * is, c0 = -(k1 * dbm) - c1 * mu;
+      if (k & 1) { A[k / 2].y = a_; B[k / 2].y = be - mu * a_; K1[k / 2].y = k1; C0[k / 2].y = c0; C1[k / 2].y = c1; }
+      else { A[k / 2].x = a_; B[k / 2].x = be - mu * a_; K1[k / 2].x = k1; C0[k / 2].x = c0; C1[k / 2].x = c1; }
+    }
+    auto load = [&](int64_t rr, raw (&xv)[U], raw (&gv)[U]) {         // (whole stages only: see bn16_fwd_kernel)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t row = rr + (int64_t)u * mp.rstep;
+        xv[u] = RV::ld(px + row * p.x_cs + p.x_co + c);
+        gv[u] = RV::ld(pdy + row * p.dy_cs + p.dy_co + c);
+      }
+    };
+    auto one_row = [&](int64_t row, const raw& xv, const raw& gv) {
+      float o[V];
+#pragma unroll
+      for (int k = 0; k < V; k += 2) {
+        f32x2_t x2, g2;
+        x2.x = (float)xv[k]; x2.y = (float)xv[k + 1];
+        g2.x = (float)gv[k]; g2.y = (float)gv[k + 1];
+        const f32x2_t gg = g2 * mish_grad2c(__builtin_elementwise_fma(x2, A[k / 2], B[k / 2]));
+        const f32x2_t d2 = __builtin_elementwise_fma(K1[k / 2], gg, __builtin_elementwise_fma(C1[k / 2], x2, C0[k / 2]));
+        o[k] = d2.x; o[k + 1] = d2.y;
+      }
+      RV::st(pdx + row * p.dx_cs + p.dx_co + c, o);
+    };
+    auto work = [&](int64_t rr, const raw (&xv)[U], const raw (&gv)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) one_row(rr + (int64_t)u * mp.rstep, xv[u], gv[u]);
+    };
+    raw xa[U], ga[U], xb[U], gb[U];
+    int64_t rr = r0 + mp.rsub;
+    const int64_t span = (int64_t)(2 * U - 1) * mp.rstep;
+    if (rr + span < r1) {
+      load(rr, xa, ga);
+      for (;;) {
+        load(rr + step, xb, gb);
+        work(rr, xa, ga);
+        const int64_t nx = rr + 2 * step;
+        const bool more = nx + span < r1;
+        load(more ? nx : rr, xa, ga);      // (always issued -- past the end it re-reads this stage: a branch here makes the
+                                             // compiler wait for EVERY load at the join, the next stage's included)
+        work(rr + step, xb, gb);
+        rr = nx;
+        if (!more) break;
+      }
+    }
+    for (; rr < r1; rr += mp.rstep)
+      one_row(rr, RV::ld(px + rr * p.x_cs + p.x_co + c), RV::ld(pdy + rr * p.dy_cs + p.dy_co + c));
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // SPP backward (darknetcsp.py:176-181,203-206,222-226: cat([x, mp5(x), mp9(x), mp13(x)])):
 //   dx[p] = dcat[0][p] + sum over k in {5,9,13}, over output positions q whose window argmax is p,
 //   of dcat[k][q].
@@ -2081,6 +2399,15 @@ using namespace yv4;
 // forward pass and 20 % SLOWER on the backward apply pass over YOLOv4-L's shapes, tools/bn_bench.py --kernels: the
 // passes are bound by bytes in flight per CU, which the extra registers reduce)
 static const bool g_bn_vec8 = YV4_ENV_INT("YV4_BN_VEC8", 0) == 1;
+// the pipelined 16-bit Mish passes (bn16_*): on / off, channels per thread (4 or 8) and rows per pipeline stage
+static const int g_bn16 = YV4_ENV_INT("YV4_BN16", 1);
+static const int g_bn16_v = YV4_ENV_INT("YV4_BN16_V", 4);
+#ifndef YV4_BN16_U
+#define YV4_BN16_U 2
+#endif
+#define YV4_DISPATCH_H16V(dtype, v8, CALL)                                                                      \
+  if ((dtype) == YV4_F16) { typedef _Float16 T; if (v8) { constexpr int V = 8; CALL; } else { constexpr int V = 4; CALL; } } \
+  else { typedef __bf16 T; if (v8) { constexpr int V = 8; CALL; } else { constexpr int V = 4; CALL; } }
 
 // test / ablation switch: route 16-bit inputs through the widening fp32-MFMA kernel instead of the
 // 16-bit MFMA one (YV4_WGRAD_WIDEN=1 in the environment)
@@ -2239,6 +2566,8 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     a.tiles = (int)tl;
     a.chunks = (int)ch;
     a.xcd_map = 0;         // (one round of workgroups, compute-bound: the mapping gains nothing here)
+    static const int w3_ablate = YV4_ENV_INT("YV4_W3_ABLATE", 0);
+    a.ablate = w3_ablate;
     const dim3 grid3 = wgrad_grid(tl, ch, a.xcd_map);
     if (dtype == YV4_BF16)
       hipLaunchKernelGGL(conv_wgrad3x3_h16_kernel<true>, grid3, dim3(kW3Threads), (size_t)kW3Lds,
@@ -2338,6 +2667,14 @@ static int bn_fwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   const dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
   const bool v8 = dtype != YV4_F32 && g_bn_vec8 && ((C | x_cstride | x_coff | y_cstride | y_coff) & 7) == 0 &&
                   (!residual || ((r_cstride | r_coff) & 7) == 0);
+  if (dtype != YV4_F32 && act == YV4_ACT_MISH && g_bn16) {
+    const bool w8 = g_bn16_v == 8 && ((C | x_cstride | x_coff | y_cstride | y_coff) & 7) == 0 &&
+                    (!residual || ((r_cstride | r_coff) & 7) == 0);
+    YV4_DISPATCH_H16V(dtype, w8, hipLaunchKernelGGL((bn16_fwd_kernel<T, V, YV4_BN16_U>), grid, dim3(256), 0,
+                                                    reinterpret_cast<hipStream_t>(stream), a));
+    YV4_CHECK_LAUNCH("bn_act_fwd");
+    return YV4_OK;
+  }
   YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_fwd_kernel<T, V>), grid, dim3(256), 0,
                                                 reinterpret_cast<hipStream_t>(stream), a));
   YV4_CHECK_LAUNCH("bn_act_fwd");
@@ -2378,6 +2715,8 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
   a.rows_per_block = bn_rows_per_block(M);
   dim3 grid((unsigned)((M + a.rows_per_block - 1) / a.rows_per_block));
   const bool v8 = dtype != YV4_F32 && g_bn_vec8 && ((C | x_cstride | x_coff | dy_cstride | dy_coff | dx_cstride | dx_coff) & 7) == 0;
+  const bool b16 = dtype != YV4_F32 && act == YV4_ACT_MISH && g_bn16;
+  const bool w8 = g_bn16_v == 8 && ((C | x_cstride | x_coff | dy_cstride | dy_coff | dx_cstride | dx_coff) & 7) == 0;
   if (phase != 2) {
     // channel groups of >= 64 channels (whole 128-byte lines of 16-bit rows), the row blocks shrunk so that the
     // workgroup count stays what bn_rows_per_block aims at
@@ -2391,14 +2730,23 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
     if (rpb > g_bn_rows_cap) rpb = g_bn_rows_cap;
     r.rows_per_block = (int)rpb;
     const dim3 rgrid((unsigned)((M + rpb - 1) / rpb), (unsigned)groups);
-    YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, V>), rgrid, dim3(256), sizeof(double) * (det ? 4 : 2) * r.red_cg, s, r));
+    if (b16) {
+      YV4_DISPATCH_H16V(dtype, w8, hipLaunchKernelGGL((bn16_bwd_reduce_kernel<T, V, YV4_BN16_U>), rgrid, dim3(256),
+                                                      sizeof(double) * (det ? 4 : 2) * r.red_cg, s, r));
+    } else {
+      YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, V>), rgrid, dim3(256), sizeof(double) * (det ? 4 : 2) * r.red_cg, s, r));
+    }
   }
   if (phase == 1) {
     if (det) hipLaunchKernelGGL(fx_decode_kernel<kFxGrad>, dim3((2 * C + 255) / 256), dim3(256), 0, s, work, 2 * C);
     hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work, C, dbeta);
     hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, work + C, C, dgamma);
   } else {
-    YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, a));
+    if (b16) {
+      YV4_DISPATCH_H16V(dtype, w8, hipLaunchKernelGGL((bn16_bwd_apply_kernel<T, V, YV4_BN16_U>), grid, dim3(256), 0, s, a));
+    } else {
+      YV4_DISPATCH_TV(dtype, v8, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, a));
+    }
   }
   YV4_CHECK_LAUNCH("bn_act_bwd");
   return YV4_OK;

@@ -622,3 +622,56 @@ def test_packed_weight_cache_follows_the_weights(gpu_device):
     T.clear_pack_cache()
     assert torch.equal(got, T.packed_weight(fresh_w, torch.bfloat16)[0]), (fresh_w.data_ptr() == old_ptr)
     T.clear_pack_cache()
+
+
+def _ulp16(ref, dtype):
+    """One unit in the last place of the 16-bit type at |ref| (fp32 tensor), with the type's smallest normal as the floor."""
+    mant, emin = (7, -126) if dtype == torch.bfloat16 else (10, -14)
+    e = torch.floor(torch.log2(ref.abs().clamp(min=2.0 ** emin)))
+    return torch.pow(2.0, e - mant)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(128, 3, 37, 41), (32, 2, 97, 53), (256, 5, 19, 19), (36, 1, 23, 9), (512, 2, 10, 10)])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_bn16_passes_within_one_ulp_of_fp32_evaluation(gpu_device, dtype, shape, with_res):
+    """The pipelined 16-bit BatchNorm + Mish passes (train.hip bn16_*: folded affine constants, exponent clamp instead of
+    the asymptote select; semantics mmdet/ops/mish_cuda/src/mish.h:16-50 + torch.nn.BatchNorm2d of darknetcsp.py:15-35)
+    against the SAME 16-bit values pushed through the fp32 kernels: every 16-bit output within one ulp of the fp32-evaluated
+    value rounded to the type, dgamma / dbeta / running statistics to fp32 rounding.  Shapes
+    with row counts that leave every tail length of the software pipeline (and C % 8 != 0: the 4-channel form)."""
+    C, N, H, W = shape
+    g = torch.Generator(device='cpu').manual_seed(C * 7 + N)
+    x16 = (torch.randn(N, C, H, W, generator=g) * 2.5 + 0.7).to(gpu_device).to(dtype).contiguous(memory_format=torch.channels_last)
+    dy16 = torch.randn(N, C, H, W, generator=g).to(gpu_device).to(dtype).contiguous(memory_format=torch.channels_last)
+    res16 = torch.randn(N, C, H, W, generator=g).to(gpu_device).to(dtype).contiguous(memory_format=torch.channels_last) \
+        if with_res else None
+    bn = torch.nn.BatchNorm2d(C).to(gpu_device).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+
+    def run(x, dy, res):
+        bn.zero_grad()
+        bn.running_mean.zero_()
+        bn.running_var.fill_(1.0)
+        xr = x.clone().requires_grad_(True)
+        rr = res.clone().requires_grad_(True) if res is not None else None
+        y = T.bn_act(xr, bn, (pkg._lib.ACT_MISH, 0.0), residual=rr)
+        y.backward(dy)
+        return (y.detach().float(), xr.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                bn.running_mean.clone(), bn.running_var.clone())
+    got = run(x16, dy16, res16)
+    ref = run(x16.float(), dy16.float(), res16.float() if with_res else None)
+    for name, a, b in zip(('y', 'dx'), got[:2], ref[:2]):
+        rounded = b.to(dtype).float()                    # the fp32-evaluated value, rounded once to the type
+        err = (a - rounded).abs()
+        # one ulp of the type; where an output is itself a difference of O(1) terms (dx = k1 (g - dbm - xhat dgm), y near
+        # Mish's zero) the re-associated fp32 affine map moves it by fp32 rounding of those terms: floor 1e-6 of the range
+        tol = torch.maximum(_ulp16(b, dtype), torch.full_like(b, 1e-6 * float(b.abs().max())))
+        bad = err > tol
+        assert not bad.any(), (name, float(err.max()), int(bad.sum()), float((err / tol).max()))
+        assert float((a == rounded).float().mean()) > 0.9, name      # and the large majority land on the same value
+    for name, a, b in zip(('dgamma', 'dbeta', 'running_mean', 'running_var'), got[2:], ref[2:]):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (name, float((a - b).abs().max()), scale)
