@@ -684,6 +684,247 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
 }
 
 // ---------------------------------------------------------------------------------
+// The same kernel with its loop overhead removed (round 5).  The disassembly of the kernel above has, per 64-row slice and
+// wave, 24 MFMAs (768 matrix-pipe cycles) beside 340 VALU and 173 scalar instructions: 1 360 cycles of vector issue for 768
+// of matrix work, two waves per SIMD -- the loop was bound by its address arithmetic, not by LDS or the matrix pipe
+// (ablation, profiles/r05_wgrad3x3_v2.md: without the border masks alone 265 -> 204 us in the measurement build).  What
+// the instructions were: the per-lane border masks (8 rows x 2 divisions by invariant divisors per slice), one 32-bit add
+// per fragment read (buffer pointer + precomputed offset), a compare + select pair per masked read on top of the bit test,
+// the DMA offsets rebuilt from the row index with 64-bit multiplies.  Here:
+//   * border flags are computed ONCE per slice row by one wave (64 lanes = 64 rows) when the slice's DMA is issued and
+//     left in 64 bytes of LDS beside the slice buffer, laid out so that a lane fetches the flags of its eight rows with one
+//     ds_read_b64 a whole slice ahead of their use;
+//   * fragment addresses are lane constants + the slice buffer's offset + an immediate (the swizzle is periodic in 16
+//     rows, so the four 16-row steps differ by 4 096 bytes): 4 adds per slice for the 16 dY reads; a masked X read is
+//     zero-row + flag * (lane constant) -- one bit-field extract and one multiply-add, no compare, no select;
+//   * DMA offsets advance by a constant per slice and are range-checked as OFFSETS against lane-constant limits.
+// The MFMAs, their order and the LDS images are the kernel's above: the results are bit-identical to it
+// (tools/ab_w3g.sh compares the two in the measurement build; tests/test_gpu_h16.py::test_h16_wgrad3x3_kernel holds this one to
+// fp64 per tap and to run-to-run bit-identity).
+// ---------------------------------------------------------------------------------
+constexpr int kW3FlagBase = kW3Lds;                  // kW3NBuf x 64 flag bytes behind the slice buffers
+constexpr int kW3LdsV2 = kW3Lds + kW3NBuf * 64;
+
+template <bool BF16>
+__global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_v2_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4_t;
+  typedef __attribute__((address_space(3))) unsigned long long* lds_u64_t;
+  typedef __attribute__((address_space(3))) unsigned char* lds_u8_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_w3b[];
+  constexpr int kRowB = 256;
+  constexpr int kDBytes = kW3Rows * kRowB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 2;
+  const int wk = wave & 3;
+
+  const int tiles_ci = p.Cin >> 7;
+  int tile, chunk;
+  if (!wgrad_tile_chunk(p.tiles, p.chunks, p.xcd_map, tile, chunk)) return;
+  const int tci = tile % tiles_ci;
+  const int kh = (tile / tiles_ci) % 3;
+  const int tco = tile / (3 * tiles_ci);
+  const int co0 = tco * 128, ci0 = tci * 128;
+  const int m_lo = chunk * p.rows_per_chunk;
+  const int m_hi = min(m_lo + p.rows_per_chunk, p.M);
+  if (m_lo >= m_hi) return;
+  const int NHW = p.N * p.H * p.W;
+
+  const u32x4_t rsX = make_rsrc_t(p.x, x_bytes);
+  const u32x4_t rsD = make_rsrc_t(p.dy, dy_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_w3b;
+
+  // ---- staging (as above): wave w fills rows 8w .. 8w+7 of dY and of the X image, wave 0 also rows 64 .. 67 of the image.
+  // Byte offsets of slice 0 and their limits; both advance by a constant per slice.
+  const int srow = lane >> 4;
+  const int pc = lane & 15;
+  auto swz_of = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+  const int x_shift = (kh - 1) * p.W - 1;            // image row ir <-> pixel m_slice + ir + x_shift
+  const unsigned d_step = (unsigned)(kW3Rows * p.dy_cs * 2), x_step = (unsigned)(kW3Rows * p.x_cs * 2);
+  unsigned d_off[2], d_lim[2], x_off[3], x_lim[3];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 8 * wave + 4 * q + srow;
+    const int lc = pc ^ swz_of(row);
+    const int co = co0 + lc * 8;
+    const unsigned cb = (unsigned)((p.dy_co + co) * 2);
+    d_off[q] = (unsigned)(m_lo + row) * (unsigned)(p.dy_cs * 2) + cb;
+    d_lim[q] = co < p.Cout ? (unsigned)m_hi * (unsigned)(p.dy_cs * 2) + cb : 0u;        // 0: never below -> out of range
+    const unsigned xb_ = (unsigned)((p.x_co + ci0 + lc * 8) * 2);
+    x_off[q] = (unsigned)(m_lo + row + x_shift) * (unsigned)(p.x_cs * 2) + xb_;          // (a negative pixel wraps to ~2^32)
+    x_lim[q] = (unsigned)NHW * (unsigned)(p.x_cs * 2) + xb_;
+  }
+  {
+    const int row = 64 + srow;
+    const unsigned xb_ = (unsigned)((p.x_co + ci0 + (pc ^ swz_of(row)) * 8) * 2);
+    x_off[2] = (unsigned)(m_lo + row + x_shift) * (unsigned)(p.x_cs * 2) + xb_;
+    x_lim[2] = row < 66 ? (unsigned)NHW * (unsigned)(p.x_cs * 2) + xb_ : 0u;             // rows 66, 67 stay zero
+  }
+  // border flags of slice row r = lane (written by wave 1): position of the byte inside the slice's 64 flag bytes
+  const int f_wr = (((lane & 3) * 2 + ((lane >> 3) & 1)) << 3) + ((lane >> 4) << 1) + ((lane >> 2) & 1);
+  int f_m = m_lo + lane;                             // (wave 1) the row this lane decodes next
+  auto issue = [&](int sl) {
+    const int buf = sl & (kW3NBuf - 1);
+    const unsigned lb = lds_base + (unsigned)(buf * kW3BufBytes + 8 * wave * kRowB);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      lds_dma16_t(rsD, lb + (unsigned)(4 * q * kRowB), d_off[q] < d_lim[q] ? d_off[q] : kOOB, 0u);
+      lds_dma16_t(rsX, lb + (unsigned)(kDBytes + 4 * q * kRowB), x_off[q] < x_lim[q] ? x_off[q] : kOOB, 0u);
+      d_off[q] += d_step;
+      x_off[q] += x_step;
+    }
+    if (wave == 0) {
+      lds_dma16_t(rsX, lds_base + (unsigned)(buf * kW3BufBytes + kDBytes + 64 * kRowB), x_off[2] < x_lim[2] ? x_off[2] : kOOB, 0u);
+      x_off[2] += x_step;
+    }
+    if (wave == 1) {
+      unsigned b3 = 0u;
+      if (f_m < m_hi) {
+        const int n = fd_div(f_m, p.fd_hw);
+        const int rm = f_m - n * (p.H * p.W);
+        const int ho = fd_div(rm, p.fd_wo);
+        const int wo = rm - ho * p.W;
+        if ((unsigned)(ho + kh - 1) < (unsigned)p.H) b3 = (wo > 0 ? 1u : 0u) | 2u | (wo + 1 < p.W ? 4u : 0u);
+      }
+      *(lds_u8_t)(smem_w3b + kW3FlagBase + buf * 64 + f_wr) = (unsigned char)b3;
+      f_m += kW3Rows;
+    }
+  };
+
+  // ---- transposed fragment reads: lane = 16 g + 4 qq + pp supplies row (block + qq), columns 4 pp .. 4 pp + 3 of its
+  // 16-column half; step S adds 16 rows = 4 096 bytes (the swizzle only sees the row's low four bits)
+  const int g = lane >> 4, i16 = lane & 15;
+  const int hh = g >> 1, colhalf = g & 1;
+  const int qq = i16 >> 2, pp = i16 & 3;
+  auto row_addr = [&](int row, int col_base) -> int {
+    const int chunk_ = (col_base + 16 * colhalf) / 8 + (pp >> 1);
+    return kRowB * row + 16 * (chunk_ ^ swz_of(row)) + 8 * (pp & 1);
+  };
+  constexpr int kZeroRd = kDBytes + kW3ZeroRow * kRowB;
+  int a_base[2][2];                                  // dY: [co tile a][j], step 0, buffer 0
+  int b_dlt[2][3][4];                                // X: (address of row 16 S + 8 hh + 4 j + qq + kw) - (zero row), [j][kw][S]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) a_base[a][j] = row_addr(8 * hh + 4 * j + qq, wc * 64 + a * 32);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int S = 0; S < 4; ++S) b_dlt[j][kw][S] = kDBytes + row_addr(16 * S + 8 * hh + 4 * j + qq + kw, wk * 32) - kZeroRd;
+  }
+  const int f_rd = kW3FlagBase + ((qq * 2 + hh) << 3);
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int nsl = (m_hi - m_lo + kW3Rows - 1) / kW3Rows;
+  s16x8_t fa[2][2], fb[2][3];                        // fragment sets: step s computes from set s & 1
+  // FL: the eight flag bytes of this lane's rows of the slice ([S][j], bits kw); BO: the slice buffer's byte offset
+#define YV4_W3B_LOAD(SET, BO, S, FL)                                                                          \
+  {                                                                                                           \
+    const char* ab_ = smem_w3b + (BO) + 4096 * (S);                                                           \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                           \
+      const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(ab_ + a_base[a][0]));            \
+      const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(ab_ + a_base[a][1]));            \
+      fa[SET][a] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);                                   \
+    }                                                                                                         \
+    const unsigned fw_ = (unsigned)((FL) >> (((S) >> 1) * 32));                                               \
+    const int zb_ = (BO) + kZeroRd;                                                                           \
+    _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                        \
+      const int f0_ = (int)((fw_ >> ((((S) & 1) * 2 + 0) * 8 + kw)) & 1u);                                    \
+      const int f1_ = (int)((fw_ >> ((((S) & 1) * 2 + 1) * 8 + kw)) & 1u);                                    \
+      const int r0_ = __mul24(f0_, b_dlt[0][kw][S]) + zb_;                                   \
+      const int r1_ = __mul24(f1_, b_dlt[1][kw][S]) + zb_;                                   \
+      const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(smem_w3b + r0_));                 \
+      const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(smem_w3b + r1_));                 \
+      fb[SET][kw] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);                                  \
+    }                                                                                                         \
+  }
+#define YV4_W3B_MFMA(SET)                                                                                     \
+  {                                                                                                           \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                             \
+      _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                      \
+        if (BF16)                                                                                             \
+          acc[a][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, fa[SET][a]),      \
+                                                               __builtin_bit_cast(bf16x8_w, fb[SET][kw]), acc[a][kw], 0, 0, 0); \
+        else                                                                                                  \
+          acc[a][kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_w, fa[SET][a]),        \
+                                                              __builtin_bit_cast(f16x8_w, fb[SET][kw]), acc[a][kw], 0, 0, 0); \
+      }                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  }
+  // pieces per slice: 4 (5 on wave 0); DMA(t + 2) and DMA(t + 3) may stay in flight at the wait of slice t
+#define YV4_W3B_WAIT()                                                                                        \
+  {                                                                                                           \
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");                               \
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                          \
+  }
+
+  issue(0);
+  issue(1);
+  issue(2);
+  YV4_W3B_WAIT();                                     // DMA(0) landed (newer: 1, 2); the flag bytes are written
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  unsigned long long fl = *(lds_u64_t)(smem_w3b + f_rd);
+  YV4_W3B_LOAD(0, 0, 0, fl);
+  for (int sl = 0; sl < nsl; ++sl) {
+    const int bo = (sl & (kW3NBuf - 1)) * kW3BufBytes;
+    const int nb = (sl + 1) & (kW3NBuf - 1);
+    const int nbo = nb * kW3BufBytes;
+    // flags of slice sl + 1: written when its DMA was issued (two barriers ago), wanted after this slice's barrier
+    const unsigned long long fln = *(lds_u64_t)(smem_w3b + f_rd + nb * 64);
+    YV4_W3B_LOAD(1, bo, 1, fl);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_W3B_MFMA(0);
+    issue(sl + 3);                                    // into the buffer slice sl - 1 read (freed by the previous barrier)
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_W3B_LOAD(0, bo, 2, fl);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_W3B_MFMA(1);
+    YV4_W3B_LOAD(1, bo, 3, fl);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_W3B_MFMA(0);
+    YV4_W3B_WAIT();                                   // own DMA(sl + 1) landed; every read of slice sl has returned
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    YV4_W3B_LOAD(0, nbo, 0, fln);                     // (beyond the last slice: zero-filled buffers, never used)
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_W3B_MFMA(1);
+    fl = fln;
+  }
+#undef YV4_W3B_WAIT
+#undef YV4_W3B_MFMA
+#undef YV4_W3B_LOAD
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the dummy tail DMAs must land before the LDS is released
+
+  // D[row = co][col = ci]: row = (e&3) + 8*(e>>2) + 4*(lane>>5), col = lane&31
+  const int r = lane & 31, h5 = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int kcol = (kh * 3 + kw) * p.Cin + ci0 + wk * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wc * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h5;
+        if (co < p.Cout) {
+          if (p.ws) p.ws[(size_t)chunk * p.ws_stride + (size_t)co * p.K + kcol] = acc[a][kw][e];
+          else atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[a][kw][e]);
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Weight gradient of the 3x3 / stride-1 / pad-1 layers with FEW channels (Cin 16, 32 or 64 per pixel, Cout 32 or 64):
 // the stem, the first Bottleneck and the first CSP stage of CSPDarknet at 608 / 304 / 152 pixels.  These layers are bound
 // by their bytes (dY + X once = 0.23-0.45 ms at batch 64) and the 128 x 128 tiles above serve them badly: dW is 32-64
@@ -2569,6 +2810,22 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     static const int w3_ablate = YV4_ENV_INT("YV4_W3_ABLATE", 0);
     a.ablate = w3_ablate;
     const dim3 grid3 = wgrad_grid(tl, ch, a.xcd_map);
+    static const int w3v2 = YV4_ENV_INT("YV4_W3V2", 1);
+    // (the second form range-checks 32-bit byte OFFSETS: both maps well below 4 GB, so that a row in front of the map --
+    // a wrapped offset -- can never fall below a limit)
+    if (w3v2 && xb < 0xC0000000LL && db < 0xC0000000LL) {
+      static LdsAttrOnce once3vb, once3vh;
+      if (int rc = ensure_dyn_lds(once3vb, reinterpret_cast<const void*>(conv_wgrad3x3_v2_h16_kernel<true>), (size_t)kW3LdsV2, "conv_wgrad3x3_v2_h16")) return rc;
+      if (int rc = ensure_dyn_lds(once3vh, reinterpret_cast<const void*>(conv_wgrad3x3_v2_h16_kernel<false>), (size_t)kW3LdsV2, "conv_wgrad3x3_v2_h16")) return rc;
+      if (dtype == YV4_BF16)
+        hipLaunchKernelGGL(conv_wgrad3x3_v2_h16_kernel<true>, grid3, dim3(kW3Threads), (size_t)kW3LdsV2,
+                           reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
+      else
+        hipLaunchKernelGGL(conv_wgrad3x3_v2_h16_kernel<false>, grid3, dim3(kW3Threads), (size_t)kW3LdsV2,
+                           reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
+      YV4_CHECK_LAUNCH("conv_wgrad3x3_v2_h16");
+      return finish();
+    }
     if (dtype == YV4_BF16)
       hipLaunchKernelGGL(conv_wgrad3x3_h16_kernel<true>, grid3, dim3(kW3Threads), (size_t)kW3Lds,
                          reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
