@@ -436,6 +436,227 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void conv_wgrad_h16_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// The kernel above with its staging arithmetic removed from the lanes (round 5).  Per 64-row slice and wave the loop
+// above issues 16 MFMAs (512 matrix-pipe cycles) and 119 VALU instructions of which 40 are 32-bit integer multiplies
+// (quarter rate: 16 issue cycles each) -- the row decode (two divisions by invariant divisors) and the byte offsets of
+// four rows per lane, rebuilt from the row index every slice: ~960 cycles of vector issue per 512 of matrix work, two
+// waves per SIMD.  Here:
+//   * LINEAR (1x1, stride 1, no padding -- 27 of YOLOv4-L's layers): both operands' offsets advance by a constant per
+//     slice and are range-checked as offsets against lane-constant limits: an add, a compare and a select per piece;
+//   * otherwise one wave decodes each of the slice's 64 rows ONCE (64 lanes = 64 rows) two slices ahead and leaves
+//     {byte offset of the row's window origin, (hi0, wi0)} in an LDS table beside the slice buffers; a lane reads the
+//     entries of its four rows, adds its taps' lane-constant offset and checks the window bounds -- no division, no multiply.
+// Same tiles, same MFMAs in the same order, same slab output: dW is bit-identical to the kernel above.
+// ---------------------------------------------------------------------------------
+constexpr int kWhLds2 = 2 * 2 * kWhRows * 256;       // two slice buffers
+constexpr int kWhTabBytes = kWhRows * 8;             // one row table
+constexpr int kWhLdsV2 = kWhLds2 + 2 * kWhTabBytes;
+
+template <bool BF16, bool LINEAR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_v2_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4_t;
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) u32x2_t* lds_u2_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_wv[];
+  constexpr int kRowB = 256;
+  constexpr int kOpBytes = kWhRows * kRowB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int tile_id, chunk;
+  if (!wgrad_tile_chunk(p.tiles, p.chunks, p.xcd_map, tile_id, chunk)) return;
+  const int tile_k = tile_id % p.tiles_k;
+  const int tile_c = tile_id / p.tiles_k;
+  const int co0 = tile_c * kWhTile;
+  const int k0 = tile_k * kWhTile;
+  const int m_lo = chunk * p.rows_per_chunk;
+  const int m_hi = min(m_lo + p.rows_per_chunk, p.M);
+  if (m_lo >= m_hi) return;
+
+  const u32x4_t rsX = make_rsrc_t(p.x, x_bytes);
+  const u32x4_t rsD = make_rsrc_t(p.dy, dy_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_wv;
+
+  // ---- staging: instruction q of this wave fills rows 16*wave + 4q + lane/16, physical chunk lane%16
+  const int srow = lane >> 4;
+  const int pc = lane & 15;
+  const unsigned d_step = (unsigned)(kWhRows * p.dy_cs * 2), x_step = (unsigned)(kWhRows * p.x_cs * 2);
+  unsigned d_off[4], d_lim[4];       // dY: byte offset of this lane's 16 bytes at slice 0, and its limit (0: never)
+  unsigned a_off[4], a_lim[4];       // LINEAR: the same for the activation
+  unsigned a_tap[4];                 // general: byte offset of the lane's (tap, channel chunk) from the row's window origin
+  int a_kh[4], a_kw[4];              // general: the tap (kh = -30000 for a column beyond K: never inside the map)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int lc = pc ^ ((srow << 2) | q);                    // swizzle: row&3 = srow, (row>>2)&3 = q
+    const int row = 16 * wave + srow + 4 * q;
+    const int co = co0 + lc * 8;
+    const unsigned cb = (unsigned)((p.dy_co + co) * 2);
+    d_off[q] = (unsigned)(m_lo + row) * (unsigned)(p.dy_cs * 2) + cb;
+    d_lim[q] = co < p.Cout ? (unsigned)m_hi * (unsigned)(p.dy_cs * 2) + cb : 0u;
+    const int kk = k0 + lc * 8;
+    int tap = 0, ci = 0;
+    const bool kok = kk < p.K;
+    if (kok) { tap = kk / p.Cin; ci = kk - tap * p.Cin; }
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const unsigned xb_ = (unsigned)((p.x_co + ci) * 2);
+    if (LINEAR) {      // tap 0 only; input pixel = output pixel
+      a_off[q] = (unsigned)(m_lo + row) * (unsigned)(p.x_cs * 2) + xb_;
+      a_lim[q] = kok ? (unsigned)m_hi * (unsigned)(p.x_cs * 2) + xb_ : 0u;
+    } else {
+      a_kh[q] = kok ? kh : -30000;
+      a_kw[q] = kw;
+      a_tap[q] = (unsigned)(kh * p.W + kw) * (unsigned)(p.x_cs * 2) + xb_;
+    }
+  }
+  // general form: the row table.  Entry of slice row r: {byte offset of input pixel (n, ho*s - p, wo*s - p) -- may be in
+  // front of the map: arithmetic modulo 2^32 --, (hi0 << 16) | (wi0 & 0xFFFF)}; rows past the chunk get hi0 = -30000.
+  int t_m = m_lo + lane;             // (wave 0) the row this lane decodes next
+  auto table = [&](int sl) {
+    if (LINEAR || wave != 0) return;
+    unsigned off0 = 0u;
+    int hi0 = -30000, wi0 = 0;
+    if (t_m < m_hi) {
+      const int n = fd_div(t_m, p.fd_hw);
+      const int rm = t_m - n * (p.Ho * p.Wo);
+      const int ho = fd_div(rm, p.fd_wo);
+      const int wo = rm - ho * p.Wo;
+      hi0 = ho * p.stride - p.pad;
+      wi0 = wo * p.stride - p.pad;
+      off0 = (unsigned)((n * p.H + hi0) * p.W + wi0) * (unsigned)(p.x_cs * 2);
+    }
+    u32x2_t ent;
+    ent.x = off0;
+    ent.y = ((unsigned)hi0 << 16) | ((unsigned)wi0 & 0xFFFFu);
+    *(lds_u2_t)(smem_wv + kWhLds2 + (sl & 1) * kWhTabBytes + lane * 8) = ent;
+    t_m += kWhRows;
+  };
+  auto issue = [&](int sl) {
+    const int buf = sl & 1;
+    const unsigned lrow0 = (unsigned)(buf * 2 * kOpBytes + (16 * wave) * kRowB);
+    u32x2_t te[4];
+    if (!LINEAR) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        te[q] = *(lds_u2_t)(smem_wv + kWhLds2 + buf * kWhTabBytes + (16 * wave + srow + 4 * q) * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned lrow = lrow0 + (unsigned)(4 * q * kRowB);
+      lds_dma16_t(rsD, lds_base + lrow, d_off[q] < d_lim[q] ? d_off[q] : kOOB, 0u);
+      d_off[q] += d_step;
+      unsigned aoff;
+      if (LINEAR) {
+        aoff = a_off[q] < a_lim[q] ? a_off[q] : kOOB;
+        a_off[q] += x_step;
+      } else {
+        const int hi = ((int)te[q].y >> 16) + a_kh[q];
+        const int wi = (int)(short)(te[q].y & 0xFFFFu) + a_kw[q];
+        aoff = ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? te[q].x + a_tap[q] : kOOB;
+      }
+      lds_dma16_t(rsX, lds_base + (unsigned)kOpBytes + lrow, aoff, 0u);
+    }
+  };
+
+  // ---- transposed fragment reads (conv_wgrad_h16_kernel)
+  const int g = lane >> 4, i16 = lane & 15;
+  const int hh = g >> 1, colhalf = g & 1;
+  const int qq = i16 >> 2, pp = i16 & 3;
+  auto frag_addr = [&](int col_base, int s_, int j) -> unsigned {
+    const int m0 = 16 * s_ + 8 * hh + 4 * j;
+    const int chunk_ = (col_base + 16 * colhalf) / 8 + (pp >> 1);
+    const int swz = (qq << 2) | ((2 * hh + j) & 3);
+    return (unsigned)(kRowB * (m0 + qq) + 16 * (chunk_ ^ swz) + 8 * (pp & 1));
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int nslices = (m_hi - m_lo + kWhRows - 1) / kWhRows;
+  table(0);
+  table(1);
+  if (!LINEAR) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  issue(0);
+  for (int sl = 0; sl < nslices; ++sl) {
+    const int buf = sl & 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // slice sl is in LDS (and table sl + 1); every wave is done with slice sl - 1
+    asm volatile("" ::: "memory");
+    issue(sl + 1);                                   // into the buffer slice sl - 1 left
+    table(sl + 2);                                   // into the table slice sl's issue read (before the barrier above)
+    char* dbuf = smem_wv + buf * 2 * kOpBytes;
+    char* abuf = dbuf + kOpBytes;
+    __builtin_amdgcn_s_setprio(1);
+    s16x8_t fa[2][2], fb[2][2];
+#define YV4_WV_LOAD(SET, S)                                                                                           \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                   \
+      const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(dbuf + frag_addr(wm * 64 + t * 32, S, 0))); \
+      const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(dbuf + frag_addr(wm * 64 + t * 32, S, 1))); \
+      const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(abuf + frag_addr(wn * 64 + t * 32, S, 0))); \
+      const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(abuf + frag_addr(wn * 64 + t * 32, S, 1))); \
+      fa[SET][t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);                                          \
+      fb[SET][t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);                                          \
+    }
+#define YV4_WV_MFMA(SET)                                                                                              \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                     \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                 \
+        if (BF16)                                                                                                     \
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, fa[SET][a]),               \
+                                                              __builtin_bit_cast(bf16x8_w, fb[SET][b]), acc[a][b], 0, 0, 0); \
+        else                                                                                                          \
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_w, fa[SET][a]),                 \
+                                                             __builtin_bit_cast(f16x8_w, fb[SET][b]), acc[a][b], 0, 0, 0);   \
+      }                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_WV_LOAD(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_WV_LOAD(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_WV_MFMA(0);
+    YV4_WV_LOAD(0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_WV_MFMA(1);
+    YV4_WV_LOAD(1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    YV4_WV_MFMA(0);
+    YV4_WV_MFMA(1);
+#undef YV4_WV_MFMA
+#undef YV4_WV_LOAD
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range slice issued past the end
+  const int r = lane & 31, h5 = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int kcol = k0 + wn * 64 + b * 32 + r;
+      if (kcol >= p.K) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h5;
+        if (co < p.Cout) {
+          if (p.ws) p.ws[(size_t)chunk * p.ws_stride + (size_t)co * p.K + kcol] = acc[a][b][e];
+          else atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[a][b][e]);
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Weight gradient of the 3x3 / stride-1 / pad-1 layers with Cin % 128 == 0 (71 % of YOLOv4-L's weight-gradient FLOPs):
 // the three kw taps of one (kh, 128-channel chunk) share ONE LDS image of the slice's source pixels.
 //   dW[co][kh][kw][ci] = sum_m dY[m][co] * X[m + (kh - 1) W + (kw - 1)][ci]      (flattened pixel index m; borders masked)
@@ -2852,6 +3073,27 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     a.xcd_map = g_wgrad_xcd && tl >= 2 && ch >= 16 && a.Cout >= 128 && tl * (ch + 8) < (1LL << 31) ? 1 : 0;
     const dim3 grid = wgrad_grid(tl, ch, a.xcd_map);
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    static const int whv2 = YV4_ENV_INT("YV4_WGRAD_V2", 1);
+    const bool linear = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
+    // (second form: offsets are range-checked as 32-bit byte offsets, window origins travel as 16-bit coordinates.  Not for
+    // the few-channel windowed layers -- 32 -> 64 s2 @608 streams 2.3 GB through 288 columns of dW and is bound by its
+    // bytes: the table's LDS round trip in front of every slice's DMA cost it 7 %, 836 -> 894 us)
+    if (whv2 && nbuf == 2 && xb < 0xC0000000LL && db < 0xC0000000LL && d->H < 16000 && d->W < 16000 &&
+        (linear || d->Cin >= 64)) {
+#define YV4_WV_LAUNCH(LIN)                                                                                             \
+  {                                                                                                                    \
+    static LdsAttrOnce once_b, once_h;                                                                                 \
+    if (int rc = ensure_dyn_lds(once_b, reinterpret_cast<const void*>(conv_wgrad_v2_h16_kernel<true, LIN>), (size_t)kWhLdsV2, "conv_wgrad_v2_h16")) return rc;  \
+    if (int rc = ensure_dyn_lds(once_h, reinterpret_cast<const void*>(conv_wgrad_v2_h16_kernel<false, LIN>), (size_t)kWhLdsV2, "conv_wgrad_v2_h16")) return rc; \
+    if (dtype == YV4_BF16) hipLaunchKernelGGL((conv_wgrad_v2_h16_kernel<true, LIN>), grid, dim3(256), (size_t)kWhLdsV2, hs, a, (unsigned)xb, (unsigned)db);     \
+    else hipLaunchKernelGGL((conv_wgrad_v2_h16_kernel<false, LIN>), grid, dim3(256), (size_t)kWhLdsV2, hs, a, (unsigned)xb, (unsigned)db);                      \
+  }
+      if (linear) YV4_WV_LAUNCH(true)
+      else YV4_WV_LAUNCH(false)
+#undef YV4_WV_LAUNCH
+      YV4_CHECK_LAUNCH("conv_wgrad_v2_h16");
+      return finish();
+    }
 #define YV4_WH_LAUNCH(NB)                                                                                              \
   {                                                                                                                    \
     static LdsAttrOnce once_b, once_h;                                                                                 \
