@@ -371,11 +371,17 @@ def launch_ranks(n, argv, script=None, python=None, timeout=None):
     t.start()
     t0 = time.time()
     rcs = [None] * n
+    killed = set()                                             # ranks the launcher itself took down
+    seen_at = [None] * n                                       # the poll in which a rank's exit was first seen
     failed_at = None
+    polls = 0
     while any(rc is None for rc in rcs):
+        polls += 1
         for i, p in enumerate(procs):
             if rcs[i] is None:
                 rcs[i] = p.poll()
+                if rcs[i] is not None:
+                    seen_at[i] = polls
         bad = [rc for rc in rcs if rc not in (None, 0)]
         if bad and failed_at is None:
             failed_at = time.time()
@@ -384,13 +390,24 @@ def launch_ranks(n, argv, script=None, python=None, timeout=None):
                 if rcs[i] is None:
                     p.kill()                                   # exactly the PIDs started here
                     rcs[i] = p.wait()
+                    killed.add(i)
             break
         time.sleep(0.2)
     t.join(timeout=5)
-    worst = max((abs(rc) for rc in rcs), default=0)
-    if worst:
-        print(f'bench.py launcher: rank exit codes {rcs}', file=sys.stderr)
-    return min(worst, 255)
+    # the exit code of the run = the non-zero code of the rank that died FIRST by itself (the ranks that follow abort in
+    # their collectives with whatever the backend exits with; a rank this launcher killed returns -9, which must not mask
+    # the real failure); the larger code among ranks seen dead in the same poll; 124 (timeout's convention) when only
+    # launcher kills happened
+    own = sorted((seen_at[i], -abs(rc), rc) for i, rc in enumerate(rcs) if i not in killed and rc not in (None, 0))
+    code = 0
+    if own:
+        rc0 = own[0][2]
+        code = rc0 if 0 < rc0 < 256 else 128 + min(abs(rc0), 127)              # a signal: the shell's 128 + n
+    elif killed:
+        code = 124
+    if code:
+        print(f'bench.py launcher: rank exit codes {rcs} (killed by the launcher: {sorted(killed)})', file=sys.stderr)
+    return code
 
 
 def main():
@@ -611,6 +628,7 @@ def main():
     if args.batch >= 2 and not args.no_output_check:
         small = det.compile(2, args.size, args.size, device=dev, rescale=True,
                             dtype={'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.dtype])
+        pin_note = ''
         if not h16:
             # fp32: the wide-tile 3x3 kernel (16x16x4 MFMAs) groups the K sum differently from the 32x32x2 tiles a
             # batch-2 plan would pick by itself, so the check plan is PINNED to the timed plan's tile ids layer by layer
@@ -620,13 +638,22 @@ def main():
             big_convs = [o for o in plan.ops if o.kind == 'conv' and 'desc' in o.info]
             small_convs = [o for o in small.ops if o.kind == 'conv' and 'desc' in o.info]
             if len(big_convs) == len(small_convs):
+                pick = pkg._lib.lib().yv4_conv_pick_tile
                 for ob, os_ in zip(big_convs, small_convs):
                     db, ds = ob.info['desc'], os_.info['desc']
                     if ob.info.get('fused') or ob.info.get('stem32') or os_.info.get('fused') or os_.info.get('stem32'):
                         continue
-                    t = db.tile if db.tile else pkg._lib.lib().yv4_conv_pick_tile(ctypes.byref(db))
-                    if t >= 26:                       # a pinned wide-tile shape
+                    t = db.tile if db.tile else pick(ctypes.byref(db))
+                    ts = ds.tile if ds.tile else pick(ctypes.byref(ds))
+                    # either side on a wide-tile form (the timed plan's fill rule depends on M: a batch-2 layer can take a
+                    # wide tile the batch-N plan rejected, and the other way round): the check plan runs the TIMED plan's
+                    # resolved tile id.  The 32x32x2 tiles (ids 1-9) give the same bits as one another.
+                    if t != ts and (t >= 10 or ts >= 10):
                         ds.tile = t
+            else:
+                pin_note = (f'; NOTE: the timed plan has {len(big_convs)} conv launches, the batch-2 plan {len(small_convs)}: '
+                            'tile ids NOT pinned layer by layer')
+                print('bench.py: output check' + pin_note[2:], file=sys.stderr)
         small.run(img[:2])
         torch.cuda.synchronize()
         for n in range(2):
@@ -638,7 +665,7 @@ def main():
                 check_failed = f'image {n} of the batch-{args.batch} step differs from the batch-2 plan'
         del small
         output_check = f'images 0-1 of the timed batch-{args.batch} step == a batch-2 plan on the same images (bit-exact; ' \
-                       f'{int(host_count[0])} + {int(host_count[1])} detections)'
+                       f'{int(host_count[0])} + {int(host_count[1])} detections)' + pin_note
         if check_failed:
             output_check = 'FAILED: ' + check_failed
     else:

@@ -138,8 +138,8 @@ typedef struct yv4_conv_desc {
  * YV4_TILE_WIDE_SHAPE(i) pins the workgroup tile shape as above and is what yv4_conv_pick_tile reports. */
 #define YV4_TILE_WIDE 11
 #define YV4_TILE_WIDE_SHAPE(i) (11 + 16 * ((i) + 1))
-/* (id 10 was the fp32 ping-pong 3x3 form of round 2: measured at the same 117-125 TFLOP/s plateau as the DMA tiles on
- * every layer, DESIGN 9.12, and removed in round 3; the id is refused) */
+/* (round 2's fp32 ping-pong 3x3 form, removed in round 3 -- DESIGN 9.12 -- used to own id 10; the id now names the wide
+ * 3x3 kernel above and is accepted and chosen automatically) */
 
 int yv4_conv_bn_act_fwd(const yv4_conv_desc* d, const float* x, const float* w,
                         const float* scale1, const float* shift1,

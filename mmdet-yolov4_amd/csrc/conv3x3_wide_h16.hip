@@ -436,7 +436,8 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
 bool conv3x3_wide_h16_applies(const ConvArgsH& a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && (a.Cin & 63) == 0 &&
          a.Kw == 9 * a.Cin && !a.ys_on && !a.out_f32 && a.Cout >= 64 && (a.Cout & 15) == 0 &&
-         ((a.y_cs | a.y_co) & 7) == 0 && (a.res == nullptr || ((a.r_cs | a.r_co) & 7) == 0) && a.Cout <= 1024;
+         ((a.y_cs | a.y_co) & 7) == 0 && (a.res == nullptr || ((a.r_cs | a.r_co) & 7) == 0) && a.Cout <= 1024 &&
+         a.ksplit <= 1;
 }
 
 static int g_w3_cus = 0;

@@ -547,7 +547,7 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   const int w3_forced = (d->tile > 8 && (d->tile & 7) == YV4_HTILE_W3x3 && d->tile <= YV4_HTILE_W3x3_SHAPE(4)) ? (d->tile >> 3) - 1 : -1;
   if (d->tile == YV4_HTILE_W3x3 || w3_forced >= 0)
     YV4_REQUIRE(conv3x3_wide_h16_applies(a), "conv h16: the wide 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with Cin %% 64 == 0, "
-                "Cout %% 16 == 0 (64 .. 1024), 16-bit output, 8-aligned channel strides / offsets and no statistics");
+                "Cout %% 16 == 0 (64 .. 1024), 16-bit output and 8-aligned channel strides / offsets");
   if (d->tile == YV4_HTILE_W3x3 || w3_forced >= 0 || (d->tile == YV4_TILE_AUTO && prefer_w3(a))) {
     static const int shape = YV4_ENV_INT("YV4_W3_SHAPE", -1);
     return conv3x3_wide_h16_launch(a, dtype == YV4_BF16, w3_forced >= 0 ? w3_forced : shape, s);

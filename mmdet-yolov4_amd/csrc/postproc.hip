@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_images_kernel(NmsArgs p) {
             bk = kbox[k];
             ak = karea[k];
           } else {
-            // written earlier by thread 0 of this workgroup: read around the L1
+            // written earlier by this workgroup (one thread per kept box, after the walk of its chunk): read around the L1
             const volatile float* vd = odet;
             const volatile int32_t* vl = olab;
             const float off = (float)vl[k] * off_unit;
@@ -635,7 +635,11 @@ static int decode_impl(const yv4_level_desc* levels, int num_levels, int N, int 
   static const int ablate = YV4_ENV_INT("YV4_DEC_ABLATE", 0);
   a.ablate = ablate;
   const size_t lds = (size_t)kDecBoxes * (5 + num_classes) * sizeof(float);
-  YV4_REQUIRE(lds <= 64 * 1024, "decode_filter: num_classes %d too large for the LDS tile", num_classes);
+  // the kernel's static LDS (the key buffer, its counters, the per-wave maxima) shares the 64 KB a launch may use
+  // without the opt-in attribute
+  constexpr size_t kDecStaticLds = sizeof(uint64_t) * kDecKeyBuf + 3 * sizeof(int) + 4 * sizeof(float) + 64;
+  YV4_REQUIRE(lds + kDecStaticLds <= 64 * 1024, "decode_filter: num_classes %d too large for the LDS tile (%zu + %zu bytes)",
+              num_classes, lds, kDecStaticLds);
   hipLaunchKernelGGL(decode_filter_kernel, dim3((blocks + kDecTiles - 1) / kDecTiles, N), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
   YV4_CHECK_LAUNCH("decode_filter");
   return YV4_OK;

@@ -315,6 +315,9 @@ LAUNCHED = textwrap.dedent('''
     rank, local_rank, world = D.init(backend='gloo')          # the rendezvous the launcher's environment describes
     if '--die' in sys.argv and rank == 1:
         sys.exit(7)
+    if '--hang' in sys.argv and rank == 0:
+        import time
+        time.sleep(600)                                       # a rank the launcher has to take down itself
     worst = D.max_over_ranks(0.5 * (rank + 1))
     D.barrier(sync_device=False)
     print('noise from rank %%d' %% rank, flush=True)
@@ -346,6 +349,24 @@ def test_bench_launcher_reports_the_worst_rank(tmp_path, capfd):
     rc = bench.launch_ranks(2, ['--gpus', '2', '--die'], script=str(script), timeout=60)
     assert rc == 7
     assert 'rank exit codes' in capfd.readouterr().err
+
+
+def test_bench_launcher_kill_does_not_mask_the_failing_rank(tmp_path, capfd, monkeypatch):
+    """rank 1 exits 7 by itself, rank 0 hangs and is killed by the launcher after the grace period (-9):
+    the run's exit code is the rank's own 7, not 9; with only launcher kills (a timeout) it is 124."""
+    import bench
+    import time as _time
+    script = tmp_path / 'ranks.py'
+    script.write_text(LAUNCHED % ROOT)
+    real = _time.time
+    t0 = real()
+    monkeypatch.setattr(bench.time, 'time', lambda: t0 + (real() - t0) * 20)      # the 30 s grace period in 1.5 s
+    rc = bench.launch_ranks(2, ['--gpus', '2', '--die', '--hang'], script=str(script), timeout=2000)
+    err = capfd.readouterr().err
+    assert rc == 7, (rc, err)
+    assert 'killed by the launcher: [0]' in err
+    rc = bench.launch_ranks(2, ['--gpus', '2', '--hang'], script=str(script), timeout=300)   # 15 s of real time
+    assert rc == 124
 
 
 def test_bench_main_self_launches_only_without_a_launcher(monkeypatch):
