@@ -249,8 +249,8 @@ def cpu_baseline_v3(det, sd, size, budget_s):
                        f'({el:.1f} s, {threads} torch threads = cgroup CPU quota), same weights as the GPU run')
 
 
-# image 0's pred maps of the timed step vs the CPU oracle, |diff| / (1 + |ref|): fp32 bounds = the ones
-# tests/test_gpu_fullsize.py holds the path to (measured mean 9e-6 / max 4e-4); 16-bit operands: one rounding per fused
+# image 0's pred maps of the timed step vs the CPU oracle, |diff| / (1 + |ref|): fp32 is anchored on the float64 oracle
+# (oracle_check; the 'f32' entry below is no longer a bound, only the 16-bit ones are); 16-bit operands: one rounding per fused
 # layer through ~110 layers (measured mean 5e-3 fp16 / 4e-2 bf16) -- bounds that a skipped MFMA, a missing
 # slice or a stale buffer exceed by orders of magnitude
 ORACLE_BOUNDS = {'f32': (5e-5, 2e-3), 'f16': (3e-2, 1.0), 'bf16': (2e-1, 4.0)}
@@ -269,17 +269,45 @@ def oracle_check(det, img0, pred0, dets0, dtype):
         ref, _ = O.forward_pred_maps(img0, sd, stages, reps, outs, neck=neck)
     mean_b, max_b = ORACLE_BOUNDS[dtype]
     worst_mean = worst_max = 0.0
-    for got, r in zip(pred0, ref):
-        r = r[0]
-        if tuple(got.shape) != tuple(r.shape):
-            return False, f'pred map shape {tuple(got.shape)} != oracle {tuple(r.shape)}'
-        e = (got - r).abs() / (1 + r.abs())
-        if not bool(torch.isfinite(e).all()):
-            return False, 'non-finite pred map'
-        worst_mean, worst_max = max(worst_mean, float(e.mean())), max(worst_max, float(e.max()))
-    msg = (f'image 0 pred maps of the timed step vs the CPU oracle: mean {worst_mean:.2e} / max {worst_max:.2e} of 1 + |logit| '
-           f'(bounds {mean_b:g} / {max_b:g})')
-    ok = worst_mean <= mean_b and worst_max <= max_b
+    if dtype == 'f32':
+        # fp32: anchored on the oracle evaluated in FLOAT64, as tests/test_gpu_fullsize.py does -- 115 layers deep two
+        # correct fp32 evaluations differ by the amplified rounding of their summation orders, so the statement is "the
+        # HIP maps are as close to the truth as the fp32 CPU oracle (the reference's own arithmetic) is": per level
+        # mean <= 1.5 x and max <= 2.5 x the fp32 oracle's own distance from float64 (a loose constant would have to
+        # be re-fitted whenever a kernel's summation order changes: round 4's 7.7e-4 -> 1.04e-3 against "2e-3")
+        sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+        with torch.no_grad():
+            ref64, _ = O.forward_pred_maps(img0.double(), sd64, stages, reps, outs, neck=neck)
+        parts = []
+        ok = True
+        for lvl, (got, r, t) in enumerate(zip(pred0, ref, ref64)):
+            r, t = r[0], t[0]
+            if tuple(got.shape) != tuple(r.shape):
+                return False, f'pred map shape {tuple(got.shape)} != oracle {tuple(r.shape)}'
+            e_gpu = (got.double() - t).abs() / (1 + t.abs())
+            e_cpu = (r.double() - t).abs() / (1 + t.abs())
+            if not bool(torch.isfinite(e_gpu).all()):
+                return False, 'non-finite pred map'
+            gm, gx, cm, cx = float(e_gpu.mean()), float(e_gpu.max()), float(e_cpu.mean()), float(e_cpu.max())
+            ok = ok and gm <= 1.5 * cm + 1e-6 and gx <= 2.5 * cx + 1e-5
+            parts.append(f'L{lvl} {gm:.1e}/{gx:.1e} vs {cm:.1e}/{cx:.1e}')
+            e = (got - r).abs() / (1 + r.abs())
+            worst_mean, worst_max = max(worst_mean, float(e.mean())), max(worst_max, float(e.max()))
+        msg = ('image 0 pred maps of the timed step vs the CPU oracle in float64, mean/max of |d| / (1 + |logit|) per level, '
+               'HIP vs fp32 CPU oracle: ' + ', '.join(parts) + ' (bound: mean <= 1.5 x, max <= 2.5 x the fp32 oracle\'s own); '
+               f'HIP vs fp32 oracle directly: mean {worst_mean:.2e} / max {worst_max:.2e}')
+    else:
+        for got, r in zip(pred0, ref):
+            r = r[0]
+            if tuple(got.shape) != tuple(r.shape):
+                return False, f'pred map shape {tuple(got.shape)} != oracle {tuple(r.shape)}'
+            e = (got - r).abs() / (1 + r.abs())
+            if not bool(torch.isfinite(e).all()):
+                return False, 'non-finite pred map'
+            worst_mean, worst_max = max(worst_mean, float(e.mean())), max(worst_max, float(e.max()))
+        msg = (f'image 0 pred maps of the timed step vs the CPU oracle: mean {worst_mean:.2e} / max {worst_max:.2e} of 1 + |logit| '
+               f'(bounds {mean_b:g} / {max_b:g})')
+        ok = worst_mean <= mean_b and worst_max <= max_b
     if dtype == 'f32' and ok:
         res = O.get_bboxes(ref, [[1.0, 1.0, 1.0, 1.0]], 80, rescale=True)[0]
         k = int(res[0].shape[0])

@@ -76,6 +76,12 @@ const char* yv4_arch(void);
 int yv4_mish_fwd(const void* in, void* out, size_t n, int dtype, void* stream);
 int yv4_mish_bwd(const void* gout, const void* in, void* gin, size_t n,
                  int dtype, void* stream);
+/* The same op on HOST memory (ABI 6): mish.cc:14-33 dispatches on input.is_cuda() and a CPU tensor runs
+ * mish_cpu_kernel's loop (src/kernel/mish_cpu.cc:6-29) over mish.h:16-29 -- float and double only (Half / BFloat16 are
+ * not dispatched there: YV4_E_UNSUPPORTED), the float forward evaluated in double as that build does.  Plain
+ * single-threaded loops over libm.  Not on any plan's or train step's path -- the op's CPU behaviour, nothing else. */
+int yv4_mish_fwd_host(const void* in, void* out, size_t n, int dtype);
+int yv4_mish_bwd_host(const void* gout, const void* in, void* gin, size_t n, int dtype);
 
 /* ---- layout adaptors -------------------------------------------------------
  * src NCHW (N,C,H,W) contiguous fp32 -> dst NHWC with `dst_cstride` channels per

@@ -95,6 +95,8 @@ SIGNATURES = {
     'yv4_arch': (C.c_char_p, []),
     'yv4_mish_fwd': (C.c_int, [_vp, _vp, _sz, _i, _vp]),
     'yv4_mish_bwd': (C.c_int, [_vp, _vp, _vp, _sz, _i, _vp]),
+    'yv4_mish_fwd_host': (C.c_int, [_vp, _vp, _sz, _i]),
+    'yv4_mish_bwd_host': (C.c_int, [_vp, _vp, _vp, _sz, _i]),
     'yv4_nchw_to_nhwc': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_nhwc_to_nchw': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'yv4_conv_bn_act_fwd': (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp,

@@ -420,3 +420,71 @@ extern "C" int yv4_resample_nearest_fwd(const float* src, float* dst, int N, int
   YV4_CHECK_LAUNCH("resample_nearest");
   return YV4_OK;
 }
+
+// ---- the op on HOST memory (ABI 6) ---------------------------------------------------------------------------------
+// mmdet/ops/mish_cuda/src/mish.cc:14-33 dispatches on input.is_cuda(): a CPU tensor goes to mish_cpu_kernel
+// (src/kernel/mish_cpu.cc:6-29), a plain loop over mish.h:16-29 under AT_DISPATCH_ALL_TYPES -- float and double; Half and
+// BFloat16 are not dispatched on the CPU and raise there, so they are refused here.  One property of that loop is part
+// of its arithmetic: mish.h is included INSIDE namespace mish_cpu_kernel, where the unqualified exp / log1p / tanh of a
+// float argument bind to the C library's double functions -- the float forward is evaluated in double and rounded once,
+// the float backward rounds at each of its named `const scalar_t` values.  The loops below do exactly that, so the
+// op's CPU results are the reference's to the bit (tests/test_abi.py, against the fixture its unmodified source made).
+// Single-threaded, like the reference's loop.  Not a path of any plan or train step.
+namespace {
+inline float mish_fwd_host_f(float x) {
+  return (float)((double)x * ::tanh(x < 20.f ? ::log1p(::exp((double)x)) : (double)x));
+}
+inline float mish_bwd_host_f(float go, float x) {
+  const float sp = (float)(x < 20.f ? ::log1p(::exp((double)x)) : (double)x);
+  const float grad_sp = (float)(1 - ::exp(-(double)sp));
+  const float tsp = (float)::tanh((double)sp);
+  const float grad_tsp = (1 - tsp * tsp) * grad_sp;
+  const float grad = x * grad_tsp + tsp;
+  return go * grad;
+}
+inline double mish_fwd_host_d(double x) { return x * ::tanh(x < 20.0 ? ::log1p(::exp(x)) : x); }
+inline double mish_bwd_host_d(double go, double x) {
+  const double sp = x < 20.0 ? ::log1p(::exp(x)) : x;
+  const double grad_sp = 1.0 - ::exp(-sp);
+  const double tsp = ::tanh(sp);
+  const double grad_tsp = (1.0 - tsp * tsp) * grad_sp;
+  const double grad = x * grad_tsp + tsp;
+  return go * grad;
+}
+}  // namespace
+
+// (no contraction: `x * grad_tsp + tsp` is a multiply and an add in the reference's build)
+#pragma clang fp contract(off)
+extern "C" int yv4_mish_fwd_host(const void* in, void* out, size_t n, int dtype) {
+  if (n == 0) return YV4_OK;
+  YV4_REQUIRE(in && out, "mish_fwd_host: null pointer");
+  if (dtype == YV4_F32) {
+    const float* x = (const float*)in; float* y = (float*)out;
+    for (size_t i = 0; i < n; ++i) y[i] = mish_fwd_host_f(x[i]);
+  } else if (dtype == YV4_F64) {
+    const double* x = (const double*)in; double* y = (double*)out;
+    for (size_t i = 0; i < n; ++i) y[i] = mish_fwd_host_d(x[i]);
+  } else {
+    set_error("mish_fwd_host: \"mish_cpu_kernel\" not implemented for this dtype (%d): the reference's CPU loop takes float "
+              "and double", dtype);
+    return YV4_E_UNSUPPORTED;
+  }
+  return YV4_OK;
+}
+
+extern "C" int yv4_mish_bwd_host(const void* gout, const void* in, void* gin, size_t n, int dtype) {
+  if (n == 0) return YV4_OK;
+  YV4_REQUIRE(gout && in && gin, "mish_bwd_host: null pointer");
+  if (dtype == YV4_F32) {
+    const float* g = (const float*)gout; const float* x = (const float*)in; float* y = (float*)gin;
+    for (size_t i = 0; i < n; ++i) y[i] = mish_bwd_host_f(g[i], x[i]);
+  } else if (dtype == YV4_F64) {
+    const double* g = (const double*)gout; const double* x = (const double*)in; double* y = (double*)gin;
+    for (size_t i = 0; i < n; ++i) y[i] = mish_bwd_host_d(g[i], x[i]);
+  } else {
+    set_error("mish_bwd_host: \"mish_backward_cpu_kernel\" not implemented for this dtype (%d): the reference's CPU loop takes "
+              "float and double", dtype);
+    return YV4_E_UNSUPPORTED;
+  }
+  return YV4_OK;
+}

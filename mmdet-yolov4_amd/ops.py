@@ -34,22 +34,30 @@ def _ptr(t):
 # ---- Mish ---------------------------------------------------------------------------
 def mish_forward(input):
     """``mish_cuda_ext.mish_forward`` (mmdet/ops/mish_cuda/src/mish.cc:14-22): new
-    tensor ``empty_like(input)``; input must be contiguous."""
-    _need_cuda(input, 'input')
+    tensor ``empty_like(input)``; input must be contiguous.  Like the reference's dispatcher a CPU tensor runs the
+    op's host loop (``yv4_mish_fwd_host``: the library's own restatement of mish.h:16-18 -- the op's CPU behaviour, not
+    a path of any plan)."""
+    if not isinstance(input, torch.Tensor):
+        raise TypeError('input must be a torch.Tensor')
     if not input.is_contiguous():
         raise RuntimeError('mish_forward: input must be contiguous')
     if input.dtype not in _DT:
         raise RuntimeError(f'mish_forward: unsupported dtype {input.dtype}')
     out = torch.empty_like(input)
+    if not input.is_cuda:
+        check(_lib.lib().yv4_mish_fwd_host(_ptr(input), _ptr(out), input.numel(), _DT[input.dtype]), 'yv4_mish_fwd_host')
+        return out
     check(_lib.lib().yv4_mish_fwd(_ptr(input), _ptr(out), input.numel(), _DT[input.dtype],
                                   stream_ptr()), 'yv4_mish_fwd')
     return out
 
 
 def mish_backward(grad_out, input):
-    """``mish_cuda_ext.mish_backward`` (mish.cc:24-33)."""
-    _need_cuda(grad_out, 'grad_out')
-    _need_cuda(input, 'input')
+    """``mish_cuda_ext.mish_backward`` (mish.cc:24-33); dispatches on ``grad_out.is_cuda`` as the reference does."""
+    if not (isinstance(grad_out, torch.Tensor) and isinstance(input, torch.Tensor)):
+        raise TypeError('grad_out and input must be torch.Tensors')
+    if grad_out.device != input.device:
+        raise RuntimeError(f'mish_backward: grad_out is on {grad_out.device}, input on {input.device}')
     if not (grad_out.is_contiguous() and input.is_contiguous()):
         raise RuntimeError('mish_backward: tensors must be contiguous')
     if grad_out.dtype != input.dtype or grad_out.shape != input.shape:
@@ -57,6 +65,10 @@ def mish_backward(grad_out, input):
     if input.dtype not in _DT:
         raise RuntimeError(f'mish_backward: unsupported dtype {input.dtype}')
     gin = torch.empty_like(input)
+    if not grad_out.is_cuda:
+        check(_lib.lib().yv4_mish_bwd_host(_ptr(grad_out), _ptr(input), _ptr(gin), input.numel(), _DT[input.dtype]),
+              'yv4_mish_bwd_host')
+        return gin
     check(_lib.lib().yv4_mish_bwd(_ptr(grad_out), _ptr(input), _ptr(gin), input.numel(),
                                   _DT[input.dtype], stream_ptr()), 'yv4_mish_bwd')
     return gin

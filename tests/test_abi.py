@@ -49,10 +49,10 @@ def test_argument_validation_without_gpu():
 
 
 def test_cpu_tensors_are_refused():
+    """Everything with a plan or kernel behind it refuses CPU tensors.  (The standalone Mish op is the exception the
+    reference makes too: mish.cc:14-22 dispatches on is_cuda -- test_mish_host_loop_matches_the_reference_fixture.)"""
     import pytest
     import torch
-    with pytest.raises(RuntimeError, match='no CPU fallback'):
-        pkg.mish_forward(torch.zeros(8))
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         pkg.batched_nms(torch.zeros(1, 4), torch.zeros(1), torch.zeros(1, dtype=torch.long), dict(iou_threshold=0.5))
     with pytest.raises(RuntimeError, match='no CPU fallback'):
@@ -97,3 +97,24 @@ def test_binding_argument_types_match_the_header():
         elif ret in scalar:
             assert restype is scalar[ret], f'{name}: returns {ret}, bound as {restype}'
     assert seen == set(pkg._lib.SIGNATURES), set(pkg._lib.SIGNATURES) - seen
+
+
+def test_mish_host_loop_matches_the_reference_fixture(golden):
+    """mish.cc:14-33: a CPU tensor runs the op's host loop.  The library's own loop (csrc/elementwise.hip
+    yv4_mish_*_host, NOT the oracle) against tests/golden/mish.npz, which the reference's unmodified mish_cpu.cc produced:
+    bit for bit in float32 and float64; Half / BFloat16 are refused as the reference's CPU dispatch refuses them."""
+    import numpy as np
+    import torch
+    g = golden('mish')
+    x, gr = torch.from_numpy(g['x']), torch.from_numpy(g['g'])
+    np.testing.assert_array_equal(pkg.mish_forward(x).numpy(), g['y'])
+    np.testing.assert_array_equal(pkg.mish_backward(gr, x).numpy(), g['gin'])
+    np.testing.assert_array_equal(pkg.mish_forward(x.double()).numpy(), g['y64'])
+    np.testing.assert_array_equal(pkg.mish_backward(gr.double(), x.double()).numpy(), g['gin64'])
+    import pytest
+    with pytest.raises(RuntimeError, match='not implemented for this dtype'):      # AT_DISPATCH_ALL_TYPES has no Half
+        pkg.mish_forward(x.half())
+    # the autograd Function on CPU tensors, end to end
+    xr = x.clone().requires_grad_(True)
+    pkg.MishFunction.apply(xr).backward(gr)
+    np.testing.assert_array_equal(xr.grad.numpy(), g['gin'])
