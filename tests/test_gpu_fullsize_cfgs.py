@@ -199,6 +199,45 @@ def test_cfg4_yolov5l_640_bf16_train_step(gpu_device):
     _check_norms(n32, n16, 'yolov5l 640 bf16')
 
 
+@pytest.mark.parametrize('model,size', [('yolov4l', 608), ('yolov5l', 640)])
+def test_cfg2_cfg4_bf16_batch64_forward_and_loss(gpu_device, model, size):
+    """configs[2] / configs[4] at their REAL per-GPU batch of 64 (tile shapes, `prefer_w3` /
+    `prefer_wide` and the weight-gradient chunking depend on the batch, and the batch-8 cases above do not exercise the
+    batch-64 selection): one bf16 training forward + fused loss + backward.  The loss of the HIP maps must equal the
+    ORACLE's head_loss (yolocsp_head.py:384-575 restated, CPU) on those same maps -- the CPU cost is the loss only --, the
+    loss terms must sit where the batch-8 step's sit per image (the images are drawn the same way), and every parameter
+    must receive a finite gradient whose global norm per image agrees with the batch-8 bf16 step's to 25 % (a different
+    batch: statistics, not equality)."""
+    torch.manual_seed(0)
+    det = pkg.build_detector(bench.model_cfg(model))
+    det.init_weights()
+    det.train().to(gpu_device)
+    pkg.wrap_fp16_model(det, torch.bfloat16)
+    sd0 = {k: v.clone() for k, v in det.state_dict().items()}
+    res = {}
+    for batch in (64, 8):
+        det.load_state_dict(sd0)
+        det.zero_grad()
+        img = bench.synthetic_images(batch, size, 1000, gpu_device)
+        gtb, gtl = bench.synthetic_gts(batch, size, 2000, gpu_device)
+        data = dict(img=img, img_metas=[dict() for _ in range(batch)], gt_bboxes=gtb, gt_labels=gtl)
+        log, raws, total, _ = _train_step(det, data)
+        assert all(r.raw.dtype == torch.bfloat16 for r in raws)
+        ora = _oracle_losses(raws, data)
+        for k in ('loss_cls', 'loss_conf', 'loss_bbox'):
+            np.testing.assert_allclose(log[k], ora[k], rtol=2e-4, err_msg=f'batch {batch} bf16 {k} vs oracle head_loss on the HIP maps')
+        total.backward()
+        norms = _grad_norms(det)
+        res[batch] = (log, float(np.sqrt(sum(v * v for v in norms.values()))))
+        del raws, total, img, data
+        torch.cuda.empty_cache()
+    (l64, g64), (l8, g8) = res[64], res[8]
+    print(f'{model} bf16: batch 64 losses {l64} |g| {g64:.4g}; batch 8 losses {l8} |g| {g8:.4g}')
+    for k in ('loss_cls', 'loss_conf', 'loss_bbox'):
+        np.testing.assert_allclose(l64[k], l8[k], rtol=0.1, err_msg=f'{k}: batch 64 vs batch 8 (means over images / positives)')
+    assert abs(g64 - g8) <= 0.25 * g8, (g64, g8)
+
+
 # ---- configs[3]: YOLOv4-S 416x416 fp16 inference, batch 256 ------------------------------------------------------
 @pytest.fixture(scope='module')
 def v4s(gpu_device):

@@ -8,7 +8,7 @@ import os
 import re
 import sys
 
-R03 = '--r03' in sys.argv
+R03 = '--r03' in sys.argv      # (the layout of rounds 3-5: one directory per profiled command)
 argv = [a for a in sys.argv[1:] if a != '--r03']
 raw, out = argv[0], argv[1]
 os.makedirs(out, exist_ok=True)
@@ -24,6 +24,38 @@ def short(name):
     if m:
         return m.group(1)
     return name.split('(')[0][:70]
+
+
+def timed_region_stats(trace_csv, steps):
+    """Per-kernel statistics over the TIMED steps only.  rocprofv3 --stats covers the whole process: model build, BatchNorm
+    calibration in fp32, warm-up -- in the 16-bit runs the fp32 calibration plan's kernels headed the table and made its
+    Percentage column meaningless.  The timed region is the last `steps` repetitions of one launch sequence: the period is
+    found as the smallest P for which the last steps * P kernel names are P-periodic, and the statistics are taken over
+    exactly those launches.  Returns (rows, period) or (None, 0) when no period is found."""
+    rows = list(csv.DictReader(open(trace_csv)))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    names = [r['Kernel_Name'] for r in rows]
+    n = len(names)
+    period = 0
+    for P in range(20, n // max(steps, 1) + 1):
+        tail = names[n - steps * P:]
+        if len(tail) == steps * P and all(tail[i] == tail[i % P] for i in range(steps * P)):
+            period = P
+            break
+    if not period:
+        return None, 0
+    agg = collections.OrderedDict()
+    for r in rows[n - steps * period:]:
+        d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+        a = agg.setdefault(r['Kernel_Name'], [0, 0, 1 << 62, 0])
+        a[0] += 1
+        a[1] += d
+        a[2] = min(a[2], d)
+        a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
+    out = [[short(k), a[0], a[1], round(a[1] / a[0], 1), round(100.0 * a[1] / tot, 3), a[2], a[3]]
+           for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+    return out, period
 
 
 def pmc_of(run_dir):
@@ -56,9 +88,24 @@ if R03:
         name = os.path.basename(run_dir)
         if not os.path.isdir(os.path.join(run_dir, 'trace')):
             continue
-        for f in glob.glob(os.path.join(run_dir, 'trace', '*', '*_kernel_stats.csv')):
+        steps_file = os.path.join(run_dir, 'steps.txt')
+        done = False
+        if os.path.exists(steps_file):
+            steps = int(open(steps_file).read().split()[0])
+            for f in glob.glob(os.path.join(run_dir, 'trace', '*', '*_kernel_trace.csv')):
+                rows, period = timed_region_stats(f, steps)
+                if rows:
+                    with open(os.path.join(out, name + '_kernel_stats.csv'), 'w', newline='') as g:
+                        g.write(f'# timed region only: the last {steps} steps x {period} launches per step of the kernel trace '
+                                f'(calibration, warm-up and set-up launches excluded)\n')
+                        w = csv.writer(g)
+                        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+                        w.writerows(rows)
+                    done = True
+        for f in ([] if done else glob.glob(os.path.join(run_dir, 'trace', '*', '*_kernel_stats.csv'))):
             rows = list(csv.DictReader(open(f)))
             with open(os.path.join(out, name + '_kernel_stats.csv'), 'w', newline='') as g:
+                g.write('# whole process (no step period found in the trace): includes set-up, calibration and warm-up launches\n')
                 w = csv.writer(g)
                 w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
                 for r in rows:
