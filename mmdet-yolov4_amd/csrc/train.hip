@@ -1453,6 +1453,255 @@ __global__ __launch_bounds__(kFcThreads, (FcGeom<CIN, COUT>::WGs)) void conv_wgr
   }
 }
 
+// ---------------------------------------------------------------------------------
+// The few-channel kernel with its per-slice bookkeeping taken off the lanes (round 5; see conv_wgrad3x3_v2_h16_kernel).  The
+// first form issues, per 64-row slice and wave, 8-24 MFMAs beside 213-316 VALU and 219-306 scalar instructions: its ~1.2 us
+// per slice on the stem's geometry IS that instruction stream (8 MFMAs = 256 matrix cycles against ~2 000 issue cycles).
+// Here the border flags are computed once per slice row by the idle role-7 wave (vertical borders included, so the DMA no
+// longer zeroes anything and the two scalar row decodes per slice are gone), a lane fetches its eight rows' flags with one
+// ds_read_b64 a slice ahead, and the DMA offsets advance by constants and are range-checked as offsets.  Same images, same
+// fragment addresses, same MFMAs in the same order: dW is bit-identical to the first form (tools/ab_wfc.sh).
+// ---------------------------------------------------------------------------------
+template <bool BF16, int CIN, int COUT>
+__global__ __launch_bounds__(kFcThreads, (FcGeom<CIN, COUT>::WGs)) void conv_wgrad_fc_v2_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
+  typedef FcGeom<CIN, COUT> G;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4_t;
+  typedef __attribute__((address_space(3))) unsigned long long* lds_u64_t;
+  typedef __attribute__((address_space(3))) unsigned char* lds_u8_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_fc[];
+  constexpr int kFlagBase = G::Lds;                  // NBuf x 3 (kh) x 64 flag bytes behind the buffers and the scratch KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = (int)blockIdx.x;
+  const int m_lo = chunk * p.rows_per_chunk;
+  const int m_hi = min(m_lo + p.rows_per_chunk, p.M);
+  if (m_lo >= m_hi) return;
+  const int NHW = p.N * p.H * p.W;
+  const u32x4_t rsX = make_rsrc_t(p.x, x_bytes);
+  const u32x4_t rsD = make_rsrc_t(p.dy, dy_bytes);
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)smem_fc;
+  auto swz128 = [](int row) { return ((row >> 1) & 1) << 2; };         // 128-byte rows only
+
+  // ---- staging: piece t = wave + 8 i of a slice.  Per lane and piece, fixed for the kernel: the row inside the slice
+  // (a huge one where the lane never fetches: padding rows of an image, dY columns past Cout) and the byte offset of its
+  // 16 bytes at slice 0; per slice the offset advances by 64 rows -- the VALU work of an issue is an add, a range
+  // check and a select per piece (the first version decoded rows and columns per slice and the kernel was bound by its
+  // 132 M VALU instructions, not by LDS or HBM).
+  int pc_kind[G::PW];                                // kind: 0 dY, 1..3 image kh = kind - 1, -1 dummy (wave-uniform)
+  unsigned pc_off[G::PW], pc_lim[G::PW], pc_lds[G::PW];   // byte offset of the next slice's 16 bytes, its limit (0: never)
+#pragma unroll
+  for (int i = 0; i < G::PW; ++i) {
+    const int t = wave + 8 * i;
+    pc_kind[i] = -1; pc_off[i] = 0u; pc_lim[i] = 0u; pc_lds[i] = 0u;
+    if (t < G::DPieces) {
+      const int L = 64 * t + lane;
+      const int row = L / G::CPD, pc = L % G::CPD;
+      const int lc = G::CPD == 8 ? (pc ^ swz128(row)) : pc;
+      pc_kind[i] = 0;
+      const unsigned cb_ = (unsigned)((p.dy_co + lc * 8) * 2);
+      pc_off[i] = (unsigned)(m_lo + row) * (unsigned)(p.dy_cs * 2) + cb_;
+      pc_lim[i] = lc * 8 < p.Cout ? (unsigned)m_hi * (unsigned)(p.dy_cs * 2) + cb_ : 0u;
+      pc_lds[i] = (unsigned)(t * 1024);
+    } else if (t < G::Pieces) {
+      const int u = t - G::DPieces;
+      const int khp = u / G::XPieces, q = u - khp * G::XPieces;
+      const int L = 64 * q + lane;
+      const int row = L / G::CPP, pc = L % G::CPP;
+      const int lc = G::CPP == 8 ? (pc ^ swz128(row)) : pc;
+      pc_kind[i] = 1 + khp;
+      const unsigned xb_ = (unsigned)((p.x_co + lc * 8) * 2);
+      // pixel = m_base + row + (khp - 1) W - 1; a pixel in front of the map wraps to ~2^32 and fails the limit
+      pc_off[i] = (unsigned)(m_lo + row + (khp - 1) * p.W - 1) * (unsigned)(p.x_cs * 2) + xb_;
+      pc_lim[i] = row < kFcZeroRow ? (unsigned)NHW * (unsigned)(p.x_cs * 2) + xb_ : 0u;
+      pc_lds[i] = (unsigned)(G::DBytes + khp * G::XBytes + q * 1024);
+    }
+  }
+  const unsigned d_step = (unsigned)(kFcRows * p.dy_cs * 2), x_step = (unsigned)(kFcRows * p.x_cs * 2);
+  // Borders are the READERS' business here: a source pixel that lies in another image row / image than the tap wants is
+  // fetched like any other and masked per lane through the flags below (the first form zeroed the vertical ones at DMA
+  // time, which cost every slice two scalar row decodes and, on border slices, a decode per lane and piece).
+  // Flags of slice row r = lane, one byte per kh (bits kw), written by the wave of role 7 (it never computes) when the
+  // slice's DMA is issued; byte position inside the 64 of a (buffer, kh): ((qq * 2 + hh) << 3) + s * 2 + j for
+  // r = 16 s + 8 hh + 4 j + qq, so that a lane fetches its eight rows' flags with one ds_read_b64.
+  const int f_wr = (((lane & 3) * 2 + ((lane >> 3) & 1)) << 3) + ((lane >> 4) << 1) + ((lane >> 2) & 1);
+  int f_m = m_lo + lane;
+  const int role_w = (wave + 8 - 2 * (((int)blockIdx.x >> 8) & 1)) & 7;
+  auto issue = [&](int sl) {
+    const int buf = sl % G::NBuf;
+#pragma unroll
+    for (int i = 0; i < G::PW; ++i) {
+      const unsigned off = pc_off[i] < pc_lim[i] ? pc_off[i] : kOOB;
+      if (pc_kind[i] == 0) {
+        lds_dma16_t(rsD, lds_base + (unsigned)(buf * G::BufBytes) + pc_lds[i], off, 0u);
+        pc_off[i] += d_step;
+      } else if (pc_kind[i] > 0) {
+        lds_dma16_t(rsX, lds_base + (unsigned)(buf * G::BufBytes) + pc_lds[i], off, 0u);
+        pc_off[i] += x_step;
+      } else {
+        lds_dma16_t(rsX, lds_base + (unsigned)(G::NBuf * G::BufBytes), kOOB, 0u);     // dummy: the scratch KB
+      }
+    }
+    if (role_w == 7) {
+      unsigned b0 = 0u, b1 = 0u, b2 = 0u;
+      if (f_m < m_hi) {
+        const int n = fd_div(f_m, p.fd_hw);
+        const int rm = f_m - n * (p.H * p.W);
+        const int ho = fd_div(rm, p.fd_wo);
+        const int wo = rm - ho * p.W;
+        const unsigned h3 = (wo > 0 ? 1u : 0u) | 2u | (wo + 1 < p.W ? 4u : 0u);
+        b0 = ho > 0 ? h3 : 0u;
+        b1 = h3;
+        b2 = ho + 1 < p.H ? h3 : 0u;
+      }
+      lds_u8_t fp = (lds_u8_t)(smem_fc + kFlagBase + buf * 192 + f_wr);
+      fp[0] = (unsigned char)b0; fp[64] = (unsigned char)b1; fp[128] = (unsigned char)b2;
+      f_m += kFcRows;
+    }
+  };
+
+  // ---- compute roles
+  // measurement-only bits (YV4_WFC_ABLATE): 1 no fragment reads / MFMAs, 2 no DMA, 4 no border masks, 8 no MFMAs
+  // Which waves compute.  A wave sits on SIMD (wave mod 4) and a computing wave keeps its SIMD busy for most of a slice
+  // (its VALU instructions take four cycles each and its MFMAs queue behind one another), so six roles on waves 0..5
+  // load the SIMDs 2-2-1-1 and the pair sets the pace of every slice.  The two workgroups that share a CU (b and b + 256
+  // of a one-round grid) therefore start their roles two waves apart: together 3-3-3-3.
+  const int role = role_w;
+  const bool computes = role < 3 * G::CB;
+  const int kh = role % 3, cb = role / 3;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int hh = g >> 1, colhalf = g & 1;
+  const int qq = i16 >> 2, pp = i16 & 3;
+  // dY fragment addresses (inside a buffer): [step s][j]
+  unsigned d_rd[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 16 * s + 8 * hh + 4 * j + qq;
+      const int chunk16 = (cb * 32 + 16 * colhalf) / 8 + (pp >> 1);
+      d_rd[s][j] = (unsigned)(row * G::DP + ((G::CPD == 8 ? (chunk16 ^ swz128(row)) : chunk16) << 4) + 8 * (pp & 1));
+    }
+  // X fragment addresses (inside a buffer) of (step s, j, column block nb), fixed for the kernel: the lane's 16-column
+  // half decides tap and channel base; x_zr[nb] = the same columns of the image's zero row
+  const unsigned ximg = (unsigned)(G::DBytes + kh * G::XBytes);
+  auto kw_of = [&](int nb) -> int { return CIN == 16 ? 2 * nb + colhalf : (CIN == 32 ? nb : nb >> 1); };
+  auto x_addr = [&](int row, int nb) -> unsigned {
+    const int kw = kw_of(nb);
+    const int cib = CIN == 16 ? 0 : (CIN == 32 ? 16 * colhalf : 32 * (nb & 1) + 16 * colhalf);
+    const int r = kw < 3 ? row + kw : kFcZeroRow;
+    const int chunk16 = cib / 8 + (pp >> 1);
+    return ximg + (unsigned)(r * G::PX + ((G::CPP == 8 ? (chunk16 ^ swz128(r)) : chunk16) << 4) + 8 * (pp & 1));
+  };
+  unsigned x_rd[4][2][G::NBK], x_zr[G::NBK];
+#pragma unroll
+  for (int nb = 0; nb < G::NBK; ++nb) {
+    x_zr[nb] = x_addr(kFcZeroRow - kw_of(nb) < 0 ? 0 : kFcZeroRow - (kw_of(nb) < 3 ? kw_of(nb) : 0), nb);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) x_rd[s][j][nb] = x_addr(16 * s + 8 * hh + 4 * j + qq, nb);
+  }
+
+  f32x16 acc[G::NBK];
+#pragma unroll
+  for (int b = 0; b < G::NBK; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+
+  const int nsl = (m_hi - m_lo + kFcRows - 1) / kFcRows;
+  const int f_rd = kFlagBase + kh * 64 + ((qq * 2 + hh) << 3);
+  static_assert(G::NBuf >= 3, "the flags of slice sl + 1 are read during slice sl: they must have been written a barrier ago");
+#pragma unroll
+  for (int s0 = 0; s0 < G::NBuf - 1; ++s0) issue(s0);
+  unsigned long long fl = 0ull, fln = 0ull;
+  for (int sl = 0; sl < nsl; ++sl) {
+    // own DMA(sl) landed: the NBuf - 2 younger slices (PW instructions each) may stay in flight
+    constexpr int kLeft = (G::NBuf - 2) * G::PW;
+    static_assert(kLeft >= 0 && kLeft < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kLeft) : "memory");
+    __builtin_amdgcn_s_barrier();                      // slice sl complete in LDS; every wave is done with slice sl - 1
+    asm volatile("" ::: "memory");
+    issue(sl + G::NBuf - 1);                           // into the buffer slice sl - 1 left
+    if (computes) {
+      const char* bufp = smem_fc + (sl % G::NBuf) * G::BufBytes;
+      // this slice's flags (slice 0: fetched now; later slices: fetched one slice ahead) and the next slice's
+      if (sl == 0) fl = *(lds_u64_t)(smem_fc + f_rd);
+      fln = *(lds_u64_t)(smem_fc + f_rd + ((sl + 1) % G::NBuf) * 192);
+      // two fragment sets: the reads of step s + 1 are issued in front of the MFMAs of step s (left to itself the
+      // compiler reuses one register set and every MFMA waits out a fresh LDS round trip: 2 400 cycles per slice)
+      s16x8_t fa[2], fb[2][G::NBK];
+#define YV4_FC_LOAD(SET, S)                                                                                   \
+      {                                                                                                       \
+        const s16x4_t a0_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(bufp + d_rd[S][0]));          \
+        const s16x4_t a1_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(bufp + d_rd[S][1]));          \
+        fa[SET] = __builtin_shufflevector(a0_, a1_, 0, 1, 2, 3, 4, 5, 6, 7);                                  \
+        _Pragma("unroll") for (int nb = 0; nb < G::NBK; ++nb) {                                               \
+          const int kw_ = kw_of(nb);                                                                          \
+          const int kb_ = kw_ < 3 ? kw_ : 0;                                                                  \
+          const unsigned fw_ = (unsigned)(fl >> (((S) >> 1) * 32));                                           \
+          const bool ok0_ = kw_ < 3 && ((fw_ >> ((((S) & 1) * 2 + 0) * 8 + kb_)) & 1u);                       \
+          const bool ok1_ = kw_ < 3 && ((fw_ >> ((((S) & 1) * 2 + 1) * 8 + kb_)) & 1u);                       \
+          const s16x4_t b0_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(bufp + (ok0_ ? x_rd[S][0][nb] : x_zr[nb]))); \
+          const s16x4_t b1_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(bufp + (ok1_ ? x_rd[S][1][nb] : x_zr[nb]))); \
+          fb[SET][nb] = __builtin_shufflevector(b0_, b1_, 0, 1, 2, 3, 4, 5, 6, 7);                            \
+        }                                                                                                     \
+      }
+#define YV4_FC_MFMA(SET)                                                                                      \
+      {                                                                                                       \
+        _Pragma("unroll") for (int nb = 0; nb < G::NBK; ++nb) {                                               \
+          if (BF16)                                                                                           \
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, fa[SET]),          \
+                                                              __builtin_bit_cast(bf16x8_w, fb[SET][nb]), acc[nb], 0, 0, 0); \
+          else                                                                                                \
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_w, fa[SET]),            \
+                                                             __builtin_bit_cast(f16x8_w, fb[SET][nb]), acc[nb], 0, 0, 0);   \
+        }                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+      }
+      YV4_FC_LOAD(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      YV4_FC_LOAD(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      YV4_FC_MFMA(0);
+      YV4_FC_LOAD(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      YV4_FC_MFMA(1);
+      YV4_FC_LOAD(1, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      YV4_FC_MFMA(0);
+      YV4_FC_MFMA(1);
+#undef YV4_FC_MFMA
+#undef YV4_FC_LOAD
+      fl = fln;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the tail's out-of-range DMAs must land before the LDS goes
+
+  if (!computes) return;
+  // D[row = co][col]: row = (e&3) + 8*(e>>2) + 4*(lane>>5), col = lane&31 -> (kw, ci) of the block
+  const int ncol = lane & 31, h5 = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < G::NBK; ++nb) {
+    int kw, ci;
+    if (CIN == 16) { kw = 2 * nb + (ncol >> 4); ci = ncol & 15; }
+    else if (CIN == 32) { kw = nb; ci = ncol; }
+    else { kw = nb >> 1; ci = 32 * (nb & 1) + ncol; }
+    if (kw >= 3 || ci >= p.Cin) continue;
+    const int kcol = (kh * 3 + kw) * p.Cin + ci;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h5;
+      if (co < p.Cout) {
+        if (p.ws) p.ws[(size_t)chunk * p.ws_stride + (size_t)co * p.K + kcol] = acc[nb][e];
+        else atomicAdd(&p.dw[(size_t)co * p.K + kcol], acc[nb][e]);
+      }
+    }
+  }
+}
+
 // domain of conv_wgrad_fc_h16_kernel, and the channels per pixel it loads (0: not applicable)
 static int wgrad_fc_cin(const yv4_conv_desc* d, int dtype) {
   static const int mode = YV4_ENV_INT("YV4_WGRAD_FC", 1);
@@ -3002,8 +3251,17 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
     static const int fc_ablate = YV4_ENV_INT("YV4_WFC_ABLATE", 0);
     a.ablate = fc_ablate;
+    static const int fcv2 = YV4_ENV_INT("YV4_WFC_V2", 1);
+    const bool use_v2 = fcv2 && xb < 0xC0000000LL && db < 0xC0000000LL;
 #define YV4_FC_LAUNCH(CI, CO)                                                                                        \
-  {                                                                                                                  \
+  if (use_v2) {                                                                                                      \
+    static LdsAttrOnce once_b2, once_h2;                                                                             \
+    constexpr size_t lds2 = FcGeom<CI, CO>::Lds + FcGeom<CI, CO>::NBuf * 192;                                        \
+    if (int rc = ensure_dyn_lds(once_b2, reinterpret_cast<const void*>(conv_wgrad_fc_v2_h16_kernel<true, CI, CO>), lds2, "conv_wgrad_fc_v2_h16")) return rc;  \
+    if (int rc = ensure_dyn_lds(once_h2, reinterpret_cast<const void*>(conv_wgrad_fc_v2_h16_kernel<false, CI, CO>), lds2, "conv_wgrad_fc_v2_h16")) return rc; \
+    if (dtype == YV4_BF16) hipLaunchKernelGGL((conv_wgrad_fc_v2_h16_kernel<true, CI, CO>), dim3((unsigned)ch), dim3(kFcThreads), lds2, hs, a, (unsigned)xb, (unsigned)db); \
+    else hipLaunchKernelGGL((conv_wgrad_fc_v2_h16_kernel<false, CI, CO>), dim3((unsigned)ch), dim3(kFcThreads), lds2, hs, a, (unsigned)xb, (unsigned)db);                  \
+  } else {                                                                                                           \
     static LdsAttrOnce once_b, once_h;                                                                               \
     constexpr size_t lds = FcGeom<CI, CO>::Lds;                                                                      \
     if (int rc = ensure_dyn_lds(once_b, reinterpret_cast<const void*>(conv_wgrad_fc_h16_kernel<true, CI, CO>), lds, "conv_wgrad_fc_h16")) return rc;  \

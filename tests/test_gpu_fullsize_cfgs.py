@@ -206,8 +206,8 @@ def test_cfg2_cfg4_bf16_batch64_forward_and_loss(gpu_device, model, size):
     batch-64 selection): one bf16 training forward + fused loss + backward.  The loss of the HIP maps must equal the
     ORACLE's head_loss (yolocsp_head.py:384-575 restated, CPU) on those same maps -- the CPU cost is the loss only --, the
     loss terms must sit where the batch-8 step's sit per image (the images are drawn the same way), and every parameter
-    must receive a finite gradient whose global norm per image agrees with the batch-8 bf16 step's to 25 % (a different
-    batch: statistics, not equality)."""
+    must receive a finite gradient whose global norm relates to the batch-8 bf16 step's as 1 / sqrt(batch) within a factor
+    of two (a different batch: statistics, not equality)."""
     torch.manual_seed(0)
     det = pkg.build_detector(bench.model_cfg(model))
     det.init_weights()
@@ -235,7 +235,9 @@ def test_cfg2_cfg4_bf16_batch64_forward_and_loss(gpu_device, model, size):
     print(f'{model} bf16: batch 64 losses {l64} |g| {g64:.4g}; batch 8 losses {l8} |g| {g8:.4g}')
     for k in ('loss_cls', 'loss_conf', 'loss_bbox'):
         np.testing.assert_allclose(l64[k], l8[k], rtol=0.1, err_msg=f'{k}: batch 64 vs batch 8 (means over images / positives)')
-    assert abs(g64 - g8) <= 0.25 * g8, (g64, g8)
+    # a randomly initialised network's per-image gradients are nearly uncorrelated: the gradient of the batch MEAN shrinks
+    # like 1 / sqrt(batch) (measured: 201 at batch 8, 61 at batch 64 = 1 / 3.3 against 1 / sqrt(8) = 1 / 2.83)
+    assert 0.5 * g8 <= g64 * (64 / 8) ** 0.5 <= 2.0 * g8, (g64, g8)
 
 
 # ---- configs[3]: YOLOv4-S 416x416 fp16 inference, batch 256 ------------------------------------------------------
