@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void conv_wgrad_h16_kernel(
 // ---------------------------------------------------------------------------------
 constexpr int kWhLds2 = 2 * 2 * kWhRows * 256;       // two slice buffers
 constexpr int kWhTabBytes = kWhRows * 8;             // one row table
-constexpr int kWhLdsV2 = kWhLds2 + 2 * kWhTabBytes;
+constexpr int kWhLdsV2 = kWhLds2 + 3 * kWhTabBytes;       // three tables: a slice's entries are read a slice ahead of its DMA
 
 template <bool BF16, bool LINEAR>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_v2_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
@@ -531,18 +531,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_v2_h16_kernel(WgradArgs p, 
     u32x2_t ent;
     ent.x = off0;
     ent.y = ((unsigned)hi0 << 16) | ((unsigned)wi0 & 0xFFFFu);
-    *(lds_u2_t)(smem_wv + kWhLds2 + (sl & 1) * kWhTabBytes + lane * 8) = ent;
+    *(lds_u2_t)(smem_wv + kWhLds2 + (sl % 3) * kWhTabBytes + lane * 8) = ent;
     t_m += kWhRows;
+  };
+  // the table entries of this lane's four rows of slice `sl`: fetched a whole slice ahead of the DMA that uses them (an LDS
+  // round trip in front of every slice's issue cost the streaming layers 7 %)
+  u32x2_t te[4] = {};
+  auto fetch = [&](int sl) {
+    if (LINEAR) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      te[q] = *(lds_u2_t)(smem_wv + kWhLds2 + (sl % 3) * kWhTabBytes + (16 * wave + srow + 4 * q) * 8);
   };
   auto issue = [&](int sl) {
     const int buf = sl & 1;
     const unsigned lrow0 = (unsigned)(buf * 2 * kOpBytes + (16 * wave) * kRowB);
-    u32x2_t te[4];
-    if (!LINEAR) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        te[q] = *(lds_u2_t)(smem_wv + kWhLds2 + buf * kWhTabBytes + (16 * wave + srow + 4 * q) * 8);
-    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned lrow = lrow0 + (unsigned)(4 * q * kRowB);
@@ -583,19 +586,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_v2_h16_kernel(WgradArgs p, 
   const int nslices = (m_hi - m_lo + kWhRows - 1) / kWhRows;
   table(0);
   table(1);
+  table(2);
   if (!LINEAR) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
+  fetch(0);
   issue(0);
+  fetch(1);
   for (int sl = 0; sl < nslices; ++sl) {
     const int buf = sl & 1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                    // slice sl is in LDS (and table sl + 1); every wave is done with slice sl - 1
+    __builtin_amdgcn_s_barrier();                    // slice sl is in LDS (and table sl + 2); every wave is done with slice sl - 1
     asm volatile("" ::: "memory");
-    issue(sl + 1);                                   // into the buffer slice sl - 1 left
-    table(sl + 2);                                   // into the table slice sl's issue read (before the barrier above)
+    issue(sl + 1);                                   // into the buffer slice sl - 1 left; its table entries are in registers
+    table(sl + 3);                                   // into the table whose entries (slice sl) every wave fetched two barriers ago
+    fetch(sl + 2);                                   // written during slice sl - 1, visible since the barrier above
     char* dbuf = smem_wv + buf * 2 * kOpBytes;
     char* abuf = dbuf + kOpBytes;
     __builtin_amdgcn_s_setprio(1);
@@ -3336,8 +3343,9 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     // (second form: offsets are range-checked as 32-bit byte offsets, window origins travel as 16-bit coordinates.  Not for
     // the few-channel windowed layers -- 32 -> 64 s2 @608 streams 2.3 GB through 288 columns of dW and is bound by its
     // bytes: the table's LDS round trip in front of every slice's DMA cost it 7 %, 836 -> 894 us)
+    static const int whv2_min_cin = YV4_ENV_INT("YV4_WGRAD_V2_MINCIN", 0);
     if (whv2 && nbuf == 2 && xb < 0xC0000000LL && db < 0xC0000000LL && d->H < 16000 && d->W < 16000 &&
-        (linear || d->Cin >= 64)) {
+        (linear || d->Cin >= whv2_min_cin)) {
 #define YV4_WV_LAUNCH(LIN)                                                                                             \
   {                                                                                                                    \
     static LdsAttrOnce once_b, once_h;                                                                                 \
