@@ -3343,7 +3343,7 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     // (second form: offsets are range-checked as 32-bit byte offsets, window origins travel as 16-bit coordinates.  Not for
     // the few-channel windowed layers -- 32 -> 64 s2 @608 streams 2.3 GB through 288 columns of dW and is bound by its
     // bytes: the table's LDS round trip in front of every slice's DMA cost it 7 %, 836 -> 894 us)
-    static const int whv2_min_cin = YV4_ENV_INT("YV4_WGRAD_V2_MINCIN", 0);
+    static const int whv2_min_cin = YV4_ENV_INT("YV4_WGRAD_V2_MINCIN", 64);
     if (whv2 && nbuf == 2 && xb < 0xC0000000LL && db < 0xC0000000LL && d->H < 16000 && d->W < 16000 &&
         (linear || d->Cin >= whv2_min_cin)) {
 #define YV4_WV_LAUNCH(LIN)                                                                                             \
