@@ -489,15 +489,52 @@ _WGRAD_ATOMIC = os.environ.get('YV4_WGRAD_ATOMIC', '0') == '1'
 _WGRAD_WS = {}
 
 
-def _wgrad_workspace(nbytes, device):
-    """One growing fp32 scratch per device, shared by all layers (kernels on one stream run in order)."""
+def _wgrad_workspace(nbytes, device, stream_key=None):
+    """One growing fp32 scratch per (device, stream), shared by all layers (kernels on one stream run in order)."""
     if not nbytes:
         return None
-    ws = _WGRAD_WS.get(device)
+    key = (device, stream_key)
+    ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        _WGRAD_WS[device] = ws
+        _WGRAD_WS[key] = ws
     return ws
+
+
+# The weight gradient of a layer is needed by nobody before the optimizer (or the gradient exchange), while the data gradient
+# is on backward's critical path: with dW going straight into the gradient arena, ``yv4_conv_wgrad*`` is launched on a SIDE
+# stream.  It then runs beside the BatchNorm backward passes of the layers in front of it -- matrix-pipe-bound work
+# beside HBM-bound work -- instead of between them.  Ordering: the side stream waits for the current stream at every launch
+# (dY, x and the zeroed arena are ready), the tensors are handed to the allocator with ``record_stream``, and the current
+# stream waits for the side stream in a callback the autograd engine runs at the END of this backward pass (so every
+# ``.backward()`` leaves finished gradients behind, whoever called it).  Not with gradient listeners registered (the
+# multi-GPU exchange launches a bucket when its last weight gradient has been ISSUED on the current stream).
+# YV4_WGRAD_STREAM=0 keeps everything on one stream.
+_WGRAD_STREAM = _os.environ.get('YV4_WGRAD_STREAM', '1') != '0'
+_SIDE_STREAMS = {}
+_side_join_pending = [False]
+
+
+def _wgrad_side_stream(device):
+    if not _WGRAD_STREAM or _direct_grad_listeners:
+        return None
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[device] = st
+    return st
+
+
+def _join_side_streams():
+    _side_join_pending[0] = False
+    for dev, st in _SIDE_STREAMS.items():
+        torch.cuda.current_stream(dev).wait_stream(st)
+
+
+def join_side_streams():
+    """Make the current stream wait for every weight gradient launched on a side stream (idempotent; the autograd callback
+    does this at the end of every backward pass already)."""
+    _join_side_streams()
 
 
 class ConvFunction(torch.autograd.Function):
@@ -587,9 +624,23 @@ class ConvFunction(torch.autograd.Function):
             else:
                 # deterministic form: partial sums of the reduction chunks in a workspace, added in chunk order
                 need = int(L.yv4_conv_wgrad_workspace(C.byref(d), code))
-                ws = _wgrad_workspace(need, x.device)
-                check(L.yv4_conv_wgrad_det(C.byref(d), code, x.data_ptr(), dy.data_ptr(), dwp.data_ptr(),
-                                           ws.data_ptr() if need else None, need, stream_ptr()), 'yv4_conv_wgrad_det')
+                side = _wgrad_side_stream(x.device) if target is not None else None
+                ws = _wgrad_workspace(need, x.device, 'side' if side is not None else None)
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream(x.device))
+                    with torch.cuda.stream(side):
+                        check(L.yv4_conv_wgrad_det(C.byref(d), code, x.data_ptr(), dy.data_ptr(), dwp.data_ptr(),
+                                                   ws.data_ptr() if need else None, need, stream_ptr()), 'yv4_conv_wgrad_det')
+                    x.record_stream(side)
+                    dy.record_stream(side)
+                    if ws is not None:
+                        ws.record_stream(side)       # (a grown workspace frees its predecessor while the side stream may still read it)
+                    if not _side_join_pending[0]:
+                        _side_join_pending[0] = True
+                        torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+                else:
+                    check(L.yv4_conv_wgrad_det(C.byref(d), code, x.data_ptr(), dy.data_ptr(), dwp.data_ptr(),
+                                               ws.data_ptr() if need else None, need, stream_ptr()), 'yv4_conv_wgrad_det')
             if target is None:
                 dw = dwp.view(Cout, KH, KW, cp)[..., :Cin].permute(0, 3, 1, 2)
                 if cp != Cin:

@@ -36,16 +36,34 @@ def timed_region_stats(trace_csv, steps):
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     names = [r['Kernel_Name'] for r in rows]
     n = len(names)
-    period = 0
-    for P in range(20, n // max(steps, 1) + 1):
-        tail = names[n - steps * P:]
-        if len(tail) == steps * P and all(tail[i] == tail[i % P] for i in range(steps * P)):
-            period = P
-            break
-    if not period:
+    # candidate periods: the spacing of any kernel whose last occurrences are equally spaced `steps` times in a row
+    occ = collections.defaultdict(list)
+    for i, nm in enumerate(names):
+        occ[nm].append(i)
+    cands = set()
+    for o in occ.values():
+        d = [o[i + 1] - o[i] for i in range(len(o) - 1)]
+        run = 1
+        for i in range(1, len(d)):
+            run = run + 1 if (d[i] == d[i - 1] and d[i] >= 20) else 1
+            if run >= steps - 1:
+                cands.add(d[i])
+    # the LAST stretch of steps * P launches that is P-periodic (what follows it -- instrumented steps with event records,
+    # read-backs -- is not part of the timed region); the smallest such period
+    best = None
+    for P in sorted(cands):
+        for e in range(n, steps * P - 1, -1):
+            seg = names[e - steps * P:e]
+            if all(seg[i] == seg[i - P] for i in range(P, steps * P)):
+                if best is None or e > best[0]:
+                    best = (e, P)
+                break
+    if best is None:
         return None, 0
+    end, period = best
+    n = end
     agg = collections.OrderedDict()
-    for r in rows[n - steps * period:]:
+    for r in rows[end - steps * period:end]:
         d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
         a = agg.setdefault(r['Kernel_Name'], [0, 0, 1 << 62, 0])
         a[0] += 1
