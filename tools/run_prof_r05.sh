@@ -36,11 +36,15 @@ prof_train () {   # name, train_bench arguments...
   local name="$1"; shift
   rm -rf "$OUT/$name"; mkdir -p "$OUT/$name"
   echo 4 > "$OUT/$name/steps.txt"
+  # one stream under the profiler: with the weight gradients on their side stream (the default) the launch ORDER in the trace
+  # differs from step to step and no step period can be cut out of it; the kernels and their durations are the same
+  export YV4_WGRAD_STREAM=0
   TB="tools/train_bench.py --batch 64 --steps 4 --warmup 3 --dtype bf16 $*"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name/trace" -- python3 $TB > "$OUT/$name/trace.log" 2>&1 < /dev/null
   grep '^{"metric"' "$OUT/$name/trace.log" | tail -1 > "$OUT/$name/bench_profiled.json"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$name/pmc_fetch" -- python3 $TB > "$OUT/$name/pmc_fetch.log" 2>&1 < /dev/null
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$name/pmc_write" -- python3 $TB > "$OUT/$name/pmc_write.log" 2>&1 < /dev/null
+  unset YV4_WGRAD_STREAM
   echo "$name: done"
 }
 
