@@ -237,3 +237,47 @@ def test_default_mode_is_not_claimed_deterministic():
         pkg.set_deterministic(False)
     assert abs(a[0][0] - b[0][0]) <= 1e-5 * abs(b[0][0]), (a[0], b[0])
     assert abs(a[1][0] - b[1][0]) <= 1e-3 * abs(b[1][0]), (a[1], b[1])
+
+
+def test_side_stream_weight_gradients_are_the_same_gradients(det_mode, monkeypatch):
+    """The weight gradients run on a side stream by default (train_ops._wgrad_side_stream: off backward's critical path,
+    joined by an end-of-backward callback of the autograd engine).  In deterministic mode the whole state after two
+    recipe steps must be bit-identical with and without it -- a missing wait (a weight gradient reading dY before the
+    BatchNorm backward wrote it, the optimizer reading .grad before the side stream finished, the arena zeroed under a
+    running kernel) would show as different bits or as NaN."""
+    from mmdet_yolov4_amd import train_ops as T2
+    monkeypatch.setattr(T2, '_WGRAD_STREAM', True)
+    a = _recipe_steps(torch.bfloat16, 2, 8)
+    assert T2._SIDE_STREAMS, 'the side stream was never used'
+    monkeypatch.setattr(T2, '_WGRAD_STREAM', False)
+    b = _recipe_steps(torch.bfloat16, 2, 8)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (a[0], b[0], a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+
+
+@pytest.mark.parametrize('det', [False, True])
+def test_conv_stats_fold_in_both_modes(det):
+    """yv4_conv_stats_fold (what SyncBN all-reduces): the totals of a conv epilogue's statistics replicas as doubles, in the
+    default layout (64 replicas of doubles) and in the deterministic one (32 pairs of fixed-point words)."""
+    import ctypes as C
+    from mmdet_yolov4_amd import _lib
+    from mmdet_yolov4_amd.ops import stream_ptr
+    pkg.set_deterministic(det)
+    try:
+        torch.manual_seed(2)
+        m = pkg.Conv(64, 128, 3, 1).to(DEV).train()
+        pkg.wrap_fp16_model(m, torch.bfloat16)
+        x = torch.randn(4, 64, 38, 38, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+        stats = T.conv_stats_buffer(128, x.device)
+        y = T.conv2d(x, m.conv.weight, 1, 1, dtype=torch.bfloat16, stats=stats)
+        out = torch.empty(2 * 128, dtype=torch.float64, device=DEV)
+        rc = _lib.lib().yv4_conv_stats_fold(stats.data_ptr(), 128, 0, out.data_ptr(), stream_ptr())
+        assert rc == 0
+        yf = y.float().permute(0, 2, 3, 1).reshape(-1, 128).double()
+        ref = torch.cat([yf.sum(0), (yf * yf).sum(0)])
+        err = float((out - ref.detach()).abs().max() / ref.detach().abs().max())
+        assert err <= 1e-6, err
+    finally:
+        pkg.set_deterministic(False)
