@@ -611,7 +611,9 @@ int yv4_ema_update(float* ema, const float* online, int64_t n, float momentum, v
  *   2*L*3 doubles; gpos (backward): L*5*A*G*(5+C) float in a buffer of 4x that many floats; dbias: A*(5+C)
  *   doubles per level in a buffer of twice as many (the second halves are the deterministic mode's lo words;
  *   results are always the doubles / floats at the front).
- * Losses (host, from sums/npos): cls = w_cls*sum/(npos*C), conf = w_conf*sum/(N*H*W*A), bbox = w_bbox*sum/npos.
+ * Losses: cls = w_cls*sum/(npos*C), conf = w_conf*sum/(N*H*W*A), bbox = w_bbox*sum/npos (0 where a level has no positive) --
+ *   written to `losses` (L*3 float, [cls | conf | bbox] per level) by the forward call itself when the pointer is given
+ *   (ABI 6: what yolocsp_head.py:553-575 computes with a dozen tensor ops per level), else left to the host.
  * yv4_yolo_loss_bwd: grad_out (L,3) float (device) = upstream gradients of [cls, conf, bbox] per level. */
 #define YV4_LOSS_MAX_LEVELS 5
 typedef struct yv4_loss_level {
@@ -636,6 +638,7 @@ typedef struct yv4_loss_desc {
   float* conf_t;
   float* gpos;
   double* sums;
+  float* losses;       /* optional (ABI 6): L*3 float results of the forward, see above */
 } yv4_loss_desc;
 int yv4_yolo_loss_fwd(const yv4_loss_desc* d, void* stream);
 int yv4_yolo_loss_bwd(const yv4_loss_desc* d, const float* grad_out, void* stream);

@@ -66,7 +66,7 @@ class LossDesc(C.Structure):
                 ('shape_thr', C.c_float), ('smooth', C.c_float), ('ratio', C.c_float), ('eps', C.c_float),
                 ('w_cls', C.c_float), ('w_conf', C.c_float), ('w_bbox', C.c_float),
                 ('slot_anchor', C.c_void_p), ('winner', C.c_void_p), ('npos', C.c_void_p), ('conf_t', C.c_void_p),
-                ('gpos', C.c_void_p), ('sums', C.c_void_p)]
+                ('gpos', C.c_void_p), ('sums', C.c_void_p), ('losses', C.c_void_p)]
 
 
 class AugImage(C.Structure):

@@ -47,6 +47,7 @@ struct LossArgs {
   float shape_thr, smooth, ratio, eps, w_cls, w_conf, w_bbox;
   int32_t* slot_anchor; int32_t* winner; int32_t* npos; float* conf_t; float* gpos; double* sums;
   const float* gout;
+  float* losses;          // optional: (L, 3) float [cls | conf | bbox] written by the forward's last kernel
   int det;                // yv4_set_deterministic: sums / dbias / gpos are fixed-point words, [hi (n) | lo (n)] each
   long long gpos_n;       // L * S * attr
 };
@@ -56,6 +57,18 @@ __device__ __forceinline__ void loss_sum_add(const LossArgs& p, int i, double v)
   if (p.det) fx_add<kFxStat>(reinterpret_cast<u64_t*>(p.sums) + i, reinterpret_cast<u64_t*>(p.sums) + 3 * p.L + i, v);
   else atomicAdd(&p.sums[i], v);
 }
+// sums (doubles by now) + npos -> the (L, 3) losses: one thread per level
+__global__ void loss_finish_kernel(LossArgs p) {
+  const int l = threadIdx.x;
+  if (l >= p.L) return;
+  const double n = (double)p.npos[l];
+  const double per_pos = n > 0.0 ? 1.0 / n : 0.0;
+  const double boxes = (double)p.N * p.lv[l].H * p.lv[l].W * p.A;
+  p.losses[l * 3 + 0] = (float)(p.sums[l * 3 + 0] * per_pos / (double)(p.C > 0 ? p.C : 1) * (double)p.w_cls);
+  p.losses[l * 3 + 1] = (float)(p.sums[l * 3 + 1] / boxes * (double)p.w_conf);
+  p.losses[l * 3 + 2] = (float)(p.sums[l * 3 + 2] * per_pos * (double)p.w_bbox);
+}
+
 template <int SHIFT>
 __global__ void loss_fx_decode_kernel(double* __restrict__ buf, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -428,6 +441,7 @@ static int fill_args(const yv4_loss_desc* d, LossArgs& a, const char* who) {
   a.w_cls = d->w_cls; a.w_conf = d->w_conf; a.w_bbox = d->w_bbox;
   a.slot_anchor = d->slot_anchor; a.winner = d->winner; a.npos = d->npos; a.conf_t = d->conf_t; a.gpos = d->gpos;
   a.sums = d->sums;
+  a.losses = d->losses;
   a.det = deterministic() ? 1 : 0;
   a.gpos_n = a.S * a.L * a.attr;
   return YV4_OK;
@@ -462,6 +476,7 @@ extern "C" int yv4_yolo_loss_fwd(const yv4_loss_desc* d, void* stream) {
   YV4_LOSS_DISPATCH(d->dtype, hipLaunchKernelGGL(yolo_dense_fwd_kernel<T>, dim3((unsigned)((boxes + 255) / 256)), dim3(256), 0,
                                                  s, a));
   if (a.det) hipLaunchKernelGGL(loss_fx_decode_kernel<kFxStat>, dim3(1), dim3(256), 0, s, a.sums, 3 * a.L);
+  if (a.losses) hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, a);
   YV4_CHECK_LAUNCH("yolo_loss_fwd");
   return YV4_OK;
 }

@@ -149,6 +149,18 @@ class SingleStageDetector(HipModule):
         sync) PER log variable (base.py:197-202); here the variables are stacked on the device, exchanged by ONE
         all-reduce and read back by ONE device-to-host copy -- same values, one sync per step, taken when a value is
         first read (``DeferredLogVars``)."""
+        if getattr(losses, 'total', None) is not None and not getattr(losses, 'built', True):
+            # the fused head's loss matrix (yolocsp_head.FusedLosses): the same sums from the matrix itself
+            m = losses.weighted.detach()
+            cols = m.sum(0)
+            names = (['loss_cls'] if losses.with_cls else []) + ['loss_conf', 'loss_bbox', 'num_gts', 'loss']
+            stacked = torch.cat([cols if losses.with_cls else cols[1:], losses.num_gts.detach().float().reshape(1),
+                                 losses.total.detach().reshape(1)])
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(stacked.div_(dist.get_world_size()))
+            if stacked.is_cuda:
+                return losses.total, read_back_later(stacked, names)
+            return losses.total, OrderedDict(zip(names, stacked.tolist()))
         log_vars = OrderedDict()
         for name, value in losses.items():
             if isinstance(value, torch.Tensor):

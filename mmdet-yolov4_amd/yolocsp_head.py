@@ -13,6 +13,7 @@ per-image python loop (:298-309), its (anchors x 81) score matrix and its 29 MB 
 box tensor never exist.
 """
 import ctypes as C
+from collections import OrderedDict
 import math
 import os
 
@@ -125,17 +126,14 @@ class YoloLossFunction(torch.autograd.Function):
         d.w_conf, d.w_bbox = float(head.loss_conf.loss_weight), float(head.loss_bbox_weight)
         d.slot_anchor, d.winner, d.npos, d.conf_t, d.sums = (t.data_ptr() for t in (slot_anchor, winner, npos, conf_t,
                                                                                    sums))
+        out = torch.empty(L, 3, dtype=torch.float32, device=dev)
+        d.losses = out.data_ptr()
         check(_lib.lib().yv4_yolo_loss_fwd(C.byref(d), ops.stream_ptr()), 'yv4_yolo_loss_fwd')
         ctx.desc = d
         ctx.keep = (raws, keep, gt, gt_label, gt_img, slot_anchor, winner, npos, conf_t, sums)
         ctx.meta = (L, S, A, attr)
-        n = npos.double()
-        has = n > 0
-        per_pos = torch.where(has, 1. / n.clamp(min=1), torch.zeros_like(n))
-        boxes = _upload(torch.tensor([float(N * r.shape[2] * r.shape[3] * A) for r in raws], dtype=sums.dtype), dev)
-        out = torch.stack([sums[:, 0] * per_pos / max(C_, 1) * d.w_cls, sums[:, 1] / boxes * d.w_conf,
-                           sums[:, 2] * per_pos * d.w_bbox], dim=1)
-        return out.float()
+        # (the (L, 3) losses come out of the forward call itself: d.losses, set above)
+        return out
 
     @staticmethod
     def backward(ctx, gout):
@@ -153,6 +151,60 @@ class YoloLossFunction(torch.autograd.Function):
         d.gpos = gpos.data_ptr()
         check(_lib.lib().yv4_yolo_loss_bwd(C.byref(d), gout.data_ptr(), ops.stream_ptr()), 'yv4_yolo_loss_bwd')
         return (None, None, None, None) + tuple(draws) + tuple(b.float() for b in dbias)
+
+
+class FusedLosses(OrderedDict):
+    """The loss dict of ``YOLOCSPHead.loss`` (yolocsp_head.py:384-436: per key a list of per-level tensors) when the fused
+    kernels produced it.  ``weighted`` is the (num_levels, 3) matrix [loss_cls | loss_conf * level balance | loss_bbox]
+    and ``total`` its sum -- what ``_parse_losses`` (detectors/base.py:171-204) adds up one tensor at a time: a detector
+    that knows this class takes the total and the column sums directly (a handful of launches instead of ~80 tiny ones
+    through the forward and the backward of the aggregation, during which the device idles on a host-bound stream of
+    5 us kernels).  The per-level lists of the reference's dict are built the first time anybody looks at the mapping."""
+
+    def __init__(self, weighted, num_gts, with_cls):
+        super().__init__()
+        self.weighted, self.num_gts, self.with_cls = weighted, num_gts, with_cls
+        self.total = weighted.sum()
+        self.built = False
+
+    def _build(self):
+        if not self.built:
+            self.built = True
+            w = self.weighted
+            L = w.shape[0]
+            if self.with_cls:
+                OrderedDict.__setitem__(self, 'loss_cls', [w[l, 0].reshape(1) for l in range(L)])
+            OrderedDict.__setitem__(self, 'loss_conf', [w[l, 1] for l in range(L)])
+            OrderedDict.__setitem__(self, 'loss_bbox', [w[l, 2].reshape(1) for l in range(L)])
+            OrderedDict.__setitem__(self, 'num_gts', self.num_gts)
+        return self
+
+    def __getitem__(self, k):
+        return OrderedDict.__getitem__(self._build(), k)
+
+    def __iter__(self):
+        return OrderedDict.__iter__(self._build())
+
+    def __len__(self):
+        return OrderedDict.__len__(self._build())
+
+    def __contains__(self, k):
+        return OrderedDict.__contains__(self._build(), k)
+
+    def keys(self):
+        return OrderedDict.keys(self._build())
+
+    def items(self):
+        return OrderedDict.items(self._build())
+
+    def values(self):
+        return OrderedDict.values(self._build())
+
+    def get(self, k, default=None):
+        return OrderedDict.get(self._build(), k, default)
+
+    def __repr__(self):
+        return OrderedDict.__repr__(self._build())
 
 
 def _upload(host, device):
@@ -399,12 +451,18 @@ class YOLOCSPHead(HipModule):
         labels = torch.cat(list(gt_labels), dim=0).reshape(-1)
         img = _upload(torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)), device)
         out = YoloLossFunction.apply(self, gt, labels, img, *[p.raw for p in pred_maps], *[p.bias for p in pred_maps])
-        l_cls = [out[l, 0].reshape(1) for l in range(self.num_levels)]
-        l_conf = [out[l, 1] * self.conf_level_balance_weight[l] for l in range(self.num_levels)]
-        l_box = [out[l, 2].reshape(1) for l in range(self.num_levels)]
-        if not self.class_agnostic:
-            return dict(loss_cls=l_cls, loss_conf=l_conf, loss_bbox=l_box, num_gts=num_gts)
-        return dict(loss_conf=l_conf, loss_bbox=l_box, num_gts=num_gts)
+        key = (str(device), self.num_levels)
+        wts = self._loss_wts.get(key) if hasattr(self, '_loss_wts') else None
+        if wts is None:
+            if not hasattr(self, '_loss_wts'):
+                self._loss_wts = {}
+            wts = _upload(torch.tensor([[1.0, float(self.conf_level_balance_weight[l]), 1.0] for l in range(self.num_levels)],
+                                       dtype=torch.float32), device)
+            self._loss_wts[key] = wts
+        fl = FusedLosses(out * wts, num_gts, with_cls=not self.class_agnostic)
+        if os.environ.get('YV4_LOSS_MATRIX', '1') == '0':      # A/B: the reference's one-tensor-at-a-time aggregation
+            fl._build()
+        return fl
 
     def loss_single_no_assigner(self, pred_map, anchors, stride, pos_indices, target_bboxes, target_labels):
         num_imgs = len(pred_map)

@@ -27,9 +27,9 @@ def test_header_binding_library_agree():
 def test_struct_layout_matches_header():
     import ctypes
     assert ctypes.sizeof(pkg._lib.ConvDesc) == 22 * 4
-    # yv4_loss_level / yv4_loss_desc (gcc sizeof on include/yv4.h: 176 / 1008, slot_anchor at 960)
-    assert ctypes.sizeof(pkg._lib.LossLevel) == 176 and ctypes.sizeof(pkg._lib.LossDesc) == 1008
-    assert pkg._lib.LossDesc.slot_anchor.offset == 960
+    # yv4_loss_level / yv4_loss_desc (gcc sizeof on include/yv4.h: 176 / 1016, slot_anchor at 960, ABI 6's losses at 1008)
+    assert ctypes.sizeof(pkg._lib.LossLevel) == 176 and ctypes.sizeof(pkg._lib.LossDesc) == 1016
+    assert pkg._lib.LossDesc.slot_anchor.offset == 960 and pkg._lib.LossDesc.losses.offset == 1008
     assert ctypes.sizeof(pkg._lib.LevelDesc) == 8 + 3 * 4 + 4 + 8 * 4 * 4 or ctypes.sizeof(pkg._lib.LevelDesc) == 8 + 3 * 4 + 8 * 4 * 4 + 4
 
 
