@@ -933,7 +933,9 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
 constexpr int kW3FlagBase = kW3Lds;                  // kW3NBuf x 64 flag bytes behind the slice buffers
 constexpr int kW3LdsV2 = kW3Lds + kW3NBuf * 64;
 
-template <bool BF16>
+// ABL (measurement build only, compile-time so that the timed kernel carries no extra branches): 1 no DMA inside the loop,
+// 2 no workgroup barrier, 4 no MFMAs, 8 no fragment reads -- wrong results on purpose, to time the kernel without a part
+template <bool BF16, int ABL = 0>
 __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_v2_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef __attribute__((address_space(3))) s16x4_t* lds_v4_t;
@@ -1054,10 +1056,10 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_v2_h16_kernel(Wgr
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   const int nsl = (m_hi - m_lo + kW3Rows - 1) / kW3Rows;
-  s16x8_t fa[2][2], fb[2][3];                        // fragment sets: step s computes from set s & 1
+  s16x8_t fa[2][2] = {}, fb[2][3] = {};              // fragment sets: step s computes from set s & 1
   // FL: the eight flag bytes of this lane's rows of the slice ([S][j], bits kw); BO: the slice buffer's byte offset
 #define YV4_W3B_LOAD(SET, BO, S, FL)                                                                          \
-  {                                                                                                           \
+  if constexpr (!(ABL & 8)) {                                                                                 \
     const char* ab_ = smem_w3b + (BO) + 4096 * (S);                                                           \
     _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                           \
       const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(ab_ + a_base[a][0]));            \
@@ -1080,6 +1082,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_v2_h16_kernel(Wgr
   {                                                                                                           \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                             \
       _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                      \
+        if constexpr (ABL & 4) { asm volatile("" :: "v"(fa[SET][a]), "v"(fb[SET][kw])); continue; }          \
         if (BF16)                                                                                             \
           acc[a][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w, fa[SET][a]),      \
                                                                __builtin_bit_cast(bf16x8_w, fb[SET][kw]), acc[a][kw], 0, 0, 0); \
@@ -1113,7 +1116,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_v2_h16_kernel(Wgr
     YV4_W3B_LOAD(1, bo, 1, fl);
     __builtin_amdgcn_sched_barrier(0);
     YV4_W3B_MFMA(0);
-    issue(sl + 3);                                    // into the buffer slice sl - 1 read (freed by the previous barrier)
+    if constexpr (!(ABL & 1)) issue(sl + 3);          // into the buffer slice sl - 1 read (freed by the previous barrier)
     __builtin_amdgcn_sched_barrier(0);
     YV4_W3B_LOAD(0, bo, 2, fl);
     __builtin_amdgcn_sched_barrier(0);
@@ -1121,8 +1124,9 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_v2_h16_kernel(Wgr
     YV4_W3B_LOAD(1, bo, 3, fl);
     __builtin_amdgcn_sched_barrier(0);
     YV4_W3B_MFMA(0);
-    YV4_W3B_WAIT();                                   // own DMA(sl + 1) landed; every read of slice sl has returned
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(ABL & 1)) YV4_W3B_WAIT()          // own DMA(sl + 1) landed; every read of slice sl has returned
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (!(ABL & 2)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     YV4_W3B_LOAD(0, nbo, 0, fln);                     // (beyond the last slice: zero-filled buffers, never used)
     __builtin_amdgcn_sched_barrier(0);
@@ -1722,6 +1726,12 @@ static int wgrad_fc_cin(const yv4_conv_desc* d, int dtype) {
   if (d->Cin == 8 && d->x_coff + 16 <= d->x_cstride) return 16;
   return 0;
 }
+
+// The tiles of one reduction chunk read the same rows of dY and (shifted by a row) of the activation; workgroups go to the
+// eight XCDs round-robin, so with the plain (tile, chunk) grid a chunk's tiles sit on different XCDs and every XCD's L2
+// fetches those rows for itself.  With the mapping of wgrad_tile_chunk they share one L2.
+static const int g_w3_xcd = YV4_ENV_INT("YV4_W3_XCD", 0);   // measured: 112 -> 115 / 113 -> 122 us on 128->128 @76 / 256->256 @38 -- off
+static bool w3_xcd_map(long long tiles, long long chunks) { return g_w3_xcd && tiles >= 2 && chunks >= 16; }
 
 // domain of conv_wgrad3x3_h16_kernel
 static bool wgrad3x3_applies(const yv4_conv_desc* d, int dtype) {
@@ -3159,6 +3169,8 @@ static void wgrad_chunks(const yv4_conv_desc* d, int dtype, long long* chunks, l
     if (ch > mx) ch = mx;
     if (ch < 1) ch = 1;
     if (ch > 65535) ch = 65535;
+    // XCD-aware mapping (wgrad_tile_chunk): a chunk's tiles on ONE XCD need the chunk count in whole groups of eight
+    if (w3_xcd_map(tl, ch)) ch = ch / 8 * 8;
     long long rw = (M + ch - 1) / ch;
     rw = (rw + kW3Rows - 1) / kW3Rows * kW3Rows;
     *rows = rw;
@@ -3292,7 +3304,7 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     if (int rc = ensure_dyn_lds(once3h, reinterpret_cast<const void*>(conv_wgrad3x3_h16_kernel<false>), (size_t)kW3Lds, "conv_wgrad3x3_h16")) return rc;
     a.tiles = (int)tl;
     a.chunks = (int)ch;
-    a.xcd_map = 0;         // (one round of workgroups, compute-bound: the mapping gains nothing here)
+    a.xcd_map = w3_xcd_map(tl, ch) && tl * (ch + 8) < (1LL << 31) ? 1 : 0;
     static const int w3_ablate = YV4_ENV_INT("YV4_W3_ABLATE", 0);
     a.ablate = w3_ablate;
     const dim3 grid3 = wgrad_grid(tl, ch, a.xcd_map);
@@ -3303,6 +3315,20 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
       static LdsAttrOnce once3vb, once3vh;
       if (int rc = ensure_dyn_lds(once3vb, reinterpret_cast<const void*>(conv_wgrad3x3_v2_h16_kernel<true>), (size_t)kW3LdsV2, "conv_wgrad3x3_v2_h16")) return rc;
       if (int rc = ensure_dyn_lds(once3vh, reinterpret_cast<const void*>(conv_wgrad3x3_v2_h16_kernel<false>), (size_t)kW3LdsV2, "conv_wgrad3x3_v2_h16")) return rc;
+#ifdef YV4_MEASURE
+      static const int w3abl = YV4_ENV_INT("YV4_W3V2_ABL", 0);
+#define YV4_W3ABL(N)                                                                                                   \
+      if (w3abl == N && dtype == YV4_BF16) {                                                                           \
+        static LdsAttrOnce once_abl;                                                                                   \
+        if (int rc = ensure_dyn_lds(once_abl, reinterpret_cast<const void*>(conv_wgrad3x3_v2_h16_kernel<true, N>), (size_t)kW3LdsV2, "w3v2 abl")) return rc; \
+        hipLaunchKernelGGL((conv_wgrad3x3_v2_h16_kernel<true, N>), grid3, dim3(kW3Threads), (size_t)kW3LdsV2,         \
+                           reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);                      \
+        YV4_CHECK_LAUNCH("w3v2 abl");                                                                                  \
+        return finish();                                                                                               \
+      }
+      YV4_W3ABL(1) YV4_W3ABL(2) YV4_W3ABL(3) YV4_W3ABL(4) YV4_W3ABL(8) YV4_W3ABL(12) YV4_W3ABL(5) YV4_W3ABL(13) YV4_W3ABL(15)
+#undef YV4_W3ABL
+#endif
       if (dtype == YV4_BF16)
         hipLaunchKernelGGL(conv_wgrad3x3_v2_h16_kernel<true>, grid3, dim3(kW3Threads), (size_t)kW3LdsV2,
                            reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
