@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the pipelined 16-bit BatchNorm passes (train.hip bn16_*) against the general kernels, same box, measure build:
 # tools/bn_bench.py --kernels over YOLOv4-L's activation shapes at batch 64.
-export YV4_LIB_PATH=mmdet-yolov4_amd/lib_alt/libyv4_hip_measure.so
+source "$(dirname "$0")/_measure_lib.sh"
 for cfg in "0 4" "1 4" "1 8" "0 4" "1 4"; do
   set -- $cfg
   echo "== YV4_BN16=$1 YV4_BN16_V=$2"

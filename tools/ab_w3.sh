@@ -1,5 +1,5 @@
 # same-box A/B of the round-4 wide-tile kernels (measurement build: YV4_W3 / YV4_WIDE switch them off)
-export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_alt/libyv4_hip_measure.so
+source "$(dirname "$0")/_measure_lib.sh"
 for i in 1 2; do
 for w in "0 0" "1 0" "1 1"; do
 set -- $w

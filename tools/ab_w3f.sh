@@ -1,5 +1,5 @@
 # same-box A/B of the fp32 wide-tile 3x3 kernel (measurement build: YV4_W3F=0 switches it off), then the product line
-export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_alt/libyv4_hip_measure.so
+source "$(dirname "$0")/_measure_lib.sh"
 for i in 1 2 3; do
 for w in 0 1; do
 echo -n "fp32 inf W3F=$w: "; YV4_W3F=$w python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-output-check 2>/dev/null | python -c "

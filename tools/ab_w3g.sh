@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the 3x3 weight-gradient kernel's second form (conv_wgrad3x3_v2_h16_kernel) against the first, measure build, same
 # box: per-layer times, then bit-identity of the two kernels' dW on a few layers (tools/w3g_bitwise.py).
-export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_alt/libyv4_hip_measure.so
+source "$(dirname "$0")/_measure_lib.sh"
 for v in 0 1 0 1; do
   echo "== YV4_W3V2=$v"
   YV4_W3V2=$v python tools/wgrad_bench.py --det --filter k3s1 2>&1 | grep -v amdgpu.ids

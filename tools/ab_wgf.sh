@@ -1,5 +1,5 @@
 # same-box A/B of the general fp32 wide-tile kernel (measurement build: YV4_WGF=0 switches it off)
-export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_alt/libyv4_hip_measure.so
+source "$(dirname "$0")/_measure_lib.sh"
 for i in 1 2; do
 for cfg in "YV4_WGF=0" "YV4_WGF=1" "YV4_WGF=1 YV4_WGF_MINOUT=16384" "YV4_WGF=1 YV4_WGF_MINOUT=8192 YV4_WGF_MAXWASTE=40"; do
 echo -n "fp32 inf $cfg: "; env $cfg python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-output-check 2>/dev/null | python -c "

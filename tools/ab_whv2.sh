@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the generic 16-bit weight-gradient kernel's second form (conv_wgrad_v2_h16_kernel) against the first, measure build,
 # same box; then bit-identity of dW on 1x1, stride-2 and odd shapes (tools/whv2_bitwise.py).
-export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_alt/libyv4_hip_measure.so
+source "$(dirname "$0")/_measure_lib.sh"
 for v in 0 1 0 1; do
   echo "== YV4_WGRAD_V2=$v"
   YV4_WGRAD_V2=$v python tools/wgrad_bench.py --det 2>&1 | grep -E 'k1s1|k3s2|weighted'

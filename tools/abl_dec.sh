@@ -5,7 +5,7 @@
 set -u
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_alt/libyv4_hip_measure.so
+source "$(dirname "$0")/_measure_lib.sh"
 for ab in ${ABLATIONS:-0 2}; do
   for cfg in "--dtype bf16" "--model yolov4s --size 416 --batch 256 --dtype f16"; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/abl_dec/$ab; rm -rf "$OUT"; mkdir -p "$OUT"

@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_alt/libyv4_hip_measure.so
+source "$(dirname "$0")/_measure_lib.sh"
 for ab in 0 1 8; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/abl_nms/$ab; rm -rf "$OUT"; mkdir -p "$OUT"
   YV4_NMS_ABLATE=$ab rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 bench.py --dtype bf16 --steps 6 --warmup 2 --no-cpu-baseline --no-train --no-output-check > "$OUT/log.txt" 2>&1 < /dev/null
