@@ -18,37 +18,19 @@
 // NOT bit-identical to the 32x32x2 tiles (fp32 products are not exact; the grouping of the K sum differs): a plan that
 // must reproduce another plan's bits pins the tile id (bench.py's batch-2 check plan does).
 #include "conv_f32_common.h"
+#include "conv_wide_common.h"
 
 
 namespace yv4 {
 
 typedef float f32x4f __attribute__((ext_vector_type(4)));
 
-constexpr int kF3Threads = 512;
 constexpr int kF3BK = 32;          // channels per chunk = floats per 128-byte LDS row
 
-template <int PT, int WAVES_M> struct F3Geom {
-  static constexpr int WAVES_N = 8 / WAVES_M;
-  static constexpr int BN = 64 * WAVES_N;
-  static constexpr int WMr = 16 * PT;               // pixel rows of a wave
-  static constexpr int BM = WMr * WAVES_M;
-  static constexpr int QA = (BM + 3 + 63) / 64;     // DMA passes (64 rows each) of an image of BM + 2 pixels + a zero row
-  static constexpr int ARows = 64 * QA;
-  static constexpr int ZeroRow = BM + 2;            // never a source pixel: only ever zero-filled
-  static constexpr int PB = BN / 64;                // weight pieces per wave and tap
-  static constexpr int ABytes = ARows * 128;
-  static constexpr int BBytes = BN * 128;
-  static constexpr int RingBytes = 2 * ABytes + 2 * BBytes;
-};
-
-// swizzle of the weight image: the 16 lanes of a ds_read_b128 group read rows {R..R+3, R+48..R+51} at chunk q and
-// {R+16..R+19, R+32..R+35} at chunk q + 1 (the channel permutation above), which (row >> 1) & 7 would fold onto each other
-__device__ __forceinline__ int f3_swz_b(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
-
 template <int PT, int WAVES_M>
-__global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
+__global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
   typedef f32x4f V8;                         // one fragment read: four K values of a row
-  typedef F3Geom<PT, WAVES_M> G_;
+  typedef WideGeom<PT, WAVES_M, true> G_;
   constexpr int WAVES_N = G_::WAVES_N, BN = G_::BN, BM = G_::BM, WMr = G_::WMr, QA = G_::QA, PB = G_::PB;
   constexpr int PH = PT / 2;                 // pixel tiles per half
   constexpr int kRowB = 128;
@@ -92,7 +74,7 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
   const int srow = 8 * wave + (lane >> 3);               // 0..63, + 64 per pass
   const int pc = lane & 7;
   const int lcA = pc ^ ((srow >> 1) & 7);                // invariant under row + 64 q
-  const int lcB = pc ^ f3_swz_b(srow);                   // likewise
+  const int lcB = pc ^ wide_swz_b(srow);                   // likewise
   int a_s[QA];                                           // source pixel of LDS row (srow + 64 q) for kh = 1, NEXT group's tile
   unsigned a_off[QA];
   unsigned b_cur[PB], b_nxt[PB];                         // weight row offsets: current K tile's tile / next group's tile
@@ -128,7 +110,7 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
   {
     const int row = wn * 64 + 16 * (fr >> 2) + (fr & 3);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) w_rd[ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ f3_swz_b(row)) << 4));
+    for (int ks = 0; ks < 2; ++ks) w_rd[ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ wide_swz_b(row)) << 4));
   }
 
   const int nchunks = p.Cin >> 5;
@@ -136,7 +118,7 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
 
   // ---- the layer's affine into LDS, once per workgroup ----
   const bool has2 = p.s2 != nullptr;
-  for (int c = tid; c < p.Cout; c += kF3Threads) {
+  for (int c = tid; c < p.Cout; c += kWideThreads) {
     aff[c] = p.s1[c];
     aff[p.Cout + c] = p.t1[c];
     aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
@@ -315,77 +297,10 @@ __global__ __launch_bounds__(kF3Threads, 2) void conv3x3_wide_f32_kernel(ConvArg
     }
     // (kh, c0 now describe group 0 of this workgroup's next tile: reset by the assignments at the top of the loop)
 
-    // ---- epilogue: lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + pr, channels n0 + wn 64 + 16 fq .. + 15 (fp32: four
-    // 16-byte stores).  Expressions: fmaf(acc, s1, t1) -> act (the contraction-free scalar Mish of the fp32 kernels) ->
-    // + residual -> fmaf(., s2, t2) -> act, as conv_mfma_f32.hip's epilogue_tile ----
-    const int cl = n0 + wn * 64 + 16 * fq;
-    const bool c_ok = cl + 15 < p.Cout;
-    const int ca = c_ok ? cl : 0;
-    float s1[16], t1[16];
-#pragma unroll
-    for (int u = 0; u < 16; u += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(aff + ca + u), b = *reinterpret_cast<const float4*>(aff + p.Cout + ca + u);
-      s1[u] = a.x; s1[u + 1] = a.y; s1[u + 2] = a.z; s1[u + 3] = a.w;
-      t1[u] = b.x; t1[u + 1] = b.y; t1[u + 2] = b.z; t1[u + 3] = b.w;
-    }
-    float st[32];                            // training forward: [sum | sum of squares] of the lane's 16 channels
-#pragma unroll
-    for (int u = 0; u < 32; ++u) st[u] = 0.f;
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const int m = m0 + wm * WMr + 16 * pt + pr;
-      const bool ok = c_ok && m < p.M;
-      float v[16];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * t + j] = apply_act(__builtin_fmaf(acc[pt][t][j], s1[4 * t + j], t1[4 * t + j]), p.act1, p.slope1);
-      if (p.res && ok) {
-        const float* rp = p.res + (int64_t)m * p.r_cs + p.r_co + cl;
-#pragma unroll
-        for (int u = 0; u < 16; u += 4) {
-          const float4 r4 = *reinterpret_cast<const float4*>(rp + u);
-          v[u] += r4.x; v[u + 1] += r4.y; v[u + 2] += r4.z; v[u + 3] += r4.w;
-        }
-      }
-      if (has2) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          v[u] = apply_act(__builtin_fmaf(v[u], aff[2 * p.Cout + ca + u], aff[3 * p.Cout + ca + u]), p.act2, p.slope2);
-      }
-      if (ok) {
-        float* yp = p.y + (int64_t)m * p.y_cs + p.y_co + cl;
-#pragma unroll
-        for (int u = 0; u < 16; u += 4) *reinterpret_cast<float4*>(yp + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
-        if (p.stats) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) { st[e] += v[e]; st[16 + e] += v[e] * v[e]; }
-        }
-      }
-    }
-    if (p.stats) {
-      int idx = 0;
-#pragma unroll
-      for (int sft = 0; sft < 4; ++sft) {
-        const int half = 16 >> sft;
-        const bool bit = (lane >> sft) & 1;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-          const float send = bit ? st[i] : st[i + half];
-          const float recv = __shfl_xor(send, 1 << sft);
-          st[i] = (bit ? st[i + half] : st[i]) + recv;
-        }
-        idx += bit ? half : 0;
-      }
-      if (c_ok) {
-        const StatRep rep = stat_rep(p.stats, (unsigned)((tile_m * WAVES_M + wm)), p.Cout);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int id = idx + k;
-          stat_add(rep, (id >> 4) * p.Cout + cl + (id & 15), st[k]);
-        }
-      }
-    }
+    // ---- epilogue (conv_wide_common.h): lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + pr, channels n0 + wn 64 + 16 fq .. + 15
+    // (fp32: four 16-byte stores) ----
+    wide_epilogue_f32<PT, false>(p, aff, has2, acc, m0 + wm * WMr + pr, n0 + wn * 64 + 16 * fq, lane,
+                                 (unsigned)(tile_m * WAVES_M + wm));
     c0 = 0; kh = 0;
   }
 #undef YV4_W3_ISSUE_A
@@ -401,85 +316,18 @@ bool conv3x3_wide_f32_applies(const ConvArgs& a) {
          ((a.y_cs | a.y_co) & 3) == 0 && (a.res == nullptr || ((a.r_cs | a.r_co) & 3) == 0);
 }
 
-static int g_f3_cus = 0;
-static int f3_cus() {
-  if (g_f3_cus == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus <= 0) {
-      (void)hipGetLastError();
-      cus = 256;
-    }
-    g_f3_cus = cus;
-  }
-  return g_f3_cus;
-}
-
 template <int PT, int WAVES_M>
 static int launch_f3(const ConvArgs& a, hipStream_t stream) {
-  typedef F3Geom<PT, WAVES_M> G_;
-  ConvArgs p = a;
-  const int tiles_m = (p.M + G_::BM - 1) / G_::BM;
-  p.tiles_n = (p.Cout + G_::BN - 1) / G_::BN;
-  p.fd_hw = make_fastdiv((unsigned)(p.H * p.W));
-  p.fd_wo = make_fastdiv((unsigned)p.W);
-  const long long tiles = (long long)tiles_m * p.tiles_n;
-  if (tiles <= 0 || tiles > 0x7fffffffLL) {
-    set_error("conv3x3 wide f32: grid of %lld tiles out of range", tiles);
-    return YV4_E_INVALID;
-  }
-  const size_t lds = (size_t)G_::RingBytes + (size_t)4 * p.Cout * 4;
-  if (lds > 160 * 1024) {
-    set_error("conv3x3 wide f32: %zu bytes of LDS for this tile shape and Cout", lds);
-    return YV4_E_UNSUPPORTED;
-  }
-  const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 4, wb = (long long)p.Cout * p.Kw * 4;
-  if (xb >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) {
-    set_error("conv3x3 wide f32: tensors of 4 GiB or more are not addressable through a buffer descriptor");
-    return YV4_E_UNSUPPORTED;
-  }
-  auto kern = conv3x3_wide_f32_kernel<PT, WAVES_M>;
   static LdsAttrOnce once;
-  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024, "conv3x3_wide_f32")) return rc;
-  const int cus = f3_cus();
-  const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kF3Threads), lds, stream, p, (unsigned)xb, (unsigned)wb, (int)tiles);
-  YV4_CHECK_LAUNCH("conv3x3_wide_f32");
-  return YV4_OK;
+  return wide_launch<WideGeom<PT, WAVES_M, true>>(conv3x3_wide_f32_kernel<PT, WAVES_M>, once, "conv3x3_wide_f32", a, 4, stream);
 }
 
-// tile shapes as conv3x3_wide_h16.hip: 256 x 256, 192 x 256, 128 x 256, 384 x 128, 256 x 128
-struct F3Shape { int pt, wm; };
-static const F3Shape kF3Shapes[5] = {{8, 2}, {6, 2}, {4, 2}, {6, 4}, {4, 4}};
-static size_t f3_lds(int pt, int wmv, int Cout) {
-  const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
-  const int arows = 64 * ((bm + 3 + 63) / 64);
-  return (size_t)2 * arows * 128 + (size_t)2 * bn * 128 + (size_t)16 * Cout;
-}
-int conv3x3_wide_f32_pick(const ConvArgs& a, double* rounds_eff) {
-  const int cus = f3_cus();
-  int best = -1;
-  double best_cost = 0.0;
-  for (int i = 0; i < 5; ++i) {
-    const int pt = kF3Shapes[i].pt, wmv = kF3Shapes[i].wm;
-    const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
-    if (f3_lds(pt, wmv, a.Cout) > 160 * 1024) continue;
-    if (bn > ((a.Cout + 127) / 128) * 128) continue;
-    const long long tiles = ((long long)a.M + bm - 1) / bm * ((a.Cout + bn - 1) / bn);
-    const long long rounds = (tiles + cus - 1) / cus;
-    const double cost = (double)rounds * bm * bn;      // matrix-bound: the wave tile's read ratio does not show
-    if (best < 0 || cost < best_cost * 0.999) { best = i; best_cost = cost; }
-  }
-  if (rounds_eff && best >= 0) *rounds_eff = best_cost / ((double)a.M * a.Cout / cus);
-  return best;
-}
+// shape choice and launch: conv_wide_common.h
+int conv3x3_wide_f32_pick(const ConvArgs& a, double* rounds_eff) { return wide_pick(a, true, false, rounds_eff); }
 
 int conv3x3_wide_f32_launch(const ConvArgs& a, int shape, hipStream_t s) {
   if (shape < 0) shape = conv3x3_wide_f32_pick(a, nullptr);
-  if (shape < 0 || shape >= 5 || f3_lds(kF3Shapes[shape].pt, kF3Shapes[shape].wm, a.Cout) > 160 * 1024) {
-    set_error("conv3x3 wide f32: no tile shape of this layer fits the LDS");
-    return YV4_E_UNSUPPORTED;
-  }
+  if (!wide_shape_fits("conv3x3_wide_f32", true, shape, a.Cout)) return YV4_E_UNSUPPORTED;
   switch (shape) {
     case 0: return launch_f3<8, 2>(a, s);
     case 1: return launch_f3<6, 2>(a, s);

@@ -28,6 +28,7 @@
 // read only after the barrier that followed its wait.  Inside a K tile there is no barrier: the two waves of a SIMD drift
 // apart by themselves, one reading fragments while the other's MFMAs occupy the pipe.
 #include "conv_h16_common.h"
+#include "conv_wide_common.h"
 
 namespace yv4 {
 
@@ -41,31 +42,11 @@ template <> struct Mfma16<false> {
   static __device__ __forceinline__ f32x4v run(f16x8 a, f16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
-constexpr int kW3Threads = 512;
-
-template <int PT, int WAVES_M> struct W3Geom {
-  static constexpr int WAVES_N = 8 / WAVES_M;
-  static constexpr int BN = 64 * WAVES_N;
-  static constexpr int WMr = 16 * PT;               // pixel rows of a wave
-  static constexpr int BM = WMr * WAVES_M;
-  static constexpr int QA = (BM + 3 + 63) / 64;     // DMA passes (64 rows each) of an image of BM + 2 pixels + a zero row
-  static constexpr int ARows = 64 * QA;
-  static constexpr int ZeroRow = BM + 2;            // never a source pixel: only ever zero-filled
-  static constexpr int PB = BN / 64;                // weight pieces per wave and tap
-  static constexpr int ABytes = ARows * 128;
-  static constexpr int BBytes = BN * 128;
-  static constexpr int RingBytes = 2 * ABytes + 2 * BBytes;
-};
-
-// swizzle of the weight image: the 16 lanes of a ds_read_b128 group read rows {R..R+3, R+48..R+51} at chunk q and
-// {R+16..R+19, R+32..R+35} at chunk q + 1 (the channel permutation above), which (row >> 1) & 7 would fold onto each other
-__device__ __forceinline__ int w3_swz_b(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
 
 template <bool BF16, int PT, int WAVES_M>
-__global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
+__global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
   typedef typename Elem<BF16>::V8 V8;
-  typedef typename Elem<BF16>::T T;
-  typedef W3Geom<PT, WAVES_M> G_;
+  typedef WideGeom<PT, WAVES_M, true> G_;
   constexpr int WAVES_N = G_::WAVES_N, BN = G_::BN, BM = G_::BM, WMr = G_::WMr, QA = G_::QA, PB = G_::PB;
   constexpr int PH = PT / 2;                 // pixel tiles per half
   constexpr int kRowB = 128;
@@ -109,7 +90,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
   const int srow = 8 * wave + (lane >> 3);               // 0..63, + 64 per pass
   const int pc = lane & 7;
   const int lcA = pc ^ ((srow >> 1) & 7);                // invariant under row + 64 q
-  const int lcB = pc ^ w3_swz_b(srow);                   // likewise
+  const int lcB = pc ^ wide_swz_b(srow);                   // likewise
   int a_s[QA];                                           // source pixel of LDS row (srow + 64 q) for kh = 1, NEXT group's tile
   unsigned a_off[QA];
   unsigned b_cur[PB], b_nxt[PB];                         // weight row offsets: current K tile's tile / next group's tile
@@ -145,7 +126,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
   {
     const int row = wn * 64 + 16 * (fr >> 2) + (fr & 3);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) w_rd[ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ w3_swz_b(row)) << 4));
+    for (int ks = 0; ks < 2; ++ks) w_rd[ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ wide_swz_b(row)) << 4));
   }
 
   const int nchunks = p.Cin >> 6;
@@ -153,7 +134,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
 
   // ---- the layer's affine into LDS, once per workgroup ----
   const bool has2 = p.s2 != nullptr;
-  for (int c = tid; c < p.Cout; c += kW3Threads) {
+  for (int c = tid; c < p.Cout; c += kWideThreads) {
     aff[c] = p.s1[c];
     aff[p.Cout + c] = p.t1[c];
     aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
@@ -327,103 +308,14 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv3x3_wide_h16_kernel(ConvArg
     }
     // (kh, c0 now describe group 0 of this workgroup's next tile: reset by the assignments at the top of the loop)
 
-    // ---- epilogue: lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + pr, channels n0 + wn 64 + 16 fq .. + 15 ----
-    const int cl = n0 + wn * 64 + 16 * fq;
-    const bool c_ok = cl + 15 < p.Cout;
-    const int ca = c_ok ? cl : 0;
-    float s1[16], t1[16];
-#pragma unroll
-    for (int u = 0; u < 16; u += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(aff + ca + u), b = *reinterpret_cast<const float4*>(aff + p.Cout + ca + u);
-      s1[u] = a.x; s1[u + 1] = a.y; s1[u + 2] = a.z; s1[u + 3] = a.w;
-      t1[u] = b.x; t1[u + 1] = b.y; t1[u + 2] = b.z; t1[u + 3] = b.w;
-    }
-    float st[32];                            // training forward: [sum | sum of squares] of the lane's 16 channels (stored values)
-#pragma unroll
-    for (int u = 0; u < 32; ++u) st[u] = 0.f;
+    // ---- epilogue (conv_wide_common.h): lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + pr, channels n0 + wn 64 + 16 fq .. + 15 ----
     if (YV4_ABLATE(p.ablate, 16)) {           // (measurement: no epilogue; keep the accumulators live)
       if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.y)[0] = acc[PT - 1][3][3] + acc[1][1][1];
       c0 = 0; kh = 0;
       continue;
     }
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const int m = m0 + wm * WMr + 16 * pt + pr;
-      const bool ok = c_ok && m < p.M;
-      float v[16];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * t + j] = __builtin_fmaf(acc[pt][t][j], s1[4 * t + j], t1[4 * t + j]);
-      {
-        float lo[8], hi[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[e + 8]; }
-        act_row8(lo, p.act1, p.slope1);
-        act_row8(hi, p.act1, p.slope1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] = lo[e]; v[e + 8] = hi[e]; }
-      }
-      if (p.res && ok) {
-        const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.r_cs + p.r_co + cl;
-        const V8 r0 = *reinterpret_cast<const V8*>(rp), r1 = *reinterpret_cast<const V8*>(rp + 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] += (float)r0[e]; v[e + 8] += (float)r1[e]; }
-      }
-      if (has2) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = __builtin_fmaf(v[u], aff[2 * p.Cout + ca + u], aff[3 * p.Cout + ca + u]);
-        float lo[8], hi[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[e + 8]; }
-        act_row8(lo, p.act2, p.slope2);
-        act_row8(hi, p.act2, p.slope2);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] = lo[e]; v[e + 8] = hi[e]; }
-      }
-      if (ok) {
-        V8 o0, o1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { o0[e] = (T)v[e]; o1[e] = (T)v[e + 8]; }
-        T* yp = reinterpret_cast<T*>(p.y) + (int64_t)m * p.y_cs + p.y_co + cl;
-        *reinterpret_cast<V8*>(yp) = o0;
-        *reinterpret_cast<V8*>(yp + 8) = o1;
-        if (p.stats) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float a = (float)o0[e], b = (float)o1[e];
-            st[e] += a; st[16 + e] += a * a;
-            st[8 + e] += b; st[24 + e] += b * b;
-          }
-        }
-      }
-    }
-    if (p.stats) {
-      // BatchNorm statistics of the tile (identity epilogue): the 16 lanes fr of a channel group fq hold partial sums of
-      // the same 32 quantities over different pixels -- a halving butterfly over lane bits 0..3 (16 + 8 + 4 + 2 exchanges)
-      // leaves two finished sums per lane, added to the replica of this wave's row slab (yv4_conv_fwd_stats)
-      int idx = 0;
-#pragma unroll
-      for (int sft = 0; sft < 4; ++sft) {
-        const int half = 16 >> sft;
-        const bool bit = (lane >> sft) & 1;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-          const float send = bit ? st[i] : st[i + half];
-          const float recv = __shfl_xor(send, 1 << sft);
-          st[i] = (bit ? st[i + half] : st[i]) + recv;
-        }
-        idx += bit ? half : 0;
-      }
-      if (c_ok) {
-        const StatRep rep = stat_rep(p.stats, (unsigned)((tile_m * WAVES_M + wm)), p.Cout);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int id = idx + k;            // 0..15: sums, 16..31: sums of squares, of channel cl + (id & 15)
-          stat_add(rep, (id >> 4) * p.Cout + cl + (id & 15), st[k]);
-        }
-      }
-    }
+    wide_epilogue_h16<BF16, PT, false>(p, aff, has2, acc, m0 + wm * WMr + pr, n0 + wn * 64 + 16 * fq, lane,
+                                       (unsigned)(tile_m * WAVES_M + wm));
     c0 = 0; kh = 0;
   }
 #undef YV4_W3_ISSUE_A
@@ -440,85 +332,19 @@ bool conv3x3_wide_h16_applies(const ConvArgsH& a) {
          a.ksplit <= 1;
 }
 
-static int g_w3_cus = 0;
-static int w3_cus() {
-  if (g_w3_cus == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus <= 0) {
-      (void)hipGetLastError();
-      cus = 256;
-    }
-    g_w3_cus = cus;
-  }
-  return g_w3_cus;
-}
-
 template <bool BF16, int PT, int WAVES_M>
 static int launch_w3(const ConvArgsH& a, hipStream_t stream) {
-  typedef W3Geom<PT, WAVES_M> G_;
-  ConvArgsH p = a;
-  const int tiles_m = (p.M + G_::BM - 1) / G_::BM;
-  p.tiles_n = (p.Cout + G_::BN - 1) / G_::BN;
-  p.fd_hw = make_fastdiv((unsigned)(p.H * p.W));
-  p.fd_wo = make_fastdiv((unsigned)p.W);
-  const long long tiles = (long long)tiles_m * p.tiles_n;
-  if (tiles <= 0 || tiles > 0x7fffffffLL) {
-    set_error("conv3x3 wide h16: grid of %lld tiles out of range", tiles);
-    return YV4_E_INVALID;
-  }
-  const size_t lds = (size_t)G_::RingBytes + (size_t)4 * p.Cout * 4;
-  if (lds > 160 * 1024) {
-    set_error("conv3x3 wide h16: %zu bytes of LDS for this tile shape and Cout", lds);
-    return YV4_E_UNSUPPORTED;
-  }
-  const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 2, wb = (long long)p.Cout * p.Kw * 2;
-  auto kern = conv3x3_wide_h16_kernel<BF16, PT, WAVES_M>;
   static LdsAttrOnce once;
-  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024, "conv3x3_wide_h16")) return rc;
-  const int cus = w3_cus();
-  const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kW3Threads), lds, stream, p, (unsigned)xb, (unsigned)wb, (int)tiles);
-  YV4_CHECK_LAUNCH("conv3x3_wide_h16");
-  return YV4_OK;
+  return wide_launch<WideGeom<PT, WAVES_M, true>>(conv3x3_wide_h16_kernel<BF16, PT, WAVES_M>, once, "conv3x3_wide_h16", a, 2, stream);
 }
 
-// Tile shape per layer: (pixel tiles per wave, waves along M) in {(8,2): 256 x 256, (6,2): 192 x 256, (4,2): 128 x 256,
-// (6,4): 384 x 128, (4,4): 256 x 128}.  Cost model = rounds of one workgroup per CU x the tile's work, with the
-// smaller wave tiles charged for their extra fragment reads per MFMA (measured ratios, tools/conv_bench.py).
-// Returns an index into the table, or -1 when no shape fits (LDS) -- `shape` >= 0 forces one (measurement / tests).
-struct W3Shape { int pt, wm; };
-static const W3Shape kW3Shapes[5] = {{8, 2}, {6, 2}, {4, 2}, {6, 4}, {4, 4}};
-static size_t w3_lds(int pt, int wmv, int Cout) {
-  const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
-  const int arows = 64 * ((bm + 3 + 63) / 64);
-  return (size_t)2 * arows * 128 + (size_t)2 * bn * 128 + (size_t)16 * Cout;
-}
-int conv3x3_wide_h16_pick(const ConvArgsH& a, double* rounds_eff) {
-  const int cus = w3_cus();
-  int best = -1;
-  double best_cost = 0.0;
-  for (int i = 0; i < 5; ++i) {
-    const int pt = kW3Shapes[i].pt, wmv = kW3Shapes[i].wm;
-    const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
-    if (w3_lds(pt, wmv, a.Cout) > 160 * 1024) continue;
-    if (bn > ((a.Cout + 127) / 128) * 128) continue;                  // a 256-wide tile on a 128-channel layer is half empty
-    const long long tiles = ((long long)a.M + bm - 1) / bm * ((a.Cout + bn - 1) / bn);
-    const long long rounds = (tiles + cus - 1) / cus;
-    const double eff = pt == 8 ? 1.0 : (pt == 6 ? 1.04 : 1.12);
-    const double cost = (double)rounds * bm * bn * eff;
-    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
-  }
-  if (rounds_eff && best >= 0) *rounds_eff = best_cost / ((double)a.M * a.Cout / cus);
-  return best;
-}
+// Tile shape per layer and launch: conv_wide_common.h.  pick() returns an index into kWideShapes, or -1 when no shape
+// fits (LDS) -- `shape` >= 0 forces one (measurement / tests).
+int conv3x3_wide_h16_pick(const ConvArgsH& a, double* rounds_eff) { return wide_pick(a, true, true, rounds_eff); }
 
 int conv3x3_wide_h16_launch(const ConvArgsH& a, bool bf16, int shape, hipStream_t s) {
   if (shape < 0) shape = conv3x3_wide_h16_pick(a, nullptr);
-  if (shape < 0 || shape >= 5 || w3_lds(kW3Shapes[shape].pt, kW3Shapes[shape].wm, a.Cout) > 160 * 1024) {
-    set_error("conv3x3 wide h16: no tile shape of this layer fits the LDS");
-    return YV4_E_UNSUPPORTED;
-  }
+  if (!wide_shape_fits("conv3x3_wide_h16", true, shape, a.Cout)) return YV4_E_UNSUPPORTED;
 #define YV4_W3_CASE(I, PT_, WM_) case I: return bf16 ? launch_w3<true, PT_, WM_>(a, s) : launch_w3<false, PT_, WM_>(a, s);
   switch (shape) {
     YV4_W3_CASE(0, 8, 2)

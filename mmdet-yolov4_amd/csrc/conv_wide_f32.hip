@@ -6,33 +6,17 @@
 // borders and the M tail are out-of-range DMA offsets.  NOT bit-identical to the 32x32x2 tiles; yv4_conv_pick_tile
 // reports the pinned shape id (YV4_TILE_WIDE_SHAPE(i)).
 #include "conv_f32_common.h"
+#include "conv_wide_common.h"
 
 
 namespace yv4 {
 
-typedef float f32x4g __attribute__((ext_vector_type(4)));
-
-constexpr int kFgThreads = 512;
 constexpr int kFgBK = 32;
 
-template <int PT, int WAVES_M> struct FgGeom {
-  static constexpr int WAVES_N = 8 / WAVES_M;
-  static constexpr int BN = 64 * WAVES_N;
-  static constexpr int WMr = 16 * PT;
-  static constexpr int BM = WMr * WAVES_M;
-  static constexpr int QA = BM / 64;                // pixel pieces per wave and K tile
-  static constexpr int PB = BN / 64;                // weight pieces per wave and K tile
-  static constexpr int ABytes = BM * 128;
-  static constexpr int BBytes = BN * 128;
-  static constexpr int RingBytes = 2 * ABytes + 2 * BBytes;
-};
-
-__device__ __forceinline__ int fg_swz_b(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
-
 template <int PT, int WAVES_M>
-__global__ __launch_bounds__(kFgThreads, 2) void conv_wide_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
-  typedef f32x4g V8;                         // one fragment read: four K values of a row
-  typedef FgGeom<PT, WAVES_M> G_;
+__global__ __launch_bounds__(kWideThreads, 2) void conv_wide_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
+  typedef wide_acc_t V8;                         // one fragment read: four K values of a row
+  typedef WideGeom<PT, WAVES_M, false> G_;
   constexpr int WAVES_N = G_::WAVES_N, BN = G_::BN, BM = G_::BM, WMr = G_::WMr, QA = G_::QA, PB = G_::PB;
   constexpr int PH = PT / 2;
   constexpr int kRowB = 128;
@@ -68,7 +52,7 @@ __global__ __launch_bounds__(kFgThreads, 2) void conv_wide_f32_kernel(ConvArgs p
   const int srow = 8 * wave + (lane >> 3);
   const int pc = lane & 7;
   const int lcA = pc ^ ((srow >> 1) & 7);
-  const int lcB = pc ^ fg_swz_b(srow);
+  const int lcB = pc ^ wide_swz_b(srow);
   unsigned a_off[QA];
   unsigned long long a_mask[QA];
   unsigned b_off[PB];
@@ -112,7 +96,7 @@ __global__ __launch_bounds__(kFgThreads, 2) void conv_wide_f32_kernel(ConvArgs p
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       a_rd[ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ ((row >> 1) & 7)) << 4));
-      w_rd[ks] = (unsigned)(rw * kRowB + (((fq + 4 * ks) ^ fg_swz_b(rw)) << 4));
+      w_rd[ks] = (unsigned)(rw * kRowB + (((fq + 4 * ks) ^ wide_swz_b(rw)) << 4));
     }
   }
 
@@ -121,7 +105,7 @@ __global__ __launch_bounds__(kFgThreads, 2) void conv_wide_f32_kernel(ConvArgs p
   const int NK = nchunks * ntaps;            // K tiles per output tile (chunk-major, taps inside)
 
   const bool has2 = p.s2 != nullptr;
-  for (int c = tid; c < p.Cout; c += kFgThreads) {
+  for (int c = tid; c < p.Cout; c += kWideThreads) {
     aff[c] = p.s1[c];
     aff[p.Cout + c] = p.t1[c];
     aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
@@ -163,11 +147,11 @@ __global__ __launch_bounds__(kFgThreads, 2) void conv_wide_f32_kernel(ConvArgs p
     const int tile_m = (int)(tile / (unsigned)p.tiles_n);
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
-    f32x4g acc[PT][4];
+    wide_acc_t acc[PT][4];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[pt][t] = f32x4g{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 4; ++t) acc[pt][t] = wide_acc_t{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < NK; ++kt) {
       const unsigned slot = T_ & 1u;
@@ -245,77 +229,10 @@ __global__ __launch_bounds__(kFgThreads, 2) void conv_wide_f32_kernel(ConvArgs p
       T_ += 1u;
     }
 
-    // ---- epilogue: lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + fr, channels n0 + wn 64 + 16 fq .. + 15 (fp32: four
-    // 16-byte stores).  Expressions: fmaf(acc, s1, t1) -> act (the contraction-free scalar Mish of the fp32 kernels) ->
-    // + residual -> fmaf(., s2, t2) -> act, as conv_mfma_f32.hip's epilogue_tile ----
-    const int cl = n0 + wn * 64 + 16 * fq;
-    const bool c_ok = cl + 15 < p.Cout;
-    const int ca = c_ok ? cl : 0;
-    float s1[16], t1[16];
-#pragma unroll
-    for (int u = 0; u < 16; u += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(aff + ca + u), b = *reinterpret_cast<const float4*>(aff + p.Cout + ca + u);
-      s1[u] = a.x; s1[u + 1] = a.y; s1[u + 2] = a.z; s1[u + 3] = a.w;
-      t1[u] = b.x; t1[u + 1] = b.y; t1[u + 2] = b.z; t1[u + 3] = b.w;
-    }
-    float st[32];                            // training forward: [sum | sum of squares] of the lane's 16 channels
-#pragma unroll
-    for (int u = 0; u < 32; ++u) st[u] = 0.f;
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const int m = m0 + wm * WMr + 16 * pt + fr;
-      const bool ok = c_ok && m < p.M;
-      float v[16];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * t + j] = apply_act(__builtin_fmaf(acc[pt][t][j], s1[4 * t + j], t1[4 * t + j]), p.act1, p.slope1);
-      if (p.res && ok) {
-        const float* rp = p.res + (int64_t)m * p.r_cs + p.r_co + cl;
-#pragma unroll
-        for (int u = 0; u < 16; u += 4) {
-          const float4 r4 = *reinterpret_cast<const float4*>(rp + u);
-          v[u] += r4.x; v[u + 1] += r4.y; v[u + 2] += r4.z; v[u + 3] += r4.w;
-        }
-      }
-      if (has2) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          v[u] = apply_act(__builtin_fmaf(v[u], aff[2 * p.Cout + ca + u], aff[3 * p.Cout + ca + u]), p.act2, p.slope2);
-      }
-      if (ok) {
-        float* yp = p.y + out_row(p, m) * p.y_cs + p.y_co + cl;
-#pragma unroll
-        for (int u = 0; u < 16; u += 4) *reinterpret_cast<float4*>(yp + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
-        if (p.stats) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) { st[e] += v[e]; st[16 + e] += v[e] * v[e]; }
-        }
-      }
-    }
-    if (p.stats) {
-      int idx = 0;
-#pragma unroll
-      for (int sft = 0; sft < 4; ++sft) {
-        const int half = 16 >> sft;
-        const bool bit = (lane >> sft) & 1;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-          const float send = bit ? st[i] : st[i + half];
-          const float recv = __shfl_xor(send, 1 << sft);
-          st[i] = (bit ? st[i + half] : st[i]) + recv;
-        }
-        idx += bit ? half : 0;
-      }
-      if (c_ok) {
-        const StatRep rep = stat_rep(p.stats, (unsigned)((tile_m * WAVES_M + wm)), p.Cout);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int id = idx + k;
-          stat_add(rep, (id >> 4) * p.Cout + cl + (id & 15), st[k]);
-        }
-      }
-    }
+    // ---- epilogue (conv_wide_common.h): lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + fr, channels n0 + wn 64 + 16 fq .. + 15
+    // (fp32: four 16-byte stores) ----
+    wide_epilogue_f32<PT, true>(p, aff, has2, acc, m0 + wm * WMr + fr, n0 + wn * 64 + 16 * fq, lane,
+                                (unsigned)(tile_m * WAVES_M + wm));
   }
 #undef YV4_WG_ISSUE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -329,83 +246,18 @@ bool conv_wide_f32_applies(const ConvArgs& a) {
          a.ksplit <= 1 && !(a.ys_on && a.stats);
 }
 
-static int g_fg_cus = 0;
-static int fg_cus() {
-  if (g_fg_cus == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus <= 0) {
-      (void)hipGetLastError();
-      cus = 256;
-    }
-    g_fg_cus = cus;
-  }
-  return g_fg_cus;
-}
-
 template <int PT, int WAVES_M>
 static int launch_fg(const ConvArgs& a, hipStream_t stream) {
-  typedef FgGeom<PT, WAVES_M> G_;
-  ConvArgs p = a;
-  const int tiles_m = (p.M + G_::BM - 1) / G_::BM;
-  p.tiles_n = (p.Cout + G_::BN - 1) / G_::BN;
-  p.fd_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
-  p.fd_wo = make_fastdiv((unsigned)p.Wo);
-  const long long tiles = (long long)tiles_m * p.tiles_n;
-  if (tiles <= 0 || tiles > 0x7fffffffLL) {
-    set_error("conv wide f32: grid of %lld tiles out of range", tiles);
-    return YV4_E_INVALID;
-  }
-  const size_t lds = (size_t)G_::RingBytes + (size_t)4 * p.Cout * 4;
-  if (lds > 160 * 1024) {
-    set_error("conv wide f32: %zu bytes of LDS for this tile shape and Cout", lds);
-    return YV4_E_UNSUPPORTED;
-  }
-  const long long xb = (long long)p.N * p.H * p.W * p.x_cs * 4, wb = (long long)p.Cout * p.Kw * 4;
-  if (xb >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) {
-    set_error("conv wide f32: tensors of 4 GiB or more are not addressable through a buffer descriptor");
-    return YV4_E_UNSUPPORTED;
-  }
-  auto kern = conv_wide_f32_kernel<PT, WAVES_M>;
   static LdsAttrOnce once;
-  if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024, "conv_wide_f32")) return rc;
-  const int cus = fg_cus();
-  const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kFgThreads), lds, stream, p, (unsigned)xb, (unsigned)wb, (int)tiles);
-  YV4_CHECK_LAUNCH("conv_wide_f32");
-  return YV4_OK;
+  return wide_launch<WideGeom<PT, WAVES_M, false>>(conv_wide_f32_kernel<PT, WAVES_M>, once, "conv_wide_f32", a, 4, stream);
 }
 
-struct FgShape { int pt, wm; };
-static const FgShape kFgShapes[5] = {{8, 2}, {6, 2}, {4, 2}, {6, 4}, {4, 4}};
-static size_t fg_lds(int pt, int wmv, int Cout) {
-  const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
-  return (size_t)2 * (bm + bn) * 128 + (size_t)16 * Cout;
-}
-int conv_wide_f32_pick(const ConvArgs& a, double* rounds_eff) {
-  const int cus = fg_cus();
-  int best = -1;
-  double best_cost = 0.0;
-  for (int i = 0; i < 5; ++i) {
-    const int pt = kFgShapes[i].pt, wmv = kFgShapes[i].wm;
-    const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
-    if (fg_lds(pt, wmv, a.Cout) > 160 * 1024) continue;
-    if (bn > ((a.Cout + 127) / 128) * 128) continue;
-    const long long tiles = ((long long)a.M + bm - 1) / bm * ((a.Cout + bn - 1) / bn);
-    const long long rounds = (tiles + cus - 1) / cus;
-    const double cost = (double)rounds * bm * bn;
-    if (best < 0 || cost < best_cost * 0.999) { best = i; best_cost = cost; }
-  }
-  if (rounds_eff && best >= 0) *rounds_eff = best_cost / ((double)a.M * a.Cout / cus);
-  return best;
-}
+// shape choice and launch: conv_wide_common.h
+int conv_wide_f32_pick(const ConvArgs& a, double* rounds_eff) { return wide_pick(a, false, false, rounds_eff); }
 
 int conv_wide_f32_launch(const ConvArgs& a, int shape, hipStream_t s) {
   if (shape < 0) shape = conv_wide_f32_pick(a, nullptr);
-  if (shape < 0 || shape >= 5 || fg_lds(kFgShapes[shape].pt, kFgShapes[shape].wm, a.Cout) > 160 * 1024) {
-    set_error("conv wide f32: no tile shape of this layer fits the LDS");
-    return YV4_E_UNSUPPORTED;
-  }
+  if (!wide_shape_fits("conv_wide_f32", false, shape, a.Cout)) return YV4_E_UNSUPPORTED;
   switch (shape) {
     case 0: return launch_fg<8, 2>(a, s);
     case 1: return launch_fg<6, 2>(a, s);
