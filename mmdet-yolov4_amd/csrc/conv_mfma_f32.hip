@@ -827,6 +827,28 @@ __global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31;
   const int h = lane >> 5;
+#ifdef YV4_MEASURE
+  // YV4_WSF_STAMP=1 (bit 8 of cpr_shift): cycles per wave in [1] the counted wait for a stage, [2] fragment reads + MFMAs +
+  // the stage's DMA pieces, [3] epilogue up to its vmcnt(0), [4] rest of the epilogue; printed by two workgroups
+  const bool stamp_on = (cpr_shift & 256) != 0;
+  // YV4_WSF_ABL (wrong results on purpose): 1 a quarter of the output stores, 2 no stage DMAs, 4 no MFMAs, 8 no epilogue,
+  // 16 stage DMAs issued but out of range (zero fill, nothing fetched)
+  const bool few_stores = (cpr_shift & 512) != 0;
+  const bool abl_nodma = (cpr_shift & 1024) != 0, abl_nomfma = (cpr_shift & 2048) != 0, abl_noepi = (cpr_shift & 4096) != 0;
+  const bool abl_oob = (cpr_shift & 8192) != 0;
+  cpr_shift &= 255;
+  unsigned long long tsum[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+  const unsigned long long tbegin = tlast;
+#define YV4_WSF_STAMP(SLOT) if (stamp_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tsum[SLOT] += n_ - tlast; tlast = n_; }
+#define YV4_WSF_OOB abl_oob
+#define YV4_WSF_NODMA abl_nodma
+#define YV4_WSF_NOMFMA abl_nomfma
+#else
+#define YV4_WSF_STAMP(SLOT)
+#define YV4_WSF_OOB false
+#define YV4_WSF_NODMA false
+#define YV4_WSF_NOMFMA false
+#endif
   const int kc_n = p.Cin >> 5;          // 32-channel stages per strip
   const int cpr = 1 << cpr_shift;       // 16-byte chunks per weight row (Cin / 4 >= 16)
   const int wpitch = p.Cin * 4;
@@ -885,27 +907,43 @@ __global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs
   const int lrow = lane >> 3;
   const unsigned lch_even = (unsigned)(((lane & 7) ^ ((lane >> 4) & 7)) * 4);
   const unsigned lch_odd = (unsigned)(((lane & 7) ^ (((lane >> 4) + 4) & 7)) * 4);
+  // Issue side: the stage DMAs of a strip start at per-lane offsets that are computed once per strip (iss_voff: rows
+  // 8 j + lrow, chunk swizzled by row); the stage adds its 128 bytes through the scalar offset.  In the loop the four
+  // 1 KB pieces of stage kc + 2 are issued one per j step BETWEEN the wave's own MFMAs, where a piece's issue cost
+  // (~60-180 cycles, MI355X_MICROARCH.md) runs under the MFMA in flight; issued in one block at the top of the stage
+  // they were 1.0-1.4 k cycles per stage that only the partner wave's MFMAs could cover (stamps: DESIGN 12.9).
   int iss_i = 0, iss_kc = 0, iss_slot = 0;
-#define YV4_WSF_ISSUE()                                                                                     \
+  unsigned iss_voff[4];
+#define YV4_WSF_ISSUE_STRIP()                                                                               \
   {                                                                                                         \
     const int row0_ = (gw + iss_i * NW) * 32 + lrow;                                                        \
-    const bool live_ = iss_i < my_n;                                                                        \
-    const unsigned lds_ = ring_lds + (unsigned)(iss_slot * kWsfStageBytes);                                 \
+    const bool live_ = iss_i < my_n && !YV4_WSF_OOB;                                                        \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
       const int row_ = row0_ + 8 * j;                                                                       \
       const unsigned lch_ = (j & 1) ? lch_odd : lch_even;                                                   \
-      const unsigned voff_ = (live_ && row_ < p.M)                                                          \
-                                 ? (unsigned)(((int64_t)row_ * p.x_cs + p.x_co + iss_kc * 32 + (int)lch_) * 4) \
-                                 : kOOB;                                                                    \
-      lds_dma16(rsA, lds_ + (unsigned)(j * 1024), voff_, 0u);                                               \
+      iss_voff[j] = (live_ && row_ < p.M) ? (unsigned)(((int64_t)row_ * p.x_cs + p.x_co + (int)lch_) * 4) : kOOB; \
     }                                                                                                       \
+  }
+#define YV4_WSF_ISSUE_PIECE(J)                                                                              \
+  if (!YV4_WSF_NODMA)                                                                                       \
+    lds_dma16(rsA, ring_lds + (unsigned)(iss_slot * kWsfStageBytes + (J) * 1024), iss_voff[J], (unsigned)(iss_kc << 7));
+#define YV4_WSF_ISSUE_ADVANCE()                                                                             \
+  {                                                                                                         \
     iss_kc += 1;                                                                                            \
-    const int wrap_ = iss_kc == kc_n ? 1 : 0;                                                               \
-    iss_kc = wrap_ ? 0 : iss_kc;                                                                            \
-    iss_i += wrap_;                                                                                         \
+    if (iss_kc == kc_n) {                                                                                   \
+      iss_kc = 0;                                                                                           \
+      iss_i += 1;                                                                                           \
+      YV4_WSF_ISSUE_STRIP();                                                                                \
+    }                                                                                                       \
     iss_slot = iss_slot + 1 == kWsfStages ? 0 : iss_slot + 1;                                               \
   }
+#define YV4_WSF_ISSUE()                                                                                     \
+  {                                                                                                         \
+    YV4_WSF_ISSUE_PIECE(0) YV4_WSF_ISSUE_PIECE(1) YV4_WSF_ISSUE_PIECE(2) YV4_WSF_ISSUE_PIECE(3)             \
+    YV4_WSF_ISSUE_ADVANCE();                                                                                \
+  }
 
+  YV4_WSF_ISSUE_STRIP();
   YV4_WSF_ISSUE();
   YV4_WSF_ISSUE();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -924,14 +962,16 @@ __global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs
       for (int e = 0; e < 16; ++e) { acc[t][e] = 0.f; acc2[t][e] = 0.f; }
 
     for (int kc = 0; kc < kc_n; ++kc) {
-      YV4_WSF_ISSUE();
-      // stages 0 and 1 of a strip were confirmed in front of the previous strip's stores; later ones by count
-      // (see conv1x1_ws_h16.hip)
-      if (kc >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      YV4_WSF_STAMP(4);
+      // stages 0 and 1 of a strip were confirmed in front of the previous strip's stores; later ones by count: only the
+      // four pieces of stage kc + 1 (issued during stage kc - 1) may still be in flight (see conv1x1_ws_h16.hip)
+      if (kc >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      YV4_WSF_STAMP(1);
       const char* st = ring + rslot * kWsfStageBytes;
       const unsigned kx = (unsigned)(kc << 7);               // (kc * 8) << 4: chunk index inside the weight row
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (YV4_WSF_NOMFMA) { YV4_WSF_ISSUE_PIECE(j) continue; }
         const float4 fa = *reinterpret_cast<const float4*>(st + (a_rd ^ (unsigned)(j << 5)));
         float4 fb[NT];
 #pragma unroll
@@ -943,16 +983,30 @@ __global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs
           ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[t].y, ac_, 0, 0, 0);
           ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[t].z, ac_, 0, 0, 0);
           ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[t].w, ac_, 0, 0, 0);
+          if (t == 0) {                      // piece j of stage kc + 2, under the MFMA just issued
+            __builtin_amdgcn_sched_barrier(0);
+            YV4_WSF_ISSUE_PIECE(j)
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      YV4_WSF_ISSUE_ADVANCE();
       rslot = rslot + 1 == kWsfStages ? 0 : rslot + 1;
+      YV4_WSF_STAMP(2);
     }
 
     // epilogue: lane (r, h) holds channel n0 + 32t + r of pixels m0 + (e&3) + 8(e>>2) + 4h; the arithmetic is
     // epilogue_tile's, operation for operation
     const int m0 = (gw + i * NW) * 32;
     const bool full = m0 + 32 <= p.M;
+#ifdef YV4_MEASURE
+    if (abl_noepi) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (acc[0][0] == 12345.678f) p.y[0] = acc[NT - 1][3] + acc2[0][1];
+      continue;
+    }
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int c = n0 + t * 32 + r;
@@ -978,6 +1032,13 @@ __global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs
       }
       float* yb = p.y + ((int64_t)(m0 + 4 * h) * p.y_cs + p.y_co + c);
       if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stages in flight, before the stores join the counter
+      if (t == 0) { YV4_WSF_STAMP(3); }
+#ifdef YV4_MEASURE
+      if (few_stores) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yb[(int64_t)((e & 3) + 8 * (e >> 2)) * p.y_cs] = v[e] + v[e + 4] + v[e + 8] + v[e + 12];
+      } else
+#endif
       if (full) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) yb[(int64_t)((e & 3) + 8 * (e >> 2)) * p.y_cs] = v[e];
@@ -989,7 +1050,20 @@ __global__ __launch_bounds__(kWsfThreads, 1) void conv1x1_ws_f32_kernel(ConvArgs
     }
   }
 #undef YV4_WSF_ISSUE
+#undef YV4_WSF_ISSUE_PIECE
+#undef YV4_WSF_ISSUE_ADVANCE
+#undef YV4_WSF_ISSUE_STRIP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's out-of-range stage DMAs still write this wave's ring
+#ifdef YV4_MEASURE
+  YV4_WSF_STAMP(4);
+  if (stamp_on && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 101))
+    printf("wsf wg %d wave %d strips %d: total %llu | issue %llu wait %llu reads+mfma %llu epi-to-vmcnt0 %llu epi-rest %llu (cycles)\n",
+           (int)blockIdx.x, wave, my_n, __builtin_amdgcn_s_memtime() - tbegin, tsum[0], tsum[1], tsum[2], tsum[3], tsum[4]);
+#endif
+#undef YV4_WSF_STAMP
+#undef YV4_WSF_OOB
+#undef YV4_WSF_NODMA
+#undef YV4_WSF_NOMFMA
 
   if (p.stats && my_n > 0) {
     const StatRep rep = stat_rep(p.stats, (unsigned)(gw), p.Cout);
@@ -1036,6 +1110,12 @@ static int launch_wsf(const ConvArgs& a, hipStream_t stream) {
   auto kern = conv1x1_ws_f32_kernel<NT>;
   static LdsAttrOnce once;
   if (int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024, "conv1x1_ws_f32")) return rc;
+#ifdef YV4_MEASURE
+  static const int stamp = YV4_ENV_INT("YV4_WSF_STAMP", 0);
+  if (stamp) cpr_shift |= 256;
+  static const int abl = YV4_ENV_INT("YV4_WSF_ABL", 0);
+  cpr_shift |= (abl & 31) << 9;
+#endif
   hipLaunchKernelGGL(kern, dim3(kWsfGrid), dim3(kWsfThreads), lds, stream, a, (unsigned)xb, (unsigned)wb, ncol, nstrips,
                      cpr_shift);
   YV4_CHECK_LAUNCH("conv1x1_ws_f32");

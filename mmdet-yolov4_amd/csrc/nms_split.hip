@@ -6,20 +6,121 @@
 // unspecified), the same rule as everywhere else in this library.
 //
 // Pipeline (all on the caller's stream, n is a host value):
-//   1. radix sort of the 64-bit candidate keys (score desc, index asc)           [rocPRIM]
-//   2. stable radix sort of those by class label -> class-major, order kept      [rocPRIM]
+//   1. radix sort of the 64-bit candidate keys (score desc, index asc)           [rs_* kernels below]
+//   2. stable radix sort of those by class label -> class-major, order kept      [rs_* kernels below]
 //   3. one workgroup per class: greedy NMS over its segment in chunks of 256, survivors
 //      of earlier chunks kept as class-offset boxes in a global scratch list
 //   4. survivors' keys (others = ~0) sorted again, the first max_out become detections
 // Built with -ffp-contract=off (see nms_common.h).
-#include <hipcub/hipcub.hpp>
-
 #include "nms_common.h"
 
 namespace yv4 {
 
 constexpr int kSplitThreads = 1024;
 constexpr int kSplitChunk = 256;
+
+// ---- stable LSD radix sort, 8 bits per pass (this path is cold: >= 10 000 candidates of one image; three launches per
+// pass, nothing tuned).  Per pass: (a) every workgroup counts the digits of its tile of 1 024 keys -> hist[digit][tile];
+// (b) one workgroup turns the digit-major table into exclusive offsets; (c) every workgroup scatters its tile, a key's
+// position = offset[digit][tile] + its rank among the tile's earlier keys with the same digit.  A workgroup is ONE wave:
+// tile order = (round, lane), so a rank is the running count of the digit over earlier rounds plus the number of lower
+// lanes with the same digit in this round (eight ballots) -- no cross-wave ordering to get wrong.
+constexpr int kRsLanes = 64;
+constexpr int kRsRounds = 16;
+constexpr int kRsTile = kRsLanes * kRsRounds;
+
+template <class K>
+__global__ __launch_bounds__(kRsLanes) void rs_hist_kernel(const K* __restrict__ keys, int64_t n, int shift,
+                                                          uint32_t* __restrict__ hist, int ntiles) {
+  __shared__ uint32_t cnt[256];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += kRsLanes) cnt[i] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kRsTile;
+#pragma unroll 4
+  for (int r = 0; r < kRsRounds; ++r) {
+    const int64_t idx = base + r * kRsLanes + lane;
+    if (idx < n) atomicAdd(&cnt[(unsigned)(keys[idx] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  for (int i = lane; i < 256; i += kRsLanes) hist[(int64_t)i * ntiles + blockIdx.x] = cnt[i];
+}
+
+// exclusive scan of `total` counters in place (their sum is n < 2^31): a thread sums its contiguous chunk, thread 0 scans
+// the 1 024 chunk sums, the thread walks its chunk again
+__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ h, int64_t total) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t chunk = (total + 1023) / 1024;
+  const int64_t lo = t * chunk < total ? t * chunk : total;
+  const int64_t hi = lo + chunk < total ? lo + chunk : total;
+  uint32_t su = 0u;
+  for (int64_t i = lo; i < hi; ++i) su += h[i];
+  part[t] = su;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0u;
+    for (int i = 0; i < 1024; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; }
+  }
+  __syncthreads();
+  uint32_t run = part[t];
+  for (int64_t i = lo; i < hi; ++i) { const uint32_t v = h[i]; h[i] = run; run += v; }
+}
+
+template <class K, class V, bool HAS_V>
+__global__ __launch_bounds__(kRsLanes) void rs_scatter_kernel(const K* __restrict__ kin, K* __restrict__ kout,
+                                                             const V* __restrict__ vin, V* __restrict__ vout, int64_t n,
+                                                             int shift, const uint32_t* __restrict__ offs, int ntiles) {
+  __shared__ uint32_t run[256];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += kRsLanes) run[i] = offs[(int64_t)i * ntiles + blockIdx.x];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kRsTile;
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < kRsRounds; ++r) {           // (uniform trip count: the barriers below are reached by every lane)
+    const int64_t idx = base + r * kRsLanes + lane;
+    const bool valid = idx < n;
+    const K k = valid ? kin[idx] : (K)0;
+    const unsigned d = (unsigned)(k >> shift) & 255u;
+    unsigned long long peers = __ballot(valid);    // lanes of this round with my digit
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const unsigned rank = (unsigned)__popcll(peers & below);
+    if (valid) {
+      const uint32_t pos = run[d] + rank;
+      kout[pos] = k;
+      if (HAS_V) vout[pos] = vin[idx];
+    }
+    __syncthreads();                               // every read of run[] of this round is done
+    if (valid && rank + 1u == (unsigned)__popcll(peers)) run[d] += (uint32_t)__popcll(peers);   // the group's highest lane
+    __syncthreads();
+  }
+}
+
+// Sorts `bits` low bits (a multiple of 16: an even number of passes) of n keys, ascending and stable; values follow when
+// HAS_V.  The input is only read; the result lands in (kx, vx), (ky, vy) is the other side of the ping-pong.
+template <class K, class V, bool HAS_V>
+static int rs_sort(const K* kin, K* kx, K* ky, const V* vin, V* vx, V* vy, int64_t n, int bits, uint32_t* hist, hipStream_t s) {
+  const int ntiles = (int)((n + kRsTile - 1) / kRsTile);
+  const K* sk = kin;
+  const V* sv = vin;
+  for (int pass = 0; pass * 8 < bits; ++pass) {
+    K* dk = (pass & 1) ? kx : ky;
+    V* dv = (pass & 1) ? vx : vy;
+    hipLaunchKernelGGL(rs_hist_kernel<K>, dim3((unsigned)ntiles), dim3(kRsLanes), 0, s, sk, n, pass * 8, hist, ntiles);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, s, hist, (int64_t)256 * ntiles);
+    hipLaunchKernelGGL((rs_scatter_kernel<K, V, HAS_V>), dim3((unsigned)ntiles), dim3(kRsLanes), 0, s, sk, dk, sv, dv, n,
+                       pass * 8, hist, ntiles);
+    sk = dk;
+    sv = dv;
+  }
+  YV4_CHECK_LAUNCH("nms_split: radix sort");
+  return YV4_OK;
+}
 
 __global__ __launch_bounds__(256) void split_labels_kernel(const uint64_t* __restrict__ keys, int64_t n,
                                                            const int32_t* __restrict__ labels, int fused,
@@ -189,7 +290,7 @@ __global__ __launch_bounds__(256) void split_emit_kernel(const uint64_t* __restr
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct SplitLayout {
-  size_t keys_a, keys_b, lab_a, lab_b, seg, kbox, karea, cub, total;
+  size_t keys_a, keys_b, keys_t, lab_a, lab_b, lab_t, hist, seg, kbox, karea, total;
 };
 
 static SplitLayout split_layout(int64_t n, int num_classes) {
@@ -203,11 +304,9 @@ static SplitLayout split_layout(int64_t n, int num_classes) {
   L.seg = take((size_t)(num_classes + 2) * 8);
   L.kbox = take((size_t)n * 16);
   L.karea = take((size_t)n * 4);
-  size_t t1 = 0, t2 = 0;
-  hipcub::DeviceRadixSort::SortKeys(nullptr, t1, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);
-  hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (const int32_t*)nullptr, (int32_t*)nullptr, (const uint64_t*)nullptr,
-                                     (uint64_t*)nullptr, (int)n, 0, 16);
-  L.cub = take(t1 > t2 ? t1 : t2);
+  L.keys_t = take((size_t)n * 8);                                              // the sorts' other ping-pong side
+  L.lab_t = take((size_t)n * 4);
+  L.hist = take((size_t)256 * (size_t)((n + kRsTile - 1) / kRsTile) * 4);     // digit-major counters of a pass
   L.total = off;
   return L;
 }
@@ -242,20 +341,17 @@ extern "C" int yv4_nms_split(const uint64_t* keys, int64_t n, float max_coord, c
   int32_t* lab_a = reinterpret_cast<int32_t*>(w + L.lab_a);
   int32_t* lab_b = reinterpret_cast<int32_t*>(w + L.lab_b);
   int64_t* seg = reinterpret_cast<int64_t*>(w + L.seg);
-  size_t cub_bytes = L.total - L.cub;
-  void* cub = w + L.cub;
+  uint64_t* keys_t = reinterpret_cast<uint64_t*>(w + L.keys_t);
+  uint32_t* lab_t = reinterpret_cast<uint32_t*>(w + L.lab_t);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(w + L.hist);
   const unsigned g = (unsigned)((n + 255) / 256);
   // 1. by (score desc, index asc)
-  if (hipcub::DeviceRadixSort::SortKeys(cub, cub_bytes, keys, keys_a, (int)n, 0, 64, s) != hipSuccess) {
-    set_error("nms_split: radix sort failed");
-    return YV4_E_LAUNCH;
-  }
-  // 2. stable by label
+  if (int rc = rs_sort<uint64_t, int, false>(keys, keys_a, keys_t, nullptr, nullptr, nullptr, n, 64, hist, s)) return rc;
+  // 2. stable by label (labels are < 65536: two passes)
   hipLaunchKernelGGL(split_labels_kernel, dim3(g), dim3(256), 0, s, keys_a, n, labels, fused_classes, lab_a);
-  if (hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, lab_a, lab_b, keys_a, keys_b, (int)n, 0, 16, s) != hipSuccess) {
-    set_error("nms_split: radix sort by label failed");
-    return YV4_E_LAUNCH;
-  }
+  if (int rc = rs_sort<uint32_t, uint64_t, true>(reinterpret_cast<const uint32_t*>(lab_a), reinterpret_cast<uint32_t*>(lab_b),
+                                                 lab_t, keys_a, keys_b, keys_t, n, 16, hist, s))
+    return rc;
   hipLaunchKernelGGL(split_segments_kernel, dim3((num_classes + 1 + 255) / 256), dim3(256), 0, s, lab_b, n, num_classes, seg);
   // 3. per-class NMS; survivors' keys into keys_a (others ~0)
   SplitArgs a;
@@ -264,10 +360,7 @@ extern "C" int yv4_nms_split(const uint64_t* keys, int64_t n, float max_coord, c
   a.out_keys = keys_a;
   hipLaunchKernelGGL(split_class_nms_kernel, dim3(num_classes), dim3(kSplitThreads), 0, s, a);
   // 4. survivors by (score desc, index asc), first max_out
-  if (hipcub::DeviceRadixSort::SortKeys(cub, cub_bytes, keys_a, keys_b, (int)n, 0, 64, s) != hipSuccess) {
-    set_error("nms_split: final radix sort failed");
-    return YV4_E_LAUNCH;
-  }
+  if (int rc = rs_sort<uint64_t, int, false>(keys_a, keys_b, keys_t, nullptr, nullptr, nullptr, n, 64, hist, s)) return rc;
   const int lim = (int)(n < max_out ? n : max_out);
   hipLaunchKernelGGL(split_emit_kernel, dim3((lim + 255) / 256), dim3(256), 0, s, keys_b, n, boxes, labels, fused_classes,
                      max_out, out_dets, out_labels, out_index, out_count);

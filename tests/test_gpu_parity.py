@@ -524,7 +524,7 @@ def test_batched_nms_bit_exact_vs_oracle(golden, gpu_device, tag):
         np.testing.assert_array_equal(inds.cpu().numpy(), ro[2].numpy())
 
 
-@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 255, 256, 257, 1000, 5000, 9999, 10000, 30000])
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 255, 256, 257, 1000, 5000, 9999, 10000, 10241, 30000, 70001])
 def test_nms_sizes_and_ties_bit_exact(gpu_device, n):
     rng = np.random.RandomState(n)
     c = rng.rand(max(n // 20, 1), 2) * 200

@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--json', default='')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'])
     ap.add_argument('--chain', type=int, default=1, help='launches per timed region (steady-state time per launch)')
+    ap.add_argument('--act', type=int, default=1, help='activation id of the epilogue (0 none, 1 Mish, 2 leaky, 3 swish)')
     ap.add_argument('--zeros', action='store_true', help='all-zero operands: the clock the chip holds on trivial data (DVFS check)')
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(',')]
@@ -70,7 +71,7 @@ def main():
         d.KH = d.KW = k
         d.stride, d.pad = s, pad
         d.x_cstride, d.y_cstride = cp, (ycs if h16 else cout)
-        d.act1 = 1
+        d.act1 = a.act
         flops = 2.0 * a.batch * ho * ho * cout * k * k * cin
         res = {}
         for t in tiles:
