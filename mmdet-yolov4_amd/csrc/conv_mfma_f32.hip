@@ -419,17 +419,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
     s_kb = (unsigned)((s_tap * p.Cin + s_c0) * 4);
   }
 
-#define YV4_V3_DMA(BUF)                                                             \
+  // The kDmaPerSlice LDS-DMA pieces of a slice: the prologue issues them in one block (YV4_V3_DMA); in the K loop they
+  // go out between the MFMAs of the slice being computed, a quarter per 8-deep K step (YV4_V3_DMA_PIECES inside
+  // YV4_V3_COMPUTE) -- a piece costs 60-180 cycles of issue (MI355X_MICROARCH.md) during which the wave cannot feed the
+  // matrix pipe unless its own MFMAs are already in flight (the weight-stationary kernel's stamps).
+  unsigned d_step = 0u, d_la = 0u, d_lb = 0u;
+#define YV4_V3_DMA_SETUP(BUF)                                                       \
   {                                                                                 \
-    const unsigned step = (unsigned)((((int64_t)s_kh * p.W + s_kw) * p.x_cs + s_c0) * 4); \
-    const unsigned la_ = lds_base + (unsigned)(((BUF) * BM + 8 * wave) * kRow * 4);  \
-    const unsigned lb_ = lds_base + (unsigned)((NBUF * BM + (BUF) * BN + 8 * wave) * kRow * 4); \
-    _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                \
-      const bool ok = (a_mask[q] >> s_tap) & 1ull;                                  \
-      lds_dma16(rsA, la_ + 32 * q * kRow * 4, ok ? a_off[q] + step : kOOB, 0u);      \
+    d_step = (unsigned)((((int64_t)s_kh * p.W + s_kw) * p.x_cs + s_c0) * 4);        \
+    d_la = lds_base + (unsigned)(((BUF) * BM + 8 * wave) * kRow * 4);               \
+    d_lb = lds_base + (unsigned)((NBUF * BM + (BUF) * BN + 8 * wave) * kRow * 4);   \
+  }
+#define YV4_V3_DMA_PIECE(Q)                                                         \
+  {                                                                                 \
+    if ((Q) < PA) {                                                                 \
+      const int qa_ = (Q) < PA ? (Q) : 0;                                           \
+      const bool ok = (a_mask[qa_] >> s_tap) & 1ull;                                \
+      lds_dma16(rsA, d_la + 32 * qa_ * kRow * 4, ok ? a_off[qa_] + d_step : kOOB, 0u); \
+    } else {                                                                        \
+      const int qb_ = (Q) >= PA ? (Q) - PA : 0;                                     \
+      lds_dma16(rsB, d_lb + 32 * qb_ * kRow * 4, b_off[qb_], s_kb);                  \
     }                                                                               \
-    _Pragma("unroll") for (int q = 0; q < PB; ++q)                                  \
-      lds_dma16(rsB, lb_ + 32 * q * kRow * 4, b_off[q], s_kb);                       \
+  }
+#define YV4_V3_DMA_ADVANCE()                                                        \
+  {                                                                                 \
     s_tap += 1;                                                                     \
     s_kw += 1;                                                                      \
     const int wrap_w = s_kw == p.KW ? 1 : 0;                                        \
@@ -440,6 +453,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
     s_kh = wrap_t ? 0 : s_kh;                                                       \
     s_c0 += wrap_t ? kBK : 0;                                                       \
     s_kb = (unsigned)((s_tap * p.Cin + s_c0) * 4);                                  \
+  }
+#define YV4_V3_DMA(BUF)                                                             \
+  {                                                                                 \
+    YV4_V3_DMA_SETUP(BUF);                                                          \
+    _Pragma("unroll") for (int q = 0; q < kDmaPerSlice; ++q) YV4_V3_DMA_PIECE(q);   \
+    YV4_V3_DMA_ADVANCE();                                                           \
+  }
+  constexpr bool kPiecewise = TM * TN >= 2;   // (the 64 x 64 tile has ONE MFMA quad per K step to issue under: no gain, -2 %)
+#define YV4_V3_DMA_PIECES(J)                                                        \
+  if (kPiecewise && dma_on) {                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    _Pragma("unroll") for (int q = (J) * kDmaPerSlice / 4; q < ((J) + 1) * kDmaPerSlice / 4; ++q) YV4_V3_DMA_PIECE(q); \
+    __builtin_amdgcn_sched_barrier(0);                                              \
   }
 
   // fragment read addresses: row*128 B + ((chunk ^ swz) << 4); chunk = 2j + h
@@ -472,6 +498,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
           ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[jn].y, ac_, 0, 0, 0); \
           ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[jn].z, ac_, 0, 0, 0); \
           ac_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[jn].w, ac_, 0, 0, 0); \
+          if (i == 0 && jn == 0) YV4_V3_DMA_PIECES(j)                               \
         }                                                                           \
     }                                                                               \
   }
@@ -513,14 +540,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
 
   int rbuf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (issued < nk) {                 // slot wbuf was last read before the previous barrier
-      YV4_V3_DMA(wbuf);
-      ++issued;
-      wbuf = wbuf + 1 == NBUF ? 0 : wbuf + 1;
+    const bool dma_on = issued < nk;   // slot wbuf was last read before the previous barrier
+    if (dma_on) {
+      YV4_V3_DMA_SETUP(wbuf);
+      if (!kPiecewise) {
+#pragma unroll
+        for (int q = 0; q < kDmaPerSlice; ++q) YV4_V3_DMA_PIECE(q);
+      }
     }
     __builtin_amdgcn_s_setprio(1);   // keep the MFMA cluster ahead of the other resident waves' setup code
     YV4_V3_COMPUTE(rbuf);
     __builtin_amdgcn_s_setprio(0);
+    if (dma_on) {
+      YV4_V3_DMA_ADVANCE();
+      ++issued;
+      wbuf = wbuf + 1 == NBUF ? 0 : wbuf + 1;
+    }
     rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
     if (kt + 1 < nk) {
       // fragment reads of this slot returned (lgkmcnt(0)), slice kt+1 landed (counted
@@ -531,6 +566,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_f32_dma_kernel(ConvArgs
   }
 #undef YV4_V3_WAIT
 #undef YV4_V3_DMA
+#undef YV4_V3_DMA_SETUP
+#undef YV4_V3_DMA_PIECE
+#undef YV4_V3_DMA_PIECES
+#undef YV4_V3_DMA_ADVANCE
 #undef YV4_V3_COMPUTE
 
   // ---- epilogue: transposed through a wave-private LDS patch (the K-loop buffers are free
