@@ -38,15 +38,20 @@ one of the three was the wrong model and is replaced, as recorded here:
   * direction / magnitude: first stated as "g16 = b g32 + uncorrelated noise, so the projection b stays 1 whatever
     delta" -- WRONG: the measurement shows a ROTATION (norm ratio 0.93-1.02 globally while cos = b = 1 - delta^2 / 2 to two
     digits in every row, probe included).  Replaced by the norm ratio: | |g16| / |g32| - 1 | <= 2 * | ratio_probe - 1 | +
-    0.1 + 0.25 * min(delta_probe, 1), globally and per group -- a missing term, a wrong scale or a dropped residual
+    0.15 + 0.25 * min(delta_probe, 1), globally and per group -- a missing term, a wrong scale or a dropped residual
     changes the norm; a rotation does not.  The last term was added when the bound went red for the right reason to
     widen it: the reverse triangle inequality gives | ratio - 1 | <= delta exactly, so while the probe says the state is
     chaotic (delta_probe ~ 1) a fixed 0.1 asserts more than the comparison can resolve.  It did hold on the trajectory
     it was written on (worst: the head at step 50 in bf16, 0.82 with its probe at 0.875); then the fp32 tile choice of
     two layers changed (same arithmetic, a different grouping of the float partial sums of the BatchNorm statistics: a
     different, equally valid trajectory) and the bf16 backbone.csp2 group at step 50 came out at 1.15 with its probe at
-    1.02 and delta_probe 0.97.  A quarter of the probe's distance keeps the assertion below 0.5 -- a factor-2 scale
-    error (loss scale, a doubled or dropped term) fails it in every regime -- and returns to 0.1 + as delta_probe -> 0.
+    1.02 and delta_probe 0.97.  The bound is now 2 * | ratio_probe - 1 | + 0.15 + 0.25 * min(delta_probe, 1): over the two
+    deterministic trajectories and three default-mode draws of the recipe (tools/teacher_forced_margin.py,
+    profiles/r05_teacher_forced_margins.txt: 550 (snapshot, precision, group) samples) the smallest margin of the 0.1 form
+    was 0.045 (fp16, head, step 100: 0.905 with its probe at 0.992 and delta_probe 0.10), so the constant went to 0.15;
+    the distance bound's smallest margin is 0.10.  At step 149 (delta_probe 0.1-0.45) the bound is 0.18-0.3: a factor-2
+    scale error (loss scale, a doubled or dropped term: | ratio - 1 | >= 0.5) fails there whatever the early, chaotic
+    snapshots allow.
 """
 import os
 import sys
@@ -218,7 +223,7 @@ def test_teacher_forced_16bit_gradients(trajectory, step):
             print(f'    {g:32s} delta {st["delta"]:.4f} (probe global {dpg:.4f}) cos {st["cos"]:.4f} ratio {st["ratio"]:.4f} '
                   f'(probe {rp:.4f}) proj {st["proj"]:.4f}')
             assert st['delta'] <= 4 * dpg + 0.02, (name, g, st, dpg)
-            assert abs(st['ratio'] - 1) <= 2 * abs(rp - 1) + 0.1 + 0.25 * min(dpg, 1.0), (name, g, st, rp, dpg)
+            assert abs(st['ratio'] - 1) <= 2 * abs(rp - 1) + 0.15 + 0.25 * min(dpg, 1.0), (name, g, st, rp, dpg)
 
 
 @pytest.mark.parametrize('name', ['fp16', 'bf16'])
