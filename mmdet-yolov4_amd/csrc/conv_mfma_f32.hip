@@ -1177,7 +1177,11 @@ static bool prefer_ws_f32(const ConvArgs& a) {
   static const int mode = YV4_ENV_INT("YV4_WS", 1);
   static const int min_strips = YV4_ENV_INT("YV4_WS_MINSTRIPS", 2);
   if (!mode || !conv1x1_ws_f32_applies(a)) return false;
-  return ((long long)a.M + 31) / 32 >= (long long)min_strips * 2048;
+  // strips per persistent wave: the 256 workgroups are dealt over the column slabs, 8 waves each (with the DMA pieces
+  // issued under the MFMAs the kernel beats the 128x64 tile on 256 -> 256 @38 too: 62 against 67 us, tools/ab_wsf.sh)
+  const int bn = wsf_slab_cols(a);
+  const long long ncol = (a.Cout + bn - 1) / bn;
+  return (((long long)a.M + 31) / 32) * ncol >= (long long)min_strips * 2048;
 }
 
 static bool stem_ok(const yv4_conv_desc* d, bool has_res, bool has2) {

@@ -23,7 +23,7 @@ SHAPES = [
     (256, 256, 1, 1, 38, 15), (256, 256, 3, 1, 38, 12), (512, 512, 1, 1, 38, 1), (512, 1024, 3, 2, 38, 1),
     (1024, 512, 1, 1, 19, 7), (512, 512, 1, 1, 19, 9), (512, 512, 3, 1, 19, 8), (1024, 1024, 1, 1, 19, 1),
     (2048, 512, 1, 1, 19, 1), (128, 256, 3, 1, 76, 1), (256, 512, 3, 1, 38, 1), (512, 1024, 3, 1, 19, 1),
-    (128, 256, 3, 2, 76, 1), (256, 512, 3, 2, 38, 1), (256, 255, 1, 1, 76, 1), (512, 255, 1, 1, 38, 1),
+    (128, 256, 3, 2, 76, 1), (256, 512, 3, 2, 38, 1), (256, 512, 1, 1, 38, 2), (256, 255, 1, 1, 76, 1), (512, 255, 1, 1, 38, 1),
     (1024, 255, 1, 1, 19, 1),
 ]
 
