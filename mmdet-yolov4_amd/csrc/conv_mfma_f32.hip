@@ -1197,8 +1197,7 @@ static int pick_tile(long long M, int Cout, bool fast_ok, long long K = 0) {
   if (fast_ok) {
     auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
     if (K >= 576 && Cout >= 128 && ntiles(128, 128) >= 700) return YV4_TILE_DMA_128x128;
-    // (K = 288, the 32-channel 3x3 layers at 304 / 608 pixels: 64x64 is 5 % faster, tools/conv_bench.py round 5)
-    if (Cout >= 64 && (K > 288 || Cout >= 256) && ntiles(128, 64) >= 512) return YV4_TILE_DMA_128x64;
+    if (Cout >= 64 && (K >= 288 || Cout >= 256) && ntiles(128, 64) >= 512) return YV4_TILE_DMA_128x64;
     return YV4_TILE_DMA_64x64;
   }
   // 256 CUs x 2 resident workgroups.  Prefer the biggest tile that still gives the
