@@ -2146,14 +2146,25 @@ __device__ __forceinline__ double bn_sum(const BnArgs& p, int i) {
 // Elementwise passes use the reductions' thread map too: a thread keeps ONE channel group of V channels (its
 // mean / invstd / gamma / beta live in registers) and walks rows -- no per-element index division,
 // kBnUnroll independent row loads in flight.  V = 4 channels per thread (V = 8 for 16-bit rows: YV4_BN_VEC8=1).
+// YV4_BN_NT (build-time, tools/ab_bn_nt.sh): 1 = the BatchNorm passes' row loads non-temporal, 2 = their stores.  Measured at
+// YOLOv4-L 608 batch 64 bf16 on one box (profiles/r05_bn_nt_ab.txt): non-temporal STORES take the forward pass from 4.04 to
+// 3.78 ms per step and the backward apply pass from 6.21 to 6.11, the train step from 1 194 to 1 199-1 204 images/s;
+// non-temporal loads cost 4 % on both.  Default: stores only.
+#ifndef YV4_BN_NT
+#define YV4_BN_NT 2
+#endif
 template <typename T, int V> struct RowVec {
   typedef T raw __attribute__((ext_vector_type(V)));
-  static __device__ __forceinline__ raw ld(const T* p) { return *reinterpret_cast<const raw*>(p); }
+  static __device__ __forceinline__ raw ld(const T* p) {
+    if (YV4_BN_NT & 1) return __builtin_nontemporal_load(reinterpret_cast<const raw*>(p));
+    return *reinterpret_cast<const raw*>(p);
+  }
   static __device__ __forceinline__ void st(T* p, const float (&v)[V]) {
     raw o;
 #pragma unroll
     for (int k = 0; k < V; ++k) o[k] = (T)v[k];
-    *reinterpret_cast<raw*>(p) = o;
+    if (YV4_BN_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<raw*>(p));
+    else *reinterpret_cast<raw*>(p) = o;
   }
   static __device__ __forceinline__ raw zero() {
     raw o;
