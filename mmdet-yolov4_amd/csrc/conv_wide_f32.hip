@@ -157,7 +157,10 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv_wide_f32_kernel(ConvArgs
       const unsigned slot = T_ & 1u;
       const char* as_ = As + slot * G_::ABytes;
       const char* bs_ = Bs + slot * G_::BBytes;
-      YV4_WG_ISSUE(slot ^ 1u);
+      // The DMA pieces of the next K tile (other slot) are NOT issued here, behind the barrier, where all eight waves
+      // would issue at once with the matrix pipe idle (7-8 pieces x 60-180 cycles): waves 0-3 issue them
+      // after phase 1, waves 4-7 (their partners on the SIMDs) after phase 2 -- one wave of a SIMD issues while the
+      // other multiplies.  A K tile is ~12 k cycles: pieces issued at its middle still have 2.5 us to land.
       V8 wf[4][2], pf[PH][2];
       // ---- phase 1
 #pragma unroll
@@ -181,6 +184,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv_wide_f32_kernel(ConvArgs
               acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][ks][j], pf[i][ks][j], acc[i][t], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      if (wave < 4) { YV4_WG_ISSUE(slot ^ 1u); }
+      __builtin_amdgcn_sched_barrier(0);
       // ---- phase 2 (fragments already in registers)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -193,6 +198,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv_wide_f32_kernel(ConvArgs
             for (int i = 0; i < PH; ++i)
               acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][ks][j], pf[i][ks][j], acc[i][t], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (wave >= 4) { YV4_WG_ISSUE(slot ^ 1u); }
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase 3
 #pragma unroll
