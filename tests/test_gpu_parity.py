@@ -543,6 +543,25 @@ def test_nms_sizes_and_ties_bit_exact(gpu_device, n):
         np.testing.assert_array_equal(d.cpu().numpy(), rd.numpy())
 
 
+@pytest.mark.parametrize('n', [400003, 1048577])
+def test_nms_split_sorts_at_scale(gpu_device, n):
+    """The split path's own radix sorts (nms_split.hip: rs_* kernels) on hundreds of tiles: with iou_threshold = 1 nothing
+    is suppressed, so the result must be ALL candidates in (score descending, index ascending) order -- a stable sort torch
+    can state -- whatever the class-major regrouping in between did.  Scores on a grid of 64 values: ~n / 64 exact ties
+    per value."""
+    g = torch.Generator().manual_seed(n)
+    xy = torch.rand(n, 2, generator=g) * 1000
+    wh = torch.rand(n, 2, generator=g) * 30 + 1
+    b = torch.cat([xy, xy + wh], 1)
+    s = (torch.randint(1, 65, (n,), generator=g).float() / 64)
+    idx = torch.randint(0, 80, (n,), generator=g)
+    d, keep = pkg.batched_nms(b.to(gpu_device), s.to(gpu_device), idx, dict(type='nms', iou_threshold=1.0))
+    order = torch.sort(s, descending=True, stable=True).indices
+    assert keep.shape[0] == n
+    assert torch.equal(keep.cpu(), order)
+    assert torch.equal(d[:, 4].cpu(), s[order]) and torch.equal(d[:, :4].cpu(), b[order])
+
+
 def test_nms_negative_coordinates_cross_class(gpu_device):
     """Boxes with negative coordinates make mmcv's class offset overlap adjacent classes; the
     kernel works on the offset boxes, so it reproduces whatever that implies."""
