@@ -933,6 +933,9 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
 constexpr int kW3FlagBase = kW3Lds;                  // kW3NBuf x 64 flag bytes behind the slice buffers
 constexpr int kW3LdsV2 = kW3Lds + kW3NBuf * 64;
 
+#ifndef YV4_W3V2_STAGGER
+#define YV4_W3V2_STAGGER 1     // build-time A/B (tools/ab_prev.sh): 0 = all eight waves issue DMA(sl + 3) at the same point
+#endif
 // ABL (measurement build only, compile-time so that the timed kernel carries no extra branches): 1 no DMA inside the loop,
 // 2 no workgroup barrier, 4 no MFMAs, 8 no fragment reads -- wrong results on purpose, to time the kernel without a part
 template <bool BF16, int ABL = 0>
@@ -1116,11 +1119,16 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_v2_h16_kernel(Wgr
     YV4_W3B_LOAD(1, bo, 1, fl);
     __builtin_amdgcn_sched_barrier(0);
     YV4_W3B_MFMA(0);
-    if constexpr (!(ABL & 1)) issue(sl + 3);          // into the buffer slice sl - 1 read (freed by the previous barrier)
+    // DMA(sl + 3) into the buffer slice sl - 1 read (freed by the previous barrier): waves 0-3 issue their 4-5 pieces
+    // here, waves 4-7 (their partners on the SIMDs) one MFMA step later -- issued by all eight waves at the same point
+    // the pieces' 400-500 issue cycles left the matrix pipe idle (compile-time ablation: -10 % without the DMA)
+    if constexpr (!(ABL & 1)) { if (wave < 4 || !YV4_W3V2_STAGGER) issue(sl + 3); }
     __builtin_amdgcn_sched_barrier(0);
     YV4_W3B_LOAD(0, bo, 2, fl);
     __builtin_amdgcn_sched_barrier(0);
     YV4_W3B_MFMA(1);
+    if constexpr (!(ABL & 1)) { if (wave >= 4 && YV4_W3V2_STAGGER) issue(sl + 3); }
+    __builtin_amdgcn_sched_barrier(0);
     YV4_W3B_LOAD(1, bo, 3, fl);
     __builtin_amdgcn_sched_barrier(0);
     YV4_W3B_MFMA(0);
@@ -2153,6 +2161,7 @@ __device__ __forceinline__ double bn_sum(const BnArgs& p, int i) {
 #ifndef YV4_BN_NT
 #define YV4_BN_NT 2
 #endif
+
 template <typename T, int V> struct RowVec {
   typedef T raw __attribute__((ext_vector_type(V)));
   static __device__ __forceinline__ raw ld(const T* p) {
