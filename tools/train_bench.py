@@ -133,8 +133,11 @@ def main():
             red.enable_timing()
     D.barrier()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(a.steps):
-        l1 = step()
+        ts = time.perf_counter()
+        l1 = step()                      # (returns the logged loss: one host synchronisation per step)
+        step_ms.append(round((time.perf_counter() - ts) * 1e3, 1))
     D.barrier()
     el = D.max_over_ranks(time.perf_counter() - t0, dev)
     phase_rep = None
@@ -154,7 +157,7 @@ def main():
                    'yolov3': 140.692e9 / 608.0 ** 2}    # 75 convs, Plan.total_flops() (= darknet's 140.69 BFLOPs)
         fl = 3 * per_img[a.model] * a.size ** 2      # fwd + dgrad + wgrad conv FLOPs
         print(json.dumps(dict(metric='images/sec (train step) ' + a.model, value=round(a.batch * world * a.steps / el, 2),
-                              n_gpus=world, ms_per_step=round(el / a.steps * 1e3, 1), batch_per_gpu=a.batch,
+                              n_gpus=world, ms_per_step=round(el / a.steps * 1e3, 1), step_ms=step_ms, batch_per_gpu=a.batch,
                               dtype=a.dtype, loss_first=round(float(l0), 3), loss_last=round(float(l1), 3),
                               optimizer='torch SGD + DDP' if a.torch_optim else 'flat arenas + recipe hooks',
                               backend=D.backend_name(), grad_exchange=D.exchange_name(a.grad_exchange, world),
