@@ -316,6 +316,34 @@ def oracle_check(det, img0, pred0, dets0, dtype):
     return ok, msg
 
 
+def pin_check_plan(plan, small):
+    import mmdet_yolov4_amd as pkg
+    """fp32 only: the wide-tile kernels (16x16x4 MFMAs) group the K sum differently from the 32x32x2 tiles a batch-2 plan
+    would pick by itself, so a check plan is PINNED to the timed plan's tile ids layer by layer (yv4_conv_pick_tile
+    reports the pinned form; every tile kernel is batch-invariant).  The 16-bit tiles are all bit-identical to each
+    other (tests/test_gpu_h16.py::test_*_matches_generic_bitwise) and need no pinning.  Returns '' or a note when the
+    two plans' launch lists do not line up.  Used by the output check below and by tests/test_gpu_fullsize.py."""
+    import ctypes
+    big_convs = [o for o in plan.ops if o.kind == 'conv' and 'desc' in o.info]
+    small_convs = [o for o in small.ops if o.kind == 'conv' and 'desc' in o.info]
+    if len(big_convs) != len(small_convs):
+        return (f'; NOTE: the timed plan has {len(big_convs)} conv launches, the batch-2 plan {len(small_convs)}: '
+                'tile ids NOT pinned layer by layer')
+    pick = pkg._lib.lib().yv4_conv_pick_tile
+    for ob, os_ in zip(big_convs, small_convs):
+        db, ds = ob.info['desc'], os_.info['desc']
+        if ob.info.get('fused') or ob.info.get('stem32') or os_.info.get('fused') or os_.info.get('stem32'):
+            continue
+        t = db.tile if db.tile else pick(ctypes.byref(db))
+        ts = ds.tile if ds.tile else pick(ctypes.byref(ds))
+        # either side on a wide-tile form (the timed plan's fill rule depends on M: a batch-2 layer can take a wide tile the
+        # batch-N plan rejected, and the other way round): the check plan runs the TIMED plan's resolved tile id.  The
+        # 32x32x2 tiles (ids 1-9) give the same bits as one another.
+        if t != ts and (t >= 10 or ts >= 10):
+            ds.tile = t
+    return ''
+
+
 def vs_published(args, value):
     """BASELINE.md holds published numbers only for upstream YOLOv3-DarkNet53 at batch 1 (fwd + post-processing,
     one V100, configs/yolo/README.md:22-24); every other configuration has none."""
@@ -656,32 +684,9 @@ def main():
     if args.batch >= 2 and not args.no_output_check:
         small = det.compile(2, args.size, args.size, device=dev, rescale=True,
                             dtype={'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.dtype])
-        pin_note = ''
-        if not h16:
-            # fp32: the wide-tile 3x3 kernel (16x16x4 MFMAs) groups the K sum differently from the 32x32x2 tiles a
-            # batch-2 plan would pick by itself, so the check plan is PINNED to the timed plan's tile ids layer by layer
-            # (yv4_conv_pick_tile reports the pinned form; every tile kernel is batch-invariant).  The 16-bit tiles
-            # are all bit-identical to each other (tests/test_gpu_h16.py::test_*_matches_generic_bitwise)
-            import ctypes
-            big_convs = [o for o in plan.ops if o.kind == 'conv' and 'desc' in o.info]
-            small_convs = [o for o in small.ops if o.kind == 'conv' and 'desc' in o.info]
-            if len(big_convs) == len(small_convs):
-                pick = pkg._lib.lib().yv4_conv_pick_tile
-                for ob, os_ in zip(big_convs, small_convs):
-                    db, ds = ob.info['desc'], os_.info['desc']
-                    if ob.info.get('fused') or ob.info.get('stem32') or os_.info.get('fused') or os_.info.get('stem32'):
-                        continue
-                    t = db.tile if db.tile else pick(ctypes.byref(db))
-                    ts = ds.tile if ds.tile else pick(ctypes.byref(ds))
-                    # either side on a wide-tile form (the timed plan's fill rule depends on M: a batch-2 layer can take a
-                    # wide tile the batch-N plan rejected, and the other way round): the check plan runs the TIMED plan's
-                    # resolved tile id.  The 32x32x2 tiles (ids 1-9) give the same bits as one another.
-                    if t != ts and (t >= 10 or ts >= 10):
-                        ds.tile = t
-            else:
-                pin_note = (f'; NOTE: the timed plan has {len(big_convs)} conv launches, the batch-2 plan {len(small_convs)}: '
-                            'tile ids NOT pinned layer by layer')
-                print('bench.py: output check' + pin_note[2:], file=sys.stderr)
+        pin_note = '' if h16 else pin_check_plan(plan, small)
+        if pin_note:
+            print('bench.py: output check' + pin_note[2:], file=sys.stderr)
         small.run(img[:2])
         torch.cuda.synchronize()
         for n in range(2):

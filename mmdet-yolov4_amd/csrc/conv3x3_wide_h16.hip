@@ -21,12 +21,20 @@
 //
 // Pipeline.  Tiles are square in work, not in shape: BM = 16 PT WAVES_M pixels x BN = 64 (8 / WAVES_M) channels, chosen
 // per layer so that the tile count fills whole rounds of CUs (256 x 256 leaves 29 % of the chip idle on a 181-tile
-// layer; 192 x 256 makes it 241 tiles).  Per K tile (one tap of one chunk) every wave issues the NEXT tap's weight
-// pieces (two LDS slots) and, when the tap opens a (chunk, kh) group, the next group's pixel image (two images); its
-// own DMAs are confirmed by a counted s_waitcnt vmcnt at the end of the K tile, then ONE workgroup barrier publishes
-// them -- a buffer is re-filled only in the K tile after the barrier that followed its last reads, a staged buffer is
-// read only after the barrier that followed its wait.  Inside a K tile there is no barrier: the two waves of a SIMD drift
-// apart by themselves, one reading fragments while the other's MFMAs occupy the pipe.
+// layer; 192 x 256 makes it 241 tiles).  One workgroup barrier per K tile (one tap of one chunk); a buffer is re-filled
+// only in the K tile after the barrier that followed its last reads, a staged buffer is read only after the barrier
+// that followed its issuer's s_waitcnt.
+//
+// Issue roles (round 6).  A K tile's LDS fill is 32-45 one-KB LDS-DMA pieces per workgroup, which the CU takes in at
+// ~33 cycles per piece: ~1 500 cycles during which an issuing wave sits in its vector-memory issue and multiplies
+// nothing.  With every wave issuing its share at the top of the K tile (rounds 4-5) all eight waves were parked there
+// together and the K tile cost fill time PLUS matrix time (3 650 cycles for 2 048 of MFMAs).  Now the two waves of a
+// SIMD (w and w + 4) have different jobs: waves 0-3 issue ALL the weight pieces of the next K tile first and multiply
+// afterwards; waves 4-7 multiply first and then issue ALL the pieces of the next (chunk, kh) group's pixel image, which
+// is not needed before the group ends (at kw = 0 and kw = 1, so that every piece has a K tile or more to land).  While
+// one wave of a SIMD is parked in its issue the other owns the matrix pipe, and the pieces with one K tile of slack
+// (the weights) are the ones issued early.  Per-piece offsets are a lane constant + scalar arithmetic (no per-piece
+// registers), and image pieces beyond the BM + 3 rows the fragments can touch are not issued at all.
 #include "conv_h16_common.h"
 #include "conv_wide_common.h"
 
@@ -43,12 +51,36 @@ template <> struct Mfma16<false> {
 };
 
 
+// Compile-time ablation (-DYV4_W3_ABL=bits, tools/abl_w3.sh: one library per variant, no run-time branch in any timed
+// kernel -- the run-time switches of the measurement build cost this loop more than the parts they remove): 1 no weight
+// DMA in the loop, 128 no image DMA, 2 no MFMA, 4 no barrier, 8 no fragment reads, 16 no epilogue.  Wrong results on purpose.
+#ifndef YV4_W3_ABL
+#define YV4_W3_ABL 0
+#endif
+#define W3_ABL(BIT) ((YV4_W3_ABL & (BIT)) != 0)
+#ifndef YV4_W3_ROLES
+#define YV4_W3_ROLES 1                      // waves 0-3 issue every weight piece, waves 4-7 every image piece (SK = 2 shapes)
+#endif
+// Diagnostic build only (-DYV4_W3_STAMP, tools/stamp_w3.sh): s_memtime sums per wave over the parts of a K tile, read
+// back through yv4_debug_w3_stamps.  No stamp executes in the product.
+#ifdef YV4_W3_STAMP
+__device__ unsigned long long g_w3_stamps[1024 * 8 * 8];
+#define YV4_W3_ST(i) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); st_[i] += t__ - tl_; tl_ = t__; }
+#else
+#define YV4_W3_ST(i)
+#endif
+
 template <bool BF16, int PT, int WAVES_M>
 __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvArgsH p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
   typedef typename Elem<BF16>::V8 V8;
   typedef WideGeom<PT, WAVES_M, true> G_;
   constexpr int WAVES_N = G_::WAVES_N, BN = G_::BN, BM = G_::BM, WMr = G_::WMr, QA = G_::QA, PB = G_::PB;
-  constexpr int PH = PT / 2;                 // pixel tiles per half
+  constexpr int QH = (QA + 1) / 2;           // image passes issued at kw = 0 (the rest at kw = 1)
+#ifdef YV4_W3_SK
+  constexpr int SK = YV4_W3_SK;
+#else
+  constexpr int SK = PT >= 8 ? 1 : 2;        // k steps (of 32) per LOAD / MFMA interval: the fragments of SK steps are in registers
+#endif
   constexpr int kRowB = 128;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -57,6 +89,9 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
   char* Bs = smem_w3 + 2 * G_::ABytes;       // [2][BN][128 B]
   float* aff = reinterpret_cast<float*>(smem_w3 + G_::RingBytes);   // [s1 | t1 | s2 | t2] x Cout
 
+#ifdef YV4_W3_STAMP
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,41 +121,41 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
     return (x < rem8 ? x * (q8 + 1) : rem8 * (q8 + 1) + (x - rem8) * q8) + ((unsigned)vt >> 3);
   };
 
-  // ---- staging lanes: a DMA instruction of a wave fills 8 LDS rows (lane / 8) x 8 chunks (lane % 8) ----
-  const int srow = 8 * wave + (lane >> 3);               // 0..63, + 64 per pass
+  // ---- staging lanes: a DMA instruction (one 1 KB "piece") of a wave fills 8 LDS rows (lane / 8) x 8 chunks (lane % 8):
+  // rows 8 wave + lane / 8 of every 64-row pass q.  Per-piece offsets are a lane constant + scalar arithmetic.
+  // ROLES (the SK = 2 shapes): waves 0-3 issue EVERY weight piece (both 32-row halves vv of a pass from issue position
+  // wave & 3), waves 4-7 every image piece.  A wave's vmcnt is one in-order counter: a wave that confirms its weight pieces
+  // every K tile thereby also waits for every older image piece, i.e. gives the image ONE K tile to arrive whatever the
+  // schedule says -- too little when the image comes from HBM (inside a network: profiles/r06_w3_modes.txt).  With the
+  // roles split, waves 4-7 wait once per (chunk, kh) group and the image has two to three K tiles.
+  constexpr bool ROLES = YV4_W3_ROLES != 0 && SK == 2;
+  constexpr int NV = ROLES ? 2 : 1, PR = 64 / NV;          // pieces per wave and pass; rows between them
+  const bool grpB = wave >= 4;                             // second wave of its SIMD (wave-uniform)
+  const bool issW = !ROLES || !grpB, issI = !ROLES || grpB;
+  const int iw = ROLES ? (wave & 3) : wave;
+  const int srow = 8 * iw + (lane >> 3);                   // 0..PR-1
   const int pc = lane & 7;
-  const int lcA = pc ^ ((srow >> 1) & 7);                // invariant under row + 64 q
-  const int lcB = pc ^ wide_swz_b(srow);                   // likewise
-  int a_s[QA];                                           // source pixel of LDS row (srow + 64 q) for kh = 1, NEXT group's tile
-  unsigned a_off[QA];
-  unsigned b_cur[PB], b_nxt[PB];                         // weight row offsets: current K tile's tile / next group's tile
+  const int lcA = pc ^ ((srow >> 1) & 7);                  // invariant under row + 32
+  const int lcB = pc ^ wide_swz_b(srow);                   // row + 32 flips bit 2 of the swizzle, row + 64 nothing
+  const unsigned a_lane = (unsigned)((srow * p.x_cs + p.x_co + lcA * 8) * 2);
+  const unsigned b_lane = (unsigned)((srow * p.Kw + lcB * 8) * 2);
+  const unsigned b_lane1 = (unsigned)(((srow + 32) * p.Kw + (lcB ^ 4) * 8) * 2);
+  // scalars of the NEXT group's tile (issue side); sB_*: byte offset of weight row n0 (beyond the tensor when not live)
+  int n_m0 = 0;
+  bool n_live = false;
+  unsigned sB_cur = 0u, sB_nxt = 0u;
   auto issue_tile_setup = [&](int vt) {
-    const bool live = vt < ntiles;
-    const unsigned tile = live ? tile_of(vt) : 0u;
-    const int tn = (int)(tile % (unsigned)p.tiles_n);
-    const int m0i = (int)(tile / (unsigned)p.tiles_n) * BM;
-    const int n0i = tn * BN;
-#pragma unroll
-    for (int q = 0; q < QA; ++q) {
-      const int row = srow + 64 * q;
-      a_s[q] = (live && row < BM + 2) ? m0i - 1 + row : (int)0x40000000;     // beyond the image for every kh: zero
-      a_off[q] = (unsigned)((((int64_t)(m0i - 1 + row)) * p.x_cs + p.x_co + lcA * 8) * 2);
-    }
-#pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int co = n0i + srow + 64 * q;
-      b_nxt[q] = (live && co < p.Cout) ? (unsigned)(((int64_t)co * p.Kw + lcB * 8) * 2) : kOOB;
-    }
+    n_live = vt < ntiles;
+    const unsigned tile = n_live ? tile_of(vt) : 0u;
+    n_m0 = (int)(tile / (unsigned)p.tiles_n) * BM;
+    sB_nxt = n_live ? (tile % (unsigned)p.tiles_n) * (unsigned)(BN * p.Kw * 2) : 0xF0000000u;
   };
 
   // ---- fragment read addresses (tile-independent) ----
-  unsigned a_rd[3][2];                       // pixel fragments: tap kw, k step; + pt * 2048 per pixel tile
-#pragma unroll
-  for (int kw = 0; kw < 3; ++kw) {
-    const int row = wm * WMr + pr + kw;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) a_rd[kw][ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ ((row >> 1) & 7)) << 4));
-  }
+  // pixel fragments: tap kw reads LDS row arow0 + kw (+ 16 per pixel tile), k step ks its chunk fq + 4 ks under the row's
+  // swizzle -- computed where it is used (six loop-invariant addresses and their 6 PT sums with 2048 pt would otherwise be
+  // hoisted out of the loops and spilled by the epilogue's register pressure, to be reloaded INSIDE the K loop)
+  const int arow0 = wm * WMr + pr;
   const unsigned zero_rd = (unsigned)(G_::ZeroRow * kRowB);
   unsigned w_rd[2];                          // weight fragments: k step; + t * 512 per channel tile
   {
@@ -141,34 +176,40 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
     aff[3 * p.Cout + c] = has2 ? p.t2[c] : 0.f;
   }
 
-#define YV4_W3_ISSUE_B(SLOT, BOFF, KB)                                                              \
-  {                                                                                                 \
-    const unsigned lb_ = lds_base + (unsigned)(2 * G_::ABytes + (SLOT) * G_::BBytes + 8 * wave * kRowB); \
-    _Pragma("unroll") for (int q = 0; q < PB; ++q)                                                  \
-        lds_dma16_h(rsB, lb_ + 64 * q * kRowB, BOFF[q], (KB));   /* (the range check sees voffset only) */ \
-  }
-#define YV4_W3_ISSUE_A(ABUF, Q0, Q1, KH, C0)                                                        \
-  {                                                                                                 \
-    const unsigned la_ = lds_base + (unsigned)((ABUF) * G_::ABytes + 8 * wave * kRowB);              \
-    const int ds_ = ((KH) - 1) * p.W;                                                               \
-    const unsigned step_ = (unsigned)(((int64_t)ds_ * p.x_cs + (C0)) * 2);                          \
-    _Pragma("unroll") for (int q = (Q0); q < (Q1); ++q) {                                           \
-      const bool ok_ = (unsigned)(a_s[q] + ds_) < (unsigned)NHW;                                    \
-      lds_dma16_h(rsA, la_ + 64 * q * kRowB, ok_ ? a_off[q] + step_ : kOOB, 0u);                     \
-    }                                                                                               \
+  // weight piece q of a K tile: rows n0 + srow + 64 q.  A row at or beyond Cout has its vector offset beyond the tensor and
+  // reads as zeros (the descriptor's range check sees the vector offset only: the K offset is the soffset)
+#define YV4_W3_PIECE_B(SLOT, SB, KB, q, vv)                                                          \
+  lds_dma16_h(rsB, lds_base + (unsigned)(2 * G_::ABytes + (SLOT) * G_::BBytes + (8 * iw + 64 * (q) + 32 * (vv)) * kRowB), \
+              ((vv) ? b_lane1 : b_lane) + ((SB) + (unsigned)(64 * (q)) * (unsigned)(p.Kw * 2)), (KB));
+  // image piece q of a (chunk, kh) group: LDS row r = srow + 64 q holds source pixel m0 - 1 + r + (kh - 1) W.  Pixels outside
+  // the tensor and the rows from BM + 2 on (row BM + 2 is the fragments' zero row) are zero-filled.
+#define YV4_W3_PIECE_A(ABUF, KH, C0, q, vv)                                                          \
+  if (!ROLES || 64 * (q) + 32 * (vv) <= BM + 2) {      /* (ROLES: a piece that starts beyond the zero row is never read) */ \
+    const int sS_ = n_m0 - 1 + ((KH) - 1) * p.W;                                                    \
+    const unsigned sOff_ = ((unsigned)sS_ * (unsigned)p.x_cs + (unsigned)(C0)) * 2u;                 \
+    const int r0_ = 64 * (q) + 32 * (vv);                                                           \
+    const bool ok_ = n_live && (r0_ + PR <= BM + 2 || srow < BM + 2 - r0_) && (unsigned)(srow + sS_ + r0_) < (unsigned)NHW; \
+    lds_dma16_h(rsA, lds_base + (unsigned)((ABUF) * G_::ABytes + (8 * iw + r0_) * kRowB),            \
+                ok_ ? a_lane + (sOff_ + (unsigned)r0_ * (unsigned)(p.x_cs * 2)) : kOOB, 0u);         \
   }
 
   // ---- prologue: group 0's image and tap 0's weights of the first tile; the issue side then points at group 1 ----
   int n_vt = (int)blockIdx.x;                // tile of the NEXT group (issue side)
   issue_tile_setup(n_vt);
+  sB_cur = sB_nxt;
+  if (issW) {
 #pragma unroll
-  for (int q = 0; q < PB; ++q) b_cur[q] = b_nxt[q];
-  YV4_W3_ISSUE_B(0, b_cur, 0u);
-  YV4_W3_ISSUE_A(0, 0, QA, 0, 0);
+    for (int q = 0; q < PB * NV; ++q) YV4_W3_PIECE_B(0, sB_cur, 0u, q / NV, q % NV)
+  }
+  if (issI) {
+#pragma unroll
+    for (int q = 0; q < QA * NV; ++q) YV4_W3_PIECE_A(0, 0, 0, q / NV, q % NV)
+  }
   int n_g = 1, n_kh = 1, n_c0 = 0;           // G >= 3: group 1 is in the same tile
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();              // (also publishes the affine)
 
+  YV4_W3_ST(0)                               // (diagnostic build: the prologue)
   unsigned T_ = 0u, GG = 0u;                 // global K-tile / group counters: weight slot T_ & 1, image GG & 1
   for (int vt = (int)blockIdx.x; vt < ntiles; vt += nwg) {
     const unsigned tile = tile_of(vt);
@@ -176,20 +217,23 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
     const int tile_m = (int)(tile / (unsigned)p.tiles_n);
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
-    unsigned mask9[PT];
+    // border masks of the wave's PT pixels: tap (kh, kw) of pixel tile pt is inside the image iff bit 3 pt + kh of rowm and
+    // bit 3 pt + kw of colm are set (two registers instead of PT 9-bit masks; a pixel beyond M has no row bit)
+    unsigned rowm = 0u, colm = 0u;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const int m = m0 + wm * WMr + 16 * pt + pr;
-      unsigned mk = 0u;
       if (m < p.M) {
         const int hw = p.H * p.W;
         const int n = fd_div(m, p.fd_hw);
         const int rm = m - n * hw;
         const int ho = fd_div(rm, p.fd_wo);
         const int wo = rm - ho * p.W;
-        mk = (unsigned)tap_mask(ho - 1, wo - 1, 3, 3, p.H, p.W);
+        const unsigned rb = (ho > 0 ? 1u : 0u) | 2u | (ho + 1 < p.H ? 4u : 0u);
+        const unsigned cb = (wo > 0 ? 1u : 0u) | 2u | (wo + 1 < p.W ? 4u : 0u);
+        rowm |= rb << (3 * pt);
+        colm |= cb << (3 * pt);
       }
-      mask9[pt] = mk;
     }
     f32x4v acc[PT][4];
 #pragma unroll
@@ -197,6 +241,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[pt][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
+    if (grpB) __builtin_amdgcn_s_barrier();   // waves 4-7 run one interval behind their SIMD partners
     int c0 = 0, kh = 0;
     for (int g = 0; g < G; ++g) {
       const unsigned ab = GG & 1u;
@@ -205,98 +250,104 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
         const unsigned slot = T_ & 1u;
         const char* as_ = As + ab * G_::ABytes;
         const char* bs_ = Bs + slot * G_::BBytes;
-        const int tapbit = 3 * kh + kw;
-        // ---- DMA of the next K tile's weights (other slot) and, at kw == 0, of the next group's image (other image)
-        // (measurement build, YV4_H16_ABLATE: 1 no weight DMA in the loop, 128 no image DMA, 2 no MFMA, 4 no barrier -- wrong
-        // results on purpose, to time the loop without one of its parts)
-        if (!YV4_ABLATE(p.ablate, 1)) {
-          if (kw < 2) {
-            YV4_W3_ISSUE_B(slot ^ 1u, b_cur, (unsigned)((((kh * 3 + kw + 1) * p.Cin) + c0) * 2));
-          } else {
-            YV4_W3_ISSUE_B(slot ^ 1u, b_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 2));
+        const unsigned okm = (rowm >> kh) & (colm >> kw);      // bit 3 pt: tap (kh, kw) of pixel tile pt is inside
+#pragma unroll
+        for (int ks0 = 0; ks0 < 2; ks0 += SK) {
+          // ================= LOAD interval of steps ks0 .. ks0 + SK - 1: the SIMD partner is in its MFMA interval =================
+          // Order inside the interval (measured, profiles/r06_w3_order.txt): an LDS-DMA piece parks the wave in its vector-memory
+          // issue for ~100 cycles (four waves issuing), a fragment read is issued in a few cycles and returns by itself.  SK = 2:
+          // the weight pieces FIRST (those of waves 4-7 have to land within this interval), then the reads, then the next group's
+          // image; SK = 1: the reads first (their latency runs under the pieces' issue), then the pieces.  Reads in front of
+          // every piece (interleaved) lost 8 % against either.
+          V8 wf[SK][4] = {}, pf[SK][PT] = {};
+          unsigned ard[SK];
+#pragma unroll
+          for (int k = 0; k < SK; ++k) {
+            int arow = arow0;
+            asm volatile("" : "+v"(arow));
+            arow += kw;
+            ard[k] = (unsigned)(arow * kRowB + (((fq + 4 * (ks0 + k)) ^ ((arow >> 1) & 7)) << 4));
           }
+          constexpr int NR = (4 + PT) * SK;                                   // fragment reads of the interval
+          const int NPW = (ks0 == 0 && !W3_ABL(1)) ? PB * NV : 0;             // its weight pieces ...
+          const int q0i = (kw == 0 ? 0 : QH) * NV;
+          const int NPI = (ks0 + SK == 2 && kw < 2 && !W3_ABL(128)) ? (kw == 0 ? QH : QA - QH) * NV : 0;   // ... and image pieces
+#define YV4_W3_READ1(r)                                                                              \
+          if (!W3_ABL(8)) {                                                                          \
+            const int k_ = (r) / (4 + PT), j_ = (r) % (4 + PT);                                      \
+            if (j_ < 4) {                                                                            \
+              wf[k_][j_] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks0 + k_] + j_ * 512);            \
+            } else {                                                                                 \
+              const bool ok = (okm >> (3 * (j_ - 4))) & 1u;                                          \
+              pf[k_][j_ - 4] = *reinterpret_cast<const V8*>(as_ + (ok ? ard[k_] + (unsigned)((j_ - 4) * 2048) : zero_rd)); \
+            }                                                                                        \
+          }
+#define YV4_W3_WEIGHT_PIECES                                                                         \
+          if (issW) {                                                                                \
+            _Pragma("unroll") for (int q = 0; q < NPW; ++q) {                                        \
+              if (kw < 2) YV4_W3_PIECE_B(slot ^ 1u, sB_cur, (unsigned)((((kh * 3 + kw + 1) * p.Cin) + c0) * 2), q / NV, q % NV) \
+              else YV4_W3_PIECE_B(slot ^ 1u, sB_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 2), q / NV, q % NV) \
+            }                                                                                        \
+          }
+          if (SK == 2) {
+            YV4_W3_WEIGHT_PIECES
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int r = 0; r < NR; ++r) YV4_W3_READ1(r)
+          __builtin_amdgcn_sched_barrier(0);
+          if (SK == 1) {
+            YV4_W3_WEIGHT_PIECES
+          }
+          if (issI) {
+#pragma unroll
+            for (int q = 0; q < NPI; ++q) YV4_W3_PIECE_A(ab ^ 1u, n_kh, n_c0, (q0i + q) / NV, (q0i + q) % NV)
+          }
+#undef YV4_W3_WEIGHT_PIECES
+#undef YV4_W3_READ1
+          // waves 4-7 confirm their DMAs here, waves 0-3 at the end of their MFMA interval: the same barrier publishes both.
+          // In flight and allowed to stay: the image pieces issued in this K tile (kw = 0: QH passes, kw = 1: the rest).
+          if (ks0 + SK == 2 && grpB) {
+            if (kw == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (ROLES) {}                                   // (image pieces only: confirmed once per group)
+            else if (kw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA - QH) : "memory");
+          }
+          __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the fragments are in registers before the roles swap
+          YV4_W3_ST(1)
+          if (!W3_ABL(4)) __builtin_amdgcn_s_barrier();
+          YV4_W3_ST(2)
+          // ================= MFMA interval: SK x 4 PT MFMAs from registers =================
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int k = 0; k < SK; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int i = 0; i < PT; ++i) {
+                if (!W3_ABL(2)) acc[i][t] = Mfma16<BF16>::run(wf[k][t], pf[k][i], acc[i][t]);
+                else asm volatile("" ::"v"(wf[k][t]), "v"(pf[k][i]));      // (ablation: the fragment reads stay)
+              }
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          YV4_W3_ST(3)
+          if (ks0 + SK == 2 && !grpB) {
+            if (ROLES || kw == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (ROLES: weight pieces only)
+            else if (kw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA - QH) : "memory");
+          }
+          YV4_W3_ST(4)
+          if (!W3_ABL(4)) __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          YV4_W3_ST(5)
         }
-        V8 wf[4][2] = {}, pf[PH][2] = {};
-        const bool rd_ = !YV4_ABLATE(p.ablate, 8);
-        // ---- phase 1: weights of channel tiles 0, 1, pixels of the first half
-        if (rd_) {
-        // (all four channel tiles' weight fragments now: they stay in registers for phases 2-4 anyway, and phase 2 then
-        // starts its MFMAs without an LDS round trip)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
-#pragma unroll
-        for (int i = 0; i < PH; ++i) {
-          const bool ok = (mask9[i] >> tapbit) & 1u;
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
-            pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)(i * 2048) : zero_rd));
-        }
-        }
-        if (kw == 0 && !YV4_ABLATE(p.ablate, 128)) YV4_W3_ISSUE_A(ab ^ 1u, 0, (QA + 1) / 2, n_kh, n_c0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < PH; ++i) if (!YV4_ABLATE(p.ablate, 2)) acc[i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[i][t]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 2: channel tiles 2, 3 (fragments already in registers)
-        if (kw == 0 && !YV4_ABLATE(p.ablate, 128)) YV4_W3_ISSUE_A(ab ^ 1u, (QA + 1) / 2, QA, n_kh, n_c0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int t = 2; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < PH; ++i) if (!YV4_ABLATE(p.ablate, 2)) acc[i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[i][t]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 3: pixels of the second half
-        if (rd_) {
-#pragma unroll
-        for (int i = 0; i < PH; ++i) {
-          const bool ok = (mask9[PH + i] >> tapbit) & 1u;
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
-            pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)((PH + i) * 2048) : zero_rd));
-        }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int t = 2; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < PH; ++i) if (!YV4_ABLATE(p.ablate, 2)) acc[PH + i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[PH + i][t]);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 4: the last quadrant (both operand sets are in registers)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < PH; ++i) if (!YV4_ABLATE(p.ablate, 2)) acc[PH + i][t] = Mfma16<BF16>::run(wf[t][ks], pf[i][ks], acc[PH + i][t]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // this wave's DMAs of the next K tile have landed (the next group's image, issued last at kw == 0, may still fly)
-        if (kw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!YV4_ABLATE(p.ablate, 4)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
         T_ += 1u;
       }
       // ---- group advance: current <- next; the issue side moves on by one group (possibly into the next tile) ----
       GG += 1u;
       kh = n_kh; c0 = n_c0;
-#pragma unroll
-      for (int q = 0; q < PB; ++q) b_cur[q] = b_nxt[q];
+      sB_cur = sB_nxt;
       n_g += 1;
       n_kh += 1;
       if (n_kh == 3) { n_kh = 0; n_c0 += kHBK; }
@@ -306,10 +357,12 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
         issue_tile_setup(n_vt);
       }
     }
+    if (!grpB) __builtin_amdgcn_s_barrier();  // waves 0-3 wait one interval: both groups run their epilogues together
+    YV4_W3_ST(6)
     // (kh, c0 now describe group 0 of this workgroup's next tile: reset by the assignments at the top of the loop)
 
     // ---- epilogue (conv_wide_common.h): lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + pr, channels n0 + wn 64 + 16 fq .. + 15 ----
-    if (YV4_ABLATE(p.ablate, 16)) {           // (measurement: no epilogue; keep the accumulators live)
+    if (W3_ABL(16)) {           // (measurement: no epilogue; keep the accumulators live)
       if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.y)[0] = acc[PT - 1][3][3] + acc[1][1][1];
       c0 = 0; kh = 0;
       continue;
@@ -317,9 +370,16 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
     wide_epilogue_h16<BF16, PT, false>(p, aff, has2, acc, m0 + wm * WMr + pr, n0 + wn * 64 + 16 * fq, lane,
                                        (unsigned)(tile_m * WAVES_M + wm));
     c0 = 0; kh = 0;
+    YV4_W3_ST(7)
   }
-#undef YV4_W3_ISSUE_A
-#undef YV4_W3_ISSUE_B
+#ifdef YV4_W3_STAMP
+  if (lane == 0 && blockIdx.x < 1024) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_w3_stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = st_[i];
+  }
+#endif
+#undef YV4_W3_PIECE_A
+#undef YV4_W3_PIECE_B
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-filling tail DMAs must land before the LDS is released
 }
 
@@ -359,3 +419,11 @@ int conv3x3_wide_h16_launch(const ConvArgsH& a, bool bf16, int shape, hipStream_
 }
 
 }  // namespace yv4
+
+#ifdef YV4_W3_STAMP
+extern "C" int yv4_debug_w3_stamps(unsigned long long* out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  const size_t bytes = sizeof(unsigned long long) * (size_t)(n < 1024 * 64 ? n : 1024 * 64);
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(yv4::g_w3_stamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -78,7 +78,7 @@ __device__ __forceinline__ void wide_load_affine1(const float* aff, int Cout, in
 }
 
 // 16-bit: packed activation rows (act_row8), two 16-byte stores per pixel; the statistics are those of the STORED values
-template <bool BF16, int PT, bool SCATTER>
+template <bool BF16, int PT, bool SCATTER, int RD = (PT <= 6 ? PT : 4)>
 __device__ __forceinline__ void wide_epilogue_h16(const ConvArgsH& p, const float* aff, bool has2, const wide_acc_t (&acc)[PT][4],
                                                   int mlane, int cl, int lane, unsigned replica) {
   typedef typename Elem<BF16>::V8 V8;
@@ -87,6 +87,26 @@ __device__ __forceinline__ void wide_epilogue_h16(const ConvArgsH& p, const floa
   const int ca = c_ok ? cl : 0;
   float s1[16], t1[16];
   wide_load_affine1(aff, p.Cout, ca, s1, t1);
+  // The residual of ALL the wave's pixel tiles is requested before the first value is finished: inside a network it comes
+  // from HBM (profiles/r06_w3_stamps_cold.txt: the epilogue of a 3x3 Bottleneck layer took 17-40 k cycles against 7-12 k with
+  // warm caches -- one memory round trip per pixel tile, PT of them in a row); the K loop's fragment registers are free here.
+  // (RD tiles ahead: all of them up to six pixel tiles, four at eight -- 64 more registers beside 128 accumulators spill)
+  constexpr int D = RD;
+  V8 rres[D][2] = {};
+#define YV4_WIDE_RES_LOAD(pt_)                                                                        \
+  {                                                                                                  \
+    const int m_ = mlane + 16 * (pt_);                                                               \
+    if (c_ok && m_ < p.M) {                                                                          \
+      const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m_ * p.r_cs + p.r_co + cl;          \
+      rres[(pt_) % D][0] = *reinterpret_cast<const V8*>(rp);                                         \
+      rres[(pt_) % D][1] = *reinterpret_cast<const V8*>(rp + 8);                                     \
+    }                                                                                                \
+  }
+  if (p.res) {
+#pragma unroll
+    for (int pt = 0; pt < D; ++pt) YV4_WIDE_RES_LOAD(pt)
+    __builtin_amdgcn_sched_barrier(0);
+  }
   float st[32];
 #pragma unroll
   for (int u = 0; u < 32; ++u) st[u] = 0.f;
@@ -108,11 +128,16 @@ __device__ __forceinline__ void wide_epilogue_h16(const ConvArgsH& p, const floa
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v[e] = lo[e]; v[e + 8] = hi[e]; }
     }
-    if (p.res && ok) {
-      const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.r_cs + p.r_co + cl;
-      const V8 r0 = *reinterpret_cast<const V8*>(rp), r1 = *reinterpret_cast<const V8*>(rp + 8);
+    if (p.res) {
+      if (ok) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { v[e] += (float)r0[e]; v[e + 8] += (float)r1[e]; }
+        for (int e = 0; e < 8; ++e) { v[e] += (float)rres[pt % D][0][e]; v[e + 8] += (float)rres[pt % D][1][e]; }
+      }
+      if (pt + D < PT) {                       // the slot is free: the tile D ahead
+        __builtin_amdgcn_sched_barrier(0);
+        YV4_WIDE_RES_LOAD(pt + D)
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (has2) {
 #pragma unroll
@@ -143,6 +168,7 @@ __device__ __forceinline__ void wide_epilogue_h16(const ConvArgsH& p, const floa
     }
   }
   if (p.stats) YV4_WIDE_STATS_FLUSH(st, lane, c_ok, p.stats, replica, p.Cout, cl)
+#undef YV4_WIDE_RES_LOAD
 }
 
 // fp32: the contraction-free scalar activations of the fp32 kernels (apply_act), four 16-byte stores per pixel
@@ -223,11 +249,16 @@ inline size_t wide_lds(bool k3, int pt, int wmv, int Cout) {
 // their extra fragment reads per MFMA (measured ratios, tools/conv_bench.py: 1.04 at six pixel tiles, 1.12 at four);
 // the fp32 kernels are matrix-bound and do not (ties go to the first shape).  Returns an index into kWideShapes, or -1
 // when no shape fits the LDS; *rounds_eff = cost relative to a perfectly divided layer.
+// The 16-bit 3x3 kernel (round 6: LOAD / MFMA intervals between SIMD partners) is chosen by a TIME model instead, fitted
+// on profiles/r06_w3_shapes.txt (batch 32, bf16): a round of tiles costs F + bm bn K c with (F us, c us per 1e6) =
+// (14, 0.311) at eight pixel tiles per wave, (10, 0.353) at six, (4.5, 0.417) at four -- the big wave tile has the
+// cheapest K loop and the most expensive epilogue.  *rounds_eff keeps its meaning (tile work incl. the old read weights).
 template <class Args>
 inline int wide_pick(const Args& a, bool k3, bool charge_reads, double* rounds_eff) {
   const int cus = wide_cus();
+  const bool time_model = k3 && charge_reads;
   int best = -1;
-  double best_cost = 0.0;
+  double best_cost = 0.0, best_eff = 0.0;
   for (int i = 0; i < 5; ++i) {
     const int pt = kWideShapes[i].pt, wmv = kWideShapes[i].wm;
     const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
@@ -236,10 +267,15 @@ inline int wide_pick(const Args& a, bool k3, bool charge_reads, double* rounds_e
     const long long tiles = ((long long)a.M + bm - 1) / bm * ((a.Cout + bn - 1) / bn);
     const long long rounds = (tiles + cus - 1) / cus;
     const double eff = !charge_reads || pt == 8 ? 1.0 : (pt == 6 ? 1.04 : 1.12);
-    const double cost = (double)rounds * bm * bn * eff;
-    if (best < 0 || cost < best_cost * (charge_reads ? 1.0 : 0.999)) { best = i; best_cost = cost; }
+    const double work = (double)rounds * bm * bn * eff;
+    double cost = work;
+    if (time_model) {
+      const double F = pt == 8 ? 14.0 : (pt == 6 ? 10.0 : 4.5), c = pt == 8 ? 0.311 : (pt == 6 ? 0.353 : 0.417);
+      cost = (double)rounds * (F + (double)bm * bn * 9.0 * a.Cin * c * 1e-6);
+    }
+    if (best < 0 || cost < best_cost * (charge_reads ? 1.0 : 0.999)) { best = i; best_cost = cost; best_eff = work; }
   }
-  if (rounds_eff && best >= 0) *rounds_eff = best_cost / ((double)a.M * a.Cout / cus);
+  if (rounds_eff && best >= 0) *rounds_eff = best_eff / ((double)a.M * a.Cout / cus);
   return best;
 }
 

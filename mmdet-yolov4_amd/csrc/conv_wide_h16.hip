@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv_wide_h16_kernel(ConvArgs
     }
 
     // ---- epilogue (conv_wide_common.h): lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + fr, channels cl .. cl + 15 ----
-    wide_epilogue_h16<BF16, PT, true>(p, aff, has2, acc, m0 + wm * WMr + fr, n0 + wn * 64 + 16 * fq, lane,
+    wide_epilogue_h16<BF16, PT, true, (PT <= 6 ? PT : 1)>(p, aff, has2, acc, m0 + wm * WMr + fr, n0 + wn * 64 + 16 * fq, lane,
                                       (unsigned)(tile_m * WAVES_M + wm));
   }
 #undef YV4_WG_ISSUE

@@ -52,6 +52,23 @@ def _ious(b):
     return inter / (area[:, None] + area[None, :] - inter)
 
 
+def _assert_maps_float64_anchored(got, ref, ref64, size):
+    """`got` (HIP), `ref` (fp32 CPU oracle), `ref64` (the oracle in float64): per level the HIP maps must be as close to
+    float64 as the reference's own fp32 arithmetic is (mean <= 1.5 x, max <= 2.5 x), and within 5e-5 of the fp32 oracle
+    in the mean of |d| / (1 + |logit|)."""
+    for i, (a, b, t) in enumerate(zip(got, ref, ref64)):
+        assert a.shape == b.shape == (1, 255, size // (8 << i), size // (8 << i))
+        e_gpu = (a.double() - t).abs() / (1 + t.abs())
+        e_cpu = (b.double() - t).abs() / (1 + t.abs())
+        e_ab = (a - b).abs() / (1 + b.abs())
+        print(f'level {i}: HIP vs fp64 max {float(e_gpu.max()):.2e} mean {float(e_gpu.mean()):.2e} | '
+              f'CPU fp32 vs fp64 max {float(e_cpu.max()):.2e} mean {float(e_cpu.mean()):.2e} | '
+              f'HIP vs CPU fp32 max {float(e_ab.max()):.2e} mean {float(e_ab.mean()):.2e}')
+        assert float(e_gpu.mean()) <= 1.5 * float(e_cpu.mean()) + 1e-6
+        assert float(e_gpu.max()) <= 2.5 * float(e_cpu.max()) + 1e-5
+        assert float(e_ab.mean()) <= 5e-5
+
+
 @pytest.mark.parametrize('case', ['608', '416_single_image'])
 def test_fullsize_parity_with_the_oracle_on_one_image(request, case):
     """Case 416_single_image is BASELINE.json configs[0]'s workload (416x416, one image) through the HIP path.
@@ -72,17 +89,7 @@ def test_fullsize_parity_with_the_oracle_on_one_image(request, case):
         got = [p.cpu() for p in det.forward_dummy(one)[0]]
     ref, _ = O.forward_pred_maps(one.cpu(), sd, stages, reps, [3, 4, 5], neck='v4')
     ref64, _ = O.forward_pred_maps(one.cpu().double(), sd64, stages, reps, [3, 4, 5], neck='v4')
-    for i, (a, b, t) in enumerate(zip(got, ref, ref64)):
-        assert a.shape == b.shape == (1, 255, SIZE // (8 << i), SIZE // (8 << i))
-        e_gpu = (a.double() - t).abs() / (1 + t.abs())
-        e_cpu = (b.double() - t).abs() / (1 + t.abs())
-        e_ab = (a - b).abs() / (1 + b.abs())
-        print(f'level {i}: HIP vs fp64 max {float(e_gpu.max()):.2e} mean {float(e_gpu.mean()):.2e} | '
-              f'CPU fp32 vs fp64 max {float(e_cpu.max()):.2e} mean {float(e_cpu.mean()):.2e} | '
-              f'HIP vs CPU fp32 max {float(e_ab.max()):.2e} mean {float(e_ab.mean()):.2e}')
-        assert float(e_gpu.mean()) <= 1.5 * float(e_cpu.mean()) + 1e-6
-        assert float(e_gpu.max()) <= 2.5 * float(e_cpu.max()) + 1e-5
-        assert float(e_ab.mean()) <= 5e-5
+    _assert_maps_float64_anchored(got, ref, ref64, SIZE)
     # scores and boxes (what the north star names), HIP decode of HIP maps vs oracle decode of oracle maps
     boxes_o, conf_o, cls_o = O.decode_maps(ref, 80)
     plan = pkg.Plan(img.device)
@@ -237,4 +244,51 @@ def test_single_image_16bit_plan_splits_k(v4l, dtype, bound):
     p1.run(img[:1])
     again = [v.buf.tensor.view(v.N, v.H, v.W, v.C).float() for v in p1.pred_views]
     assert all(torch.equal(a, b) for a, b in zip(again, got))
+    det._engines.clear()
+
+
+def test_headline_config_at_its_batch_of_32(gpu_device):
+    """BASELINE.json configs[1] as it is quoted: YOLOv4-L 608 x 608 fp32 at batch 32.  Tile choice depends on M (the wide
+    kernels' fill rules, the 1x1 pick), so the batch-32 plan runs kernels the batch-2 fixture above never selects.
+    (a) images 0 and 31 of the batch against the oracle, float64-anchored exactly as the batch-2 test; (b) images 0-1 of
+    the batch-32 step bit-equal -- pred maps, detections, labels -- to a batch-2 plan of the same images pinned to the
+    batch-32 plan's tile ids layer by layer (bench.py's output check, here under -m gpu)."""
+    det, img = _make(gpu_device, 32, SIZE)
+    plan = det.compile(32, SIZE, SIZE, device=gpu_device, rescale=True)
+    plan.run(img)
+    torch.cuda.synchronize()
+    maps = [v.buf.tensor.view(v.N, v.H, v.W, v.C).permute(0, 3, 1, 2).clone() for v in plan.pred_views]
+    dets, labels, count = plan.post['dets'].clone(), plan.post['labels'].clone(), plan.post['count'].clone()
+    import ctypes
+    pick = pkg._lib.lib().yv4_conv_pick_tile
+    ids = [o.info['desc'].tile or pick(ctypes.byref(o.info['desc'])) for o in plan.ops if o.kind == 'conv' and 'desc' in o.info]
+    names = sorted({pkg._lib.TILE_NAMES.get(t, str(t)) for t in ids})
+    print('batch-32 plan, fp32 conv tile classes:', names)
+    assert 'w3x3' in names and 'ws_1x1' in names          # the kernels the headline number is made of are the ones under test
+    # (a) the oracle
+    sd = {k: v.detach().cpu() for k, v in det.state_dict().items()}
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    stages, reps = O.ARCH['v4l5p']
+    for n in (0, 31):
+        one = img[n:n + 1].cpu()
+        ref, _ = O.forward_pred_maps(one, sd, stages, reps, [3, 4, 5], neck='v4')
+        ref64, _ = O.forward_pred_maps(one.double(), sd64, stages, reps, [3, 4, 5], neck='v4')
+        print(f'image {n} of 32:')
+        _assert_maps_float64_anchored([m[n:n + 1].cpu() for m in maps], ref, ref64, SIZE)
+        if n == 0:
+            ores = O.get_bboxes(ref, [[1.0, 1.0, 1.0, 1.0]], 80, rescale=True)[0]
+            assert abs(int(ores[0].shape[0]) - int(count[0])) <= 2       # near-ties at the max_per_img cut
+    # (b) the batch-2 plan, pinned
+    small = det.compile(2, SIZE, SIZE, device=gpu_device, rescale=True)
+    note = bench.pin_check_plan(plan, small)
+    assert note == '', note
+    small.run(img[:2])
+    torch.cuda.synchronize()
+    for v32, v2 in zip(maps, small.pred_views):
+        assert torch.equal(v32[:2], v2.buf.tensor.view(v2.N, v2.H, v2.W, v2.C).permute(0, 3, 1, 2))
+    for n in range(2):
+        k = int(count[n])
+        assert k == int(small.post['count'][n]) and k > 0
+        assert torch.equal(small.post['dets'][n, :k], dets[n, :k])
+        assert torch.equal(small.post['labels'][n, :k], labels[n, :k])
     det._engines.clear()

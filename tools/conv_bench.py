@@ -40,6 +40,9 @@ def main():
     ap.add_argument('--chain', type=int, default=1, help='launches per timed region (steady-state time per launch)')
     ap.add_argument('--warm-ms', type=float, default=30.0, help='untimed launches of a tile before it is timed (ms of wall time)')
     ap.add_argument('--act', type=int, default=1, help='activation id of the epilogue (0 none, 1 Mish, 2 leaky, 3 swish)')
+    ap.add_argument('--flush-mb', type=int, default=0, help='overwrite a buffer of this many MB before every timed launch (64: the '
+                    'per-XCD L2s forget the layer, the memory-side cache keeps it: the state a layer meets inside a network)')
+    ap.add_argument('--res', action='store_true', help='with a residual tensor added in the epilogue (the Bottleneck 3x3 layers)')
     ap.add_argument('--zeros', action='store_true', help='all-zero operands: the clock the chip holds on trivial data (DVFS check)')
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(',')]
@@ -74,15 +77,19 @@ def main():
         d.stride, d.pad = s, pad
         d.x_cstride, d.y_cstride = cp, (ycs if h16 else cout)
         d.act1 = a.act
+        res_t = torch.randn_like(y.float()).to(tdt) if a.res else None
+        res_p = res_t.data_ptr() if a.res else None
+        if a.res:
+            d.r_cstride = (ycs if h16 else cout)
         flops = 2.0 * a.batch * ho * ho * cout * k * k * cin
         res = {}
         def launch(code_=None):
             if h16:
                 code = 1 if a.dtype == 'f16' else 2
                 return lib.yv4_conv_bn_act_fwd_h16(C.byref(d), code, code, x.data_ptr(), w.data_ptr(), sc.data_ptr(),
-                                                   sh.data_ptr(), None, None, None, y.data_ptr(), stream)
+                                                   sh.data_ptr(), None, None, res_p, y.data_ptr(), stream)
             return lib.yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, None,
-                                           None, y.data_ptr(), stream)
+                                           res_p, y.data_ptr(), stream)
 
         for t in tiles:
             d.tile = t
@@ -95,6 +102,10 @@ def main():
             torch.cuda.synchronize()
             ts = []
             for r in range(a.reps + 1):
+                if a.flush_mb:
+                    if not hasattr(main, '_flush'):
+                        main._flush = torch.empty(a.flush_mb << 20, dtype=torch.uint8, device=dev)
+                    main._flush.fill_(r & 255)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -102,11 +113,11 @@ def main():
                     if h16:
                         code = 1 if a.dtype == 'f16' else 2
                         rc = lib.yv4_conv_bn_act_fwd_h16(C.byref(d), code, code, x.data_ptr(), w.data_ptr(),
-                                                         sc.data_ptr(), sh.data_ptr(), None, None, None, y.data_ptr(),
+                                                         sc.data_ptr(), sh.data_ptr(), None, None, res_p, y.data_ptr(),
                                                          stream)
                     else:
                         rc = lib.yv4_conv_bn_act_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), sc.data_ptr(),
-                                                     sh.data_ptr(), None, None, None, y.data_ptr(), stream)
+                                                     sh.data_ptr(), None, None, res_p, y.data_ptr(), stream)
                 e1.record()
                 torch.cuda.synchronize()
                 if rc != 0:
