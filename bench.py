@@ -494,6 +494,13 @@ def main():
                     help='replay the launch list as ONE hipGraph per step (the batch-1 protocol of '
                          'tools/analysis_tools/benchmark.py:83-109 is launch-bound otherwise); the per-conv HIP events of '
                          'the roofline block then come from extra eager steps after the timed region')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='run the step as this many part-batch plans on as many HIP streams (default 1; 2: every conv launch has a '
+                         'compute phase that leaves HBM idle and a memory phase that leaves the matrix pipe idle, and one '
+                         'persistent workgroup per CU keeps all CUs in the same phase; two independent half-batch plans fill each '
+                         'other\'s phases and kernel boundaries.  Measured (profiles/r06_two_stream_probe.txt, r06_ab_streams.txt): fp32 +0.9-2.2 %, '
+                         'configs[3] -1 to +8 %, bf16 0, and the batch-16 launches fill the chip worse (dominant tile 0.79 -> 0.71 of its '
+                         'roof) -- not the default')
     ap.add_argument('--event-every', type=int, default=4,
                     help='bracket the conv launches with HIP events in every n-th timed step (events cost ~2 %%)')
     args = ap.parse_args()
@@ -541,41 +548,89 @@ def main():
     if args.autotune and not args.no_autotune:
         plan.autotune()
 
-    conv_ops = [o for o in plan.ops if o.kind == 'conv']
+    # ---- the step as NS part-batch plans on NS streams (default 2; --streams 1: one plan on the current stream) ----------
+    NS = args.streams if (args.streams > 1 and not args.graph and not args.autotune and args.batch % args.streams == 0
+                          and args.batch // args.streams >= 2) else 1
+    tdt = {'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.dtype]
     stream = torch.cuda.current_stream()
-    sptr = __import__('ctypes').c_void_p(stream.cuda_stream)
+    ctypes_ = __import__('ctypes')
+    if NS > 1:
+        nb = args.batch // NS
+        del plan
+        torch.cuda.empty_cache()
+        plans = []
+        for _ in range(NS):
+            det._engines.clear()                        # distinct plan instances (own buffers) for the same geometry
+            plans.append(det.compile(nb, args.size, args.size, device=dev, rescale=True, dtype=tdt))
+        streams_ = [stream] + [torch.cuda.Stream(device=dev) for _ in range(NS - 1)]
+        plan = plans[0]                                 # (image 0 lives here: output check, oracle leg, tile ids)
+    else:
+        nb = args.batch
+        plans, streams_ = [plan], [stream]
+    sptrs = [ctypes_.c_void_p(s_.cuda_stream) for s_ in streams_]
+    conv_ops = [o for pl in plans for o in pl.ops if o.kind == 'conv']
     post = plan.post
-    host_dets = torch.empty(post['dets'].shape, dtype=torch.float32, pin_memory=True)
-    host_labels = torch.empty(post['labels'].shape, dtype=torch.int32, pin_memory=True)
-    host_count = torch.empty(post['count'].shape, dtype=torch.int32, pin_memory=True)
-    plan.inputs[0]['src'] = img
+    host_dets = torch.empty((args.batch,) + tuple(post['dets'].shape[1:]), dtype=torch.float32, pin_memory=True)
+    host_labels = torch.empty((args.batch,) + tuple(post['labels'].shape[1:]), dtype=torch.int32, pin_memory=True)
+    host_count = torch.empty((args.batch,) + tuple(post['count'].shape[1:]), dtype=torch.int32, pin_memory=True)
+    for i, pl in enumerate(plans):
+        pl.inputs[0]['src'] = img[i * nb:(i + 1) * nb]
     if args.graph:
         plan.capture()                                  # static input buffer + one graph of the whole launch list
         plan.inputs[0]['src'].copy_(img)
         torch.cuda.synchronize()
+    step_done = [torch.cuda.Event() for _ in range(NS)]
+
+    def copy_out(i):
+        pl, sl = plans[i], slice(i * nb, (i + 1) * nb)
+        with torch.cuda.stream(streams_[i]):
+            host_dets[sl].copy_(pl.post['dets'], non_blocking=True)
+            host_labels[sl].copy_(pl.post['labels'], non_blocking=True)
+            host_count[sl].copy_(pl.post['count'], non_blocking=True)
 
     def step(events=None):
         if args.graph and events is None:
             plan.graph.replay()
-            host_dets.copy_(post['dets'], non_blocking=True)
-            host_labels.copy_(post['labels'], non_blocking=True)
-            host_count.copy_(post['count'], non_blocking=True)
+            copy_out(0)
             return
-        for op in plan.ops:
-            if events is not None and op.kind == 'conv':
-                # events come from a pool created before the timed region: creating two per launch inside it made the
-                # instrumented 16-bit steps host-bound, and the gap where the GPU caught up read as one slow kernel
-                e0, e1 = ev_pool.pop() if ev_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                e0.record(stream)
-                op.fn(sptr)
-                e1.record(stream)
-                events.append((op, e0, e1))
-            else:
-                op.fn(sptr)
-        host_dets.copy_(post['dets'], non_blocking=True)
-        host_labels.copy_(post['labels'], non_blocking=True)
-        host_count.copy_(post['count'], non_blocking=True)
+        if events is not None:
+            # instrumented step: one part at a time, so that every bracketed launch has the chip to itself.  Events come from a
+            # pool created before the timed region: creating two per launch inside it made the instrumented 16-bit steps
+            # host-bound, and the gap where the GPU caught up read as one slow kernel
+            for i, pl in enumerate(plans):
+                if NS > 1:
+                    torch.cuda.synchronize()
+                for op in pl.ops:
+                    if op.kind == 'conv':
+                        e0, e1 = ev_pool.pop() if ev_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        e0.record(streams_[i])
+                        op.fn(sptrs[i])
+                        e1.record(streams_[i])
+                        events.append((op, e0, e1))
+                    else:
+                        op.fn(sptrs[i])
+                copy_out(i)
+            return
+        if NS > 1:                                      # a step is one batch: every stream starts it behind the whole last step
+            for i in range(NS):
+                for j in range(NS):
+                    if j != i:
+                        streams_[i].wait_event(step_done[j])
+            for ops in zip(*[pl.ops for pl in plans]):  # launch lists interleaved: both streams stay fed by one host thread
+                for i, op in enumerate(ops):
+                    op.fn(sptrs[i])
+        else:
+            for op in plan.ops:
+                op.fn(sptrs[0])
+        for i in range(NS):
+            copy_out(i)
+            if NS > 1:
+                step_done[i].record(streams_[i])
 
+    # per-conv HIP events: with one stream, every n-th step INSIDE the timed region is instrumented; with several streams
+    # (and under --graph) instrumented steps run after it -- a launch bracketed while the other stream's kernels share the chip
+    # would time the mixture, not the kernel
+    events_inside = NS == 1 and not args.graph
     n_instr = (args.steps + max(args.event_every, 1) - 1) // max(args.event_every, 1) + 2
     ev_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                for _ in range(n_instr * len(conv_ops))]
@@ -591,11 +646,11 @@ def main():
     events = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(events if (i % max(args.event_every, 1) == 0 and not args.graph) else None)
+        step(events if (i % max(args.event_every, 1) == 0 and events_inside) else None)
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev)
     gc.enable()
-    if args.graph:                                      # per-conv events: eager steps outside the timed region
+    if not events_inside:                               # per-conv events: instrumented steps outside the timed region
         for _ in range(max(2, args.steps // max(args.event_every, 1))):
             step(events)
         torch.cuda.synchronize()
@@ -641,7 +696,7 @@ def main():
                                   gflop_per_launch=round(tf / tn / 1e9, 3), algorithmic_bytes_per_launch=round(tb / tn),
                                   tflops=round(tf / tt / 1e12, 1), gbps=round(tb / tt / 1e9, 1),
                                   share_of_conv_time=round(tt / conv_time, 4))
-    run_key = f'{args.model}_{args.size}_b{args.batch}_{args.dtype}'
+    run_key = f'{args.model}_{args.size}_b{args.batch}_{args.dtype}' + (f'_s{NS}' if NS > 1 else '')
     traffic, traffic_src = pmc_traffic(dom, run_key, dbytes / dn, dn // n_instr_steps)
     kname = {'w3x3': 'conv3x3_wide_f32_kernel', 'wide': 'conv_wide_f32_kernel', 'h16_w3x3': 'conv3x3_wide_h16_kernel', 'h16_wide': 'conv_wide_h16_kernel',
              'h16_pp3x3': 'conv3x3_pp_h16_kernel'}.get(dom, f'conv_mfma_{"h16" if h16 else "f32"}_kernel<{dom}>')
@@ -656,7 +711,12 @@ def main():
                     all_convs_frac=round(conv_flops / conv_time / 1e12 / peak, 4),
                     conv_share_of_step=round(conv_time / max(len(events) // len(conv_ops), 1) /
                                              (elapsed / args.steps), 4),
-                    instrumented_steps=len(events) // len(conv_ops), run_key=run_key, tiles=tiles_block)
+                    instrumented_steps=len(events) // len(conv_ops), run_key=run_key, tiles=tiles_block,
+                    launch_batch=nb, streams=NS,
+                    measured=('HIP events around every conv launch in every %d-th step of the timed region' % max(args.event_every, 1))
+                    if events_inside else 'HIP events around every conv launch in instrumented steps AFTER the timed region, one '
+                    'part-batch plan at a time (a launch bracketed while another stream\'s kernels share the chip would time the '
+                    'mixture); the launches are those of the timed region')
     # which roof bounds the dominant kernel: the higher of its two floors (FLOPs / matrix peak, algorithmic bytes /
     # HBM peak).  fp32: the matrix core by 14x; the 16-bit operands move the small-model / batch-256 configurations
     # (BASELINE.json configs[3]) and most tile classes of YOLOv4-L under the HBM roof
@@ -714,7 +774,7 @@ def main():
     D.finalize()
     train = None
     if not args.no_train:
-        del plan, conv_ops, events, per_layer, post
+        del plan, plans, conv_ops, events, per_layer, post
         det._engines.clear()
         torch.cuda.empty_cache()
         train = train_step_leg(args, rank, local_rank, world)
@@ -733,6 +793,7 @@ def main():
                                  f'{args.size}x{args.size} {dict(f32="fp32", f16="fp16", bf16="bf16")[args.dtype]} inference, batch {args.batch}/GPU: image -> '
                                  'fused conv path -> decode -> per-class NMS -> detections on host ' +
                                  ('[one hipGraph replay per step] ' if args.graph else '') +
+                                 (f'[the step runs as {NS} batch-{nb} plans on {NS} HIP streams, joined at every step] ' if NS > 1 else '') +
                                  ('(BASELINE.json configs[1])' if (args.model, args.size, args.batch, args.dtype) == ('yolov4l', 608, 32, 'f32')
                                   else '(not the headline configuration)'),
                         global_batch=args.batch * world, per_gpu_batch=args.batch, input=f'{args.size}x{args.size}',

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define YV4_ABI_VERSION 6
+#define YV4_ABI_VERSION 7
 
 /* error codes */
 #define YV4_OK 0
@@ -115,7 +115,15 @@ typedef struct yv4_conv_desc {
   int32_t act1, act2;        /* YV4_ACT_* */
   float slope1, slope2;      /* LeakyReLU negative slopes */
   int32_t tile;              /* 0 = auto; else a YV4_TILE_* id (benchmarking) */
+  int32_t flags;             /* ABI 7: YV4_CONV_* bits, 0 = none (appended: an ABI-6 caller's struct is a prefix) */
 } yv4_conv_desc;
+
+/* flags: the output is written with NON-TEMPORAL stores (the lines are not kept in the XCD's L2).  A per-plan choice:
+ * inference plans of the 16-bit wide-tile kernels gain 0.6-1.3 % with it (their outputs are next read by a kernel that
+ * streams them once), training loses 0.2-0.7 % (the BatchNorm pass right behind a conv re-reads its output from the
+ * cache), the fp32 wide kernels lose 2.8 % (DESIGN, non-temporal stores).  Same bits either way; kernels without a
+ * non-temporal form ignore the flag. */
+#define YV4_CONV_NT_OUT 1
 
 #define YV4_TILE_AUTO 0
 #define YV4_TILE_128x128 1

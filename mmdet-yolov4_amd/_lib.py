@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('YV4_LIB_PATH') or os.path.join(LIB_DIR, 'libyv4_hip.s
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 # ---- constants mirrored from include/yv4.h -------------------------------------
-ABI_VERSION = 6
+ABI_VERSION = 7
 STATS_REPLICAS = 64        # YV4_STATS_REPLICAS
 GRAD_PREPARE_MAX_WG = 2048  # YV4_GRAD_PREPARE_MAX_WG
 F32, F16, BF16, F64 = 0, 1, 2, 3
@@ -32,6 +32,7 @@ TILE_NAMES = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '64x128', 5: 
               7: 'dma128x128', 8: 'stem3x3', 9: 'ws_1x1', 10: 'w3x3', 26: 'w3x3', 42: 'w3x3', 58: 'w3x3', 74: 'w3x3', 90: 'w3x3',
               11: 'wide', 27: 'wide', 43: 'wide', 59: 'wide', 75: 'wide', 91: 'wide'}
 TILE_W3x3 = 10
+CONV_NT_OUT = 1            # yv4_conv_desc.flags (ABI 7): non-temporal output stores
 TILE_WIDE = 11
 
 
@@ -41,7 +42,7 @@ class ConvDesc(C.Structure):
         'N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride', 'pad',
         'x_cstride', 'x_coff', 'y_cstride', 'y_coff', 'r_cstride', 'r_coff',
         'act1', 'act2')] + [('slope1', C.c_float), ('slope2', C.c_float),
-                            ('tile', C.c_int32)]
+                            ('tile', C.c_int32), ('flags', C.c_int32)]
 
 
 class LevelDesc(C.Structure):
@@ -215,7 +216,10 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         got = handle.yv4_abi_version()
-        if got != ABI_VERSION:
+        if got != ABI_VERSION and not (os.environ.get('YV4_LIB_PATH') and os.environ.get('YV4_LIB_ABI_ANY') == '1'
+                                       and got == ABI_VERSION - 1):
+            # (YV4_LIB_ABI_ANY=1 with YV4_LIB_PATH: same-box A/B against the previous ABI's build -- ABI 7 only APPENDED
+            # yv4_conv_desc.flags, which an ABI-6 library never reads)
             raise RuntimeError(f'libyv4_hip.so ABI {got} != binding ABI {ABI_VERSION}; rebuild')
         form = os.environ.get('YV4_NMS_IOU_FORM', '').lower()
         if form in ('mul', '1', 'product', 'cuda'):

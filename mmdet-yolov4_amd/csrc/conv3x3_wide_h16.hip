@@ -58,6 +58,9 @@ template <> struct Mfma16<false> {
 #define YV4_W3_ABL 0
 #endif
 #define W3_ABL(BIT) ((YV4_W3_ABL & (BIT)) != 0)
+#ifndef YV4_W3_ILV
+#define YV4_W3_ILV 0                        // 1: the issuing role interleaves its fragment reads with its pieces (measured: nothing, profiles/r06_w3_modes3.txt)
+#endif
 #ifndef YV4_W3_ROLES
 #define YV4_W3_ROLES 1                      // waves 0-3 issue every weight piece, waves 4-7 every image piece (SK = 2 shapes)
 #endif
@@ -289,6 +292,24 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
               else YV4_W3_PIECE_B(slot ^ 1u, sB_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 2), q / NV, q % NV) \
             }                                                                                        \
           }
+#if YV4_W3_ILV
+          if (ROLES && issW && NPW > 0) {
+            // the issuing role: a few reads behind every piece -- they return while the wave is parked in the next piece's issue
+            constexpr int CH = (NR + PB * NV - 1) / (PB * NV);
+#pragma unroll
+            for (int q = 0; q < NPW; ++q) {
+              if (kw < 2) YV4_W3_PIECE_B(slot ^ 1u, sB_cur, (unsigned)((((kh * 3 + kw + 1) * p.Cin) + c0) * 2), q / NV, q % NV)
+              else YV4_W3_PIECE_B(slot ^ 1u, sB_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 2), q / NV, q % NV)
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int r = q * CH; r < (q + 1) * CH && r < NR; ++r) YV4_W3_READ1(r)
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = NPW * CH; r < NR; ++r) YV4_W3_READ1(r)
+          } else
+#endif
+          {
           if (SK == 2) {
             YV4_W3_WEIGHT_PIECES
             __builtin_amdgcn_sched_barrier(0);
@@ -298,6 +319,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
           __builtin_amdgcn_sched_barrier(0);
           if (SK == 1) {
             YV4_W3_WEIGHT_PIECES
+          }
           }
           if (issI) {
 #pragma unroll

@@ -31,6 +31,7 @@ struct ConvArgsH {
   int tiles_n;
   int out_f32;    // store fp32 instead of the operand type (pred maps feeding the fp32 decode kernel)
   int ys_on, ys_H, ys_W, ys_sh, ys_sw, ys_oh, ys_ow;   // scattered output, see conv_mfma_f32.hip
+  int nt_out;     // yv4_conv_desc.flags & YV4_CONV_NT_OUT: non-temporal output stores (the wide-tile epilogue)
   int ablate;     // measurement only (YV4_H16_ABLATE): 1 = issue no DMA after the first slice, 2 = no MFMA, 4 = no barrier
   double* stats;  // training: per-channel [sum | sum of squares] of the STORED outputs, YV4_STATS_REPLICAS x 2*Cout
   FastDiv fd_hw, fd_wo;   // m / (Ho*Wo), r / Wo (set by launch_h16)

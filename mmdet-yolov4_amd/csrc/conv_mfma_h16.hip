@@ -541,6 +541,7 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   a.ksplit = 0; a.ks_slices = 0; a.ws_cs = 0; a.ws = nullptr;
   static const int ablate = YV4_ENV_INT("YV4_H16_ABLATE", 0);
   a.ablate = ablate;
+  a.nt_out = (d->flags & YV4_CONV_NT_OUT) ? 1 : 0;
   a.stats = stats;
   const bool general = (d->Cin % kHBK) != 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -726,7 +727,7 @@ extern "C" int yv4_conv_bn_act_fwd_h16_splitk(const yv4_conv_desc* d, int dtype,
   a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff;
   a.r_cs = d->r_cstride; a.r_co = d->r_coff;
   a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
-  a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.Kw = a.K; a.tiles_n = 0; a.ys_on = 0; a.stats = nullptr; a.ablate = 0;
+  a.M = (int)M; a.K = d->KH * d->KW * d->Cin; a.Kw = a.K; a.tiles_n = 0; a.ys_on = 0; a.stats = nullptr; a.ablate = 0; a.nt_out = 0;
   a.out_f32 = out_dtype == YV4_F32 ? 1 : 0;
   const int nk = a.K / kHBK;
   a.ks_slices = (nk + ks - 1) / ks;
@@ -770,7 +771,7 @@ extern "C" int yv4_conv_scatter_fwd_h16(const yv4_conv_desc* d, int dtype, const
   a.KH = d->KH; a.KW = d->KW; a.stride = 1; a.pad = d->pad;
   a.x_cs = d->x_cstride; a.x_co = d->x_coff; a.y_cs = d->y_cstride; a.y_co = d->y_coff; a.r_cs = 0; a.r_co = 0;
   a.act1 = 0; a.act2 = 0; a.slope1 = 0.f; a.slope2 = 0.f; a.stats = nullptr;
-  a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0; a.out_f32 = 0; a.ablate = 0;
+  a.M = (int)M; a.K = (int)K; a.Kw = (int)K; a.tiles_n = 0; a.out_f32 = 0; a.ablate = 0; a.nt_out = (d->flags & YV4_CONV_NT_OUT) ? 1 : 0;
   a.ksplit = 0; a.ks_slices = 0; a.ws_cs = 0; a.ws = nullptr;
   a.ys_on = 1; a.ys_H = Hy; a.ys_W = Wy; a.ys_sh = sh; a.ys_sw = sw; a.ys_oh = oh; a.ys_ow = ow;
   const bool general = (d->Cin % kHBK) != 0;

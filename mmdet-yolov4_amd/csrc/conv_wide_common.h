@@ -155,8 +155,13 @@ __device__ __forceinline__ void wide_epilogue_h16(const ConvArgsH& p, const floa
 #pragma unroll
       for (int e = 0; e < 8; ++e) { o0[e] = (T)v[e]; o1[e] = (T)v[e + 8]; }
       T* yp = reinterpret_cast<T*>(p.y) + (SCATTER ? out_row_h(p, m) : (int64_t)m) * p.y_cs + p.y_co + cl;
-      *reinterpret_cast<V8*>(yp) = o0;
-      *reinterpret_cast<V8*>(yp + 8) = o1;
+      if (p.nt_out) {                       // (a per-plan choice, include/yv4.h YV4_CONV_NT_OUT; wave-uniform)
+        __builtin_nontemporal_store(o0, reinterpret_cast<V8*>(yp));
+        __builtin_nontemporal_store(o1, reinterpret_cast<V8*>(yp + 8));
+      } else {
+        *reinterpret_cast<V8*>(yp) = o0;
+        *reinterpret_cast<V8*>(yp + 8) = o1;
+      }
       if (p.stats) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {

@@ -686,6 +686,7 @@ constexpr int kW3BufBytes = (kW3Rows + kW3XRows) * 256;
 constexpr int kW3NBuf = 4;
 constexpr int kW3Lds = kW3NBuf * kW3BufBytes;      // 135 168 B: one workgroup per CU
 
+#ifdef YV4_MEASURE   // the FIRST form of the 3x3 weight gradient: the measurement build's A/B partner of the second form (same bits); the product takes the generic 16-bit kernel where the second form does not apply
 template <bool BF16>
 __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -910,6 +911,7 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_h16_kernel(WgradA
       }
     }
 }
+#endif  // YV4_MEASURE
 
 // ---------------------------------------------------------------------------------
 // The same kernel with its loop overhead removed (round 5).  The disassembly of the kernel above has, per 64-row slice and
@@ -1214,6 +1216,7 @@ template <int CIN, int COUT> struct FcGeom {
   static constexpr int Lds = NBuf * BufBytes + 1024;                   // + the dummies' scratch
 };
 
+#ifdef YV4_MEASURE   // the FIRST form of the few-channel weight gradient: the measurement build's A/B partner of the second form (same bits); the product takes the generic 16-bit kernel where the second form does not apply
 template <bool BF16, int CIN, int COUT>
 __global__ __launch_bounds__(kFcThreads, (FcGeom<CIN, COUT>::WGs)) void conv_wgrad_fc_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
   typedef FcGeom<CIN, COUT> G;
@@ -1471,6 +1474,7 @@ __global__ __launch_bounds__(kFcThreads, (FcGeom<CIN, COUT>::WGs)) void conv_wgr
     }
   }
 }
+#endif  // YV4_MEASURE
 
 // ---------------------------------------------------------------------------------
 // The few-channel kernel with its per-slice bookkeeping taken off the lanes (round 5; see conv_wgrad3x3_v2_h16_kernel).  The
@@ -3286,21 +3290,23 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     YV4_CHECK_LAUNCH("conv_wgrad reduce");
     return YV4_OK;
   };
-  if (const int fc = g_wgrad_widen ? 0 : wgrad_fc_cin(d, dtype)) {
+  // (the second forms range-check 32-bit byte OFFSETS: both maps below 3 GB.  Beyond that the product takes the generic
+  // 16-bit kernel further down; the first forms of the two special kernels exist in the measurement build only)
+  static const int fcv2 = YV4_ENV_INT("YV4_WFC_V2", 1);
+  const bool fc_v2_ok = fcv2 && xb < 0xC0000000LL && db < 0xC0000000LL;
+#ifdef YV4_MEASURE
+  const bool fc_any = true;
+#else
+  const bool fc_any = fc_v2_ok;
+#endif
+  if (const int fc = (g_wgrad_widen || !fc_any) ? 0 : wgrad_fc_cin(d, dtype)) {
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
     static const int fc_ablate = YV4_ENV_INT("YV4_WFC_ABLATE", 0);
     a.ablate = fc_ablate;
-    static const int fcv2 = YV4_ENV_INT("YV4_WFC_V2", 1);
-    const bool use_v2 = fcv2 && xb < 0xC0000000LL && db < 0xC0000000LL;
-#define YV4_FC_LAUNCH(CI, CO)                                                                                        \
-  if (use_v2) {                                                                                                      \
-    static LdsAttrOnce once_b2, once_h2;                                                                             \
-    constexpr size_t lds2 = FcGeom<CI, CO>::Lds + FcGeom<CI, CO>::NBuf * 192;                                        \
-    if (int rc = ensure_dyn_lds(once_b2, reinterpret_cast<const void*>(conv_wgrad_fc_v2_h16_kernel<true, CI, CO>), lds2, "conv_wgrad_fc_v2_h16")) return rc;  \
-    if (int rc = ensure_dyn_lds(once_h2, reinterpret_cast<const void*>(conv_wgrad_fc_v2_h16_kernel<false, CI, CO>), lds2, "conv_wgrad_fc_v2_h16")) return rc; \
-    if (dtype == YV4_BF16) hipLaunchKernelGGL((conv_wgrad_fc_v2_h16_kernel<true, CI, CO>), dim3((unsigned)ch), dim3(kFcThreads), lds2, hs, a, (unsigned)xb, (unsigned)db); \
-    else hipLaunchKernelGGL((conv_wgrad_fc_v2_h16_kernel<false, CI, CO>), dim3((unsigned)ch), dim3(kFcThreads), lds2, hs, a, (unsigned)xb, (unsigned)db);                  \
-  } else {                                                                                                           \
+    const bool use_v2 = fc_v2_ok;
+#ifdef YV4_MEASURE
+#define YV4_FC_FIRST(CI, CO)                                                                                         \
+  else {                                                                                                             \
     static LdsAttrOnce once_b, once_h;                                                                               \
     constexpr size_t lds = FcGeom<CI, CO>::Lds;                                                                      \
     if (int rc = ensure_dyn_lds(once_b, reinterpret_cast<const void*>(conv_wgrad_fc_h16_kernel<true, CI, CO>), lds, "conv_wgrad_fc_h16")) return rc;  \
@@ -3308,30 +3314,51 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
     if (dtype == YV4_BF16) hipLaunchKernelGGL((conv_wgrad_fc_h16_kernel<true, CI, CO>), dim3((unsigned)ch), dim3(kFcThreads), lds, hs, a, (unsigned)xb, (unsigned)db); \
     else hipLaunchKernelGGL((conv_wgrad_fc_h16_kernel<false, CI, CO>), dim3((unsigned)ch), dim3(kFcThreads), lds, hs, a, (unsigned)xb, (unsigned)db);                  \
   }
+#else
+#define YV4_FC_FIRST(CI, CO)
+#endif
+#define YV4_FC_LAUNCH(CI, CO)                                                                                        \
+  { if (use_v2) {                                                                                                    \
+    static LdsAttrOnce once_b2, once_h2;                                                                             \
+    constexpr size_t lds2 = FcGeom<CI, CO>::Lds + FcGeom<CI, CO>::NBuf * 192;                                        \
+    if (int rc = ensure_dyn_lds(once_b2, reinterpret_cast<const void*>(conv_wgrad_fc_v2_h16_kernel<true, CI, CO>), lds2, "conv_wgrad_fc_v2_h16")) return rc;  \
+    if (int rc = ensure_dyn_lds(once_h2, reinterpret_cast<const void*>(conv_wgrad_fc_v2_h16_kernel<false, CI, CO>), lds2, "conv_wgrad_fc_v2_h16")) return rc; \
+    if (dtype == YV4_BF16) hipLaunchKernelGGL((conv_wgrad_fc_v2_h16_kernel<true, CI, CO>), dim3((unsigned)ch), dim3(kFcThreads), lds2, hs, a, (unsigned)xb, (unsigned)db); \
+    else hipLaunchKernelGGL((conv_wgrad_fc_v2_h16_kernel<false, CI, CO>), dim3((unsigned)ch), dim3(kFcThreads), lds2, hs, a, (unsigned)xb, (unsigned)db);                  \
+  } YV4_FC_FIRST(CI, CO) }
     if (a.Cout == 32) {
       if (fc == 16) YV4_FC_LAUNCH(16, 32) else if (fc == 32) YV4_FC_LAUNCH(32, 32) else YV4_FC_LAUNCH(64, 32)
     } else {
       if (fc == 16) YV4_FC_LAUNCH(16, 64) else if (fc == 32) YV4_FC_LAUNCH(32, 64) else YV4_FC_LAUNCH(64, 64)
     }
 #undef YV4_FC_LAUNCH
+#undef YV4_FC_FIRST
     YV4_CHECK_LAUNCH("conv_wgrad_fc_h16");
     return finish();
   }
-  if (!g_wgrad_widen && wgrad3x3_applies(d, dtype)) {
+  static const int w3v2 = YV4_ENV_INT("YV4_W3V2", 1);
+  const bool w3_v2_ok = w3v2 && xb < 0xC0000000LL && db < 0xC0000000LL;
+#ifdef YV4_MEASURE
+  const bool w3_any = true;
+#else
+  const bool w3_any = w3_v2_ok;
+#endif
+  if (!g_wgrad_widen && w3_any && wgrad3x3_applies(d, dtype)) {
     const long long tl = (long long)((a.Cout + 127) / 128) * 3 * (a.Cin / 128);
+#ifdef YV4_MEASURE
     static LdsAttrOnce once3b, once3h;
     if (int rc = ensure_dyn_lds(once3b, reinterpret_cast<const void*>(conv_wgrad3x3_h16_kernel<true>), (size_t)kW3Lds, "conv_wgrad3x3_h16")) return rc;
     if (int rc = ensure_dyn_lds(once3h, reinterpret_cast<const void*>(conv_wgrad3x3_h16_kernel<false>), (size_t)kW3Lds, "conv_wgrad3x3_h16")) return rc;
+#endif
     a.tiles = (int)tl;
     a.chunks = (int)ch;
     a.xcd_map = w3_xcd_map(tl, ch) && tl * (ch + 8) < (1LL << 31) ? 1 : 0;
     static const int w3_ablate = YV4_ENV_INT("YV4_W3_ABLATE", 0);
     a.ablate = w3_ablate;
     const dim3 grid3 = wgrad_grid(tl, ch, a.xcd_map);
-    static const int w3v2 = YV4_ENV_INT("YV4_W3V2", 1);
     // (the second form range-checks 32-bit byte OFFSETS: both maps well below 4 GB, so that a row in front of the map --
     // a wrapped offset -- can never fall below a limit)
-    if (w3v2 && xb < 0xC0000000LL && db < 0xC0000000LL) {
+    if (w3_v2_ok) {
       static LdsAttrOnce once3vb, once3vh;
       if (int rc = ensure_dyn_lds(once3vb, reinterpret_cast<const void*>(conv_wgrad3x3_v2_h16_kernel<true>), (size_t)kW3LdsV2, "conv_wgrad3x3_v2_h16")) return rc;
       if (int rc = ensure_dyn_lds(once3vh, reinterpret_cast<const void*>(conv_wgrad3x3_v2_h16_kernel<false>), (size_t)kW3LdsV2, "conv_wgrad3x3_v2_h16")) return rc;
@@ -3358,6 +3385,7 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
       YV4_CHECK_LAUNCH("conv_wgrad3x3_v2_h16");
       return finish();
     }
+#ifdef YV4_MEASURE
     if (dtype == YV4_BF16)
       hipLaunchKernelGGL(conv_wgrad3x3_h16_kernel<true>, grid3, dim3(kW3Threads), (size_t)kW3Lds,
                          reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
@@ -3366,6 +3394,7 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
                          reinterpret_cast<hipStream_t>(stream), a, (unsigned)xb, (unsigned)db);
     YV4_CHECK_LAUNCH("conv_wgrad3x3_h16");
     return finish();
+#endif
   }
   if (dtype != YV4_F32 && !g_wgrad_widen) {
     // 16-bit MFMA form: 128 x 128 tiles of dW, 64-row slices
@@ -3448,6 +3477,10 @@ static int bn_stats_impl(int dtype, const void* x, int64_t M, int C, int x_cstri
   YV4_REQUIRE(C <= 4096, "bn_train_stats: more than 4096 channels");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int det = deterministic() ? 1 : 0;      // work: [hi (2*C) | lo (2*C)] fixed-point words
+  if (det && C > 2048) {                        // 4 C doubles of LDS per workgroup: 64 KB at 2 048 channels
+    set_error("bn_train_stats: deterministic mode takes at most 2048 channels (%d given)", C);
+    return YV4_E_UNSUPPORTED;
+  }
   if (hipMemsetAsync(work, 0, sizeof(double) * (det ? 4 : 2) * C, s) != hipSuccess) { set_error("bn_train_stats: memset failed"); return YV4_E_LAUNCH; }
   const int rpb = bn_rows_per_block(M);
   dim3 grid((unsigned)((M + rpb - 1) / rpb));
@@ -3537,6 +3570,10 @@ static int bn_bwd_impl(int dtype, const void* x, int x_cstride, int x_coff, cons
     while (groups > 1 && (C % groups != 0 || (C / groups) % 8 != 0)) --groups;
     BnArgs r = a;
     r.red_cg = C / groups;
+    if (det && r.red_cg > 2048) {                // 4 doubles of LDS per channel of a group: 64 KB at 2 048
+      set_error("bn_act_bwd: deterministic mode takes at most 2048 channels per reduction group (%d)", r.red_cg);
+      return YV4_E_UNSUPPORTED;
+    }
     int64_t rpb = (int64_t)a.rows_per_block * groups;
     if (rpb > g_bn_rows_cap) rpb = g_bn_rows_cap;
     r.rows_per_block = (int)rpb;

@@ -101,12 +101,15 @@ static inline int ensure_dyn_lds(LdsAttrOnce& g, const void* fn, size_t bytes, c
 // becomes round(v * 2^SHIFT) split into two 64-bit words (hi = floor(t / 2^32), lo = t - hi * 2^32 in [0, 2^32)),
 // both added with integer atomics.  Integer addition is associative and commutative, so the result is the same bits
 // whatever the arrival order, the workgroup-to-CU assignment or the replica an addend lands in -- no second pass, no
-// ordered reduction, the kernels keep their structure.  Range |v| < 2^(94 - SHIFT), resolution 2^-SHIFT; a non-finite
-// or out-of-range addend sets bit 63 of the lo word (an idempotent OR: lo sums stay below 2^63 for < 2^31 addends, so
-// no carry ever reaches the bit) and the value reads back as NaN -- overflow stays loud, as in the double path.
+// ordered reduction, the kernels keep their structure.  Range of an addend AND of the sum: |v| < 2^(94 - SHIFT),
+// resolution 2^-SHIFT.  A non-finite or out-of-range addend sets bit 63 of the lo word (an idempotent OR: lo sums stay
+// below 2^63 for < 2^31 addends, so no carry ever reaches the bit) and the value reads back as NaN; the hi words are
+// summed with wrapping 64-bit adds, so fx_value also answers NaN when the decoded sum has left the range (|H| >= 2^62:
+// a sum that large is one or two addends away from wrapping into a wrong finite value) -- overflow stays loud, per
+// addend and in total, as in the double path.
 bool deterministic();          // api.hip: the process-wide switch, read by the launchers
 constexpr int kFxStat = 40;    // forward statistics, loss sums: |v| < 1.8e16, resolution 9.1e-13
-constexpr int kFxGrad = 60;    // gradient sums (loss-scaled): |v| < 1.7e10, resolution 8.7e-19
+constexpr int kFxGrad = 60;    // gradient sums (loss-scaled): addends and sums |v| < 1.7e10, resolution 8.7e-19
 typedef unsigned long long u64_t;
 
 template <int SHIFT>
@@ -128,6 +131,7 @@ template <int SHIFT>
 __device__ __forceinline__ double fx_value(u64_t hi, u64_t lo) {
   if (lo >> 63) return __builtin_nan("");
   const long long H = (long long)hi + (long long)(lo >> 32);
+  if (H >= (1ll << 62) || H <= -(1ll << 62)) return __builtin_nan("");     // the SUM is out of range (see above)
   return ((double)H * 0x1p32 + (double)(lo & 0xffffffffull)) * __builtin_ldexp(1.0, -SHIFT);
 }
 __device__ __forceinline__ void fx_fold(u64_t& hi, u64_t& lo, u64_t h2, u64_t l2) {

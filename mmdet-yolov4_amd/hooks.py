@@ -220,6 +220,8 @@ class Fp16GradAccumulateOptimizerHook(Hook):
         if self.reducer is not None and last:
             self.reducer.arm()
         (runner.outputs['loss'] * self.scale_state[0]).backward()
+        from .train_ops import join_side_streams
+        join_side_streams()          # (the end-of-backward callback does it; it is dropped when a backward raises)
         if not last:
             return
         if self.reducer is not None:

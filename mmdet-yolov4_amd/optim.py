@@ -150,6 +150,8 @@ class FlatSGD:
         if not self.flat.grads_attached():
             raise RuntimeError('FlatSGD.step: a parameter\'s .grad is not its slice of the gradient arena '
                                '(zero_grad(set_to_none=True) on the model? use the model\'s own zero_grad)')
+        from .train_ops import join_side_streams
+        join_side_streams()          # weight gradients launched on a side stream (a no-op when the backward's callback ran)
         rows = self.hyper_table()
         if rows != self._hyper_last:
             # a fresh pinned staging tensor per change: torch's caching host allocator keeps it alive

@@ -113,6 +113,7 @@ def pack_conv_weight(weight, cin_pad=None, align=4):
 
 
 _DCODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}      # YV4_F32 / YV4_F16 / YV4_BF16
+_PLAN_NT = os.environ.get('YV4_PLAN_NT', '1') != '0'                 # non-temporal output stores in 16-bit plans (ABI 7)
 
 
 class Plan:
@@ -215,6 +216,10 @@ class Plan:
         d.act1, d.slope1 = act1
         d.act2, d.slope2 = act2 if s2 is not None else (0, 0.0)
         d.tile = tile
+        # inference plans in 16 bits: outputs with non-temporal stores (ABI 7; the wide-tile kernels have the form, the others
+        # ignore the flag; same bits).  YV4_PLAN_NT=0 switches it off (A/B).
+        if self.h16 and _PLAN_NT:
+            d.flags = _lib.CONV_NT_OUT
         # everything the launch reads sits in one mutable record (calibrate.py swaps entries)
         L = dict(d=d, x=x.buf, y=out.buf, res=residual.buf if residual is not None else None,
                  w=self._dev(wp), s1=self._dev(s1.float()), t1=self._dev(t1.float()),

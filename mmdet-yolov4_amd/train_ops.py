@@ -512,7 +512,8 @@ def _wgrad_workspace(nbytes, device, stream_key=None):
 # YV4_WGRAD_STREAM=0 keeps everything on one stream.
 _WGRAD_STREAM = _os.environ.get('YV4_WGRAD_STREAM', '1') != '0'
 _SIDE_STREAMS = {}
-_side_join_pending = [False]
+_side_join_pending = [False]     # a join callback is queued with the autograd engine for the backward pass in flight
+_side_dirty = [False]            # a side stream holds weight gradients the current stream has not waited for
 
 
 def _wgrad_side_stream(device):
@@ -527,13 +528,18 @@ def _wgrad_side_stream(device):
 
 def _join_side_streams():
     _side_join_pending[0] = False
-    for dev, st in _SIDE_STREAMS.items():
-        torch.cuda.current_stream(dev).wait_stream(st)
+    if _side_dirty[0]:
+        _side_dirty[0] = False
+        for dev, st in _SIDE_STREAMS.items():
+            torch.cuda.current_stream(dev).wait_stream(st)
 
 
 def join_side_streams():
-    """Make the current stream wait for every weight gradient launched on a side stream (idempotent; the autograd callback
-    does this at the end of every backward pass already)."""
+    """Make the current stream wait for every weight gradient launched on a side stream.  Idempotent and cheap (one event
+    wait per device when something is pending, nothing otherwise).  The autograd callback does this at the end of every
+    backward pass -- but the engine DROPS queued callbacks when a backward raises (an OOM retry, ``pytest.raises``, a failed
+    check in a later node), so nothing may rely on the callback alone: the optimizer step, the gradient hooks, the gradient
+    exchange and the next forward pass all call this before they touch the gradient arena."""
     _join_side_streams()
 
 
@@ -552,6 +558,10 @@ class ConvFunction(torch.autograd.Function):
         fills (see ``CatSlot``).  ``park``: a ``GradSink`` that receives this conv's data gradient instead of autograd
         (x also feeds a conv whose backward runs LATER and adds the parked gradient in its own launch)."""
         _need_cuda(x, 'x')
+        if _side_join_pending[0] or _side_dirty[0]:
+            # a forward pass while a join is still "pending": the backward that queued it never finished (its callback was
+            # dropped with the exception) -- join now, so the one-shot flag cannot stay stuck for the rest of the process
+            _join_side_streams()
         ctx.direct = direct
         ctx.park = park
         ctx.sink = sink if stride == 1 else None     # (the stride-2 parity form has no residual input)
@@ -635,6 +645,7 @@ class ConvFunction(torch.autograd.Function):
                     dy.record_stream(side)
                     if ws is not None:
                         ws.record_stream(side)       # (a grown workspace frees its predecessor while the side stream may still read it)
+                    _side_dirty[0] = True
                     if not _side_join_pending[0]:
                         _side_join_pending[0] = True
                         torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
@@ -872,7 +883,7 @@ class BNActFunction(torch.autograd.Function):
                                         invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dgamma.data_ptr(),
                                         dbeta.data_ptr(), work.data_ptr(), M, Cc, act, slope, stream_ptr()),
                   'yv4_bn_act_bwd_sums')
-            dist.all_reduce(work, group=ctx.sync_group)
+            dist.all_reduce(work[:2 * Cc], group=ctx.sync_group)     # (the other half is the deterministic mode's scratch)
             check(L.yv4_bn_act_bwd_apply(x.data_ptr(), code, Cc, 0, dy.data_ptr(), dcs, 0, mean.data_ptr(),
                                          invstd.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), Cc, 0,
                                          work.data_ptr(), M, 0, ctx.rows.data_ptr(), Cc, act, slope, stream_ptr()),

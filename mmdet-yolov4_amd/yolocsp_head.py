@@ -166,6 +166,7 @@ class FusedLosses(OrderedDict):
         self.weighted, self.num_gts, self.with_cls = weighted, num_gts, with_cls
         self.total = weighted.sum()
         self.built = False
+        self.mutated = False
 
     def _build(self):
         if not self.built:
@@ -205,6 +206,35 @@ class FusedLosses(OrderedDict):
 
     def __repr__(self):
         return OrderedDict.__repr__(self._build())
+
+    # Mutation (a detector or wrapper that adds an auxiliary loss before ``_parse_losses``): the mapping is built first, and
+    # ``built`` then tells ``single_stage._parse_losses`` to sum every key the way detectors/base.py:171-204 does instead of
+    # taking ``total`` -- an added loss must not silently drop out of the optimised sum and of ``log_vars``.
+    def __setitem__(self, k, v):
+        self._build()
+        self.mutated = True
+        OrderedDict.__setitem__(self, k, v)
+
+    def __delitem__(self, k):
+        self._build()
+        self.mutated = True
+        OrderedDict.__delitem__(self, k)
+
+    def update(self, *a, **kw):
+        self._build()
+        self.mutated = True
+        OrderedDict.update(self, *a, **kw)
+
+    def setdefault(self, k, default=None):
+        self._build()
+        if not OrderedDict.__contains__(self, k):
+            self.mutated = True
+        return OrderedDict.setdefault(self, k, default)
+
+    def pop(self, k, *default):
+        self._build()
+        self.mutated = True
+        return OrderedDict.pop(self, k, *default)
 
 
 def _upload(host, device):

@@ -1,8 +1,10 @@
 """Build oracle/_ref/: the REFERENCE's own CPU Mish kernel, compiled from its sources where
 they lie under /root/reference (never copied), plus oracle/ref_mish_binding.cpp.
 
-Test infrastructure only.  A no-op where /root/reference is absent (the GPU box): the
-prebuilt oracle/_ref/*.so travels with the repo snapshot instead.
+Test infrastructure only.  A no-op where /root/reference is absent (the GPU box).  The built
+oracle/_ref/*.so stays in THIS container (.gitignore and .gpurunignore both list oracle/_ref/): it is
+used here to generate and re-check tests/golden/mish.npz and eval.npz, which are what travels and
+what the GPU tests compare against.
 """
 import glob
 import importlib.util

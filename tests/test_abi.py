@@ -26,7 +26,7 @@ def test_header_binding_library_agree():
 
 def test_struct_layout_matches_header():
     import ctypes
-    assert ctypes.sizeof(pkg._lib.ConvDesc) == 22 * 4
+    assert ctypes.sizeof(pkg._lib.ConvDesc) == 23 * 4 and pkg._lib.ConvDesc.flags.offset == 22 * 4     # ABI 7: + flags
     # yv4_loss_level / yv4_loss_desc (gcc sizeof on include/yv4.h: 176 / 1016, slot_anchor at 960, ABI 6's losses at 1008)
     assert ctypes.sizeof(pkg._lib.LossLevel) == 176 and ctypes.sizeof(pkg._lib.LossDesc) == 1016
     assert pkg._lib.LossDesc.slot_anchor.offset == 960 and pkg._lib.LossDesc.losses.offset == 1008

@@ -1,6 +1,6 @@
 """Evaluation row, GPU: iou_coco / match_coco / eval_map_flexible through the C ABI
-(yv4_iou_coco_batched, yv4_match_coco_batched) against the reference-made fixture, the oracle, and --
-where oracle/_ref travelled with the snapshot -- the reference's own compiled Cython ops.
+(yv4_iou_coco_batched, yv4_match_coco_batched) against the reference-made fixture (tests/golden/eval.npz, produced by the
+reference's own compiled Cython ops in the build container; oracle/_ref itself does not travel) and the oracle.
 Tolerance: none. IoU is compared bit for bit (fp32), matches and mAP tables exactly."""
 import numpy as np
 import pytest

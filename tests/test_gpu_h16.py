@@ -24,7 +24,7 @@ HT = dict(t128x128=1, t128x64=2, t64x64=3)
 
 
 def _h16_conv(dev, dtype, N, H, W, Cin, Cout, k, stride, pad, act, tile, residual=False, two_stage=False, x_off=0,
-              y_off=0, out_f32=False, seed=0, raw=False, splitk=False):
+              y_off=0, out_f32=False, seed=0, raw=False, splitk=False, nt=False):
     g = torch.Generator().manual_seed(seed)
     cp = (Cin + 7) // 8 * 8
     x = torch.randn(N, H, W, Cin, generator=g).to(dtype)
@@ -64,6 +64,7 @@ def _h16_conv(dev, dtype, N, H, W, Cin, Cout, k, stride, pad, act, tile, residua
     d.r_cstride, d.r_coff = Cout, 0
     d.act1, d.act2, d.slope1, d.slope2 = act, act if two_stage else 0, 0.1, 0.1
     d.tile = tile
+    d.flags = pkg._lib.CONV_NT_OUT if nt else 0
     dev_f = lambda t: t.to(dev).float().contiguous()
     s1d, t1d, s2d, t2d = dev_f(s1), dev_f(t1), dev_f(s2), dev_f(t2)
     dcode, ocode = 1 if dtype == torch.float16 else 2, 0 if out_f32 else (1 if dtype == torch.float16 else 2)
@@ -225,6 +226,20 @@ def test_wide3x3_matches_generic_bitwise(gpu_device, dtype):
         outs = [_h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=t, raw=True, **kw) for t in (2, 4, 5, 13, 21, 29, 37, 45)]
         for o in outs[1:]:
             assert torch.equal(outs[0], o)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_nontemporal_output_flag_gives_the_same_bits(gpu_device, dtype):
+    """yv4_conv_desc.flags & YV4_CONV_NT_OUT (ABI 7, what 16-bit inference plans set): the wide-tile kernels store with
+    non-temporal instructions, every other kernel ignores the flag -- the output is the same either way."""
+    for shape, k, stride, pad, tiles, kw in [((9, 38, 38, 256, 256), 3, 1, 1, (5, 13, 21, 37), dict(residual=True)),
+                                             ((3, 38, 38, 128, 256), 3, 2, 1, (8, 24), dict()),
+                                             ((2, 19, 19, 256, 256), 1, 1, 0, (8, 2, 6), dict(two_stage=True))]:
+        N, H, W, Cin, Cout = shape
+        for t in tiles:
+            a = _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, k, stride, pad, act=1, tile=t, raw=True, **kw)
+            b = _h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, k, stride, pad, act=1, tile=t, raw=True, nt=True, **kw)
+            assert torch.equal(a, b), (shape, t)
 
 
 WIDE_TILES = [8, 16, 24, 32, 40, 48]     # YV4_HTILE_WIDE (shape by the cost model) and YV4_HTILE_WIDE_SHAPE(0..4)

@@ -3,7 +3,7 @@
 LEGS=${1:-"bf16 f32 cfg3 train"}
 for i in 1 2; do
 for L in prev cur; do
-if [ $L = prev ]; then export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_prev/libyv4_hip_prev.so; else unset YV4_LIB_PATH; fi
+if [ $L = prev ]; then export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_prev/libyv4_hip_prev.so YV4_LIB_ABI_ANY=1; else unset YV4_LIB_PATH YV4_LIB_ABI_ANY; fi
 for leg in $LEGS; do
 case $leg in
 bf16) echo -n "$L v4l bf16 inference: "; python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-output-check 2>/dev/null | python tools/last_json.py;;
