@@ -648,7 +648,18 @@ def main():
     for i in range(args.steps):
         step(events if (i % max(args.event_every, 1) == 0 and events_inside) else None)
     D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(my_elapsed, device=dev)
+    # what every rank saw: its world size (the RCCL group's, not the launcher's word for it), device and own rate
+    import torch.distributed as tdist
+    mine = dict(rank=rank, world_size=tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1,
+                backend=D.backend_name() if hasattr(D, 'backend_name') else None, device=str(dev),
+                images_per_sec=round(args.batch * args.steps / my_elapsed, 2))
+    if tdist.is_available() and tdist.is_initialized() and world > 1:
+        per_rank = [None] * world
+        tdist.all_gather_object(per_rank, mine)
+    else:
+        per_rank = [mine]
     gc.enable()
     if not events_inside:                               # per-conv events: instrumented steps outside the timed region
         for _ in range(max(2, args.steps // max(args.event_every, 1))):
@@ -800,7 +811,7 @@ def main():
                         weights='random init (seed 0), BN statistics fitted on the batch, head bias set for '
                                 f'~{ncand:.0f} NMS candidates/image', parallelism=f'replicated weights, batch '
                                 f'sharded over {world} rank(s), no collective'),
-            roofline=roofline, output_check=output_check, train_step=train)
+            roofline=roofline, output_check=output_check, train_step=train, ranks=per_rank)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(det, args.size)
             if pred0 is not None and not MODELS[args.model].get('v3'):

@@ -192,7 +192,13 @@ class GradReducer:
         # conv weights whose dW is accumulated straight into the arena bypass autograd's accumulation (and its
         # hooks): train_ops tells us when such a gradient is final
         from . import train_ops as _T
-        self._direct_cb = _T.add_direct_grad_listener(self._on_direct_grad)
+        # Weight gradients on train_ops' side stream TOGETHER with the exchange: built (the bucket's collective is ordered behind
+        # the side stream in _launch) and measured on a one-rank RCCL group with every bucket's collective launched
+        # (tools/ab_wstream_rccl.sh, profiles/r06_ab_wstream_rccl.txt): 1 175 images/s without the side stream, 1 122 with it
+        # (all-reduce), 1 157 -> 1 080 (direct) -- a collective that has to wait for the side stream's queue starts later than
+        # one behind the backward stream alone.  Off unless YV4_WGRAD_STREAM_WITH_EXCHANGE=1.
+        self._direct_cb = _T.add_direct_grad_listener(
+            self._on_direct_grad, side_stream_ok=os.environ.get('YV4_WGRAD_STREAM_WITH_EXCHANGE') == '1')
 
     @staticmethod
     def _make_buckets(flat, bucket_mb, head_mb):
@@ -346,16 +352,34 @@ class GradReducer:
         if not self.exchange:
             return
         lo, hi, _ = self.buckets[bi]
+        # Weight gradients of this bucket may have been launched on train_ops' side stream (they are, by default): the bucket's
+        # exchange is ordered behind BOTH the backward stream and that side stream, on a stream of its own -- the backward
+        # stream itself waits for nothing here (round 5 switched the side stream off whenever a reducer existed, i.e. on every
+        # multi-GPU run).
+        from . import train_ops as _T
+        cuda = self.flat.grads.is_cuda
+        side = _T.wgrad_side_stream(self.flat.grads.device) if cuda else None
         if self.mode == 'allreduce':
+            if side is not None:
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream(device=self.flat.grads.device)
+                self._comm_stream.wait_stream(torch.cuda.current_stream())
+                self._comm_stream.wait_stream(side)
+                with torch.cuda.stream(self._comm_stream):      # (the collective's own stream waits for the stream current HERE)
+                    self._handles.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                         async_op=True))
+                return
             self._handles.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True))
             return
-        if self.flat.grads.is_cuda:
+        if cuda:
             # the staging copies and the local fp32 sum run on a side stream behind the producing kernels, so the
             # backward stream never waits for a collective before finish()
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=self.flat.grads.device)
             self._comm_stream.wait_stream(torch.cuda.current_stream())
+            if side is not None:
+                self._comm_stream.wait_stream(side)
             with torch.cuda.stream(self._comm_stream):
                 self._direct_exchange(bi)
         else:

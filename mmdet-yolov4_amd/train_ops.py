@@ -449,17 +449,25 @@ import os as _os
 
 _DIRECT_WGRAD = _os.environ.get('YV4_DIRECT_WGRAD', '1') != '0'
 _direct_grad_listeners = []
+_listeners_need_main_stream = []     # listeners that assume the gradient was written on the CURRENT stream
 
 
-def add_direct_grad_listener(cb):
-    """``cb(weight)`` is called after a conv's backward accumulated dW into ``weight.grad`` directly."""
+def add_direct_grad_listener(cb, side_stream_ok=False):
+    """``cb(weight)`` is called after a conv's backward accumulated dW into ``weight.grad`` directly.  ``side_stream_ok``:
+    the listener knows that the weight gradient may have been launched on the side stream and orders itself behind
+    ``wgrad_side_stream(device)`` (the gradient exchange does: ``GradReducer._launch``); a listener that does not say so
+    switches the side stream off while it is registered."""
     _direct_grad_listeners.append(cb)
+    if not side_stream_ok:
+        _listeners_need_main_stream.append(cb)
     return cb
 
 
 def remove_direct_grad_listener(cb):
     if cb in _direct_grad_listeners:
         _direct_grad_listeners.remove(cb)
+    if cb in _listeners_need_main_stream:
+        _listeners_need_main_stream.remove(cb)
 
 
 def _flat_f32(g, n):
@@ -507,8 +515,9 @@ def _wgrad_workspace(nbytes, device, stream_key=None):
 # beside HBM-bound work -- instead of between them.  Ordering: the side stream waits for the current stream at every launch
 # (dY, x and the zeroed arena are ready), the tensors are handed to the allocator with ``record_stream``, and the current
 # stream waits for the side stream in a callback the autograd engine runs at the END of this backward pass (so every
-# ``.backward()`` leaves finished gradients behind, whoever called it).  Not with gradient listeners registered (the
-# multi-GPU exchange launches a bucket when its last weight gradient has been ISSUED on the current stream).
+# ``.backward()`` leaves finished gradients behind, whoever called it).  Gradient listeners: the multi-GPU exchange launches
+# a bucket when its last weight gradient has been ISSUED, and orders the bucket's collective behind the side stream itself
+# (``GradReducer._launch`` -> ``wgrad_side_stream``); any other listener switches the side stream off while registered.
 # YV4_WGRAD_STREAM=0 keeps everything on one stream.
 _WGRAD_STREAM = _os.environ.get('YV4_WGRAD_STREAM', '1') != '0'
 _SIDE_STREAMS = {}
@@ -516,8 +525,13 @@ _side_join_pending = [False]     # a join callback is queued with the autograd e
 _side_dirty = [False]            # a side stream holds weight gradients the current stream has not waited for
 
 
+def wgrad_side_stream(device):
+    """The side stream that holds weight gradients not yet joined into the current stream of ``device``, or None."""
+    return _SIDE_STREAMS.get(torch.device(device)) if _side_dirty[0] else None
+
+
 def _wgrad_side_stream(device):
-    if not _WGRAD_STREAM or _direct_grad_listeners:
+    if not _WGRAD_STREAM or _listeners_need_main_stream:
         return None
     st = _SIDE_STREAMS.get(device)
     if st is None:

@@ -152,7 +152,7 @@ def _gpus():
     return torch.cuda.device_count()
 
 
-def _run_two_ranks(tmp_path, backend, mode, model='toy'):
+def _run_two_ranks(tmp_path, backend, mode, model='toy', extra_env={}):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % ROOT)
     s = socket.socket()
@@ -163,7 +163,7 @@ def _run_two_ranks(tmp_path, backend, mode, model='toy'):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank if backend == 'nccl' else 0), WORLD_SIZE='2',
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1', YV4_TEST_BACKEND=backend,
-                   YV4_TEST_MODE=mode, YV4_TEST_MODEL=model, HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   YV4_TEST_MODE=mode, YV4_TEST_MODEL=model, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -205,6 +205,17 @@ def test_two_rank_step_equals_one_process_big_batch(tmp_path, backend, mode):
     for o in outs:
         assert o['worst'] < tol, o                            # exchanged gradients == one-process gradients
         assert o['stats'] < 1e-5, o                           # running statistics == big-batch BatchNorm's
+    _check_common(outs)
+
+
+@pytest.mark.parametrize('mode', ['allreduce', 'direct'])
+def test_two_rank_step_with_weight_gradients_on_the_side_stream(tmp_path, mode):
+    """YV4_WGRAD_STREAM_WITH_EXCHANGE=1 (off by default: measured slower, profiles/r06_ab_wstream_rccl.txt): weight gradients
+    go to train_ops' side stream although a GradReducer listens, and every bucket's collective is ordered behind that stream
+    (GradReducer._launch).  The exchanged gradients must still be the one-process big-batch gradients."""
+    outs = _run_two_ranks(tmp_path, 'gloo', mode, extra_env=dict(YV4_WGRAD_STREAM_WITH_EXCHANGE='1', YV4_WGRAD_STREAM='1'))
+    for o in outs:
+        assert o['worst'] < 2e-5 and o['stats'] < 1e-5, o
     _check_common(outs)
 
 
