@@ -76,6 +76,35 @@ def timed_region_stats(trace_csv, steps):
     return out, period
 
 
+def marker_region_stats(trace_csv, steps, marker):
+    """Per-kernel statistics over the last `steps` steps of a trace whose launch ORDER is not periodic (the train step with
+    its weight gradients on a side stream: the two streams interleave differently every step).  `marker` names a kernel
+    that runs exactly once per step on the main stream (the optimizer's yv4_sgd_step): the region is everything launched
+    after the end of the (steps + 1)-th last marker up to the end of the last one."""
+    rows = list(csv.DictReader(open(trace_csv)))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    marks = [r for r in rows if marker in r['Kernel_Name']]
+    if len(marks) < steps + 1:
+        return None, 0
+    t0, t1 = int(marks[-steps - 1]['End_Timestamp']), int(marks[-1]['End_Timestamp'])
+    agg = collections.OrderedDict()
+    n = 0
+    for r in rows:
+        if not (t0 < int(r['Start_Timestamp']) and int(r['End_Timestamp']) <= t1 + 1):
+            continue
+        n += 1
+        d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+        a = agg.setdefault(r['Kernel_Name'], [0, 0, 1 << 62, 0])
+        a[0] += 1
+        a[1] += d
+        a[2] = min(a[2], d)
+        a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
+    out = [[short(k), a[0], a[1], round(a[1] / a[0], 1), round(100.0 * a[1] / tot, 3), a[2], a[3]]
+           for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+    return out, (n // steps, (t1 - t0) / steps / 1e6)
+
+
 def pmc_of(run_dir):
     """{kernel: mean counters per launch} of one profiled command (its pmc_fetch / pmc_write passes)."""
     pm = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -108,7 +137,21 @@ if R03:
             continue
         steps_file = os.path.join(run_dir, 'steps.txt')
         done = False
-        if os.path.exists(steps_file):
+        marker_file = os.path.join(run_dir, 'marker.txt')
+        if os.path.exists(steps_file) and os.path.exists(marker_file):
+            steps = int(open(steps_file).read().split()[0])
+            for f in glob.glob(os.path.join(run_dir, 'trace', '*', '*_kernel_trace.csv')):
+                rows, info = marker_region_stats(f, steps, open(marker_file).read().strip())
+                if rows:
+                    with open(os.path.join(out, name + '_kernel_stats.csv'), 'w', newline='') as g:
+                        g.write(f'# timed region only: the last {steps} steps, cut at the once-per-step marker kernel (the launch order of two '
+                                f'streams is not periodic): {info[0]} launches and {info[1]:.2f} ms of wall time per step; kernel times of both '
+                                f'streams are summed, so the column total exceeds the wall time where they overlap\n')
+                        w = csv.writer(g)
+                        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+                        w.writerows(rows)
+                    done = True
+        elif os.path.exists(steps_file):
             steps = int(open(steps_file).read().split()[0])
             for f in glob.glob(os.path.join(run_dir, 'trace', '*', '*_kernel_trace.csv')):
                 rows, period = timed_region_stats(f, steps)
