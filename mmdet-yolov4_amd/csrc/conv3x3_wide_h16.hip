@@ -170,14 +170,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
   const int nchunks = p.Cin >> 6;
   const int G = 3 * nchunks;                 // (chunk, kh) groups per tile
 
-  // ---- the layer's affine into LDS, once per workgroup ----
   const bool has2 = p.s2 != nullptr;
-  for (int c = tid; c < p.Cout; c += kWideThreads) {
-    aff[c] = p.s1[c];
-    aff[p.Cout + c] = p.t1[c];
-    aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
-    aff[3 * p.Cout + c] = has2 ? p.t2[c] : 0.f;
-  }
 
   // weight piece q of a K tile: rows n0 + srow + 64 q.  A row at or beyond Cout has its vector offset beyond the tensor and
   // reads as zeros (the descriptor's range check sees the vector offset only: the K offset is the soffset)
@@ -209,6 +202,14 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
     for (int q = 0; q < QA * NV; ++q) YV4_W3_PIECE_A(0, 0, 0, q / NV, q % NV)
   }
   int n_g = 1, n_kh = 1, n_c0 = 0;           // G >= 3: group 1 is in the same tile
+  // ---- the layer's affine into LDS, once per workgroup -- behind the first fills' issue, so that its memory round trip
+  // runs beside theirs instead of in front of them ----
+  for (int c = tid; c < p.Cout; c += kWideThreads) {
+    aff[c] = p.s1[c];
+    aff[p.Cout + c] = p.t1[c];
+    aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
+    aff[3 * p.Cout + c] = has2 ? p.t2[c] : 0.f;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();              // (also publishes the affine)
 

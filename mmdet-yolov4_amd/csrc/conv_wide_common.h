@@ -78,7 +78,16 @@ __device__ __forceinline__ void wide_load_affine1(const float* aff, int Cout, in
 }
 
 // 16-bit: packed activation rows (act_row8), two 16-byte stores per pixel; the statistics are those of the STORED values
-template <bool BF16, int PT, bool SCATTER, int RD = (PT <= 6 ? PT : 4)>
+// RD = pixel tiles whose residual is requested ahead of their turn.  Requesting ALL of them before the first value is
+// finished was built on the hypothesis that a cold epilogue is PT memory round trips in a row; the stamps say it is not
+// (profiles/r06_w3_stamps_cold.txt: the same 17-40 k cycles either way -- it is the CU's ~24 GB/s to HBM), and the registers
+// it holds cost the network 0.7 % (profiles/r06_ab_wide_rd.txt: bf16 inference 4 780-4 800 with RD = PT, 4 814-4 822 with 1).
+#ifdef YV4_WIDE_RD_ALL         /* A/B build: RD = all tiles (four at eight pixel tiles) */
+#define YV4_WIDE_RD_DEFAULT(PT) ((PT) <= 6 ? (PT) : 4)
+#else
+#define YV4_WIDE_RD_DEFAULT(PT) 1
+#endif
+template <bool BF16, int PT, bool SCATTER, int RD = YV4_WIDE_RD_DEFAULT(PT)>
 __device__ __forceinline__ void wide_epilogue_h16(const ConvArgsH& p, const float* aff, bool has2, const wide_acc_t (&acc)[PT][4],
                                                   int mlane, int cl, int lane, unsigned replica) {
   typedef typename Elem<BF16>::V8 V8;
@@ -87,10 +96,7 @@ __device__ __forceinline__ void wide_epilogue_h16(const ConvArgsH& p, const floa
   const int ca = c_ok ? cl : 0;
   float s1[16], t1[16];
   wide_load_affine1(aff, p.Cout, ca, s1, t1);
-  // The residual of ALL the wave's pixel tiles is requested before the first value is finished: inside a network it comes
-  // from HBM (profiles/r06_w3_stamps_cold.txt: the epilogue of a 3x3 Bottleneck layer took 17-40 k cycles against 7-12 k with
-  // warm caches -- one memory round trip per pixel tile, PT of them in a row); the K loop's fragment registers are free here.
-  // (RD tiles ahead: all of them up to six pixel tiles, four at eight -- 64 more registers beside 128 accumulators spill)
+  // The residual of the next RD pixel tiles is requested ahead (RD = 1: tile by tile; see YV4_WIDE_RD_DEFAULT).
   constexpr int D = RD;
   V8 rres[D][2] = {};
 #define YV4_WIDE_RES_LOAD(pt_)                                                                        \
@@ -261,7 +267,11 @@ inline size_t wide_lds(bool k3, int pt, int wmv, int Cout) {
 template <class Args>
 inline int wide_pick(const Args& a, bool k3, bool charge_reads, double* rounds_eff) {
   const int cus = wide_cus();
+#ifdef YV4_WIDE_PICK_OLD        /* A/B build: the work model of rounds 4-5 for every kernel */
+  const bool time_model = false;
+#else
   const bool time_model = k3 && charge_reads;
+#endif
   int best = -1;
   double best_cost = 0.0, best_eff = 0.0;
   for (int i = 0; i < 5; ++i) {

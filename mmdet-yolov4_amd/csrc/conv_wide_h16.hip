@@ -117,12 +117,6 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv_wide_h16_kernel(ConvArgs
   const int NK = nchunks * ntaps;            // K tiles per output tile (chunk-major, taps inside)
 
   const bool has2 = p.s2 != nullptr;
-  for (int c = tid; c < p.Cout; c += kWideThreads) {
-    aff[c] = p.s1[c];
-    aff[p.Cout + c] = p.t1[c];
-    aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
-    aff[3 * p.Cout + c] = has2 ? p.t2[c] : 0.f;
-  }
 
   // issue-side walk: the K tile after the one being computed
   int n_vt = (int)blockIdx.x, n_k = 0, n_tap = 0, n_kh = 0, n_kw = 0, n_c0 = 0;
@@ -149,6 +143,13 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv_wide_h16_kernel(ConvArgs
 
   issue_tile_setup(n_vt);
   YV4_WG_ISSUE(0);
+  // the layer's affine into LDS behind the first fills' issue: its memory round trip runs beside theirs
+  for (int c = tid; c < p.Cout; c += kWideThreads) {
+    aff[c] = p.s1[c];
+    aff[p.Cout + c] = p.t1[c];
+    aff[2 * p.Cout + c] = has2 ? p.s2[c] : 1.f;
+    aff[3 * p.Cout + c] = has2 ? p.t2[c] : 0.f;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();              // (also publishes the affine)
 
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv_wide_h16_kernel(ConvArgs
     }
 
     // ---- epilogue (conv_wide_common.h): lane (fr, fq) owns pixel m0 + wm WMr + 16 pt + fr, channels cl .. cl + 15 ----
-    wide_epilogue_h16<BF16, PT, true, (PT <= 6 ? PT : 1)>(p, aff, has2, acc, m0 + wm * WMr + fr, n0 + wn * 64 + 16 * fq, lane,
+    wide_epilogue_h16<BF16, PT, true>(p, aff, has2, acc, m0 + wm * WMr + fr, n0 + wn * 64 + 16 * fq, lane,
                                       (unsigned)(tile_m * WAVES_M + wm));
   }
 #undef YV4_WG_ISSUE

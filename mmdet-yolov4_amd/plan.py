@@ -113,7 +113,7 @@ def pack_conv_weight(weight, cin_pad=None, align=4):
 
 
 _DCODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}      # YV4_F32 / YV4_F16 / YV4_BF16
-_PLAN_NT = os.environ.get('YV4_PLAN_NT', '1') != '0'                 # non-temporal output stores in 16-bit plans (ABI 7)
+_PLAN_NT = os.environ.get('YV4_PLAN_NT', '0') == '1'                 # non-temporal output stores in 16-bit plans (ABI 7): opt-in
 
 
 class Plan:
@@ -216,8 +216,9 @@ class Plan:
         d.act1, d.slope1 = act1
         d.act2, d.slope2 = act2 if s2 is not None else (0, 0.0)
         d.tile = tile
-        # inference plans in 16 bits: outputs with non-temporal stores (ABI 7; the wide-tile kernels have the form, the others
-        # ignore the flag; same bits).  YV4_PLAN_NT=0 switches it off (A/B).
+        # YV4_PLAN_NT=1: 16-bit inference plans write their outputs with non-temporal stores (ABI 7; the wide-tile kernels have
+        # the form, the others ignore the flag; same bits).  Off by default: round 5 measured +0.6-1.3 % with it, round 6 on
+        # other boxes -0.2 to -0.8 % (profiles/r06_ab_plan_nt.txt, r06_ab_wide_rd.txt) -- inside the box-to-box spread.
         if self.h16 and _PLAN_NT:
             d.flags = _lib.CONV_NT_OUT
         # everything the launch reads sits in one mutable record (calibrate.py swaps entries)
