@@ -348,3 +348,61 @@ def test_deferred_log_vars_wait_at_the_first_value_access():
     assert make() == want and make() == make() and 'loss_cls' in repr(make())
     assert [v for v in make().values()] == [1.5, 4.0]
     assert make(lambda c: [c[1], 1.0 / c[0]])['loss'] == 1.0 / 1.5          # a map from the copied floats to the values
+
+
+def test_fused_losses_mutation_takes_the_general_path():
+    """a detector or wrapper that adds an auxiliary loss to the fused head's loss mapping must see it in the
+    optimised total and in log_vars (detectors/base.py:171-204 sums every key containing 'loss'): any mutation builds the
+    mapping, which switches `_parse_losses` from the matrix's own total to the general sum."""
+    import torch
+    from mmdet_yolov4_amd.yolocsp_head import FusedLosses
+    from mmdet_yolov4_amd.single_stage import SingleStageDetector
+    w = torch.tensor([[1.0, 2.0, 3.0], [0.5, 0.25, 0.125]])
+    fl = FusedLosses(w, torch.tensor(7.0), with_cls=True)
+    assert not fl.built and float(fl.total) == 6.875
+    total, log_vars = SingleStageDetector._parse_losses(None, fl)          # fast path: the matrix's own sums
+    assert float(total) == 6.875 and not fl.built
+    assert dict(log_vars)['loss'] == 6.875 and dict(log_vars)['loss_conf'] == 2.25
+    for mutate in (lambda d: d.__setitem__('loss_aux', torch.tensor(10.0)), lambda d: d.update(loss_aux=torch.tensor(10.0)),
+                   lambda d: d.setdefault('loss_aux', torch.tensor(10.0))):
+        fl = FusedLosses(w, torch.tensor(7.0), with_cls=True)
+        mutate(fl)
+        assert fl.built and 'loss_aux' in fl and 'loss_cls' in fl
+        total, log_vars = SingleStageDetector._parse_losses(None, fl)
+        assert float(total) == 16.875 and dict(log_vars)['loss_aux'] == 10.0 and dict(log_vars)['loss'] == 16.875
+    fl = FusedLosses(w, torch.tensor(7.0), with_cls=True)
+    assert float(sum(fl.pop('loss_bbox')).sum()) == 3.125 and fl.built
+
+
+def test_marker_region_stats_cuts_the_last_steps_of_a_two_stream_trace(tmp_path):
+    """tools/summarize_prof.py: a kernel trace whose launch order is not periodic (weight gradients on a side stream) is cut at
+    the optimizer's once-per-step kernel."""
+    import importlib.util
+    import os
+    import sys
+    rows = ['Kernel_Name,Start_Timestamp,End_Timestamp']
+    t = 0
+    for step in range(5):
+        for k in range(3 + step % 2):                       # a varying number of launches per step
+            rows.append(f'yv4::conv_kernel,{t},{t + 10}')
+            t += 12
+        rows.append(f'yv4::sgd_step_kernel,{t},{t + 5}')
+        t += 7
+    f = tmp_path / 'x_kernel_trace.csv'
+    f.write_text('\n'.join(rows) + '\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = sys.argv
+    sys.argv = ['summarize_prof.py', '--r03', str(tmp_path / 'none'), str(tmp_path / 'out')]
+    try:
+        spec = importlib.util.spec_from_file_location('summarize_prof', os.path.join(root, 'tools', 'summarize_prof.py'))
+        mod = importlib.util.module_from_spec(spec)
+        try:
+            spec.loader.exec_module(mod)
+        except SystemExit:
+            pass
+    finally:
+        sys.argv = argv
+    out, info = mod.marker_region_stats(str(f), 2, 'sgd_step')
+    calls = {r[0]: r[1] for r in out}
+    assert calls['yv4::sgd_step_kernel'] == 2 and calls['yv4::conv_kernel'] == 4 + 3        # steps 3 and 4: 4 and 3 convs
+    assert info[0] == (2 + 7) // 2
