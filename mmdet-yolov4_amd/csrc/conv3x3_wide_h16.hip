@@ -19,22 +19,26 @@
 // CONSECUTIVE channels 16 fq .. 16 fq + 15 of its pixel -- two 16-byte stores, a full 128-byte line per pixel and wave,
 // no LDS transposition and no lane exchange in the epilogue.
 //
-// Pipeline.  Tiles are square in work, not in shape: BM = 16 PT WAVES_M pixels x BN = 64 (8 / WAVES_M) channels, chosen
-// per layer so that the tile count fills whole rounds of CUs (256 x 256 leaves 29 % of the chip idle on a 181-tile
-// layer; 192 x 256 makes it 241 tiles).  One workgroup barrier per K tile (one tap of one chunk); a buffer is re-filled
-// only in the K tile after the barrier that followed its last reads, a staged buffer is read only after the barrier
-// that followed its issuer's s_waitcnt.
+// Tiles are square in work, not in shape: BM = 16 PT WAVES_M pixels x BN = 64 (8 / WAVES_M) channels, chosen per layer by
+// a time model of a round of tiles (conv_wide_common.h: wide_pick).  Two weight slots, two pixel images; a buffer is
+// re-filled only after the barrier that followed its last reads, a staged buffer is read only after the barrier that
+// followed its issuer's s_waitcnt.
 //
-// Issue roles (round 6).  A K tile's LDS fill is 32-45 one-KB LDS-DMA pieces per workgroup, which the CU takes in at
-// ~33 cycles per piece: ~1 500 cycles during which an issuing wave sits in its vector-memory issue and multiplies
-// nothing.  With every wave issuing its share at the top of the K tile (rounds 4-5) all eight waves were parked there
-// together and the K tile cost fill time PLUS matrix time (3 650 cycles for 2 048 of MFMAs).  Now the two waves of a
-// SIMD (w and w + 4) have different jobs: waves 0-3 issue ALL the weight pieces of the next K tile first and multiply
-// afterwards; waves 4-7 multiply first and then issue ALL the pieces of the next (chunk, kh) group's pixel image, which
-// is not needed before the group ends (at kw = 0 and kw = 1, so that every piece has a K tile or more to land).  While
-// one wave of a SIMD is parked in its issue the other owns the matrix pipe, and the pieces with one K tile of slack
-// (the weights) are the ones issued early.  Per-piece offsets are a lane constant + scalar arithmetic (no per-piece
-// registers), and image pieces beyond the BM + 3 rows the fragments can touch are not issued at all.
+// Pipeline (round 6; DESIGN 9.2 has the measurements).  The two waves of a SIMD -- w and w + 4 -- take turns: a wave
+// alternates a LOAD interval (its LDS-DMA pieces; the fragment reads of SK k steps of 32 into registers; its waits) and an
+// MFMA interval (SK x 4 PT MFMAs back to back from registers, one per accumulator), waves 4-7 run one interval behind waves
+// 0-3, a workgroup barrier separates the intervals, and the groups are re-aligned around the epilogue (waves 4-7 enter a
+// tile one barrier late, waves 0-3 leave it one barrier late).  While one wave of a SIMD is parked in its vector-memory
+// issue (~100 cycles per 1 KB piece with four waves issuing: the CU takes in a piece per ~28 cycles) or waits for its
+// fragments, its partner owns the matrix pipe.  SK = 1 at eight pixel tiles per wave (the fragments of one k step are 48
+// registers beside 128 accumulators), 2 below.
+// Issue roles (the SK = 2 shapes): waves 0-3 issue every weight piece and confirm them at the end of their MFMA interval,
+// waves 4-7 issue every piece of the next (chunk, kh) group's pixel image and confirm them ONCE per group -- a wave's vmcnt
+// is one in-order counter, so a wave that confirmed weight pieces every K tile would give every older image piece one K
+// tile to land, whatever the schedule says.
+// Per-piece offsets are a lane constant + scalar arithmetic (no per-piece registers), the border masks are two registers,
+// the fragment addresses are computed where they are used (hoisted they were spilled and reloaded inside the K loop).
+// Same K order and epilogue as before: the same bits (tests/test_gpu_h16.py::test_wide3x3_matches_generic_bitwise).
 #include "conv_h16_common.h"
 #include "conv_wide_common.h"
 
