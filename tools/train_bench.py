@@ -136,7 +136,12 @@ def main():
     step_ms = []
     for _ in range(a.steps):
         ts = time.perf_counter()
-        l1 = step()                      # (returns the logged loss: one host synchronisation per step)
+        # step() returns the logged loss: the host waits there for the log variables' device-to-host copy, which is queued
+        # BETWEEN the forward and the backward pass -- i.e. the host is released when the device has finished step i's forward,
+        # with step i's backward + update still queued.  step_ms is therefore host wall time from one such point to the next: it
+        # equals the device's step time in the steady state (53-55 ms), can alternate short / long while the queue depth settles
+        # (rounds 4-5 printed 23 / 90 ms pairs summing to two steps), and says nothing a barrier-closed ms_per_step does not.
+        l1 = step()
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 1))
     D.barrier()
     el = D.max_over_ranks(time.perf_counter() - t0, dev)
