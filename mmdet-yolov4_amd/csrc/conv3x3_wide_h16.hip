@@ -62,6 +62,9 @@ template <> struct Mfma16<false> {
 #define YV4_W3_ABL 0
 #endif
 #define W3_ABL(BIT) ((YV4_W3_ABL & (BIT)) != 0)
+#ifndef YV4_W3_SPLIT
+#define YV4_W3_SPLIT 0                      // weight pieces the issuing role sends from its MFMA interval (0, or up to PT): 2 and 4 measured within 2 % of 0 (profiles/r06_w3_split_issue.txt)
+#endif
 #ifndef YV4_W3_ILV
 #define YV4_W3_ILV 0                        // 1: the issuing role interleaves its fragment reads with its pieces (measured: nothing, profiles/r06_w3_modes3.txt)
 #endif
@@ -278,6 +281,10 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
           }
           constexpr int NR = (4 + PT) * SK;                                   // fragment reads of the interval
           const int NPW = (ks0 == 0 && !W3_ABL(1)) ? PB * NV : 0;             // its weight pieces ...
+          // ... of which the last NPC go out in the MFMA interval, one behind each of its first MFMAs (YV4_W3_SPLIT: the
+          // issuing role's LOAD interval is its eight pieces; four of them under its own MFMAs cost the matrix pipe a bubble
+          // each but shorten the interval both SIMD partners wait for)
+          const int NPC = (ROLES && YV4_W3_SPLIT && NPW > 0) ? YV4_W3_SPLIT : 0;
           const int q0i = (kw == 0 ? 0 : QH) * NV;
           const int NPI = (ks0 + SK == 2 && kw < 2 && !W3_ABL(128)) ? (kw == 0 ? QH : QA - QH) * NV : 0;   // ... and image pieces
 #define YV4_W3_READ1(r)                                                                              \
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
           }
 #define YV4_W3_WEIGHT_PIECES                                                                         \
           if (issW) {                                                                                \
-            _Pragma("unroll") for (int q = 0; q < NPW; ++q) {                                        \
+            _Pragma("unroll") for (int q = 0; q < NPW - NPC; ++q) {                                  \
               if (kw < 2) YV4_W3_PIECE_B(slot ^ 1u, sB_cur, (unsigned)((((kh * 3 + kw + 1) * p.Cin) + c0) * 2), q / NV, q % NV) \
               else YV4_W3_PIECE_B(slot ^ 1u, sB_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 2), q / NV, q % NV) \
             }                                                                                        \
@@ -355,6 +362,13 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
               for (int i = 0; i < PT; ++i) {
                 if (!W3_ABL(2)) acc[i][t] = Mfma16<BF16>::run(wf[k][t], pf[k][i], acc[i][t]);
                 else asm volatile("" ::"v"(wf[k][t]), "v"(pf[k][i]));      // (ablation: the fragment reads stay)
+                if (NPC > 0 && k == 0 && t == 0 && i < NPC && issW) {
+                  const int q = NPW - NPC + i;
+                  __builtin_amdgcn_sched_barrier(0);
+                  if (kw < 2) YV4_W3_PIECE_B(slot ^ 1u, sB_cur, (unsigned)((((kh * 3 + kw + 1) * p.Cin) + c0) * 2), q / NV, q % NV)
+                  else YV4_W3_PIECE_B(slot ^ 1u, sB_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 2), q / NV, q % NV)
+                  __builtin_amdgcn_sched_barrier(0);
+                }
               }
           __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);

@@ -2,7 +2,7 @@
 # between launches) or every cache flushed (300 MB), back-to-back launches.   bash tools/ab_w3modes.sh "prev cur r0 r1"
 for L in ${1:-prev cur}; do
 case $L in
-prev) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_prev/libyv4_hip_prev.so;;
+prev) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_prev/libyv4_hip_prev.so YV4_LIB_ABI_ANY=1;;
 cur) unset YV4_LIB_PATH;;
 *) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_var/libyv4_w3_$L.so;;
 esac

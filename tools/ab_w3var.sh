@@ -3,7 +3,7 @@
 B=${2:-32}
 for L in $1; do
 case $L in
-prev) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_prev/libyv4_hip_prev.so;;
+prev) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_prev/libyv4_hip_prev.so YV4_LIB_ABI_ANY=1;;
 cur) unset YV4_LIB_PATH;;
 *) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_var/libyv4_w3_$L.so;;
 esac

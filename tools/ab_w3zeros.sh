@@ -1,7 +1,7 @@
 # DVFS check: the wide 3x3 16-bit layers on all-zero operands (the clock the chip holds on trivial data) beside random data
 for L in ${1:-prev cur}; do
 case $L in
-prev) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_prev/libyv4_hip_prev.so;;
+prev) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_prev/libyv4_hip_prev.so YV4_LIB_ABI_ANY=1;;
 cur) unset YV4_LIB_PATH;;
 *) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_var/libyv4_w3_$L.so;;
 esac
