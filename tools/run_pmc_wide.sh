@@ -21,6 +21,9 @@ for d in ('sq','sqf'):
     for k,v in by.items():
         g=v.get('GRBM_GUI_ACTIVE',0)
         if g<=0: continue
-        # SQ_VALU_MFMA_BUSY_CYCLES: summed over the SEs' SQs in quad-cycles per SIMD... report the raw ratio to GUI_ACTIVE and per CU-SIMD
-        print(d, k[1], k[2], {a:round(b) for a,b in v.items()}, 'mfma_busy/gui_active/1024simd=%.3f' % (v.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/g/1024.0))
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; busy share = MFMA busy cycles / (wall cycles x 1 024 SIMDs)
+        key=(k[1],k[2],round(v.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/1e6,1))
+        if key in seen: continue
+        seen.add(key)
+        print(d, k[1], k[2], {a:round(b) for a,b in v.items()}, 'busy share=%.3f' % (v.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/(g/8.0)/1024.0))
 PY
