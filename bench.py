@@ -501,8 +501,11 @@ def main():
                          'other\'s phases and kernel boundaries.  Measured (profiles/r06_two_stream_probe.txt, r06_ab_streams.txt): fp32 +0.9-2.2 %, '
                          'configs[3] -1 to +8 %, bf16 0, and the batch-16 launches fill the chip worse (dominant tile 0.79 -> 0.71 of its '
                          'roof) -- not the default')
-    ap.add_argument('--event-every', type=int, default=4,
-                    help='bracket the conv launches with HIP events in every n-th timed step (events cost ~2 %%)')
+    ap.add_argument('--event-every', type=int, default=10,
+                    help='bracket the conv launches with HIP events in every n-th timed step.  The two event records around a '
+                         'launch keep it from overlapping its neighbours: ~0.6 ms per instrumented step, i.e. with every 4th step '
+                         'instrumented 0.5 %% of the fp32 rate, 3 %% of the bf16 rate and 1.5 %% of configs[3]\'s '
+                         '(profiles/r06_ab_events.txt)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -587,6 +590,10 @@ def main():
             host_dets[sl].copy_(pl.post['dets'], non_blocking=True)
             host_labels[sl].copy_(pl.post['labels'], non_blocking=True)
             host_count[sl].copy_(pl.post['count'], non_blocking=True)
+    # (The copies on a stream of their own, ordered behind the step's last kernel by an event and ahead of the next step's
+    # post-processing by another, so that the next step's convs do not wait for three PCIe round trips: built and measured,
+    # bf16 -5 to -8 %, configs[3] -3.6 / +0.4 %, fp32 -0.3 % -- the cross-stream event waits cost more than the copies.
+    # profiles/r06_ab_copystream_dropped.txt)
 
     def step(events=None):
         if args.graph and events is None:
