@@ -27,6 +27,15 @@ typedef float f32x4f __attribute__((ext_vector_type(4)));
 
 constexpr int kF3BK = 32;          // channels per chunk = floats per 128-byte LDS row
 
+// Diagnostic build only (-DYV4_W3F_STAMP, tools/stamp_w3f.py): s_memtime sums per wave over the parts of a K tile and the
+// kernel's s_memrealtime span (the clock the chip holds), read back through yv4_debug_w3f_stamps.  No stamp executes in the product.
+#ifdef YV4_W3F_STAMP
+__device__ unsigned long long g_w3f_stamps[1024 * 8 * 8];
+#define YV4_W3F_ST(i) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); st_[i] += t__ - tl_; tl_ = t__; }
+#else
+#define YV4_W3F_ST(i)
+#endif
+
 template <int PT, int WAVES_M>
 __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes, int ntiles) {
   typedef f32x4f V8;                         // one fragment read: four K values of a row
@@ -41,6 +50,10 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
   char* Bs = smem_f3 + 2 * G_::ABytes;       // [2][BN][128 B]
   float* aff = reinterpret_cast<float*>(smem_f3 + G_::RingBytes);   // [s1 | t1 | s2 | t2] x Cout
 
+#ifdef YV4_W3F_STAMP
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,6 +166,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();              // (also publishes the affine)
 
+  YV4_W3F_ST(0)                              // (diagnostic build: the prologue)
   unsigned T_ = 0u, GG = 0u;                 // global K-tile / group counters: weight slot T_ & 1, image GG & 1
   for (int vt = (int)blockIdx.x; vt < ntiles; vt += nwg) {
     const unsigned tile = tile_of(vt);
@@ -182,6 +196,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
       for (int t = 0; t < 4; ++t) acc[pt][t] = f32x4f{0.f, 0.f, 0.f, 0.f};
 
     int c0 = 0, kh = 0;
+    YV4_W3F_ST(5)                            // tile set-up: masks, accumulators
     for (int g = 0; g < G; ++g) {
       const unsigned ab = GG & 1u;
 #pragma unroll
@@ -196,6 +211,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
         } else {
           YV4_W3_ISSUE_B(slot ^ 1u, b_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 4));
         }
+        YV4_W3F_ST(1)                        // the weight pieces' issue (and the group advance before it)
         V8 wf[4][2], pf[PH][2];
         // ---- phase 1: weights of channel tiles 0, 1, pixels of the first half
 #pragma unroll
@@ -275,10 +291,13 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // this wave's DMAs of the next K tile have landed (the next group's image, issued last at kw == 0, may still fly)
+        YV4_W3F_ST(2)                        // the four phases: fragment reads, MFMAs, image pieces
         if (kw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        YV4_W3F_ST(3)                        // counted wait
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        YV4_W3F_ST(4)                        // barrier
         T_ += 1u;
       }
       // ---- group advance: current <- next; the issue side moves on by one group (possibly into the next tile) ----
@@ -302,7 +321,15 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
     wide_epilogue_f32<PT, false>(p, aff, has2, acc, m0 + wm * WMr + pr, n0 + wn * 64 + 16 * fq, lane,
                                  (unsigned)(tile_m * WAVES_M + wm));
     c0 = 0; kh = 0;
+    YV4_W3F_ST(6)                            // epilogue
   }
+#ifdef YV4_W3F_STAMP
+  if (lane == 0 && blockIdx.x < 1024) {
+    st_[7] = __builtin_amdgcn_s_memrealtime() - rt0_;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_w3f_stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = st_[i];
+  }
+#endif
 #undef YV4_W3_ISSUE_A
 #undef YV4_W3_ISSUE_B
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-filling tail DMAs must land before the LDS is released
@@ -340,3 +367,11 @@ int conv3x3_wide_f32_launch(const ConvArgs& a, int shape, hipStream_t s) {
 }
 
 }  // namespace yv4
+
+#ifdef YV4_W3F_STAMP
+extern "C" int yv4_debug_w3f_stamps(unsigned long long* out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  const size_t bytes = sizeof(unsigned long long) * (size_t)(n < 1024 * 64 ? n : 1024 * 64);
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(yv4::g_w3f_stamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
