@@ -27,6 +27,14 @@ typedef float f32x4f __attribute__((ext_vector_type(4)));
 
 constexpr int kF3BK = 32;          // channels per chunk = floats per 128-byte LDS row
 
+// Diagnostic builds only (-DYV4_W3F_ABL=bits, tools/build_src_variants.sh): the K loop without one of its parts -- WRONG results
+// on purpose, timing only.  1: no image pieces, 2: no weight pieces, 4: fragment reads without the border select, 8: no
+// counted wait, 16: no barrier.  The product compiles with 0: every test below is a compile-time constant.
+#ifndef YV4_W3F_ABL
+#define YV4_W3F_ABL 0
+#endif
+#define W3F_ABL(BIT) ((YV4_W3F_ABL & (BIT)) != 0)
+
 // Diagnostic build only (-DYV4_W3F_STAMP, tools/stamp_w3f.py): s_memtime sums per wave over the parts of a K tile and the
 // kernel's s_memrealtime span (the clock the chip holds), read back through yv4_debug_w3f_stamps.  No stamp executes in the product.
 #ifdef YV4_W3F_STAMP
@@ -206,7 +214,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
         const char* bs_ = Bs + slot * G_::BBytes;
         const int tapbit = 3 * kh + kw;
         // ---- DMA of the next K tile's weights (other slot) and, at kw == 0, of the next group's image (other image)
-        if (kw < 2) {
+        if (W3F_ABL(2)) {
+        } else if (kw < 2) {
           YV4_W3_ISSUE_B(slot ^ 1u, b_cur, (unsigned)((((kh * 3 + kw + 1) * p.Cin) + c0) * 4));
         } else {
           YV4_W3_ISSUE_B(slot ^ 1u, b_nxt, (unsigned)((((n_kh * 3) * p.Cin) + n_c0) * 4));
@@ -220,12 +229,12 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
           for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
 #pragma unroll
         for (int i = 0; i < PH; ++i) {
-          const bool ok = (mask9[i] >> tapbit) & 1u;
+          const bool ok = W3F_ABL(4) || ((mask9[i] >> tapbit) & 1u);
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
             pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)(i * 2048) : zero_rd));
         }
-        if (kw == 0) YV4_W3_ISSUE_A(ab ^ 1u, 0, (QA + 1) / 2, n_kh, n_c0);
+        if (kw == 0 && !W3F_ABL(1)) YV4_W3_ISSUE_A(ab ^ 1u, 0, (QA + 1) / 2, n_kh, n_c0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
         for (int t = 2; t < 4; ++t)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
-        if (kw == 0) YV4_W3_ISSUE_A(ab ^ 1u, (QA + 1) / 2, QA, n_kh, n_c0);
+        if (kw == 0 && !W3F_ABL(1)) YV4_W3_ISSUE_A(ab ^ 1u, (QA + 1) / 2, QA, n_kh, n_c0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
         // ---- phase 3: pixels of the second half
 #pragma unroll
         for (int i = 0; i < PH; ++i) {
-          const bool ok = (mask9[PH + i] >> tapbit) & 1u;
+          const bool ok = W3F_ABL(4) || ((mask9[PH + i] >> tapbit) & 1u);
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
             pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)((PH + i) * 2048) : zero_rd));
@@ -292,10 +301,11 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
         __builtin_amdgcn_sched_barrier(0);
         // this wave's DMAs of the next K tile have landed (the next group's image, issued last at kw == 0, may still fly)
         YV4_W3F_ST(2)                        // the four phases: fragment reads, MFMAs, image pieces
-        if (kw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
+        if (W3F_ABL(8)) {
+        } else if (kw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         YV4_W3F_ST(3)                        // counted wait
-        __builtin_amdgcn_s_barrier();
+        if (!W3F_ABL(16)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         YV4_W3F_ST(4)                        // barrier
         T_ += 1u;
