@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   extern __shared__ __attribute__((aligned(16))) char smem_f3[];
-  char* As = smem_f3;                        // [2][ARows][128 B]
+  // smem_f3: [2][ARows][128 B] pixel images, then
   char* Bs = smem_f3 + 2 * G_::ABytes;       // [2][BN][128 B]
   float* aff = reinterpret_cast<float*>(smem_f3 + G_::RingBytes);   // [s1 | t1 | s2 | t2] x Cout
 
@@ -126,7 +126,6 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a_rd[kw][ks] = (unsigned)(row * kRowB + (((fq + 4 * ks) ^ ((row >> 1) & 7)) << 4));
   }
-  const unsigned zero_rd = (unsigned)(G_::ZeroRow * kRowB);
   unsigned w_rd[2];                          // weight fragments: k step; + t * 512 per channel tile
   {
     const int row = wn * 64 + 16 * (fr >> 2) + (fr & 3);
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
     const int tile_m = (int)(tile / (unsigned)p.tiles_n);
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
-    unsigned mask9[PT];
+    unsigned nmask9[PT];                     // bit 3 kh + kw SET: that tap of the lane's pixel in tile pt lies outside the image
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const int m = m0 + wm * WMr + 16 * pt + pr;
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
         const int wo = rm - ho * p.W;
         mk = (unsigned)tap_mask(ho - 1, wo - 1, 3, 3, p.H, p.W);
       }
-      mask9[pt] = mk;
+      nmask9[pt] = ~mk;
     }
     f32x4f acc[PT][4];
 #pragma unroll
@@ -210,7 +209,13 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const unsigned slot = T_ & 1u;
-        const char* as_ = As + ab * G_::ABytes;
+        // pixel fragments: LDS address of tap kw's row for k step ks in this group's image; + 2048 per pixel tile.  A lane whose
+        // tap lies outside the image reads 1 MB further on, beyond the workgroup's LDS allocation, which returns zeros
+        // (wide_far_add, conv_wide_common.h): one add per read instead of a select between the row and a row of zeros
+        // (profiles/r06_w3_border_select.txt: the select was 3 % of this kernel, 6-9 % of the 16-bit one)
+        unsigned ard[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) ard[ks] = a_rd[kw][ks] + (lds_base + ab * (unsigned)G_::ABytes);
         const char* bs_ = Bs + slot * G_::BBytes;
         const int tapbit = 3 * kh + kw;
         // ---- DMA of the next K tile's weights (other slot) and, at kw == 0, of the next group's image (other image)
@@ -229,10 +234,10 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
           for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks] + t * 512);
 #pragma unroll
         for (int i = 0; i < PH; ++i) {
-          const bool ok = W3F_ABL(4) || ((mask9[i] >> tapbit) & 1u);
+          const unsigned nb = W3F_ABL(4) ? 0u : wide_far_bit(nmask9[i], tapbit);
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
-            pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)(i * 2048) : zero_rd));
+            pf[i][ks] = wide_lds_read<V8>((W3F_ABL(4) ? ard[ks] : wide_far_add_bit(nb, ard[ks])) + (unsigned)(i * 2048));
         }
         if (kw == 0 && !W3F_ABL(1)) YV4_W3_ISSUE_A(ab ^ 1u, 0, (QA + 1) / 2, n_kh, n_c0);
         __builtin_amdgcn_sched_barrier(0);
@@ -270,10 +275,10 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_f32_kernel(ConvA
         // ---- phase 3: pixels of the second half
 #pragma unroll
         for (int i = 0; i < PH; ++i) {
-          const bool ok = W3F_ABL(4) || ((mask9[PH + i] >> tapbit) & 1u);
+          const unsigned nb = W3F_ABL(4) ? 0u : wide_far_bit(nmask9[PH + i], tapbit);
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
-            pf[i][ks] = *reinterpret_cast<const V8*>(as_ + (ok ? a_rd[kw][ks] + (unsigned)((PH + i) * 2048) : zero_rd));
+            pf[i][ks] = wide_lds_read<V8>((W3F_ABL(4) ? ard[ks] : wide_far_add_bit(nb, ard[ks])) + (unsigned)((PH + i) * 2048));
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);

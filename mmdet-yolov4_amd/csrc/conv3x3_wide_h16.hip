@@ -57,7 +57,8 @@ template <> struct Mfma16<false> {
 
 // Compile-time ablation (-DYV4_W3_ABL=bits, tools/abl_w3.sh: one library per variant, no run-time branch in any timed
 // kernel -- the run-time switches of the measurement build cost this loop more than the parts they remove): 1 no weight
-// DMA in the loop, 128 no image DMA, 2 no MFMA, 4 no barrier, 8 no fragment reads, 16 no epilogue.  Wrong results on purpose.
+// DMA in the loop, 128 no image DMA, 2 no MFMA, 4 no barrier, 8 no fragment reads, 16 no epilogue, 32 fragment reads without the
+// border select.  Wrong results on purpose.
 #ifndef YV4_W3_ABL
 #define YV4_W3_ABL 0
 #endif
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   extern __shared__ __attribute__((aligned(16))) char smem_w3[];
-  char* As = smem_w3;                        // [2][ARows][128 B]
+  // smem_w3: [2][ARows][128 B] pixel images, then
   char* Bs = smem_w3 + 2 * G_::ABytes;       // [2][BN][128 B]
   float* aff = reinterpret_cast<float*>(smem_w3 + G_::RingBytes);   // [s1 | t1 | s2 | t2] x Cout
 
@@ -166,7 +167,6 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
   // swizzle -- computed where it is used (six loop-invariant addresses and their 6 PT sums with 2048 pt would otherwise be
   // hoisted out of the loops and spilled by the epilogue's register pressure, to be reloaded INSIDE the K loop)
   const int arow0 = wm * WMr + pr;
-  const unsigned zero_rd = (unsigned)(G_::ZeroRow * kRowB);
   unsigned w_rd[2];                          // weight fragments: k step; + t * 512 per channel tile
   {
     const int row = wn * 64 + 16 * (fr >> 2) + (fr & 3);
@@ -259,7 +259,6 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const unsigned slot = T_ & 1u;
-        const char* as_ = As + ab * G_::ABytes;
         const char* bs_ = Bs + slot * G_::BBytes;
         const unsigned okm = (rowm >> kh) & (colm >> kw);      // bit 3 pt: tap (kh, kw) of pixel tile pt is inside
 #pragma unroll
@@ -277,8 +276,13 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
             int arow = arow0;
             asm volatile("" : "+v"(arow));
             arow += kw;
-            ard[k] = (unsigned)(arow * kRowB + (((fq + 4 * (ks0 + k)) ^ ((arow >> 1) & 7)) << 4));
+            ard[k] = (unsigned)(arow * kRowB + (((fq + 4 * (ks0 + k)) ^ ((arow >> 1) & 7)) << 4)) + (lds_base + ab * (unsigned)G_::ABytes);
           }
+          // Border taps: a lane whose tap lies outside the image reads BEYOND the workgroup's LDS allocation, which returns
+          // zeros (tools/microbench/lds_oob_read.hip) -- one add per read (bit 3 pt of `nokm` shifted to 1 MB) instead of a
+          // select between the pixel's row and a row of zeros.  The select was 9-14 % of this kernel: its VALU work sits in
+          // the LOAD interval, the longer of the two (profiles/r06_w3_border_select.txt).
+          const unsigned nokm = ~okm;
           constexpr int NR = (4 + PT) * SK;                                   // fragment reads of the interval
           const int NPW = (ks0 == 0 && !W3_ABL(1)) ? PB * NV : 0;             // its weight pieces ...
           // ... of which the last NPC go out in the MFMA interval, one behind each of its first MFMAs (YV4_W3_SPLIT: the
@@ -293,8 +297,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
             if (j_ < 4) {                                                                            \
               wf[k_][j_] = *reinterpret_cast<const V8*>(bs_ + w_rd[ks0 + k_] + j_ * 512);            \
             } else {                                                                                 \
-              const bool ok = (okm >> (3 * (j_ - 4))) & 1u;                                          \
-              pf[k_][j_ - 4] = *reinterpret_cast<const V8*>(as_ + (ok ? ard[k_] + (unsigned)((j_ - 4) * 2048) : zero_rd)); \
+              const unsigned ad_ = W3_ABL(32) ? ard[k_] : wide_far_add(nokm, 3 * (j_ - 4), ard[k_]);   /* (32: no border handling) */ \
+              pf[k_][j_ - 4] = wide_lds_read<V8>(ad_ + (unsigned)((j_ - 4) * 2048));   /* (ard holds LDS addresses) */               \
             }                                                                                        \
           }
 #define YV4_W3_WEIGHT_PIECES                                                                         \

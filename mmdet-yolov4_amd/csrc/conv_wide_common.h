@@ -30,6 +30,38 @@ template <int PT, int WAVES_M, bool K3> struct WideGeom {
 // swizzle of the weight image: the 16 lanes of a ds_read_b128 group read rows {R..R+3, R+48..R+51} at chunk q and
 // {R+16..R+19, R+32..R+35} at chunk q + 1 (the kernels' channel permutation), which (row >> 1) & 7 would fold onto
 // each other
+// Border taps of the kw-shared 3x3 kernels: `addr` + 1 MB when bit `pos` of `nokm` is set.  A ds_read beyond the workgroup's
+// LDS allocation returns zeros (tools/microbench/lds_oob_read.hip), so a lane whose tap lies outside the image needs no
+// select between its row and a row of zeros -- one v_bfe_u32 per pixel tile and one v_lshl_add_u32 per read (plain C++ is
+// canonicalised into shift + and + add, two instructions more per pixel tile).
+template <typename T = void>
+__device__ __forceinline__ unsigned wide_far_add(unsigned nokm, int pos, unsigned addr) {
+  unsigned b, r;
+  asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(b) : "v"(nokm), "n"(pos));
+  asm("v_lshl_add_u32 %0, %1, 20, %2" : "=v"(r) : "v"(b), "v"(addr));
+  return r;
+}
+
+// a 16-byte fragment at LDS byte address `addr` (may lie beyond the allocation: zeros)
+template <typename V>
+__device__ __forceinline__ V wide_lds_read(unsigned addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) V*>(static_cast<uintptr_t>(addr));
+}
+
+// the same with the bit position in a register or scalar (the fp32 kernel's tap bit 3 kh + kw)
+template <typename T = void>
+__device__ __forceinline__ unsigned wide_far_bit(unsigned nokm, int pos) {
+  unsigned b;
+  asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(b) : "v"(nokm), "s"(pos));
+  return b;
+}
+template <typename T = void>
+__device__ __forceinline__ unsigned wide_far_add_bit(unsigned b, unsigned addr) {
+  unsigned r;
+  asm("v_lshl_add_u32 %0, %1, 20, %2" : "=v"(r) : "v"(b), "v"(addr));
+  return r;
+}
+
 __device__ __forceinline__ int wide_swz_b(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
 
 // ---- epilogue, shared by the general and the 3x3 kernel of a precision -------------------------------------------------
