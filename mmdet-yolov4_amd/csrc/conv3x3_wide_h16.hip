@@ -9,8 +9,8 @@
 // accumulator tiles of 16 x 16, so a 64-deep K tile is 2 PT x 4 MFMAs of 16 pipe cycles fed by 2 PT + 8 fragment
 // reads (0.75 reads per 32 pipe cycles at PT = 8), and its LDS-DMA fill per FLOP halves (the weight tile of a tap is
 // shared by twice the pixels).  What it keeps from the ping-pong kernel: the three kw taps of a (64-channel chunk, kh)
-// group read ONE LDS image of the BM + 2 source pixels (fragment row = output row + kw, image borders masked by
-// redirecting a lane's read to a zero row), out-of-range DMA offsets as the zero padding, a persistent grid whose
+// group read ONE LDS image of the BM + 2 source pixels (fragment row = output row + kw; a lane whose tap lies outside the
+// image reads beyond the workgroup's LDS allocation, which returns zeros), out-of-range DMA offsets as the zero padding, a persistent grid whose
 // issue side runs on across tiles.
 //
 // Operand roles.  The MFMA's A operand (16 rows) is the WEIGHT tile, its B operand (16 columns) the pixels, so a lane

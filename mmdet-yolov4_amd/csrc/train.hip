@@ -939,7 +939,8 @@ constexpr int kW3LdsV2 = kW3Lds + kW3NBuf * 64;
 #define YV4_W3V2_STAGGER 1     // build-time A/B (tools/ab_prev.sh): 0 = all eight waves issue DMA(sl + 3) at the same point
 #endif
 // ABL (measurement build only, compile-time so that the timed kernel carries no extra branches): 1 no DMA inside the loop,
-// 2 no workgroup barrier, 4 no MFMAs, 8 no fragment reads -- wrong results on purpose, to time the kernel without a part
+// 2 no workgroup barrier, 4 no MFMAs, 8 no fragment reads, 16 no border masks on the image reads -- wrong results on purpose, to
+// time the kernel without a part
 template <bool BF16, int ABL = 0>
 __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_v2_h16_kernel(WgradArgs p, unsigned x_bytes, unsigned dy_bytes) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1074,8 +1075,8 @@ __global__ __launch_bounds__(kW3Threads, 2) void conv_wgrad3x3_v2_h16_kernel(Wgr
     const unsigned fw_ = (unsigned)((FL) >> (((S) >> 1) * 32));                                               \
     const int zb_ = (BO) + kZeroRd;                                                                           \
     _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                        \
-      const int f0_ = (int)((fw_ >> ((((S) & 1) * 2 + 0) * 8 + kw)) & 1u);                                    \
-      const int f1_ = (int)((fw_ >> ((((S) & 1) * 2 + 1) * 8 + kw)) & 1u);                                    \
+      const int f0_ = (ABL & 16) ? 1 : (int)((fw_ >> ((((S) & 1) * 2 + 0) * 8 + kw)) & 1u);                   \
+      const int f1_ = (ABL & 16) ? 1 : (int)((fw_ >> ((((S) & 1) * 2 + 1) * 8 + kw)) & 1u);                   \
       const int r0_ = __mul24(f0_, b_dlt[0][kw][S]) + zb_;                                   \
       const int r1_ = __mul24(f1_, b_dlt[1][kw][S]) + zb_;                                   \
       const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(smem_w3b + r0_));                 \
@@ -3406,7 +3407,7 @@ static int wgrad_impl(const yv4_conv_desc* d, int dtype, const void* x, const vo
         YV4_CHECK_LAUNCH("w3v2 abl");                                                                                  \
         return finish();                                                                                               \
       }
-      YV4_W3ABL(1) YV4_W3ABL(2) YV4_W3ABL(3) YV4_W3ABL(4) YV4_W3ABL(8) YV4_W3ABL(12) YV4_W3ABL(5) YV4_W3ABL(13) YV4_W3ABL(15)
+      YV4_W3ABL(1) YV4_W3ABL(2) YV4_W3ABL(3) YV4_W3ABL(4) YV4_W3ABL(8) YV4_W3ABL(12) YV4_W3ABL(5) YV4_W3ABL(13) YV4_W3ABL(15) YV4_W3ABL(16)
 #undef YV4_W3ABL
 #endif
       if (dtype == YV4_BF16)
