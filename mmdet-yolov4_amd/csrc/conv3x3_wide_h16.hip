@@ -167,6 +167,23 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
   // swizzle -- computed where it is used (six loop-invariant addresses and their 6 PT sums with 2048 pt would otherwise be
   // hoisted out of the loops and spilled by the epilogue's register pressure, to be reloaded INSIDE the K loop)
   const int arow0 = wm * WMr + pr;
+#ifndef YV4_W3_HOIST
+#define YV4_W3_HOIST 1
+#endif
+  // the six fragment row addresses (tap kw, k step) in registers where six pixel tiles per wave leave room for them (253 of
+  // 256, nothing spilled -- before the border select went, 9.6d, the same six were spilled by the epilogue's pressure and
+  // reloaded inside the K loop); computed in the LOAD interval otherwise.  0-3 % per layer (profiles/r06_w3_hoist.txt)
+  constexpr bool HOIST = YV4_W3_HOIST != 0 && PT <= 6;
+  unsigned a_rd6[3][2];
+  if (HOIST) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int arow = arow0 + kw;
+        a_rd6[kw][ks] = (unsigned)(arow * kRowB + (((fq + 4 * ks) ^ ((arow >> 1) & 7)) << 4)) + lds_base;
+      }
+  }
   unsigned w_rd[2];                          // weight fragments: k step; + t * 512 per channel tile
   {
     const int row = wn * 64 + 16 * (fr >> 2) + (fr & 3);
@@ -276,7 +293,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void conv3x3_wide_h16_kernel(ConvA
             int arow = arow0;
             asm volatile("" : "+v"(arow));
             arow += kw;
-            ard[k] = (unsigned)(arow * kRowB + (((fq + 4 * (ks0 + k)) ^ ((arow >> 1) & 7)) << 4)) + (lds_base + ab * (unsigned)G_::ABytes);
+            ard[k] = HOIST ? a_rd6[kw][ks0 + k] + ab * (unsigned)G_::ABytes
+                           : (unsigned)(arow * kRowB + (((fq + 4 * (ks0 + k)) ^ ((arow >> 1) & 7)) << 4)) + (lds_base + ab * (unsigned)G_::ABytes);
           }
           // Border taps: a lane whose tap lies outside the image reads BEYOND the workgroup's LDS allocation, which returns
           // zeros (tools/microbench/lds_oob_read.hip) -- one add per read (bit 3 pt of `nokm` shifted to 1 MB) instead of a

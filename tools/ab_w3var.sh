@@ -1,12 +1,17 @@
-# same-box comparison of builds of the wide 3x3 16-bit kernel per layer and tile shape: lib_prev, lib and lib_var/libyv4_w3_<name>.so
-# bash tools/ab_w3var.sh "prev cur sk1 sk2" [batch] [extra conv_bench arguments]
-B=${2:-32}
-for L in $1; do
-case $L in
-prev) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_prev/libyv4_hip_prev.so YV4_LIB_ABI_ANY=1;;
-cur) unset YV4_LIB_PATH;;
-*) export YV4_LIB_PATH=$PWD/mmdet-yolov4_amd/lib_var/libyv4_w3_$L.so;;
-esac
-echo "== $L batch $B $3  (columns: auto shape, then shapes 256x256, 192x256, 128x256, 384x128, 256x128)"
-python tools/conv_bench.py --dtype bf16 --batch $B --tiles 5,13,21,29,37,45 --filter k3s1 --reps 7 $3 2>&1 | grep -v "^3->\|^32->\|^64->\|amdgpu.ids\|weighted" | sed 's/h16_w3x3: *//g;s/best=.*//' | cut -c1-200
-done
+#!/bin/bash
+# 16-bit wide 3x3 kernel: variants from lib_var (tools/build_src_variants.sh name:conv3x3_wide_h16:flags) against the product, per
+# layer and in the network, same box.   VARS="name ..." (lib_var/libyv4_<name>.so)
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
+cd "$GRAFT_REPO_ROOT"
+L=$GRAFT_REPO_ROOT/mmdet-yolov4_amd/lib_var
+VARS=${VARS:?VARS="name ..."}
+for i in 1 2; do
+for v in product $VARS; do
+unset YV4_LIB_PATH; [ $v != product ] && export YV4_LIB_PATH=$L/libyv4_$v.so
+echo "--- $v"; python tools/conv_bench.py --dtype bf16 --filter k3s1 --tiles 5 --reps 5 2>/dev/null | grep "@" | grep -v "inf"
+done; done
+for i in 1 2; do
+for v in product $VARS; do
+unset YV4_LIB_PATH; [ $v != product ] && export YV4_LIB_PATH=$L/libyv4_$v.so
+echo -n "bf16 inference $v: "; python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-train 2>/dev/null | python tools/last_json.py roofline.frac output_check
+done; done
