@@ -43,6 +43,7 @@ def main():
     ap.add_argument('--flush-mb', type=int, default=0, help='overwrite a buffer of this many MB before every timed launch (64: the '
                     'per-XCD L2s forget the layer, the memory-side cache keeps it: the state a layer meets inside a network)')
     ap.add_argument('--res', action='store_true', help='with a residual tensor added in the epilogue (the Bottleneck 3x3 layers)')
+    ap.add_argument('--shape', action='append', default=[], help='cin,cout,k,stride,hin: time this shape instead of the YOLOv4-L table (repeatable)')
     ap.add_argument('--zeros', action='store_true', help='all-zero operands: the clock the chip holds on trivial data (DVFS check)')
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(',')]
@@ -53,7 +54,8 @@ def main():
     rows = []
     tot = {t: 0.0 for t in tiles}
     best_tot = 0.0
-    for (cin, cout, k, s, h, cnt) in SHAPES:
+    shapes = [tuple(int(v) for v in sh.split(',')) + (1,) for sh in a.shape] or SHAPES
+    for (cin, cout, k, s, h, cnt) in shapes:
         tag = f'{cin}->{cout} k{k}s{s} @{h}'
         if a.filter and a.filter not in tag:
             continue
