@@ -374,11 +374,11 @@ int yv4_bn_act_bwd(const float* x, int x_cstride, int x_coff, const float* dy, i
  * tiles.  (Id 5, the 256 x 64 form of round 2's non-persistent kernel, is gone and refused.) */
 #define YV4_HTILE_PP3x3 4
 /* 3x3 / stride 1 / pad 1 with Cin % 64 == 0 and Cout % 16 == 0 on WIDE wave tiles (16 PT pixels x 64 channels per wave on
- * v_mfma_f32_16x16x32, PT = 4 / 6 / 8; workgroup tiles 256 x 256, 192 x 256, 128 x 256, 384 x 128 or 256 x 128 chosen
+ * v_mfma_f32_16x16x32, PT = 2 / 3 / 4 / 6 / 8; workgroup tiles 256 x 256, 192 x 256, 128 x 256, 384 x 128, 256 x 128, 384 x 64 or 256 x 64 chosen
  * per layer so that whole rounds of CUs are filled; csrc/conv3x3_wide_h16.hip).  Same K order and epilogue expressions
  * as the other tiles; measured bit-identical to them (tests/test_gpu_h16.py::test_wide3x3_matches_generic_bitwise). */
 #define YV4_HTILE_W3x3 5
-/* ... with the tile shape forced (i = 0..4: 256 x 256, 192 x 256, 128 x 256, 384 x 128, 256 x 128): tests, tile sweeps */
+/* ... with the tile shape forced (i = 0..6: 256 x 256, 192 x 256, 128 x 256, 384 x 128, 256 x 128, 384 x 64, 256 x 64): tests, tile sweeps */
 #define YV4_HTILE_W3x3_SHAPE(i) (5 + 8 * ((i) + 1))
 /* The same wave tiles as a general implicit GEMM (any kernel size / stride / padding with Cin % 64 == 0, Cout % 16 == 0,
  * 16-bit output; a K tile = one (64-channel chunk, tap) gathered with the tap's offset): the stride-2 3x3 layers, the deep

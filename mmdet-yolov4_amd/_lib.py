@@ -24,9 +24,9 @@ NMS_IOU_DIV, NMS_IOU_MUL = 0, 1
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4
 TILE_DMA_64x64, TILE_DMA_128x64, TILE_DMA_128x128, TILE_STEM, TILE_WS_1x1 = 5, 6, 7, 8, 9
 HTILE_NAMES = {1: 'h16_128x128', 2: 'h16_128x64', 3: 'h16_64x64', 4: 'h16_pp3x3', 5: 'h16_w3x3', 6: 'h16_ws_1x1', 7: 'h16_s3x3', 8: 'h16_wide'}
-# the pinned workgroup-tile shapes YV4_HTILE_W3x3_SHAPE(i) = 13, 21, .. 45 and YV4_HTILE_WIDE_SHAPE(i) = 16, 24, .. 48 (tests,
+# the pinned workgroup-tile shapes YV4_HTILE_W3x3_SHAPE(i) = 13, 21, .. 61 (i = 0 .. 6) and YV4_HTILE_WIDE_SHAPE(i) = 16, 24, .. 48 (tests,
 # tile sweeps): same kernels, same names
-HTILE_NAMES.update({5 + 8 * (i + 1): 'h16_w3x3' for i in range(5)})
+HTILE_NAMES.update({5 + 8 * (i + 1): 'h16_w3x3' for i in range(7)})
 HTILE_NAMES.update({8 + 8 * (i + 1): 'h16_wide' for i in range(5)})
 TILE_NAMES = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '64x128', 5: 'dma64x64', 6: 'dma128x64',
               7: 'dma128x128', 8: 'stem3x3', 9: 'ws_1x1', 10: 'w3x3', 26: 'w3x3', 42: 'w3x3', 58: 'w3x3', 74: 'w3x3', 90: 'w3x3',

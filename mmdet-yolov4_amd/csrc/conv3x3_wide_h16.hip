@@ -463,11 +463,11 @@ static int launch_w3(const ConvArgsH& a, hipStream_t stream) {
 
 // Tile shape per layer and launch: conv_wide_common.h.  pick() returns an index into kWideShapes, or -1 when no shape
 // fits (LDS) -- `shape` >= 0 forces one (measurement / tests).
-int conv3x3_wide_h16_pick(const ConvArgsH& a, double* rounds_eff) { return wide_pick(a, true, true, rounds_eff); }
+int conv3x3_wide_h16_pick(const ConvArgsH& a, double* rounds_eff) { return wide_pick(a, true, true, rounds_eff, kWideShapes3x3H); }
 
 int conv3x3_wide_h16_launch(const ConvArgsH& a, bool bf16, int shape, hipStream_t s) {
   if (shape < 0) shape = conv3x3_wide_h16_pick(a, nullptr);
-  if (!wide_shape_fits("conv3x3_wide_h16", true, shape, a.Cout)) return YV4_E_UNSUPPORTED;
+  if (!wide_shape_fits("conv3x3_wide_h16", true, shape, a.Cout, kWideShapes3x3H)) return YV4_E_UNSUPPORTED;
 #define YV4_W3_CASE(I, PT_, WM_) case I: return bf16 ? launch_w3<true, PT_, WM_>(a, s) : launch_w3<false, PT_, WM_>(a, s);
   switch (shape) {
     YV4_W3_CASE(0, 8, 2)
@@ -475,6 +475,8 @@ int conv3x3_wide_h16_launch(const ConvArgsH& a, bool bf16, int shape, hipStream_
     YV4_W3_CASE(2, 4, 2)
     YV4_W3_CASE(3, 6, 4)
     YV4_W3_CASE(4, 4, 4)
+    YV4_W3_CASE(5, 3, 8)
+    YV4_W3_CASE(6, 2, 8)
     default: break;
   }
 #undef YV4_W3_CASE

@@ -396,10 +396,14 @@ static bool prefer_w3(const ConvArgsH& a) {
   static const int min_out = YV4_ENV_INT("YV4_W3_MINOUT", 32768);
   // (64 input channels -- one chunk, nine K tiles per output tile -- only with a full 128-channel tile of outputs:
   // YOLOv4-S 64 -> 128 @52 at batch 256 143 us against 193 on the 128 x 64 tile, 64 -> 64 122 against 108)
-  if (!mode || !conv3x3_wide_h16_applies(a) || a.Cin < 64 || (a.Cin < 128 && a.Cout < 128)) return false;
+  if (!mode || !conv3x3_wide_h16_applies(a) || a.Cin < 64) return false;
   if ((long long)a.M * a.Cout < 256LL * min_out) return false;
   double eff = 0.0;
   if (conv3x3_wide_h16_pick(a, &eff) < 0) return false;
+  // 64 input channels (one chunk, nine K tiles per output tile): whatever the rounds -- the alternatives are the 128 x 64
+  // tile and the few-channel kernel, 15-25 % behind on these layers at any fill (64 -> 64 on the 384 x 64 shape: @52 batch
+  // 256 92 us against 113, @152 batch 32 94 against 116; 64 -> 128 @52 143 against 193; profiles/r06_w3_bn64.txt)
+  if (a.Cin < 128) return true;
   if (eff * 100.0 <= 100.0 + waste) return true;
   // A worse fill still wins where the alternative is the ping-pong kernel, whose 256 x 128 tiles quantise the same way
   // (YOLOv5-L at 640: 256->256 @40 is 800 such tiles = 3.1 rounds for either kernel; train step 1 045 -> 1 063, bf16
@@ -547,7 +551,7 @@ static int conv_h16_impl(const yv4_conv_desc* d, int dtype, int out_dtype, const
   a.stats = stats;
   const bool general = (d->Cin % kHBK) != 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int w3_forced = (d->tile > 8 && (d->tile & 7) == YV4_HTILE_W3x3 && d->tile <= YV4_HTILE_W3x3_SHAPE(4)) ? (d->tile >> 3) - 1 : -1;
+  const int w3_forced = (d->tile > 8 && (d->tile & 7) == YV4_HTILE_W3x3 && d->tile <= YV4_HTILE_W3x3_SHAPE(6)) ? (d->tile >> 3) - 1 : -1;
   if (d->tile == YV4_HTILE_W3x3 || w3_forced >= 0)
     YV4_REQUIRE(conv3x3_wide_h16_applies(a), "conv h16: the wide 3x3 tile needs a 3x3 / stride 1 / pad 1 conv with Cin %% 64 == 0, "
                 "Cout %% 16 == 0 (64 .. 1024), 16-bit output and 8-aligned channel strides / offsets");

@@ -262,9 +262,11 @@ __device__ __forceinline__ void wide_epilogue_f32(const ConvArgs& p, const float
 
 // ---- host side --------------------------------------------------------------------------------------------------------
 // Tile shapes (pixel tiles per wave, waves along M): (8,2) 256 x 256, (6,2) 192 x 256, (4,2) 128 x 256, (6,4) 384 x 128,
-// (4,4) 256 x 128.  The ids are part of the boundary (YV4_TILE_* shape arguments, include/yv4.h).
+// (4,4) 256 x 128; the 16-bit 3x3 kernel also (3,8) 384 x 64 and (2,8) 256 x 64 for layers with 64 output channels.  The ids
+// are part of the boundary (YV4_TILE_* shape arguments, include/yv4.h).
 struct WideShape { int pt, wm; };
-static const WideShape kWideShapes[5] = {{8, 2}, {6, 2}, {4, 2}, {6, 4}, {4, 4}};
+constexpr int kWideShapesGeneral = 5, kWideShapes3x3H = 7;
+static const WideShape kWideShapes[7] = {{8, 2}, {6, 2}, {4, 2}, {6, 4}, {4, 4}, {3, 8}, {2, 8}};
 
 inline int wide_cus() {
   static std::atomic<int> g{0};
@@ -297,7 +299,7 @@ inline size_t wide_lds(bool k3, int pt, int wmv, int Cout) {
 // (14, 0.311) at eight pixel tiles per wave, (10, 0.353) at six, (4.5, 0.417) at four -- the big wave tile has the
 // cheapest K loop and the most expensive epilogue.  *rounds_eff keeps its meaning (tile work incl. the old read weights).
 template <class Args>
-inline int wide_pick(const Args& a, bool k3, bool charge_reads, double* rounds_eff) {
+inline int wide_pick(const Args& a, bool k3, bool charge_reads, double* rounds_eff, int nshapes = kWideShapesGeneral) {
   const int cus = wide_cus();
 #ifdef YV4_WIDE_PICK_OLD        /* A/B build: the work model of rounds 4-5 for every kernel */
   const bool time_model = false;
@@ -306,18 +308,18 @@ inline int wide_pick(const Args& a, bool k3, bool charge_reads, double* rounds_e
 #endif
   int best = -1;
   double best_cost = 0.0, best_eff = 0.0;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < nshapes; ++i) {
     const int pt = kWideShapes[i].pt, wmv = kWideShapes[i].wm;
     const int bm = 16 * pt * wmv, bn = 64 * (8 / wmv);
     if (wide_lds(k3, pt, wmv, a.Cout) > 160 * 1024) continue;
     if (bn > ((a.Cout + 127) / 128) * 128) continue;                  // a 256-wide tile on a 128-channel layer is half empty
     const long long tiles = ((long long)a.M + bm - 1) / bm * ((a.Cout + bn - 1) / bn);
     const long long rounds = (tiles + cus - 1) / cus;
-    const double eff = !charge_reads || pt == 8 ? 1.0 : (pt == 6 ? 1.04 : 1.12);
+    const double eff = !charge_reads || pt == 8 ? 1.0 : (pt == 6 ? 1.04 : (pt == 4 ? 1.12 : 1.2));
     const double work = (double)rounds * bm * bn * eff;
     double cost = work;
     if (time_model) {
-      const double F = pt == 8 ? 14.0 : (pt == 6 ? 10.0 : 4.5), c = pt == 8 ? 0.311 : (pt == 6 ? 0.353 : 0.417);
+      const double F = pt == 8 ? 14.0 : (pt == 6 ? 10.0 : 4.5), c = pt == 8 ? 0.311 : (pt == 6 ? 0.353 : (pt == 4 ? 0.417 : 0.46));
       cost = (double)rounds * (F + (double)bm * bn * 9.0 * a.Cin * c * 1e-6);
     }
     if (best < 0 || cost < best_cost * (charge_reads ? 1.0 : 0.999)) { best = i; best_cost = cost; best_eff = work; }
@@ -326,8 +328,8 @@ inline int wide_pick(const Args& a, bool k3, bool charge_reads, double* rounds_e
   return best;
 }
 
-inline bool wide_shape_fits(const char* who, bool k3, int shape, int Cout) {
-  if (shape < 0 || shape >= 5 || wide_lds(k3, kWideShapes[shape].pt, kWideShapes[shape].wm, Cout) > 160 * 1024) {
+inline bool wide_shape_fits(const char* who, bool k3, int shape, int Cout, int nshapes = kWideShapesGeneral) {
+  if (shape < 0 || shape >= nshapes || wide_lds(k3, kWideShapes[shape].pt, kWideShapes[shape].wm, Cout) > 160 * 1024) {
     set_error("%s: no tile shape of this layer fits the LDS", who);
     return false;
   }

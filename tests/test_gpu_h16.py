@@ -191,14 +191,14 @@ def test_h16_pp3x3_kernel_epilogues(gpu_device, dtype, tile, act):
     _h16_conv(gpu_device, dtype, 30, 38, 38, 64, 128, 3, 1, 1, act, tile, residual=True, two_stage=True, y_off=8)   # 170 tiles
 
 
-W3_TILES = [5, 13, 21, 29, 37, 45]      # YV4_HTILE_W3x3 (shape chosen by the cost model) and YV4_HTILE_W3x3_SHAPE(0..4)
+W3_TILES = [5, 13, 21, 29, 37, 45, 53, 61]      # YV4_HTILE_W3x3 (shape chosen by the cost model) and YV4_HTILE_W3x3_SHAPE(0..6)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('tile', W3_TILES)
 @pytest.mark.parametrize('shape', [s for s in PP3_SHAPES if s[4] % 16 == 0] + [(33, 19, 19, 128, 512), (2, 76, 76, 128, 128)])
 def test_h16_wide3x3_kernel_shapes(gpu_device, dtype, tile, shape):
-    """conv3x3_wide_h16.hip (16x16x32 MFMAs, wave tiles of 16 PT pixels x 64 channels, five workgroup tile shapes): the
+    """conv3x3_wide_h16.hip (16x16x32 MFMAs, wave tiles of 16 PT pixels x 64 channels, seven workgroup tile shapes): the
     ping-pong kernel's shape list -- image borders inside a tile, maps narrower than a fragment group, one-row images,
     ragged row / column tiles, workgroups that walk several tiles -- against float64."""
     N, H, W, Cin, Cout = shape
@@ -223,7 +223,7 @@ def test_wide3x3_matches_generic_bitwise(gpu_device, dtype):
     for shape, kw in [((2, 19, 19, 128, 128), dict(residual=True, two_stage=True)), ((3, 38, 38, 64, 192), dict()),
                       ((9, 38, 38, 256, 256), dict(residual=True)), ((5, 19, 19, 512, 512), dict())]:
         N, H, W, Cin, Cout = shape
-        outs = [_h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=t, raw=True, **kw) for t in (2, 4, 5, 13, 21, 29, 37, 45)]
+        outs = [_h16_conv(gpu_device, dtype, N, H, W, Cin, Cout, 3, 1, 1, act=1, tile=t, raw=True, **kw) for t in (2, 4, 5, 13, 21, 29, 37, 45, 53, 61)]
         for o in outs[1:]:
             assert torch.equal(outs[0], o)
 
@@ -232,7 +232,7 @@ def test_wide3x3_matches_generic_bitwise(gpu_device, dtype):
 def test_nontemporal_output_flag_gives_the_same_bits(gpu_device, dtype):
     """yv4_conv_desc.flags & YV4_CONV_NT_OUT (ABI 7, what 16-bit inference plans set): the wide-tile kernels store with
     non-temporal instructions, every other kernel ignores the flag -- the output is the same either way."""
-    for shape, k, stride, pad, tiles, kw in [((9, 38, 38, 256, 256), 3, 1, 1, (5, 13, 21, 37), dict(residual=True)),
+    for shape, k, stride, pad, tiles, kw in [((9, 38, 38, 256, 256), 3, 1, 1, (5, 13, 21, 37, 53, 61), dict(residual=True)),
                                              ((3, 38, 38, 128, 256), 3, 2, 1, (8, 24), dict()),
                                              ((2, 19, 19, 256, 256), 1, 1, 0, (8, 2, 6), dict(two_stage=True))]:
         N, H, W, Cin, Cout = shape
