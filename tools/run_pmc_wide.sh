@@ -5,8 +5,8 @@ export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_wide
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/sq -- python3 tools/conv_bench.py --dtype bf16 --batch 32 --filter "k3s1" --tiles 4,5 --reps 1 > $OUT/sq.log 2>&1 < /dev/null
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sqf -- python3 tools/conv_bench.py --dtype f32 --batch 32 --filter "k3s1" --tiles 7,10 --reps 1 > $OUT/sqf.log 2>&1 < /dev/null
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/sq -- python3 tools/conv_bench.py --dtype bf16 --batch 32 --filter "k3s1" --tiles 4,5 --reps 1 --warm-ms 0 > $OUT/sq.log 2>&1 < /dev/null
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sqf -- python3 tools/conv_bench.py --dtype f32 --batch 32 --filter "k3s1" --tiles 7,10 --reps 1 --warm-ms 0 > $OUT/sqf.log 2>&1 < /dev/null
 python3 - <<PY
 import csv,glob,collections
 for d in ('sq','sqf'):
